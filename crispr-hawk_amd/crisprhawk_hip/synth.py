@@ -1,0 +1,213 @@
+"""Deterministic synthetic inputs for the guide-search hot path.
+
+The recipes follow SURVEY.md §8(d) / BASELINE.md §3: iid uniform ACGT contigs, a BED
+interval padded by 100 nt on each side, and a phased variant panel (SNV / deletion /
+insertion sites with log-uniform allele frequencies, every haplotype column carrying the
+alt allele independently).  Everything is driven by ``numpy.random.default_rng(seed)`` so
+the golden-fixture generator (tests/golden/make_golden.py, which feeds the *reference*),
+the parity tests and bench.py all see the same bytes.
+
+Coordinates follow the reference: a BED line ``chrom start stop`` gives a region whose
+string index 0 is the 1-based genomic position ``max(0, start-100)`` and whose sequence is
+``contig[startp-1 : stop+100]`` (reference: coordinate.py:21-43, sequence.py:340-343,
+region_constructor.py:21).
+"""
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+PADDING = 100  # reference: region_constructor.py:21
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_IUPAC_EXTRA = np.frombuffer(b"NRYSWKMBDHV", dtype=np.uint8)
+
+
+def random_sequence(rng: np.random.Generator, n: int, iupac_frac: float = 0.0) -> str:
+    """iid uniform ACGT string; with ``iupac_frac`` > 0 sprinkle N/IUPAC codes."""
+    seq = _ACGT[rng.integers(0, 4, size=n)]
+    if iupac_frac > 0.0 and n > 0:
+        mask = rng.random(n) < iupac_frac
+        seq = seq.copy()
+        seq[mask] = _IUPAC_EXTRA[rng.integers(0, len(_IUPAC_EXTRA), size=int(mask.sum()))]
+    return seq.tobytes().decode("ascii")
+
+
+@dataclass
+class VariantSite:
+    """One biallelic VCF row (left-anchored indels, VCF conventions)."""
+
+    pos: int  # 1-based genomic position of the first REF base
+    ref: str
+    alt: str
+    af: float
+    gt: np.ndarray  # uint8 [n_samples, 2]; 1 = alt on that chromosome copy
+
+    @property
+    def chain(self) -> int:
+        return len(self.alt) - len(self.ref)
+
+    @property
+    def is_snv(self) -> bool:
+        return len(self.ref) == len(self.alt)
+
+
+@dataclass
+class SynthRegion:
+    contig: str
+    contig_seq: str
+    bed_start: int
+    bed_stop: int
+    samples: List[str] = field(default_factory=list)
+    variants: List[VariantSite] = field(default_factory=list)
+
+    @property
+    def startp(self) -> int:  # padded start (reference Coordinate.start)
+        return max(0, self.bed_start - PADDING)
+
+    @property
+    def stopp(self) -> int:  # padded stop (reference Coordinate.stop)
+        return self.bed_stop + PADDING
+
+    @property
+    def sequence(self) -> str:
+        return self.contig_seq[self.startp - 1 : self.stopp]
+
+    def vcf_fields(self, v: VariantSite) -> List[str]:
+        """The tab-split VCF row the reference's VariantRecord.read_vcf_line consumes."""
+        gts = [f"{int(a)}|{int(b)}" for a, b in v.gt]
+        return [self.contig, str(v.pos), ".", v.ref, v.alt, ".", "PASS", f"AF={v.af:.6g}", "GT"] + gts
+
+
+def make_region(
+    seed: int,
+    contig: str,
+    contig_len: int,
+    bed_start: int,
+    bed_stop: int,
+    iupac_frac: float = 0.0,
+) -> SynthRegion:
+    rng = np.random.default_rng(seed)
+    return SynthRegion(contig, random_sequence(rng, contig_len, iupac_frac), bed_start, bed_stop)
+
+
+def add_phased_variants(
+    reg: SynthRegion,
+    seed: int,
+    n_sites: int,
+    n_samples: int,
+    frac_snv: float = 0.90,
+    frac_del: float = 0.05,
+    max_indel: int = 8,
+    af_min: Optional[float] = None,
+    af_max: float = 0.5,
+    edge_margin: int = 1,
+) -> SynthRegion:
+    """Place ``n_sites`` non-overlapping variant sites inside the padded region.
+
+    SNV / deletion / insertion mix 90/5/5 %, indel length 1+Geometric(0.5) capped at
+    ``max_indel``; AF log-uniform on [af_min, af_max]; every one of the 2*n_samples
+    haplotype columns carries the alt independently with probability AF.
+    """
+    rng = np.random.default_rng(seed)
+    n_hap = 2 * n_samples
+    if af_min is None:
+        af_min = 1.0 / n_hap
+    lo = reg.startp + edge_margin  # first allowed 1-based position
+    hi = reg.stopp - edge_margin - max_indel - 1  # last allowed start so REF allele fits
+    span = max_indel + 2  # footprint reserved per site: keeps sites non-overlapping
+    n_slots = (hi - lo + 1) // span
+    if n_sites > n_slots:
+        raise ValueError(f"too many variant sites ({n_sites}) for region ({n_slots} slots)")
+    slots = np.sort(rng.choice(n_slots, size=n_sites, replace=False))
+    jitter = rng.integers(0, 2, size=n_sites)  # 0/1 nt jitter inside the slot
+    kinds = rng.random(n_sites)
+    lens = np.minimum(rng.geometric(0.5, size=n_sites), max_indel)
+    afs = np.exp(rng.uniform(np.log(af_min), np.log(af_max), size=n_sites))
+    alt_pick = rng.integers(1, 4, size=n_sites)
+    ins_bases = rng.integers(0, 4, size=(n_sites, max_indel))
+    seq = reg.contig_seq
+    reg.samples = [f"S{i:04d}" for i in range(n_samples)]
+    out: List[VariantSite] = []
+    for k in range(n_sites):
+        pos = int(lo + slots[k] * span + jitter[k])
+        refb = seq[pos - 1]
+        gt = (rng.random(n_hap) < afs[k]).astype(np.uint8).reshape(n_samples, 2)
+        if not gt.any():  # keep every site carried by at least one haplotype
+            gt[rng.integers(0, n_samples), rng.integers(0, 2)] = 1
+        if kinds[k] < frac_snv:
+            altb = "ACGT"[("ACGT".index(refb) + int(alt_pick[k])) % 4]
+            out.append(VariantSite(pos, refb, altb, float(afs[k]), gt))
+        elif kinds[k] < frac_snv + frac_del:
+            ln = int(lens[k])
+            out.append(VariantSite(pos, seq[pos - 1 : pos + ln], refb, float(afs[k]), gt))
+        else:
+            ln = int(lens[k])
+            ins = "".join("ACGT"[b] for b in ins_bases[k, :ln])
+            out.append(VariantSite(pos, refb, refb + ins, float(afs[k]), gt))
+    # The reference clamps a variant's REF span with the *original* region length
+    # (haplotype.py:199-201: ``if posrel_stop > self._size``), so a site whose haplotype
+    # offset has been pushed past the region end by upstream insertions makes it raise
+    # "Mismatching reference alleles".  Keep sites out of that tail: the guard is the
+    # largest total inserted length any one haplotype carries.
+    if out:
+        ins_len = np.array([max(0, v.chain) for v in out], dtype=np.int64)
+        gt_all = np.stack([v.gt.reshape(-1) for v in out]).astype(np.int64)  # [site, hap]
+        guard = int((ins_len[:, None] * gt_all).sum(axis=0).max())
+        out = [v for v in out if v.pos + len(v.ref) + guard <= reg.stopp]
+    reg.variants = out
+    return reg
+
+
+# --- named configurations (BASELINE.json configs / SURVEY.md §8d) -----------------
+
+def config_c1() -> SynthRegion:
+    """C1/C2: 12 kb contig, BED chrS 1000 11000 -> 10 201-nt region, no VCF."""
+    return make_region(1001, "chrS", 12_000, 1_000, 11_000)
+
+
+def config_c3(n_samples: int = 2504, n_sites: int = 31_000, region_len: int = 1_000_000) -> SynthRegion:
+    """C3: 1.2 Mb synthetic chr22, BED 100000..1100000, 2504 phased samples, 31k sites."""
+    reg = make_region(1003, "chr22", region_len + 200_000, 100_000, 100_000 + region_len)
+    return add_phased_variants(reg, 1003_1, n_sites, n_samples)
+
+
+def cfd_tables(seed: int = 2001) -> Tuple[np.ndarray, np.ndarray]:
+    """Seeded synthetic CFD tables (the real Doench-2016 pickles are fetched from Zenodo by
+    the reference at run time and are not available offline).
+
+    Returns ``mm[20, 4, 4]`` indexed [position, wildtype-RNA base (A,C,G,U), sgRNA base
+    (A,C,G,T)] and ``pam[16]`` indexed by the dinucleotide 4*b0+b1 over (A,C,G,T).
+    """
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0.0, 1.0, size=(20, 4, 4)), rng.uniform(0.0, 1.0, size=16)
+
+
+def cfd_tables_as_dicts(mm: np.ndarray, pam: np.ndarray):
+    """The two dicts in the key format reference compute_cfd expects
+    (scores/cfdscore/cfdscore.py:88-94): ``r{wt}:d{RC(sg)},{i+1}`` and ``{pam[-2:]}``."""
+    rna, dna = "ACGU", "ACGT"
+    rc = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    mmd = {}
+    for i in range(20):
+        for a in range(4):
+            for b in range(4):
+                mmd[f"r{rna[a]}:d{rc[dna[b]]},{i + 1}"] = float(mm[i, a, b])
+    pamd = {dna[a] + dna[b]: float(pam[4 * a + b]) for a in range(4) for b in range(4)}
+    return mmd, pamd
+
+
+def deepcpf1_weights(seed: int = 2002) -> dict:
+    """Seeded N(0, 0.1) fp32 parameters in the torch layout of the reference's SeqDeepCpf1
+    (scores/deepCpf1/seqdeepcpf1.py:43-56): conv (80,4,5), fc 1200-80-40-40-1."""
+    rng = np.random.default_rng(seed)
+
+    def n(*shape):
+        return rng.normal(0.0, 0.1, size=shape).astype(np.float32)
+
+    return dict(
+        conv_w=n(80, 4, 5), conv_b=n(80),
+        w1=n(80, 1200), b1=n(80), w2=n(40, 80), b2=n(40),
+        w3=n(40, 40), b3=n(40), w4=n(1, 40), b4=n(1),
+    )
