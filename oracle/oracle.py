@@ -1,0 +1,259 @@
+"""ctypes front-end of the CPU parity oracle (oracle/hawk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package (crisprhawk_hip) must never import this module.
+Parity status: pinned against reference-generated vectors (tests/test_oracle_golden.py),
+except the off-target enumeration which has no reference implementation to pin to
+("parity unpinned", see hawk_oracle.c).
+"""
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ERRORS = {
+    -1: "IUPAC table error",
+    -2: "mismatching reference alleles",
+    -3: "position-map key error",
+    -4: "CFD table key error",
+    -5: "capacity",
+    -6: "variant beyond original region length (haplotype.py:199-201 clamp)",
+    -7: "duplicate REF guide",
+}
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(f"oracle error {code}: {ERRORS.get(code, '?')}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libhawk_oracle.so")
+    src = os.path.join(_HERE, "hawk_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libhawk_oracle.so"])
+    return so
+
+
+class _Guide(C.Structure):
+    _fields_ = [("start", C.c_int64), ("stop", C.c_int64), ("hap", C.c_int32), ("pos", C.c_int32),
+                ("strand", C.c_int32), ("right", C.c_int32), ("emit", C.c_int64)]
+
+
+class _OT(C.Structure):
+    _fields_ = [("guide", C.c_int32), ("strand", C.c_int32), ("pos", C.c_int64), ("mm", C.c_int32), ("pad", C.c_int32)]
+
+
+GUIDE_DTYPE = np.dtype([("start", "<i8"), ("stop", "<i8"), ("hap", "<i4"), ("pos", "<i4"),
+                        ("strand", "<i4"), ("right", "<i4"), ("emit", "<i8")])
+OT_DTYPE = np.dtype([("guide", "<i4"), ("strand", "<i4"), ("pos", "<i8"), ("mm", "<i4"), ("pad", "<i4")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ora_posmap_rev.restype = C.c_int64
+        _LIB.ora_search.restype = C.c_int64
+        _LIB.ora_offtargets.restype = C.c_int64
+    return _LIB
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+def encode(seq: str) -> np.ndarray:
+    b = seq.encode("ascii")
+    out = np.empty(len(b), dtype=np.uint8)
+    bad = C.c_int64(-1)
+    rc = lib().ora_encode(b, C.c_int64(len(b)), _p(out), C.byref(bad))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def revcomp(seq: str) -> str:
+    b = seq.encode("ascii")
+    out = C.create_string_buffer(len(b))
+    rc = lib().ora_revcomp(b, C.c_int64(len(b)), out)
+    if rc:
+        raise OracleError(rc)
+    return out.raw.decode("ascii")
+
+
+def pam_encode(pam: str) -> Tuple[int, int, str, str]:
+    b = pam.encode("ascii")
+    bits, bitsrc = C.c_uint64(), C.c_uint64()
+    up, rc_ = C.create_string_buffer(len(b)), C.create_string_buffer(len(b))
+    rc = lib().ora_pam_encode(b, len(b), C.byref(bits), C.byref(bitsrc), up, rc_)
+    if rc:
+        raise OracleError(rc)
+    return bits.value, bitsrc.value, up.raw.decode(), rc_.raw.decode()
+
+
+def cas_system(pam_upper: str, right: bool) -> int:
+    b = pam_upper.encode("ascii")
+    return lib().ora_cas_system(b, len(b), int(right))
+
+
+def scan(nibbles: np.ndarray, start: int, stop: int, bits: int, bitsrc: int, pamlen: int):
+    n = max(0, stop - start)
+    fwd = np.empty(n + 1, dtype=np.int32)
+    rev = np.empty(n + 1, dtype=np.int32)
+    nf, nr = C.c_int64(), C.c_int64()
+    lib().ora_scan(_p(nibbles), C.c_int64(start), C.c_int64(stop), C.c_uint64(bits), C.c_uint64(bitsrc),
+                   pamlen, _p(fwd), C.byref(nf), _p(rev), C.byref(nr))
+    return fwd[: nf.value].copy(), rev[: nr.value].copy()
+
+
+def hap_build(region_seq: str, startp: int, variants: Sequence[Tuple[int, str, str]]):
+    """variants: [(pos, ref, alt)] carried by this chromosome copy. -> (cased sequence, posmap)"""
+    n = len(region_seq)
+    grow = sum(max(0, len(a) - len(r)) for _, r, a in variants)
+    cap = n + grow + 8
+    buf = C.create_string_buffer(region_seq.encode("ascii"), cap)
+    nv = len(variants)
+    vpos = np.array([v[0] for v in variants], dtype=np.int64)
+    blob, ro, rl, ao, al = bytearray(), [], [], [], []
+    for _, r, a in variants:
+        ro.append(len(blob)); rl.append(len(r)); blob += r.encode()
+        ao.append(len(blob)); al.append(len(a)); blob += a.encode()
+    ro, rl, ao, al = (np.array(x, dtype=np.int32) for x in (ro, rl, ao, al))
+    posmap = np.empty(cap, dtype=np.int64)
+    out_len = C.c_int64()
+    rc = lib().ora_hap_build(buf, C.c_int64(n), C.c_int64(cap), C.c_int64(startp), nv, _p(vpos), _p(ro), _p(rl),
+                             _p(ao), _p(al), bytes(blob), C.byref(out_len), _p(posmap))
+    if rc:
+        raise OracleError(rc)
+    L = out_len.value
+    return buf.raw[:L].decode("ascii"), posmap[:L].copy()
+
+
+def posmap_rev(posmap: np.ndarray, g: int) -> int:
+    return int(lib().ora_posmap_rev(_p(posmap), C.c_int64(len(posmap)), C.c_int64(g)))
+
+
+def scan_bounds(posmap: np.ndarray, region_start: int, region_stop: int, pamlen: int,
+                hap_start: Optional[int] = None, hap_stop: Optional[int] = None) -> Tuple[int, int]:
+    hs = region_start if hap_start is None else hap_start
+    he = region_stop if hap_stop is None else hap_stop
+    a, b = C.c_int64(), C.c_int64()
+    rc = lib().ora_scan_bounds(_p(posmap), C.c_int64(len(posmap)), C.c_int64(region_start), C.c_int64(region_stop),
+                               C.c_int64(hs), C.c_int64(he), pamlen, C.byref(a), C.byref(b))
+    if rc:
+        raise OracleError(rc)
+    return a.value, b.value
+
+
+@dataclass
+class HapSet:
+    """Haplotypes in the oracle's (= the reference's) representation."""
+    seqs: List[str]
+    posmaps: List[np.ndarray]
+    is_ref: List[bool]
+    scan: List[Tuple[int, int]]
+
+    def packed(self):
+        off = np.zeros(len(self.seqs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in self.seqs])
+        blob = "".join(self.seqs).encode("ascii")
+        pm = np.concatenate(self.posmaps) if self.posmaps else np.zeros(0, dtype=np.int64)
+        return blob, off, np.ascontiguousarray(pm, dtype=np.int64)
+
+
+@dataclass
+class SearchResult:
+    guides: np.ndarray  # GUIDE_DTYPE, reference list order
+    windows: List[str]
+    n_candidates: int
+    n_hits: int
+
+
+def search(hs: HapSet, pam: str, guidelen: int, right: bool, cap: Optional[int] = None) -> SearchResult:
+    blob, off, pm = hs.packed()
+    n_hap = len(hs.seqs)
+    if cap is None:
+        cap = 2 * int(off[-1]) + 16
+    isref = np.array(hs.is_ref, dtype=np.uint8)
+    ss = np.array([s[0] for s in hs.scan], dtype=np.int64)
+    se = np.array([s[1] for s in hs.scan], dtype=np.int64)
+    out = np.zeros(cap, dtype=GUIDE_DTYPE)
+    W = guidelen + len(pam) + 20
+    win = np.zeros(cap * W, dtype=np.uint8)
+    ncand, nhits = C.c_int64(), C.c_int64()
+    m = lib().ora_search(blob, _p(off), _p(pm), _p(isref), _p(ss), _p(se), n_hap, pam.encode(), len(pam), guidelen,
+                         int(right), _p(out), _p(win), C.c_int64(cap), C.byref(ncand), C.byref(nhits))
+    if m < 0:
+        raise OracleError(int(m))
+    wb = win[: m * W].tobytes()
+    windows = [wb[i * W:(i + 1) * W].decode("ascii") for i in range(m)]
+    return SearchResult(out[:m].copy(), windows, ncand.value, nhits.value)
+
+
+def reverse_and_cfdon(res: SearchResult, is_ref: Sequence[bool], guidelen: int, pamlen: int,
+                      mm: Optional[np.ndarray] = None, pamtab: Optional[np.ndarray] = None):
+    """-> (guides with flipped `right`, reversed windows, kmers, cfdon scores, cfdon order)"""
+    n = len(res.guides)
+    W = guidelen + pamlen + 20
+    g = res.guides.copy()
+    win = np.frombuffer("".join(res.windows).encode("ascii"), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+    kmer = np.zeros(n * (W - 13), dtype=np.uint8)
+    cfd = np.full(n, np.nan)
+    order = np.zeros(n, dtype=np.int64)
+    isref = np.array(is_ref, dtype=np.uint8)
+    do_cfd = mm is not None
+    mmc = np.ascontiguousarray(mm, dtype=np.float64) if do_cfd else np.zeros(1)
+    ptc = np.ascontiguousarray(pamtab, dtype=np.float64) if do_cfd else np.zeros(1)
+    rc = lib().ora_reverse_and_cfdon(_p(g), _p(win), C.c_int64(n), guidelen, pamlen, _p(isref), _p(mmc), _p(ptc),
+                                     int(do_cfd), _p(cfd), _p(order), _p(kmer))
+    if rc:
+        raise OracleError(rc)
+    wb, kb = win.tobytes(), kmer.tobytes()
+    K = W - 13
+    windows = [wb[i * W:(i + 1) * W].decode() for i in range(n)]
+    kmers = [kb[i * K:(i + 1) * K].decode() for i in range(n)]
+    return g, windows, kmers, (cfd if do_cfd else None), (order if do_cfd else None)
+
+
+def cfd(wt: str, sg: str, pam: str, mm: np.ndarray, pamtab: np.ndarray) -> float:
+    out = C.c_double()
+    mmc = np.ascontiguousarray(mm, dtype=np.float64)
+    ptc = np.ascontiguousarray(pamtab, dtype=np.float64)
+    rc = lib().ora_cfd(wt.encode(), len(wt), sg.encode(), len(sg), pam.encode(), len(pam), _p(mmc), _p(ptc), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value
+
+
+def deepcpf1(seqs: Sequence[str], w: dict) -> np.ndarray:
+    n = len(seqs)
+    blob = "".join(seqs).encode("ascii")
+    assert len(blob) == 34 * n
+    out = np.zeros(n, dtype=np.float32)
+    arrs = [np.ascontiguousarray(w[k], dtype=np.float32) for k in
+            ("conv_w", "conv_b", "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]
+    rc = lib().ora_deepcpf1(blob, C.c_int64(n), *[_p(a) for a in arrs], _p(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def offtargets(genome: str, guides: Sequence[str], pam: str, right: bool, max_mm: int, cap: int = 1 << 22) -> np.ndarray:
+    """PARITY UNPINNED (no reference implementation; see hawk_oracle.c)."""
+    guidelen = len(guides[0])
+    out = np.zeros(cap, dtype=OT_DTYPE)
+    gb = "".join(guides).encode("ascii")
+    n = lib().ora_offtargets(genome.encode("ascii"), C.c_int64(len(genome)), gb, len(guides), guidelen, pam.encode(),
+                             len(pam), int(right), max_mm, _p(out), C.c_int64(cap))
+    if n < 0:
+        raise OracleError(int(n))
+    return out[:n].copy()
