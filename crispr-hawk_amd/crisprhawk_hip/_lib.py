@@ -1,0 +1,116 @@
+"""ctypes binding of libhawk_hip.so (C ABI: include/hawk.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is visible,
+every entry point raises HawkLibraryError / HawkDeviceError instead of computing on the host.
+"""
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhawk_hip.so")
+
+HAWK_OK = 0
+HAWK_E_INVALID = -1
+HAWK_E_HIP = -2
+HAWK_E_CAPACITY = -3
+HAWK_E_IUPAC = -4
+HAWK_E_CFD = -5
+HAWK_E_NODEVICE = -6
+HAWK_E_UNSUPPORTED = -7
+
+EXPORTS = [
+    "hawk_device_count", "hawk_init", "hawk_destroy", "hawk_strerror", "hawk_last_hip_error", "hawk_stream",
+    "hawk_sync", "hawk_hapset_create", "hawk_hapset_destroy", "hawk_hapset_pack_ascii", "hawk_hapset_set_meta",
+    "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan",
+    "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns",
+]
+
+
+class HawkLibraryError(RuntimeError):
+    """libhawk_hip.so is missing or does not export the C ABI — build it (python -c
+    'import __graft_entry__ as g; g.build()' or make -C crispr-hawk_amd/csrc)."""
+
+
+class HawkDeviceError(RuntimeError):
+    """No MI355X visible / HIP failure.  There is deliberately no CPU path."""
+
+
+class HawkStatusError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: {strerror(status)} (status {status}){': ' + detail if detail else ''}")
+
+
+class SearchParams(C.Structure):
+    _fields_ = [
+        ("pam_fwd", C.c_uint64), ("pam_rev", C.c_uint64), ("pamlen", C.c_uint32), ("guidelen", C.c_uint32),
+        ("right", C.c_uint32), ("score_cfdon", C.c_uint32), ("cfd_mm", C.c_void_p), ("cfd_pam", C.c_void_p),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("scan_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("guides_ms", C.c_float),
+        ("compact_ms", C.c_float), ("total_ms", C.c_float), ("scanned_positions", C.c_uint64),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+_ctx = {}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HawkLibraryError(f"{LIB_PATH} not found: the HIP extension has not been built")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise HawkLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        missing = [s for s in EXPORTS if not hasattr(L, s)]
+        if missing:
+            raise HawkLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+        L.hawk_strerror.restype = C.c_char_p
+        L.hawk_last_hip_error.restype = C.c_char_p
+        L.hawk_stream.restype = C.c_void_p
+        L.hawk_destroy.restype = None
+        L.hawk_hapset_destroy.restype = None
+        L.hawk_table_destroy.restype = None
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if fn.restype is C.c_int:
+                fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def strerror(status: int) -> str:
+    return lib().hawk_strerror(status).decode()
+
+
+def check(status: int, where: str) -> None:
+    if status != HAWK_OK:
+        detail = lib().hawk_last_hip_error().decode() if status == HAWK_E_HIP else ""
+        if status in (HAWK_E_HIP, HAWK_E_NODEVICE):
+            raise HawkDeviceError(f"{where}: {strerror(status)} {detail}")
+        raise HawkStatusError(status, where, detail)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().hawk_device_count(C.byref(n))
+    return n.value
+
+
+def context(device: Optional[int] = None):
+    """One hawk_ctx per process per device (include/hawk.h).  Device defaults to LOCAL_RANK."""
+    if device is None:
+        device = int(os.environ.get("HAWK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _ctx:
+        h = C.c_void_p()
+        check(lib().hawk_init(device, C.byref(h)), "hawk_init")
+        _ctx[device] = h
+    return _ctx[device]

@@ -1,0 +1,254 @@
+"""Device-resident haplotype set and guide table (thin wrappers over the C ABI).
+
+``DeviceHapSet`` owns the bit-sliced planes of a list of haplotypes in HBM together with the
+per-haplotype metadata the reference's search reads from ``Haplotype`` objects (samples ==
+"REF", scan bounds, position map).  ``GuideTable`` is the columnar result of the fused search:
+the reference materialises one Python ``Guide`` per row (search_guides.py:488-502); here rows
+stay as numpy columns and ``Guide`` objects are created on demand.
+"""
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+GUIDESEQPAD = 10  # reference guide.py:21
+_CODE2CHAR = np.frombuffer(b"?ACMGRSVTWYHKDBN?acmgrsvtwyhkdbn", dtype=np.uint8)
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def segments_from_posmap(posmap: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Position map (haplotype.py:90-159) -> unit-slope segments (rel_start, genomic_start).
+    Every index where posmap[i] != posmap[i-1] + 1 opens a segment (an inserted base repeats
+    its anchor's position and therefore opens a segment of its own)."""
+    pm = np.asarray(posmap, dtype=np.int64)
+    brk = np.flatnonzero(np.diff(pm) != 1) + 1
+    rel = np.concatenate(([0], brk)).astype(np.uint32)
+    return rel, pm[rel].copy()
+
+
+class PosSegments:
+    """Host view of one haplotype's position map; mirrors the two dicts of the reference
+    (``Haplotype.posmap`` / ``posmap_rev``) without materialising them."""
+
+    __slots__ = ("rel", "gen", "length")
+
+    def __init__(self, rel: np.ndarray, gen: np.ndarray, length: int):
+        self.rel = np.asarray(rel, dtype=np.uint32)
+        self.gen = np.asarray(gen, dtype=np.int64)
+        self.length = int(length)
+
+    @classmethod
+    def identity(cls, start: int, length: int) -> "PosSegments":
+        return cls(np.zeros(1, np.uint32), np.array([start], np.int64), length)
+
+    def lookup(self, rel) -> np.ndarray:
+        r = np.asarray(rel, dtype=np.int64)
+        k = np.searchsorted(self.rel, r, side="right") - 1
+        return self.gen[k] + (r - self.rel[k].astype(np.int64))
+
+    def full(self) -> np.ndarray:
+        return self.lookup(np.arange(self.length))
+
+    def seg_last_gen(self) -> np.ndarray:
+        ends = np.concatenate((self.rel[1:].astype(np.int64), [self.length]))
+        return self.gen + (ends - self.rel.astype(np.int64)) - 1
+
+    def max_gen(self) -> int:
+        return int(self.seg_last_gen().max())
+
+    def rev(self, g: int) -> int:
+        """posmap_rev[g]: the LAST relative position mapping to g (the reference rebuilds the
+        reverse dict by overwrite, haplotype.py:159), or -1 when g is absent (deleted)."""
+        last = self.seg_last_gen()
+        k = np.flatnonzero((self.gen <= g) & (g <= last))
+        if len(k) == 0:
+            return -1
+        k = int(k[-1])
+        return int(self.rel[k]) + int(g - self.gen[k])
+
+
+@dataclass
+class HostHaplotype:
+    """What the device search needs to know about one haplotype."""
+    seq: str  # cased: lower case = base introduced by a variant
+    seg: PosSegments
+    is_ref: bool
+    scan: Tuple[int, int]
+
+
+class DeviceHapSet:
+    def __init__(self, haps: Sequence[HostHaplotype], device: Optional[int] = None):
+        L = _lib.lib()
+        self._ctx = _lib.context(device)
+        self._L = L
+        self.n_hap = len(haps)
+        if self.n_hap == 0:
+            raise ValueError("empty haplotype set")
+        self.hap_len = np.array([len(h.seq) for h in haps], dtype=np.uint32)
+        self._h = C.c_void_p()
+        _lib.check(L.hawk_hapset_create(self._ctx, self.n_hap, _p(self.hap_len), C.byref(self._h)), "hawk_hapset_create")
+        s = C.c_uint32()
+        _lib.check(L.hawk_hapset_stride(self._h, C.byref(s)), "hawk_hapset_stride")
+        self.stride = s.value
+        # K1: ASCII -> planes
+        off = np.zeros(self.n_hap + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(self.hap_len.astype(np.uint64))
+        blob = "".join(h.seq for h in haps).encode("ascii")
+        bad = C.c_uint64(0)
+        rc = L.hawk_hapset_pack_ascii(self._h, blob, _p(off), C.byref(bad))
+        if rc == _lib.HAWK_E_IUPAC:
+            hidx = int(np.searchsorted(off, bad.value, side="right") - 1)
+            self.close()
+            raise _lib.HawkStatusError(rc, "hawk_hapset_pack_ascii",
+                                       f"haplotype {hidx} position {bad.value - int(off[hidx])} "
+                                       f"({blob[bad.value:bad.value + 1]!r})")
+        _lib.check(rc, "hawk_hapset_pack_ascii")
+        self.set_meta(haps)
+
+    def set_meta(self, haps: Sequence[HostHaplotype]) -> None:
+        is_ref = np.array([1 if h.is_ref else 0 for h in haps], dtype=np.uint8)
+        ss = np.array([h.scan[0] for h in haps], dtype=np.int32)
+        se = np.array([h.scan[1] for h in haps], dtype=np.int32)
+        seg_off = np.zeros(self.n_hap + 1, dtype=np.uint32)
+        seg_off[1:] = np.cumsum([len(h.seg.rel) for h in haps])
+        seg_rel = np.concatenate([h.seg.rel for h in haps]).astype(np.uint32)
+        seg_gen = np.concatenate([h.seg.gen for h in haps]).astype(np.int64)
+        refs = np.flatnonzero(is_ref)
+        self.ref_index = int(refs[0]) if len(refs) else -1
+        self.is_ref = is_ref
+        _lib.check(self._L.hawk_hapset_set_meta(self._h, _p(is_ref), _p(ss), _p(se), _p(seg_off), _p(seg_rel), _p(seg_gen),
+                                                self.ref_index), "hawk_hapset_set_meta")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.hawk_hapset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def planes(self) -> np.ndarray:
+        """[5, n_hap, stride] uint32 copy of the planes (tests / host-side decoding)."""
+        out = np.empty((5, self.n_hap, self.stride), dtype=np.uint32)
+        for p in range(5):
+            _lib.check(self._L.hawk_hapset_download_plane(self._h, p, _p(out[p])), "hawk_hapset_download_plane")
+        return out
+
+    def nibbles(self, h: int) -> np.ndarray:
+        """The reference's encode() output for haplotype h (encoder.py:48-57), from the planes."""
+        pl = self.planes()[:, h, :]
+        n = int(self.hap_len[h])
+        bits = ((pl[:4, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(4, -1)[:, :n].astype(np.uint8)
+        return bits[0] | (bits[1] << 1) | (bits[2] << 2) | (bits[3] << 3)
+
+    def pam_scan(self, pam_bits: int, pam_bitsrc: int, pamlen: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """pam_search() (search_guides.py:102-131): per haplotype (fwd hits, rev hits)."""
+        L = self._L
+        off_f = np.zeros(self.n_hap + 1, dtype=np.uint64)
+        off_r = np.zeros(self.n_hap + 1, dtype=np.uint64)
+        rc = L.hawk_pam_scan(self._h, C.c_uint64(pam_bits), C.c_uint64(pam_bitsrc), pamlen, None, None, C.c_uint64(0),
+                             C.c_uint64(0), _p(off_f), _p(off_r))
+        if rc not in (_lib.HAWK_OK, _lib.HAWK_E_CAPACITY):
+            _lib.check(rc, "hawk_pam_scan")
+        nf, nr = int(off_f[-1]), int(off_r[-1])
+        hf = np.empty(max(nf, 1), dtype=np.uint32)
+        hr = np.empty(max(nr, 1), dtype=np.uint32)
+        if rc == _lib.HAWK_E_CAPACITY:
+            _lib.check(L.hawk_pam_scan(self._h, C.c_uint64(pam_bits), C.c_uint64(pam_bitsrc), pamlen, _p(hf), _p(hr),
+                                       C.c_uint64(len(hf)), C.c_uint64(len(hr)), _p(off_f), _p(off_r)), "hawk_pam_scan")
+        return [(hf[int(off_f[h]):int(off_f[h + 1])].copy(), hr[int(off_r[h]):int(off_r[h + 1])].copy())
+                for h in range(self.n_hap)]
+
+    def search(self, pam_bits: int, pam_bitsrc: int, pamlen: int, guidelen: int, right: bool,
+               cfd_mm: Optional[np.ndarray] = None, cfd_pam: Optional[np.ndarray] = None,
+               download: bool = True) -> "GuideTable":
+        L = self._L
+        sp = _lib.SearchParams()
+        sp.pam_fwd, sp.pam_rev, sp.pamlen, sp.guidelen, sp.right = pam_bits, pam_bitsrc, pamlen, guidelen, int(bool(right))
+        keep = []
+        if cfd_mm is not None:
+            mm = np.ascontiguousarray(cfd_mm, dtype=np.float64).reshape(20, 4, 4)
+            pt = np.ascontiguousarray(cfd_pam, dtype=np.float64).reshape(16)
+            keep = [mm, pt]
+            sp.score_cfdon, sp.cfd_mm, sp.cfd_pam = 1, mm.ctypes.data, pt.ctypes.data
+        t = C.c_void_p()
+        tm = _lib.Timing()
+        _lib.check(L.hawk_search(self._h, C.byref(sp), C.byref(t), C.byref(tm)), "hawk_search")
+        del keep
+        tab = GuideTable(self, t, guidelen, pamlen, bool(right), tm)
+        if download:
+            tab.download()
+        return tab
+
+
+class GuideTable:
+    """Columnar guide table of one fused search (rows in (haplotype, strand, position) order)."""
+
+    def __init__(self, hs: DeviceHapSet, handle, guidelen: int, pamlen: int, right: bool, timing):
+        self._hs, self._t = hs, handle
+        self.guidelen, self.pamlen, self.right = guidelen, pamlen, right
+        self.timing = {k: getattr(timing, k) for k, _ in timing._fields_}
+        n, c, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(hs._L.hawk_table_counts(handle, C.byref(n), C.byref(c), C.byref(h)), "hawk_table_counts")
+        self.n_rows, self.n_candidates, self.n_hits = n.value, c.value, h.value
+        self._downloaded = False
+
+    def download(self) -> "GuideTable":
+        if self._downloaded:
+            return self
+        n = self.n_rows
+        self.hap = np.empty(n, np.uint32); self.pos = np.empty(n, np.uint32); self.strand = np.empty(n, np.uint8)
+        self.start = np.empty(n, np.int64); self.stop = np.empty(n, np.int64); self.flags = np.empty(n, np.uint8)
+        self.cfdon = np.empty(n, np.float64); self.win = np.empty((5, n), np.uint64)
+        _lib.check(self._hs._L.hawk_table_download(self._t, _p(self.hap), _p(self.pos), _p(self.strand), _p(self.start),
+                                                   _p(self.stop), _p(self.flags), _p(self.cfdon), _p(self.win)),
+                   "hawk_table_download")
+        self._hs._L.hawk_table_destroy(self._t)
+        self._t = None
+        self._downloaded = True
+        return self
+
+    @property
+    def window_len(self) -> int:
+        return self.guidelen + self.pamlen + 2 * GUIDESEQPAD
+
+    def right_as_stored(self) -> np.ndarray:
+        """`right` of each row as search() stores it: flipped for strand 1 (search_guides.py:538)."""
+        return (self.strand.astype(bool)) ^ self.right
+
+    def windows(self, rows: Optional[np.ndarray] = None) -> List[str]:
+        """Guide.sequence of each row: the guidelen+pamlen+20-nt window on the + strand, case
+        preserved (search_guides.py:134-160)."""
+        win = self.win if rows is None else self.win[:, rows]
+        n, W = win.shape[1], self.window_len
+        if n == 0:
+            return []
+        sh = np.arange(W, dtype=np.uint64)
+        code = np.zeros((n, W), dtype=np.uint8)
+        for p in range(5):
+            code |= (((win[p][:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
+        raw = _CODE2CHAR[code].tobytes()
+        return [raw[i * W:(i + 1) * W].decode("ascii") for i in range(n)]
+
+    def reference_order(self) -> np.ndarray:
+        """Row permutation reproducing the list order of the reference's search():
+        remove_redundant_guides (search_guides.py:340-369) walks a dict keyed by
+        f"{start}_{strand}" in first-seen order, each group in emission order."""
+        n = self.n_rows
+        if n == 0:
+            return np.zeros(0, dtype=np.int64)
+        key = self.start.astype(np.int64) * 2 + self.strand
+        _, inv = np.unique(key, return_inverse=True)
+        first = np.full(inv.max() + 1, n, dtype=np.int64)
+        np.minimum.at(first, inv, np.arange(n))
+        return np.lexsort((np.arange(n), first[inv]))

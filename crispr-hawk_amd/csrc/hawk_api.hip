@@ -1,0 +1,517 @@
+// hawk_api.hip — the C ABI of include/hawk.h over the kernels in hawk_kernels.hip.
+// Host-side responsibilities only: HBM allocation, H2D/D2H staging, launch order on one HIP
+// stream, HIP-event timing, error mapping.  No compute happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/hawk.h"
+#include "hawk_device.h"
+
+static thread_local char g_hip_err[256] = "";
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return HAWK_E_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+struct hawk_ctx {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[8];
+};
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return HAWK_OK;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    size_t want = need + need / 8 + 256;
+    HIPCHK(hipMalloc(&p, want));
+    bytes = want;
+    return HAWK_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct hawk_hapset {
+  hawk_ctx* ctx;
+  uint32_t n_hap, S;
+  uint64_t total_len;
+  std::vector<uint32_t> hap_len;
+  std::vector<int32_t> scan_start, scan_stop;
+  uint32_t* plane[HAWK_PLANES];
+  uint32_t* d_hap_len;
+  uint8_t* d_is_ref;
+  int32_t *d_scan_start, *d_scan_stop;
+  uint32_t *d_seg_off, *d_seg_rel;
+  int64_t* d_seg_gen;
+  int32_t ref_index;
+  bool has_meta;
+  // workspace reused across searches
+  DevBuf keepF, keepR, counts, aux, offsets, totals, rec, valid, misc, cfd, blocksum, blockoff;
+  DevBuf colsA[8], colsB[8];
+};
+
+struct hawk_table {
+  hawk_hapset* hs;
+  uint64_t n_rows, n_cand, n_hits, cap;
+  GuideCols cols;  // points into hs->colsA or colsB
+};
+
+extern "C" {
+
+const char* hawk_strerror(int s) {
+  switch (s) {
+    case HAWK_OK: return "ok";
+    case HAWK_E_INVALID: return "invalid argument";
+    case HAWK_E_HIP: return "HIP runtime error";
+    case HAWK_E_CAPACITY: return "output capacity too small";
+    case HAWK_E_IUPAC: return "non-IUPAC character in sequence";
+    case HAWK_E_CFD: return "non-ACGT base under a CFD table lookup";
+    case HAWK_E_NODEVICE: return "no GPU device visible";
+    case HAWK_E_UNSUPPORTED: return "parameter outside supported range";
+    default: return "unknown status";
+  }
+}
+const char* hawk_last_hip_error(void) { return g_hip_err; }
+
+int hawk_device_count(int* n) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+  if (n) *n = c;
+  return HAWK_OK;
+}
+
+int hawk_init(int device, hawk_ctx** out) {
+  if (!out) return HAWK_E_INVALID;
+  int c = 0;
+  hawk_device_count(&c);
+  if (c <= 0) return HAWK_E_NODEVICE;
+  if (device < 0 || device >= c) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(device));
+  hawk_ctx* ctx = new (std::nothrow) hawk_ctx();
+  if (!ctx) return HAWK_E_INVALID;
+  ctx->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+  *out = ctx;
+  return HAWK_OK;
+}
+
+void hawk_destroy(hawk_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void* hawk_stream(hawk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int hawk_sync(hawk_ctx* ctx) {
+  if (!ctx) return HAWK_E_INVALID;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return HAWK_OK;
+}
+
+// ---------------------------------------------------------------------------- hapset
+int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, hawk_hapset** out) {
+  if (!ctx || !n_hap || !hap_len || !out) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  hawk_hapset* hs = new (std::nothrow) hawk_hapset();
+  if (!hs) return HAWK_E_INVALID;
+  hs->ctx = ctx;
+  hs->n_hap = n_hap;
+  hs->hap_len.assign(hap_len, hap_len + n_hap);
+  uint32_t maxw = 0;
+  hs->total_len = 0;
+  for (uint32_t h = 0; h < n_hap; ++h) {
+    if (hap_len[h] >= (1u << 31) - 256) { delete hs; return HAWK_E_UNSUPPORTED; }
+    maxw = std::max(maxw, (hap_len[h] + 31) / 32);
+    hs->total_len += hap_len[h];
+  }
+  hs->S = (maxw + 2 + 3) / 4 * 4;
+  const size_t words = (size_t)n_hap * hs->S;
+  for (int p = 0; p < HAWK_PLANES; ++p) {
+    hs->plane[p] = nullptr;
+    HIPCHK(hipMalloc(&hs->plane[p], words * 4));
+    HIPCHK(hipMemsetAsync(hs->plane[p], 0, words * 4, ctx->stream));
+  }
+  HIPCHK(hipMalloc(&hs->d_hap_len, n_hap * 4));
+  HIPCHK(hipMemcpyAsync(hs->d_hap_len, hap_len, n_hap * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMalloc(&hs->d_is_ref, n_hap));
+  HIPCHK(hipMalloc(&hs->d_scan_start, n_hap * 4));
+  HIPCHK(hipMalloc(&hs->d_scan_stop, n_hap * 4));
+  HIPCHK(hipMalloc(&hs->d_seg_off, (n_hap + 1) * 4));
+  hs->d_seg_rel = nullptr;
+  hs->d_seg_gen = nullptr;
+  hs->ref_index = -1;
+  hs->has_meta = false;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *out = hs;
+  return HAWK_OK;
+}
+
+void hawk_hapset_destroy(hawk_hapset* hs) {
+  if (!hs) return;
+  (void)hipSetDevice(hs->ctx->device);
+  (void)hipStreamSynchronize(hs->ctx->stream);
+  for (int p = 0; p < HAWK_PLANES; ++p) (void)hipFree(hs->plane[p]);
+  (void)hipFree(hs->d_hap_len); (void)hipFree(hs->d_is_ref); (void)hipFree(hs->d_scan_start);
+  (void)hipFree(hs->d_scan_stop); (void)hipFree(hs->d_seg_off);
+  if (hs->d_seg_rel) (void)hipFree(hs->d_seg_rel);
+  if (hs->d_seg_gen) (void)hipFree(hs->d_seg_gen);
+  DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->aux, &hs->offsets, &hs->totals, &hs->rec,
+                    &hs->valid, &hs->misc, &hs->cfd, &hs->blocksum, &hs->blockoff};
+  for (auto* b : bufs) b->release();
+  for (auto& b : hs->colsA) b.release();
+  for (auto& b : hs->colsB) b.release();
+  delete hs;
+}
+
+int hawk_hapset_stride(const hawk_hapset* hs, uint32_t* stride_words) {
+  if (!hs || !stride_words) return HAWK_E_INVALID;
+  *stride_words = hs->S;
+  return HAWK_OK;
+}
+
+int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* seq_off, uint64_t* bad_index) {
+  if (!hs || !seqs || !seq_off) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  for (uint32_t h = 0; h < hs->n_hap; ++h)
+    if (seq_off[h + 1] - seq_off[h] != hs->hap_len[h]) return HAWK_E_INVALID;
+  uint64_t* d_off = nullptr;
+  unsigned long long* d_bad = nullptr;
+  HIPCHK(hipMalloc(&d_off, (hs->n_hap + 1) * 8));
+  HIPCHK(hipMalloc(&d_bad, 8));
+  HIPCHK(hipMemcpyAsync(d_off, seq_off, (hs->n_hap + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
+  // stage the ASCII in batches of whole haplotypes (<= 256 MiB of HBM staging)
+  const uint64_t kStage = 256ull << 20;
+  uint64_t maxlen = 0;
+  for (auto l : hs->hap_len) maxlen = std::max<uint64_t>(maxlen, l);
+  const uint64_t stage_bytes = std::max(kStage, maxlen);
+  uint8_t* d_stage = nullptr;
+  HIPCHK(hipMalloc(&d_stage, std::min<uint64_t>(stage_bytes, std::max<uint64_t>(hs->total_len, 1))));
+  uint32_t h0 = 0;
+  while (h0 < hs->n_hap) {
+    uint32_t h1 = h0;
+    uint64_t bytes = 0;
+    while (h1 < hs->n_hap && (h1 == h0 || bytes + hs->hap_len[h1] <= stage_bytes)) { bytes += hs->hap_len[h1]; ++h1; }
+    if (bytes) HIPCHK(hipMemcpyAsync(d_stage, seqs + seq_off[h0], bytes, hipMemcpyHostToDevice, ctx->stream));
+    hawk_launch_pack(ctx->stream, d_stage, d_off, h0, h1 - h0, seq_off[h0], hs->d_hap_len, hs->S, hs->plane, d_bad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next batch
+    h0 = h1;
+  }
+  unsigned long long bad = ~0ull;
+  HIPCHK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d_stage); (void)hipFree(d_off); (void)hipFree(d_bad);
+  if (bad != ~0ull) {
+    if (bad_index) *bad_index = bad;
+    return HAWK_E_IUPAC;
+  }
+  return HAWK_OK;
+}
+
+int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
+                         const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index) {
+  if (!hs || !is_ref || !scan_start || !scan_stop || !seg_off || !seg_rel || !seg_gen) return HAWK_E_INVALID;
+  if (ref_index >= (int32_t)hs->n_hap) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t n = hs->n_hap;
+  for (uint32_t h = 0; h < n; ++h) {
+    // the kernels trust these: validate on the host before anything is launched
+    if (seg_off[h + 1] <= seg_off[h] || seg_rel[seg_off[h]] != 0) return HAWK_E_INVALID;
+    if (scan_start[h] < 0 || scan_stop[h] > (int32_t)hs->hap_len[h]) return HAWK_E_INVALID;
+    for (uint32_t k = seg_off[h] + 1; k < seg_off[h + 1]; ++k)
+      if (seg_rel[k] <= seg_rel[k - 1]) return HAWK_E_INVALID;
+  }
+  if (ref_index >= 0 && seg_off[ref_index + 1] - seg_off[ref_index] != 1) return HAWK_E_INVALID;
+  const uint32_t nseg = seg_off[n];
+  if (hs->d_seg_rel) { (void)hipFree(hs->d_seg_rel); hs->d_seg_rel = nullptr; }
+  if (hs->d_seg_gen) { (void)hipFree(hs->d_seg_gen); hs->d_seg_gen = nullptr; }
+  HIPCHK(hipMalloc(&hs->d_seg_rel, (size_t)nseg * 4));
+  HIPCHK(hipMalloc(&hs->d_seg_gen, (size_t)nseg * 8));
+  HIPCHK(hipMemcpyAsync(hs->d_is_ref, is_ref, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_scan_start, scan_start, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_scan_stop, scan_stop, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_off, seg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_rel, seg_rel, (size_t)nseg * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_gen, seg_gen, (size_t)nseg * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hs->scan_start.assign(scan_start, scan_start + n);
+  hs->scan_stop.assign(scan_stop, scan_stop + n);
+  hs->ref_index = ref_index;
+  hs->has_meta = true;
+  return HAWK_OK;
+}
+
+int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words) {
+  if (!hs || plane < 0 || plane >= HAWK_PLANES || !out_words) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(hs->ctx->device));
+  HIPCHK(hipStreamSynchronize(hs->ctx->stream));
+  HIPCHK(hipMemcpy(out_words, hs->plane[plane], (size_t)hs->n_hap * hs->S * 4, hipMemcpyDeviceToHost));
+  return HAWK_OK;
+}
+
+int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes) {
+  if (!hs || !planes) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(hs->ctx->device));
+  const size_t words = (size_t)hs->n_hap * hs->S;
+  for (int p = 0; p < HAWK_PLANES; ++p)
+    HIPCHK(hipMemcpyAsync(hs->plane[p], planes + p * words, words * 4, hipMemcpyHostToDevice, hs->ctx->stream));
+  HIPCHK(hipStreamSynchronize(hs->ctx->stream));
+  return HAWK_OK;
+}
+
+static HapSetDev make_dev(const hawk_hapset* hs) {
+  HapSetDev d;
+  d.n_hap = hs->n_hap;
+  d.S = hs->S;
+  for (int p = 0; p < HAWK_PLANES; ++p) d.plane[p] = hs->plane[p];
+  d.hap_len = hs->d_hap_len;
+  d.is_ref = hs->d_is_ref;
+  d.scan_start = hs->d_scan_start;
+  d.scan_stop = hs->d_scan_stop;
+  d.seg_off = hs->d_seg_off;
+  d.seg_rel = hs->d_seg_rel;
+  d.seg_gen = hs->d_seg_gen;
+  d.ref_index = hs->ref_index;
+  return d;
+}
+
+static int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t guidelen,
+                            uint32_t right, bool need_v, ScanParams* sp) {
+  if (pamlen == 0 || pamlen > 16) return HAWK_E_UNSUPPORTED;
+  if (guidelen + pamlen > HAWK_MAX_CORE) return HAWK_E_UNSUPPORTED;
+  sp->pam_fwd = pam_fwd; sp->pam_rev = pam_rev;
+  sp->pamlen = (int32_t)pamlen; sp->guidelen = (int32_t)guidelen; sp->right = right ? 1 : 0;
+  sp->L = (int32_t)(guidelen + pamlen);
+  sp->bph = (hs->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  uint32_t need = 0;
+  for (uint32_t i = 0; i < pamlen; ++i) {
+    const uint32_t a = (uint32_t)(pam_fwd >> (4 * i)) & 15u, b = (uint32_t)(pam_rev >> (4 * i)) & 15u;
+    if (a == 0 || b == 0) return HAWK_E_INVALID;  // every PAM position is an IUPAC code (pam.py:55-58)
+    if (a != 15u) need |= a;
+    if (b != 15u) need |= b;
+  }
+  if (need_v) need |= 16u;
+  sp->need = need;
+  return HAWK_OK;
+}
+
+// ---------------------------------------------------------------------------- K2 raw hits
+int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t* hits_fwd,
+                  uint32_t* hits_rev, uint64_t cap_fwd, uint64_t cap_rev, uint64_t* off_fwd, uint64_t* off_rev) {
+  if (!hs || !hs->has_meta || !off_fwd || !off_rev) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  ScanParams sp;
+  int rc = make_scan_params(hs, pam_fwd, pam_rev, pamlen, 0, 0, false, &sp);
+  if (rc) return rc;
+  const HapSetDev d = make_dev(hs);
+  const size_t words = (size_t)hs->n_hap * hs->S;
+  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph, naux = (uint64_t)hs->n_hap * sp.bph;
+  if ((rc = hs->keepF.reserve(words * 4)) || (rc = hs->keepR.reserve(words * 4)) || (rc = hs->counts.reserve(ncnt * 4)) ||
+      (rc = hs->aux.reserve(naux * 2 * 4)) || (rc = hs->offsets.reserve((ncnt + 1) * 8)) ||
+      (rc = hs->totals.reserve(sizeof(ScanTotals))))
+    return rc;
+  hawk_launch_scan(ctx->stream, 0, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>(),
+                   hs->aux.as<uint32_t>());
+  hawk_launch_offsets(ctx->stream, hs->counts.as<uint32_t>(), hs->offsets.as<uint64_t>(), ncnt, ncnt / 2,
+                      hs->aux.as<uint32_t>(), naux, hs->totals.as<ScanTotals>());
+  HIPCHK(hipGetLastError());
+  ScanTotals tot;
+  HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint64_t> offs(ncnt + 1);
+  HIPCHK(hipMemcpyAsync(offs.data(), hs->offsets.p, (ncnt + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t nf = tot.n_keep_fwd, nr = tot.n_keep - tot.n_keep_fwd;
+  for (uint32_t h = 0; h <= hs->n_hap; ++h) {
+    off_fwd[h] = h < hs->n_hap ? offs[(size_t)h * sp.bph] : nf;
+    off_rev[h] = (h < hs->n_hap ? offs[((size_t)hs->n_hap + h) * sp.bph] : tot.n_keep) - nf;
+  }
+  if (nf > cap_fwd || nr > cap_rev || !hits_fwd || !hits_rev) return (nf || nr) ? HAWK_E_CAPACITY : HAWK_OK;
+  uint32_t *d_f = nullptr, *d_r = nullptr;
+  HIPCHK(hipMalloc(&d_f, std::max<uint64_t>(nf, 1) * 4));
+  HIPCHK(hipMalloc(&d_r, std::max<uint64_t>(nr, 1) * 4));
+  hawk_launch_emit_hits(ctx->stream, d, sp.bph, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
+                        hs->offsets.as<uint64_t>(), nf, d_f, d_r);
+  HIPCHK(hipGetLastError());
+  if (nf) HIPCHK(hipMemcpyAsync(hits_fwd, d_f, nf * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (nr) HIPCHK(hipMemcpyAsync(hits_rev, d_r, nr * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_f); (void)hipFree(d_r);
+  return HAWK_OK;
+}
+
+// ---------------------------------------------------------------------------- fused search
+static int reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
+  int rc;
+  const size_t sz[8] = {cap * 4, cap * 4, cap, cap * 8, cap * 8, cap, cap * 8, cap * 8 * HAWK_PLANES};
+  for (int i = 0; i < 8; ++i) if ((rc = b[i].reserve(std::max<size_t>(sz[i], 16)))) return rc;
+  c->hap = b[0].as<uint32_t>(); c->pos = b[1].as<uint32_t>(); c->strand = b[2].as<uint8_t>();
+  c->start = b[3].as<int64_t>(); c->stop = b[4].as<int64_t>(); c->flags = b[5].as<uint8_t>();
+  c->cfdon = b[6].as<double>(); c->win = b[7].as<uint64_t>(); c->cap = cap;
+  return HAWK_OK;
+}
+
+int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, hawk_timing* timing) {
+  if (!hs || !p || !out || !hs->has_meta) return HAWK_E_INVALID;
+  if (p->score_cfdon && (p->right || !p->cfd_mm || !p->cfd_pam || p->pamlen < 2)) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  ScanParams sp;
+  bool any_alt = false;
+  int rc = make_scan_params(hs, p->pam_fwd, p->pam_rev, p->pamlen, p->guidelen, p->right, true, &sp);
+  if (rc) return rc;
+  (void)any_alt;
+  const HapSetDev d = make_dev(hs);
+  const size_t words = (size_t)hs->n_hap * hs->S;
+  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph, naux = (uint64_t)hs->n_hap * sp.bph;
+  if ((rc = hs->keepF.reserve(words * 4)) || (rc = hs->keepR.reserve(words * 4)) || (rc = hs->counts.reserve(ncnt * 4)) ||
+      (rc = hs->aux.reserve(naux * 2 * 4)) || (rc = hs->offsets.reserve((ncnt + 1) * 8)) ||
+      (rc = hs->totals.reserve(sizeof(ScanTotals))) || (rc = hs->misc.reserve(64)) || (rc = hs->cfd.reserve(336 * 8)))
+    return rc;
+  if (p->score_cfdon) {
+    HIPCHK(hipMemcpyAsync(hs->cfd.p, p->cfd_mm, 320 * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs->cfd.as<double>() + 320, p->cfd_pam, 16 * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipMemsetAsync(hs->misc.p, 0, 64, ctx->stream));
+  hipEvent_t* ev = ctx->ev;
+  HIPCHK(hipEventRecord(ev[0], ctx->stream));
+  hawk_launch_scan(ctx->stream, 1, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>(),
+                   hs->aux.as<uint32_t>());
+  HIPCHK(hipEventRecord(ev[1], ctx->stream));
+  hawk_launch_offsets(ctx->stream, hs->counts.as<uint32_t>(), hs->offsets.as<uint64_t>(), ncnt, ncnt,
+                      hs->aux.as<uint32_t>(), naux, hs->totals.as<ScanTotals>());
+  HIPCHK(hipEventRecord(ev[2], ctx->stream));
+  HIPCHK(hipGetLastError());
+  ScanTotals tot;
+  HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t nrec = tot.n_keep;
+  GuideCols ca;
+  if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrec, 1), &ca)) || (rc = hs->rec.reserve(std::max<uint64_t>(nrec, 1) * 8)) ||
+      (rc = hs->valid.reserve(std::max<uint64_t>(nrec, 1))))
+    return rc;
+  GuideParams gp;
+  gp.pamlen = sp.pamlen; gp.guidelen = sp.guidelen; gp.right = sp.right; gp.L = sp.L;
+  gp.score_cfdon = p->score_cfdon ? 1 : 0;
+  gp.cfd_mm = hs->cfd.as<double>(); gp.cfd_pam = hs->cfd.as<double>() + 320; gp.bph = sp.bph;
+  unsigned long long* d_ninv = hs->misc.as<unsigned long long>();
+  int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 16);
+  HIPCHK(hipEventRecord(ev[3], ctx->stream));
+  if (nrec) hawk_launch_emit_records(ctx->stream, d, sp.bph, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
+                                     hs->offsets.as<uint64_t>(), hs->rec.as<uint64_t>());
+  HIPCHK(hipEventRecord(ev[4], ctx->stream));
+  hawk_launch_guides(ctx->stream, d, gp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->rec.as<uint64_t>(), nrec,
+                     ca, hs->valid.as<uint8_t>(), d_ninv, d_status);
+  HIPCHK(hipEventRecord(ev[5], ctx->stream));
+  HIPCHK(hipGetLastError());
+  struct { unsigned long long ninv; unsigned long long pad; int status; } fin;
+  HIPCHK(hipMemcpyAsync(&fin, hs->misc.p, sizeof(fin), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  GuideCols final_cols = ca;
+  uint64_t nrows = nrec;
+  HIPCHK(hipEventRecord(ev[6], ctx->stream));
+  if (fin.ninv) {
+    nrows = nrec - fin.ninv;
+    GuideCols cb;
+    const uint64_t nblk = (nrec + HAWK_BLOCK - 1) / HAWK_BLOCK;
+    if ((rc = reserve_cols(hs->colsB, std::max<uint64_t>(nrows, 1), &cb)) || (rc = hs->blocksum.reserve(nblk * 4)) ||
+        (rc = hs->blockoff.reserve((nblk + 1) * 8 + sizeof(ScanTotals))))
+      return rc;
+    hawk_launch_compact(ctx->stream, hs->valid.as<uint8_t>(), nrec, hs->blocksum.as<uint32_t>(), hs->blockoff.as<uint64_t>(),
+                        ca, cb);
+    HIPCHK(hipGetLastError());
+    final_cols = cb;
+  }
+  HIPCHK(hipEventRecord(ev[7], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (timing) {
+    memset(timing, 0, sizeof(*timing));
+    (void)hipEventElapsedTime(&timing->scan_ms, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&timing->offsets_ms, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&timing->emit_ms, ev[3], ev[4]);
+    (void)hipEventElapsedTime(&timing->guides_ms, ev[4], ev[5]);
+    (void)hipEventElapsedTime(&timing->compact_ms, ev[6], ev[7]);
+    (void)hipEventElapsedTime(&timing->total_ms, ev[0], ev[7]);
+    uint64_t pos = 0;
+    for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
+    timing->scanned_positions = pos;
+  }
+  if (fin.status) return fin.status;
+  hawk_table* t = new (std::nothrow) hawk_table();
+  if (!t) return HAWK_E_INVALID;
+  t->hs = hs; t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = final_cols; t->cap = final_cols.cap;
+  *out = t;
+  return HAWK_OK;
+}
+
+void hawk_table_destroy(hawk_table* t) { delete t; }  // columns live in the hapset's workspace
+
+int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candidates, uint64_t* n_hits) {
+  if (!t) return HAWK_E_INVALID;
+  if (n_rows) *n_rows = t->n_rows;
+  if (n_candidates) *n_candidates = t->n_cand;
+  if (n_hits) *n_hits = t->n_hits;
+  return HAWK_OK;
+}
+
+int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
+                        uint8_t* flags, double* cfdon, uint64_t* win) {
+  if (!t) return HAWK_E_INVALID;
+  hawk_ctx* ctx = t->hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t n = t->n_rows;
+  if (!n) return HAWK_OK;
+  const GuideCols& c = t->cols;
+  if (hap) HIPCHK(hipMemcpyAsync(hap, c.hap, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (pos) HIPCHK(hipMemcpyAsync(pos, c.pos, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (strand) HIPCHK(hipMemcpyAsync(strand, c.strand, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (start) HIPCHK(hipMemcpyAsync(start, c.start, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (stop) HIPCHK(hipMemcpyAsync(stop, c.stop, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (flags) HIPCHK(hipMemcpyAsync(flags, c.flags, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (cfdon) HIPCHK(hipMemcpyAsync(cfdon, c.cfdon, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (win)
+    for (int p = 0; p < HAWK_PLANES; ++p)
+      HIPCHK(hipMemcpyAsync(win + (size_t)p * n, c.win + (size_t)p * c.cap, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return HAWK_OK;
+}
+
+int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
+                              void** flags, void** cfdon, void** win) {
+  if (!t) return HAWK_E_INVALID;
+  const GuideCols& c = t->cols;
+  if (hap) *hap = c.hap;
+  if (pos) *pos = c.pos;
+  if (strand) *strand = c.strand;
+  if (start) *start = c.start;
+  if (stop) *stop = c.stop;
+  if (flags) *flags = c.flags;
+  if (cfdon) *cfdon = c.cfdon;
+  if (win) *win = c.win;
+  return HAWK_OK;
+}
+
+}  // extern "C"

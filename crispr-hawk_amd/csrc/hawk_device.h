@@ -1,0 +1,81 @@
+// hawk_device.h — device-side data model shared by the kernels (hawk_kernels.hip) and the
+// C-ABI host layer (hawk_api.hip).  gfx950 only: 64-wide wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HAWK_PLANES 5   // A, C, G, T (the IUPAC nibble's bits, encoder.py:18-34) and V (lower case)
+#define HAWK_PAD 10     // GUIDESEQPAD, guide.py:21
+#define HAWK_BLOCK 256  // threads per workgroup = 4 wavefronts
+#define HAWK_WPT 4      // 32-base words per thread (one 16-byte load per plane)
+
+// A haplotype set resident in HBM.  Plane p of haplotype h is plane[p] + h*S words; bit j of
+// word w is base 32*w + j.  Rows are zero past hap_len and S >= words(hap_len) + 2, S % 4 == 0,
+// so a 64-bit look-ahead never leaves the row and never sees another haplotype.
+struct HapSetDev {
+  uint32_t n_hap;
+  uint32_t S;
+  const uint32_t* plane[HAWK_PLANES];
+  const uint32_t* hap_len;
+  const uint8_t* is_ref;
+  const int32_t* scan_start;
+  const int32_t* scan_stop;
+  const uint32_t* seg_off;
+  const uint32_t* seg_rel;
+  const int64_t* seg_gen;
+  int32_t ref_index;
+};
+
+struct ScanParams {
+  uint64_t pam_fwd, pam_rev;  // PAM.bits / PAM.bitsrc: first PAM base in the most significant nibble
+  int32_t pamlen, guidelen, right;
+  int32_t L;                  // guidelen + pamlen
+  uint32_t bph;               // workgroups per haplotype row
+  uint32_t need;              // bit p set: plane p is read by this PAM (bit 4: V plane)
+};
+
+// Totals written by k_offsets.
+struct ScanTotals {
+  uint64_t n_keep;     // bits set in the keep planes (fwd + rev)
+  uint64_t n_keep_fwd; // raw mode: forward total (reverse hits start here in the scan order)
+  uint64_t n_cand;     // PAM hits passing is_pamhit_in_range
+  uint64_t n_hits;     // PAM hits inside the scan range
+};
+
+struct GuideCols {  // SoA guide table, capacity rows
+  uint32_t* hap;
+  uint32_t* pos;
+  uint8_t* strand;
+  int64_t* start;
+  int64_t* stop;
+  uint8_t* flags;
+  double* cfdon;
+  uint64_t* win;  // [5][cap]
+  uint64_t cap;
+};
+
+struct GuideParams {
+  int32_t pamlen, guidelen, right, L;
+  int32_t score_cfdon;
+  const double* cfd_mm;   // device, [20][4][4]
+  const double* cfd_pam;  // device, [16]
+  uint32_t bph;
+};
+
+// launch wrappers (hawk_kernels.hip)
+void hawk_launch_pack(hipStream_t st, const uint8_t* ascii, const uint64_t* seq_off, uint32_t hap0, uint32_t n_hap_batch,
+                      uint64_t batch_base, const uint32_t* hap_len, uint32_t S, uint32_t* const* plane,
+                      unsigned long long* bad_index);
+void hawk_launch_scan(hipStream_t st, int mode, const HapSetDev& hs, const ScanParams& p, uint32_t* keepF, uint32_t* keepR,
+                      uint32_t* counts, uint32_t* aux);
+void hawk_launch_offsets(hipStream_t st, const uint32_t* counts, uint64_t* offsets, uint64_t n, uint64_t n_first_half,
+                         const uint32_t* aux, uint64_t n_aux, ScanTotals* totals);
+void hawk_launch_emit_records(hipStream_t st, const HapSetDev& hs, uint32_t bph, const uint32_t* keepF, const uint32_t* keepR,
+                              const uint64_t* offsets, uint64_t* rec);
+void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, const uint32_t* keepF, const uint32_t* keepR,
+                           const uint64_t* offsets, uint64_t n_fwd_total, uint32_t* hits_fwd, uint32_t* hits_rev);
+void hawk_launch_guides(hipStream_t st, const HapSetDev& hs, const GuideParams& gp, const uint32_t* keepF,
+                        const uint32_t* keepR, const uint64_t* rec, uint64_t n_rec, GuideCols cols, uint8_t* valid,
+                        unsigned long long* n_invalid, int* status);
+void hawk_launch_compact(hipStream_t st, const uint8_t* valid, uint64_t n, uint32_t* blocksum, uint64_t* blockoff,
+                         GuideCols src, GuideCols dst);

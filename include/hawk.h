@@ -1,0 +1,132 @@
+/*
+ * hawk.h — C ABI of libhawk_hip.so: the MI355X (gfx950) implementation of CRISPR-HAWK's
+ * variant-aware guide search hot path.
+ *
+ * The reference (pinellolab/CRISPR-HAWK) has no FFI layer: its hot path is a chain of plain
+ * Python call sites in crisprhawk_search() (crisprhawk.py:121-138).  Each entry point below
+ * names the reference call it replaces; INTEGRATION.md shows the ctypes binding a maintainer
+ * would add on the reference side.  Conventions: plain pointers and sizes, no C++/torch types;
+ * every function returns HAWK_OK (0) or a negative hawk_status and never throws; outputs are
+ * caller-allocated with an explicit capacity, or stay resident in HBM behind an opaque handle
+ * until downloaded; one hawk_ctx per process per device; not fork-safe (a HIP context does
+ * not survive fork — the reference's ProcessPoolExecutor scorers, scoring.py:129, must call
+ * from the parent).
+ *
+ * Data layout in HBM: a haplotype set is five bit-planes
+ * A, C, G, T (the four bits of the reference's IUPAC nibble, encoder.py:18-34) and V
+ * ("this base came from a variant" = lower case in the reference's haplotype strings),
+ * one bit per base, 32 bases per little-endian 32-bit word, rows padded to a common
+ * 16-byte-aligned stride.
+ */
+#ifndef HAWK_H
+#define HAWK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  HAWK_OK = 0,
+  HAWK_E_INVALID = -1,    /* bad argument */
+  HAWK_E_HIP = -2,        /* HIP runtime failure (hawk_last_hip_error() has the text) */
+  HAWK_E_CAPACITY = -3,   /* caller buffer too small; required size is reported */
+  HAWK_E_IUPAC = -4,      /* non-IUPAC character: CrisprHawkIupacTableError (encoder.py:37-45) */
+  HAWK_E_CFD = -5,        /* non-ACGT base under a CFD lookup: CrisprHawkCfdScoreError (cfdscore.py:93-94) */
+  HAWK_E_NODEVICE = -6,   /* no gfx950 device visible */
+  HAWK_E_UNSUPPORTED = -7 /* parameter outside the kernel's range (e.g. guidelen+pamlen > 44) */
+} hawk_status;
+
+typedef struct hawk_ctx hawk_ctx;
+typedef struct hawk_hapset hawk_hapset;
+typedef struct hawk_table hawk_table;
+
+#define HAWK_GUIDESEQPAD 10 /* guide.py:21 */
+#define HAWK_MAX_CORE 44    /* guidelen + pamlen limit: the 20-nt padded window must fit 64 bits */
+
+/* ---- context ----------------------------------------------------------------------- */
+int hawk_device_count(int* n);
+int hawk_init(int device, hawk_ctx** out);
+void hawk_destroy(hawk_ctx* ctx);
+const char* hawk_strerror(int status);
+const char* hawk_last_hip_error(void);
+/* the hipStream_t all of this context's work is enqueued on (for external event timing) */
+void* hawk_stream(hawk_ctx* ctx);
+int hawk_sync(hawk_ctx* ctx);
+
+/* ---- haplotype set: replaces encode() per haplotype (crisprhawk.py:64-81, encoder.py:48-57)
+ * plus the Haplotype fields the search reads (haplotype.py:395-491) ---------------------- */
+
+/* Allocate planes for n_hap haplotypes of the given lengths (bases). */
+int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, hawk_hapset** out);
+void hawk_hapset_destroy(hawk_hapset* hs);
+
+/* K1: pack cased ASCII haplotypes (host memory, concatenated, seq_off[n_hap+1] byte offsets)
+ * into the planes.  Upper/lower case is data: lower case sets the V plane.  On a non-IUPAC
+ * character returns HAWK_E_IUPAC and *bad_index = its offset in `seqs` (encoder.py:37-45). */
+int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* seq_off, uint64_t* bad_index);
+
+/* Per-haplotype metadata the search needs:
+ *   is_ref[h]      1 iff haplotype.samples == "REF" (search_guides.py:468-471)
+ *   scan_start/stop  compute_scan_start_stop() (search_guides.py:49-84), relative positions
+ *   seg_off[n_hap+1], seg_rel[], seg_gen[]  the haplotype position map (haplotype.py:90-159)
+ *     as unit-slope segments: posmap[rel] = seg_gen[k] + (rel - seg_rel[k]) for the last k in
+ *     [seg_off[h], seg_off[h+1]) with seg_rel[k] <= rel.
+ *   ref_index      index of the REF haplotype, or -1 */
+int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
+                         const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index);
+
+/* Row stride in 32-bit words, and a copy of one plane (0..4 = A,C,G,T,V) to host
+ * (n_hap * stride words) — for tests and for decoding windows on the host. */
+int hawk_hapset_stride(const hawk_hapset* hs, uint32_t* stride_words);
+int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words);
+/* Upload planes computed elsewhere (5 * n_hap * stride words, plane-major). */
+int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes);
+
+/* ---- K2: pam_search() (search_guides.py:102-131) ---------------------------------------
+ * Raw PAM hits of every haplotype inside its [scan_start, scan_stop): ascending relative
+ * positions per haplotype, forward-PAM hits in hits_fwd and reverse-complement-PAM hits in
+ * hits_rev, haplotype h occupying [off_fwd[h], off_fwd[h+1]) (off arrays have n_hap+1
+ * entries).  pam_fwd/pam_rev are PAM.bits / PAM.bitsrc (pam.py:127-141). */
+int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t* hits_fwd,
+                  uint32_t* hits_rev, uint64_t cap_fwd, uint64_t cap_rev, uint64_t* off_fwd, uint64_t* off_rev);
+
+/* ---- fused search: search() (search_guides.py:510-548) + the CFDon slice of
+ * scoring_guides() (scoring.py:352-387, after annotation.reverse_guides) ------------------- */
+typedef struct {
+  uint64_t pam_fwd, pam_rev; /* PAM.bits, PAM.bitsrc */
+  uint32_t pamlen, guidelen;
+  uint32_t right;            /* --right: guide downstream of the PAM (Cpf1-like) */
+  uint32_t score_cfdon;      /* 1: compute CFDon for every kept guide (needs right == 0) */
+  const double* cfd_mm;      /* [20][4][4]: position, wildtype RNA base A,C,G,U, sgRNA base A,C,G,T */
+  const double* cfd_pam;     /* [16]: PAM[-2:] dinucleotide, 4*b0+b1 over A,C,G,T */
+} hawk_search_params;
+
+typedef struct {          /* kernel times of the last hawk_search (HIP events on the ctx stream), ms */
+  float scan_ms, offsets_ms, emit_ms, guides_ms, compact_ms, total_ms;
+  uint64_t scanned_positions; /* sum over haplotypes of (scan_stop - scan_start) */
+} hawk_timing;
+
+/* Runs the whole device pipeline; the guide table stays in HBM. `timing` may be NULL. */
+int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, hawk_timing* timing);
+void hawk_table_destroy(hawk_table* t);
+/* n_rows: guides after remove_redundant_guides; n_candidates: PAM hits passing
+ * is_pamhit_in_range (the bench metric's unit); n_hits: all PAM hits in scan range. */
+int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candidates, uint64_t* n_hits);
+/* Column download (each array n_rows long; any pointer may be NULL).  Rows are ordered by
+ * (haplotype, strand, position) — the reference's pre-dedup emission order.
+ *   pos: relative PAM position (what retrieve_guides iterates), start/stop: genomic
+ *   (search_guides.py:260-280), strand 0/1, flags bit0 = a REF guide shares (start,strand),
+ *   cfdon: NaN when no REF guide shares the key, win[5][n_rows]: bits [pos_window) of planes
+ *   A,C,G,T,V for the guidelen+pamlen+20-nt window, bit 0 = leftmost base. */
+int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
+                        uint8_t* flags, double* cfdon, uint64_t* win);
+/* Device pointers of the same columns (for a collective over xGMI without a host bounce). */
+int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
+                              void** flags, void** cfdon, void** win);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAWK_H */

@@ -1,0 +1,123 @@
+"""Parity of the HIP path (through the C ABI) against the reference-generated golden vectors
+and against the CPU oracle on seeded inputs.  Integer/byte/index work is compared bit-exact;
+CFDon is fp64 with the reference's multiplication order, also compared bit-exact."""
+import math
+
+import numpy as np
+import pytest
+
+from crisprhawk_hip import _lib, synth
+from crisprhawk_hip.hapset import DeviceHapSet, HostHaplotype, PosSegments, segments_from_posmap
+from oracle import oracle as ora
+from util import G3_CASES, hapset_from_golden, load_golden, oracle_haplotypes
+
+pytestmark = pytest.mark.gpu
+
+
+def device_set(hs: ora.HapSet) -> DeviceHapSet:
+    haps = []
+    for seq, pm, r, sc in zip(hs.seqs, hs.posmaps, hs.is_ref, hs.scan):
+        rel, gen = segments_from_posmap(pm)
+        haps.append(HostHaplotype(seq, PosSegments(rel, gen, len(seq)), r, sc))
+    return DeviceHapSet(haps)
+
+
+def test_pack_matches_encoder_table():
+    g1 = load_golden("g1_tables.json.gz")
+    letters = "".join(g1["table"].keys()) + "".join(g1["lower"].keys())
+    seq = letters * 5 + "ACGT" * 700  # > one 2048-base wave chunk
+    ds = DeviceHapSet([HostHaplotype(seq, PosSegments.identity(1, len(seq)), True, (0, len(seq) - 3))])
+    assert np.array_equal(ds.nibbles(0), ora.encode(seq))
+    vplane = ds.planes()[4, 0]
+    vbits = ((vplane[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[: len(seq)]
+    assert np.array_equal(vbits.astype(bool), np.array([c.islower() for c in seq]))
+    with pytest.raises(_lib.HawkStatusError) as e:
+        DeviceHapSet([HostHaplotype("ACGTXACGT" * 10, PosSegments.identity(1, 90), True, (0, 80))])
+    assert e.value.status == _lib.HAWK_E_IUPAC and "position 4" in str(e.value)
+
+
+def test_g2_scan_hit_lists():
+    g2 = load_golden("g2_scan.json.gz")
+    for c in g2["cases"]:
+        bits, bitsrc, _, _ = ora.pam_encode(c["pam"])
+        seq = c["seq"]
+        ds = DeviceHapSet([HostHaplotype(seq, PosSegments.identity(1, len(seq)), True, (c["start"], c["stop"]))])
+        (fwd, rev), = ds.pam_scan(bits, bitsrc, len(c["pam"]))
+        assert fwd.tolist() == c["fwd"] and rev.tolist() == c["rev"], (c["pam"], c["start"], c["stop"])
+
+
+@pytest.mark.parametrize("case", G3_CASES)
+def test_g3_search_against_reference_vectors(case):
+    fx = load_golden(f"g3_search_{case}.json.gz")
+    hs = hapset_from_golden(fx)
+    pam, guidelen, right = fx["pam"], fx["guidelen"], fx["right"]
+    bits, bitsrc, _, _ = ora.pam_encode(pam)
+    ds = device_set(hs)
+    hits = ds.pam_scan(bits, bitsrc, len(pam))
+    for h, (f, r) in enumerate(hits):
+        assert f.tolist() == fx["hits"][h][0] and r.tolist() == fx["hits"][h][1]
+    mm = pt = None
+    if "cfdon" in fx:
+        mm, pt = synth.cfd_tables()
+    tab = ds.search(bits, bitsrc, len(pam), guidelen, right, mm, pt)
+    assert tab.n_hits == sum(len(f) + len(r) for f, r in fx["hits"])
+    order = tab.reference_order()
+    wins = tab.windows()
+    got = [[int(tab.start[i]), int(tab.stop[i]), int(tab.strand[i]), wins[i], int(tab.hap[i]),
+            bool(tab.right_as_stored()[i])] for i in order]
+    assert got == fx["guides"]
+    if "cfdon" in fx:
+        ref_scores = {gi: sc for gi, sc in zip(fx["cfdon_order"], fx["cfdon"])}
+        for k, i in enumerate(order):
+            want = ref_scores[k]
+            if want is None:
+                assert math.isnan(tab.cfdon[i])
+            else:
+                assert tab.cfdon[i] == want, (k, tab.cfdon[i], want)
+
+
+@pytest.mark.parametrize("pam,guidelen,right", [("NGG", 20, False), ("TTTV", 23, True), ("NNGRRT", 21, False)])
+def test_search_against_oracle_200kb(pam, guidelen, right):
+    reg = synth.make_region(7001, "chrR", 260_000, 30_000, 230_000)
+    synth.add_phased_variants(reg, 7002, 4000, 6, af_min=0.05, af_max=0.5)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, len(pam)) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    bits, bitsrc, _, _ = ora.pam_encode(pam)
+    want = ora.search(hs, pam, guidelen, right)
+    mm = pt = None
+    if not right and pam == "NGG":
+        mm, pt = synth.cfd_tables()
+    ds = device_set(hs)
+    tab = ds.search(bits, bitsrc, len(pam), guidelen, right, mm, pt)
+    assert (tab.n_rows, tab.n_candidates, tab.n_hits) == (len(want.guides), want.n_candidates, want.n_hits)
+    order = tab.reference_order()
+    g = want.guides
+    assert np.array_equal(tab.start[order], g["start"]) and np.array_equal(tab.stop[order], g["stop"])
+    assert np.array_equal(tab.hap[order], g["hap"]) and np.array_equal(tab.pos[order], g["pos"])
+    assert np.array_equal(tab.strand[order], g["strand"])
+    wins = tab.windows()
+    assert [wins[i] for i in order] == want.windows
+    if mm is not None:
+        _, _, _, cfd, _ = ora.reverse_and_cfdon(want, hs.is_ref, guidelen, len(pam), mm, pt)
+        mine = tab.cfdon[order]
+        assert np.array_equal(np.isnan(mine), np.isnan(cfd))
+        assert np.array_equal(mine[~np.isnan(cfd)], cfd[~np.isnan(cfd)])
+
+
+def test_cfd_error_on_iupac_spacer():
+    # a REF/alt pair differing where the alt carries an IUPAC code must surface the
+    # reference's KeyError -> CrisprHawkCfdScoreError path (cfdscore.py:93)
+    ref = "ACGTACGTAC" + "ACGTTGCATGCATGCATGCA" + "TGG" + "ACGTACGTAC" + "ACGT" * 20
+    alt = ref[:15] + "r" + ref[16:]
+    n = len(ref)
+    haps = [HostHaplotype(ref, PosSegments.identity(1, n), True, (10, n - 13)),
+            HostHaplotype(alt, PosSegments.identity(1, n), False, (10, n - 13))]
+    ds = DeviceHapSet(haps)
+    bits, bitsrc, _, _ = ora.pam_encode("NGG")
+    mm, pt = synth.cfd_tables()
+    with pytest.raises(_lib.HawkStatusError) as e:
+        ds.search(bits, bitsrc, 3, 20, False, mm, pt)
+    assert e.value.status == _lib.HAWK_E_CFD
