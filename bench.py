@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — candidate guides scored per second on the BASELINE.json workload.
+
+A "step" is one pass of the device hot path (hawk_search: PAM scan fused with the in-range and
+REF-identical filters -> compaction -> coordinates / redundancy removal / window gather ->
+CFDon) over one haplotype set that is already resident in HBM as bit-sliced planes.  Default
+workload = BASELINE.json configs[2] ("C3": 1 Mb region x 2504 phased samples, NGG, 20 nt), the
+configuration the metric is quoted on.
+
+    python bench.py [--gpus N --steps K --warmup W]        # N > 1 via torch.distributed.run
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (k_scan) with the
+algorithmic 0.75 B per scanned haplotype position of SURVEY.md §8(d) against the 8 TB/s HBM
+peak, using its HIP-event duration measured on the stream it runs on.  `cpu_baseline` times the
+C oracle (a port of the reference's algorithm, oracle/hawk_oracle.c) on a bounded sample of the
+same workload on the host cores (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "crispr-hawk_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_POS = 0.75  # 0.5 B 4-bit code read + 0.25 B fwd/rev hit bits written
+
+
+def log(msg):
+    print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=2504)
+    ap.add_argument("--sites", type=int, default=31000)
+    ap.add_argument("--region-len", type=int, default=1_000_000)
+    ap.add_argument("--pam", default="NGG")
+    ap.add_argument("--guidelen", type=int, default=20)
+    ap.add_argument("--right", action="store_true")
+    ap.add_argument("--cpu-haps", type=int, default=160, help="haplotypes in the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # RCCL ("nccl") process group: barrier, timing reduce, table gather
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from crisprhawk_hip import _lib, synth
+    from crisprhawk_hip.hapset import DeviceHapSet
+    from crisprhawk_hip.pam import PAM
+    from crisprhawk_hip.workload import build_phased_haplotypes
+
+    if _lib.device_count() == 0:
+        raise _lib.HawkDeviceError("bench.py needs an MI355X: there is no CPU fallback on the product path")
+
+    # ---- workload: haplotypes are independent units -> each rank owns its own 2504 samples
+    # (weak scaling: per-GPU work fixed); REF is on every rank (needed by the alt==REF filter)
+    t0 = time.time()
+    reg = synth.make_region(1003, "chr22", args.region_len + 200_000, 100_000, 100_000 + args.region_len)
+    synth.add_phased_variants(reg, 1003_1 + 7919 * rank, args.sites, args.samples)
+    pam = PAM(args.pam, args.right, True)
+    pam.encode(0)
+    haps, _info = build_phased_haplotypes(reg, len(pam))
+    log(f"workload: {len(haps)} haplotypes x {len(haps[0].seq)} nt, {len(reg.variants)} sites, built in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    ds = DeviceHapSet(haps, device=local)
+    log(f"resident in HBM ({5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes) in {time.time() - t0:.1f}s")
+    score = (not args.right) and pam.cas_system in (3, 4)  # scoring.py:749-792: CFDon for SpCas9/xCas9 PAMs
+    mm, pt = synth.cfd_tables() if score else (None, None)
+
+    def step():
+        tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+        tab.close()
+        return tab
+
+    def barrier():
+        _lib.check(_lib.lib().hawk_sync(ds._ctx), "hawk_sync")
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_start = time.perf_counter()
+    scan_ms, tot_ms, kern = [], [], {"offsets_ms": [], "emit_ms": [], "guides_ms": [], "compact_ms": []}
+    tab = None
+    for _ in range(args.steps):
+        tab = step()
+        scan_ms.append(tab.timing["scan_ms"])
+        tot_ms.append(tab.timing["total_ms"])
+        for k in kern:
+            kern[k].append(tab.timing[k])
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    cand, rows, positions = tab.n_candidates, tab.n_rows, tab.timing["scanned_positions"]
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([cand, rows, positions], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cand_all, rows_all, pos_all = (int(x) for x in c.tolist())
+    else:
+        cand_all, rows_all, pos_all = cand, rows, positions
+
+    out = None
+    if rank == 0:
+        scan_avg_ms = float(np.mean(scan_ms))
+        algo_bytes = ALGO_BYTES_PER_POS * positions
+        achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "candidate guides scored/sec", "value": cand_all * args.steps / elapsed, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "C3: 1 Mb region x 2504 phased samples (BASELINE.json configs[2])" if (args.samples, args.region_len) == (2504, 1_000_000) else "custom",
+                       "pam": args.pam, "guidelen": args.guidelen, "right": args.right, "region_nt": len(haps[0].seq),
+                       "haplotypes_per_gpu": ds.n_hap, "samples_per_gpu": args.samples, "variant_sites": len(reg.variants),
+                       "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
+                       "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all},
+            "roofline": {"bound": "hbm", "kernel": "k_scan<1>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": scan_avg_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_position": ALGO_BYTES_PER_POS},
+            "kernels_ms": {"scan": scan_avg_ms, **{k[:-3]: float(np.mean(v)) for k, v in kern.items()},
+                           "device_total": float(np.mean(tot_ms))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(haps, pam, args, mm, pt)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(haps, pam, args, mm, pt):
+    """The oracle (C port of the reference algorithm) on REF + the first --cpu-haps haplotypes of
+    the same workload, one host thread: encode + search + reverse_guides + CFDon."""
+    from oracle import oracle as ora
+
+    n = min(len(haps), max(2, args.cpu_haps))
+    sub = haps[:n]
+    hs = ora.HapSet([bytes(h.seq).decode("ascii") for h in sub], [h.seg.full() for h in sub], [h.is_ref for h in sub],
+                    [h.scan for h in sub])
+    blob_args = hs.packed()  # input marshalling is not timed (the GPU side starts from resident planes too)
+    hs.packed = lambda: blob_args
+    t0 = time.perf_counter()
+    res = ora.search(hs, pam.pam, args.guidelen, args.right)
+    ora.reverse_and_cfdon(res, hs.is_ref, args.guidelen, len(pam), mm, pt, decode=False)
+    dt = time.perf_counter() - t0
+    return {"value": res.n_candidates / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "sample": f"REF + first {n - 1} haplotypes of the same workload ({res.n_candidates} candidates, {dt:.1f} s, 1 thread of {os.cpu_count()})"}
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,14 @@ def _p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _as_u8(seq) -> np.ndarray:
+    if isinstance(seq, np.ndarray):
+        return seq if seq.dtype == np.uint8 else seq.astype(np.uint8)
+    if isinstance(seq, str):
+        seq = seq.encode("ascii")
+    return np.frombuffer(seq, dtype=np.uint8)
+
+
 def segments_from_posmap(posmap: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """Position map (haplotype.py:90-159) -> unit-slope segments (rel_start, genomic_start).
     Every index where posmap[i] != posmap[i-1] + 1 opens a segment (an inserted base repeats
@@ -77,7 +85,7 @@ class PosSegments:
 @dataclass
 class HostHaplotype:
     """What the device search needs to know about one haplotype."""
-    seq: str  # cased: lower case = base introduced by a variant
+    seq: object  # cased ASCII (str, bytes or uint8 array): lower case = base introduced by a variant
     seg: PosSegments
     is_ref: bool
     scan: Tuple[int, int]
@@ -100,15 +108,15 @@ class DeviceHapSet:
         # K1: ASCII -> planes
         off = np.zeros(self.n_hap + 1, dtype=np.uint64)
         off[1:] = np.cumsum(self.hap_len.astype(np.uint64))
-        blob = "".join(h.seq for h in haps).encode("ascii")
+        blob = np.concatenate([_as_u8(h.seq) for h in haps]) if self.n_hap > 1 else np.ascontiguousarray(_as_u8(haps[0].seq))
         bad = C.c_uint64(0)
-        rc = L.hawk_hapset_pack_ascii(self._h, blob, _p(off), C.byref(bad))
+        rc = L.hawk_hapset_pack_ascii(self._h, _p(blob), _p(off), C.byref(bad))
         if rc == _lib.HAWK_E_IUPAC:
             hidx = int(np.searchsorted(off, bad.value, side="right") - 1)
             self.close()
             raise _lib.HawkStatusError(rc, "hawk_hapset_pack_ascii",
                                        f"haplotype {hidx} position {bad.value - int(off[hidx])} "
-                                       f"({blob[bad.value:bad.value + 1]!r})")
+                                       f"({bytes(blob[bad.value:bad.value + 1])!r})")
         _lib.check(rc, "hawk_hapset_pack_ascii")
         self.set_meta(haps)
 
@@ -185,6 +193,7 @@ class DeviceHapSet:
         tm = _lib.Timing()
         _lib.check(L.hawk_search(self._h, C.byref(sp), C.byref(t), C.byref(tm)), "hawk_search")
         del keep
+        self.last_timing = tm
         tab = GuideTable(self, t, guidelen, pamlen, bool(right), tm)
         if download:
             tab.download()
@@ -202,6 +211,11 @@ class GuideTable:
         _lib.check(hs._L.hawk_table_counts(handle, C.byref(n), C.byref(c), C.byref(h)), "hawk_table_counts")
         self.n_rows, self.n_candidates, self.n_hits = n.value, c.value, h.value
         self._downloaded = False
+
+    def close(self) -> None:
+        if self._t:
+            self._hs._L.hawk_table_destroy(self._t)
+            self._t = None
 
     def download(self) -> "GuideTable":
         if self._downloaded:

@@ -130,12 +130,16 @@ def add_phased_variants(
     seq = reg.contig_seq
     reg.samples = [f"S{i:04d}" for i in range(n_samples)]
     out: List[VariantSite] = []
+    gt_all = np.empty((n_sites, n_hap), dtype=np.uint8)
+    for k0 in range(0, n_sites, 4096):  # chunked: 31k x 5008 float64 would be 1.2 GB at once
+        k1 = min(n_sites, k0 + 4096)
+        gt_all[k0:k1] = rng.random((k1 - k0, n_hap)) < afs[k0:k1, None]
+    empty = np.flatnonzero(~gt_all.any(axis=1))  # keep every site carried by at least one haplotype
+    gt_all[empty, rng.integers(0, n_hap, size=len(empty))] = 1
     for k in range(n_sites):
         pos = int(lo + slots[k] * span + jitter[k])
         refb = seq[pos - 1]
-        gt = (rng.random(n_hap) < afs[k]).astype(np.uint8).reshape(n_samples, 2)
-        if not gt.any():  # keep every site carried by at least one haplotype
-            gt[rng.integers(0, n_samples), rng.integers(0, 2)] = 1
+        gt = gt_all[k].reshape(n_samples, 2)
         if kinds[k] < frac_snv:
             altb = "ACGT"[("ACGT".index(refb) + int(alt_pick[k])) % 4]
             out.append(VariantSite(pos, refb, altb, float(afs[k]), gt))
@@ -153,8 +157,8 @@ def add_phased_variants(
     # largest total inserted length any one haplotype carries.
     if out:
         ins_len = np.array([max(0, v.chain) for v in out], dtype=np.int64)
-        gt_all = np.stack([v.gt.reshape(-1) for v in out]).astype(np.int64)  # [site, hap]
-        guard = int((ins_len[:, None] * gt_all).sum(axis=0).max())
+        ins_rows = np.flatnonzero(ins_len > 0)  # gt_all: [site, hap]
+        guard = int((ins_len[ins_rows, None] * gt_all[ins_rows].astype(np.int64)).sum(axis=0).max()) if len(ins_rows) else 0
         out = [v for v in out if v.pos + len(v.ref) + guard <= reg.stopp]
     reg.variants = out
     return reg

@@ -173,9 +173,15 @@ class HapSet:
 @dataclass
 class SearchResult:
     guides: np.ndarray  # GUIDE_DTYPE, reference list order
-    windows: List[str]
+    win_raw: np.ndarray  # uint8 [n, W] cased ASCII windows
     n_candidates: int
     n_hits: int
+
+    @property
+    def windows(self) -> List[str]:
+        n, W = self.win_raw.shape
+        wb = self.win_raw.tobytes()
+        return [wb[i * W:(i + 1) * W].decode("ascii") for i in range(n)]
 
 
 def search(hs: HapSet, pam: str, guidelen: int, right: bool, cap: Optional[int] = None) -> SearchResult:
@@ -194,18 +200,16 @@ def search(hs: HapSet, pam: str, guidelen: int, right: bool, cap: Optional[int] 
                          int(right), _p(out), _p(win), C.c_int64(cap), C.byref(ncand), C.byref(nhits))
     if m < 0:
         raise OracleError(int(m))
-    wb = win[: m * W].tobytes()
-    windows = [wb[i * W:(i + 1) * W].decode("ascii") for i in range(m)]
-    return SearchResult(out[:m].copy(), windows, ncand.value, nhits.value)
+    return SearchResult(out[:m].copy(), win[: m * W].reshape(m, W).copy(), ncand.value, nhits.value)
 
 
 def reverse_and_cfdon(res: SearchResult, is_ref: Sequence[bool], guidelen: int, pamlen: int,
-                      mm: Optional[np.ndarray] = None, pamtab: Optional[np.ndarray] = None):
+                      mm: Optional[np.ndarray] = None, pamtab: Optional[np.ndarray] = None, decode: bool = True):
     """-> (guides with flipped `right`, reversed windows, kmers, cfdon scores, cfdon order)"""
     n = len(res.guides)
     W = guidelen + pamlen + 20
     g = res.guides.copy()
-    win = np.frombuffer("".join(res.windows).encode("ascii"), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+    win = res.win_raw.reshape(-1).copy()
     kmer = np.zeros(n * (W - 13), dtype=np.uint8)
     cfd = np.full(n, np.nan)
     order = np.zeros(n, dtype=np.int64)
@@ -217,6 +221,8 @@ def reverse_and_cfdon(res: SearchResult, is_ref: Sequence[bool], guidelen: int, 
                                      int(do_cfd), _p(cfd), _p(order), _p(kmer))
     if rc:
         raise OracleError(rc)
+    if not decode:
+        return g, win.reshape(n, W), kmer.reshape(n, W - 13), (cfd if do_cfd else None), (order if do_cfd else None)
     wb, kb = win.tobytes(), kmer.tobytes()
     K = W - 13
     windows = [wb[i * W:(i + 1) * W].decode() for i in range(n)]

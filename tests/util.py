@@ -73,3 +73,14 @@ def hapset_from_golden(fx):
     is_ref = [h["samples"] == ["REF"] for h in fx["haplotypes"]]
     scan = [tuple(s) for s in fx["scan"]]
     return ora.HapSet(seqs, pms, is_ref, scan)
+
+
+def synth_region_from_fixture(fx):
+    """Rebuild the SynthRegion a g3 fixture was generated from (only the padded region's
+    bases are stored; the contig prefix is irrelevant to every consumer)."""
+    from crisprhawk_hip import synth
+    reg = synth.SynthRegion(fx["contig"], "N" * (fx["startp"] - 1) + fx["region_seq"], fx["bed_start"], fx["bed_stop"])
+    reg.samples = fx["samples"]
+    reg.variants = [synth.VariantSite(p, r, a, af, np.array([[int(c) for c in row] for row in gt], dtype=np.uint8))
+                    for p, r, a, af, gt in fx["variants"]]
+    return reg
