@@ -1,0 +1,136 @@
+"""scoring — CFDon / DeepCpf1 / Azimuth slices of the reference's scoring.py with the arithmetic
+on the GPU.  Model parameters are explicit inputs (``set_cfd_tables`` / ``load_cfd_tables``): the
+reference downloads them from Zenodo at run time (config_utils.py:34-70) which is not possible
+offline; loaders accept the reference's pickle format.  ``threads`` is ignored (a HIP context does
+not survive the ProcessPoolExecutor fork of scoring.py:129)."""
+import ctypes as C
+import os
+import pickle
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from .crisprhawk_error import CrisprHawkCfdScoreError
+from .exception_handlers import exception_handler
+from .guide import GUIDESEQPAD, Guide
+from .pam import PAM, SPCAS9, XCAS9
+from .utils import VERBOSITYLVL, flatten_list, print_verbosity
+
+_CFD_TABLES: Optional[Tuple[np.ndarray, np.ndarray]] = None
+_RNA, _DNA = "ACGU", "ACGT"
+_RCD = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def set_cfd_tables(mm: np.ndarray, pam: np.ndarray) -> None:
+    """mm[20,4,4] = [position, wildtype RNA base, sgRNA base], pam[16] = PAM[-2:] dinucleotide."""
+    global _CFD_TABLES
+    _CFD_TABLES = (np.ascontiguousarray(mm, dtype=np.float64).reshape(20, 4, 4),
+                   np.ascontiguousarray(pam, dtype=np.float64).reshape(16))
+
+
+def cfd_tables_from_dicts(mmscores: Dict[str, float], pamscores: Dict[str, float]) -> Tuple[np.ndarray, np.ndarray]:
+    """The reference's two dicts (keys ``r{wt}:d{RC(sg)},{i}`` and ``{pam}``, cfdscore.py:88-94) -> arrays.
+    Entries the reference never looks up (wt == sg) may be absent; they are set to 1."""
+    mm = np.ones((20, 4, 4))
+    for i in range(20):
+        for a in range(4):
+            for b in range(4):
+                k = f"r{_RNA[a]}:d{_RCD[_DNA[b]]},{i + 1}"
+                if k in mmscores:
+                    mm[i, a, b] = mmscores[k]
+    pam = np.array([pamscores[_DNA[a] + _DNA[b]] for a in range(4) for b in range(4)], dtype=np.float64)
+    return mm, pam
+
+
+def load_cfd_tables(modelspath: str, debug: bool) -> None:
+    """cfdscore.load_mismatch_pam_scores (cfdscore.py:22-50): mismatch_score.pkl + pam_scores.pkl."""
+    try:
+        with open(os.path.join(modelspath, "mismatch_score.pkl"), "rb") as f:
+            mmscores = pickle.load(f)
+        with open(os.path.join(modelspath, "pam_scores.pkl"), "rb") as f:
+            pamscores = pickle.load(f)
+    except OSError as e:
+        exception_handler(CrisprHawkCfdScoreError, "An error occurred while loading CFD model files", os.EX_NOINPUT, debug, e)
+    set_cfd_tables(*cfd_tables_from_dicts(mmscores, pamscores))
+
+
+def _tables(debug: bool):
+    if _CFD_TABLES is None:
+        exception_handler(CrisprHawkCfdScoreError, "An error occurred while loading CFD model files", os.EX_NOINPUT, debug)
+    return _CFD_TABLES
+
+
+def _extract_guide_sequences(guides: List[Guide]) -> List[str]:
+    """scoring.py:50-67: 4 nt upstream + guide/PAM + 3 nt downstream, upper case."""
+    return [g.sequence[(GUIDESEQPAD - 4):(-GUIDESEQPAD + 3)].upper() for g in guides]
+
+
+def group_guides_position(guides: List[Guide], debug: bool):
+    """scoring.py:303-349"""
+    groups: Dict[str, list] = {}
+    for g in guides:
+        key = f"{g.start}_{g.strand}"
+        grp = groups.setdefault(key, [None, []])
+        if g.samples == "REF":
+            if grp[0] is not None:
+                exception_handler(CrisprHawkCfdScoreError,
+                                  f"Duplicate REF guide at position {g.start}? CFDon/Elevation-on calculation failed",
+                                  os.EX_DATAERR, debug)
+            grp[0] = g
+        grp[1].append(g)
+    return {k: (v[0], v[1]) for k, v in groups.items()}
+
+
+def compute_cfd_batch(wt: List[str], sg: List[str], pam2: List[str], debug: bool) -> np.ndarray:
+    """compute_cfd (cfdscore.py:53-95) for n (wildtype, sgRNA, PAM[-2:]) triples on the GPU."""
+    mm, pt = _tables(debug)
+    n = len(wt)
+    if n == 0:
+        return np.zeros(0)
+    ln = len(wt[0])
+    if any(len(x) != ln for x in wt) or any(len(x) != ln for x in sg) or any(len(p) != 2 for p in pam2):
+        exception_handler(CrisprHawkCfdScoreError, "CFDon score calculation failed", os.EX_DATAERR, debug)
+    out = np.empty(n, dtype=np.float64)
+    rc = _lib.lib().hawk_cfd(_lib.context(), "".join(wt).encode("ascii"), "".join(sg).encode("ascii"), ln,
+                             "".join(pam2).encode("ascii"), C.c_uint64(n), mm.ctypes.data_as(C.c_void_p),
+                             pt.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    if rc == _lib.HAWK_E_CFD:
+        exception_handler(CrisprHawkCfdScoreError, "CFDon score calculation failed", os.EX_DATAERR, debug)
+    _lib.check(rc, "hawk_cfd")
+    return out
+
+
+def cfdon(guide_ref: Union[None, Guide], guides: List[Guide], debug: bool) -> List[float]:
+    """scores/crisprhawk_scores.py:65-87"""
+    if not guide_ref:
+        return [np.nan] * len(guides)
+    return compute_cfd_batch([guide_ref.guide] * len(guides), [g.guide for g in guides], [g.pam[-2:] for g in guides],
+                             debug).tolist()
+
+
+def cfdon_score(guides: List[Guide], verbosity: int, debug: bool) -> List[Guide]:
+    """scoring.py:352-387: one device batch for all groups; returns the guides in group order."""
+    print_verbosity("Computing CFDon score", verbosity, VERBOSITYLVL[3])
+    groups = group_guides_position(guides, debug)
+    wt, sg, pm, dst = [], [], [], []
+    for _, (ref, members) in groups.items():
+        for g in members:
+            if ref is None:
+                g.cfdon_score = float("nan")
+            else:
+                wt.append(ref.guide); sg.append(g.guide); pm.append(g.pam[-2:]); dst.append(g)
+    if dst:
+        for g, s in zip(dst, compute_cfd_batch(wt, sg, pm, debug).tolist()):
+            g.cfdon_score = float(s)
+    return flatten_list([members for _, (_, members) in groups.items()])
+
+
+def scoring_guides(guides: Dict, pam: PAM, scoring_envs, args) -> Dict:
+    """scoring.py:816-867, restricted to the scorers whose parameters can be supplied offline:
+    CFDon for SpCas9/xCas9 PAMs (749-792)."""
+    for region, guides_list in guides.items():
+        if pam.cas_system in (SPCAS9, XCAS9):
+            guides_list = cfdon_score(guides_list, args.verbosity, args.debug)
+        guides[region] = guides_list
+    return guides

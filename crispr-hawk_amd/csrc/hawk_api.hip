@@ -514,4 +514,30 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
   return HAWK_OK;
 }
 
+int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
+             const double* cfd_mm, const double* cfd_pam, double* out) {
+  if (!ctx || !cfd_mm || !cfd_pam || (n && (!wt || !sg || !pam2 || !out)) || len == 0) return HAWK_E_INVALID;
+  if (!n) return HAWK_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  char *d_wt = nullptr, *d_sg = nullptr, *d_p = nullptr;
+  double *d_tab = nullptr, *d_out = nullptr;
+  int* d_status = nullptr;
+  HIPCHK(hipMalloc(&d_wt, n * len)); HIPCHK(hipMalloc(&d_sg, n * len)); HIPCHK(hipMalloc(&d_p, n * 2));
+  HIPCHK(hipMalloc(&d_tab, 336 * 8)); HIPCHK(hipMalloc(&d_out, n * 8)); HIPCHK(hipMalloc(&d_status, 4));
+  HIPCHK(hipMemcpyAsync(d_wt, wt, n * len, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_sg, sg, n * len, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_p, pam2, n * 2, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_tab, cfd_mm, 320 * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_tab + 320, cfd_pam, 16 * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream));
+  hawk_launch_cfd(ctx->stream, d_wt, d_sg, len, d_p, n, d_tab, d_tab + 320, d_out, d_status);
+  HIPCHK(hipGetLastError());
+  int status = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_wt); (void)hipFree(d_sg); (void)hipFree(d_p); (void)hipFree(d_tab); (void)hipFree(d_out); (void)hipFree(d_status);
+  return status;
+}
+
 }  // extern "C"

@@ -79,3 +79,5 @@ void hawk_launch_guides(hipStream_t st, const HapSetDev& hs, const GuideParams& 
                         unsigned long long* n_invalid, int* status);
 void hawk_launch_compact(hipStream_t st, const uint8_t* valid, uint64_t n, uint32_t* blocksum, uint64_t* blockoff,
                          GuideCols src, GuideCols dst);
+void hawk_launch_cfd(hipStream_t st, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
+                     const double* mm, const double* pamtab, double* out, int* status);

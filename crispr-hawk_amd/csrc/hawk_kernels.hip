@@ -580,3 +580,42 @@ void hawk_launch_compact(hipStream_t st, const uint8_t* valid, uint64_t n, uint3
                      (const uint32_t*)nullptr, (uint64_t)0, (ScanTotals*)(blockoff + grid + 1));
   hipLaunchKernelGGL(k_compact_scatter, dim3(grid), dim3(HAWK_BLOCK), 0, st, valid, n, blockoff, src, dst);
 }
+
+// ---------------------------------------------------------------------------------------
+// K4 stand-alone: compute_cfd on string triples (cfdscore.py:53-95)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int rna_index(char c) {
+  switch (c & 0xDF) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': case 'U': return 3; default: return -1; }
+}
+__global__ __launch_bounds__(HAWK_BLOCK) void k_cfd(const char* __restrict__ wt, const char* __restrict__ sg, uint32_t len,
+                                                     const char* __restrict__ pam2, uint64_t n, const double* __restrict__ mm,
+                                                     const double* __restrict__ pamtab, double* __restrict__ out, int* status) {
+  const uint64_t i = (uint64_t)blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const char* w = wt + i * len;
+  const char* s = sg + i * len;
+  double score = 1.0;
+  bool err = false;
+  const uint32_t m = len < 20 ? len : 20;
+  for (uint32_t k = 0; k < m; ++k) {
+    char cw = w[k] & 0xDF, cs = s[k] & 0xDF;  // upper(); '-' (0x2D) folds to 0x0D on both sides
+    if (cw == 'T') cw = 'U';
+    if (cs == 'T') cs = 'U';
+    if (cw == cs) continue;
+    if (w[k] == '-' || s[k] == '-') continue;  // bulge placeholders are skipped
+    const int a = rna_index(cw), b = rna_index(cs);
+    if (a < 0 || b < 0) { err = true; break; }
+    score *= mm[(k * 4 + a) * 4 + b];
+  }
+  const char p0c = pam2[2 * i] & 0xDF, p1c = pam2[2 * i + 1] & 0xDF;
+  const int p0 = rna_index(p0c), p1 = rna_index(p1c);
+  if (p0 < 0 || p1 < 0 || p0c == 'U' || p1c == 'U') err = true;
+  if (err) { atomicExch(status, -5); out[i] = __longlong_as_double(0x7ff8000000000000ll); return; }
+  out[i] = score * pamtab[4 * p0 + p1];
+}
+void hawk_launch_cfd(hipStream_t st, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
+                     const double* mm, const double* pamtab, double* out, int* status) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_cfd, dim3((uint32_t)((n + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, wt, sg, len, pam2, n,
+                     mm, pamtab, out, status);
+}

@@ -126,6 +126,14 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
                               void** flags, void** cfdon, void** win);
 
+/* ---- K4 stand-alone: compute_cfd() (scores/cfdscore/cfdscore.py:53-95) on n triples --------
+ * wt / sg: n spacers of `len` characters each (host, contiguous, any case, T or U); pam2: n
+ * two-character strings (the caller passes guide.pam[-2:], crisprhawk_scores.py:84-86).
+ * out[i] = prod over i<min(len,20), wt!=sg of mm[i][wt][sg] times pam[pam2], fp64, left to
+ * right.  Any non-ACGT base under a lookup -> HAWK_E_CFD (the reference's KeyError). */
+int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
+             const double* cfd_mm, const double* cfd_pam, double* out);
+
 #ifdef __cplusplus
 }
 #endif

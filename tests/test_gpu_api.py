@@ -1,0 +1,95 @@
+"""The object-level drop-in (crisprhawk_hip.search_guides.search & co.) against the reference's
+own outputs, written the way the reference's tests call its API."""
+import math
+
+import numpy as np
+import pytest
+
+from crisprhawk_hip import scoring, synth
+from crisprhawk_hip.annotation import reverse_guides
+from crisprhawk_hip.coordinate import Coordinate
+from crisprhawk_hip.crisprhawk_error import CrisprHawkCfdScoreError, CrisprHawkIupacTableError
+from crisprhawk_hip.encoder import encode
+from crisprhawk_hip.haplotype import Haplotype
+from crisprhawk_hip.haplotypes import add_variants_phased
+from crisprhawk_hip.pam import PAM
+from crisprhawk_hip.region import Region
+from crisprhawk_hip.search_guides import compute_scan_start_stop, pam_search, scan_haplotype, search
+from crisprhawk_hip.sequence import Sequence
+from crisprhawk_hip.variant import VariantRecord
+from util import G3_CASES, load_golden, synth_region_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def test_encode_matches_reference_tests():
+    # reference tests/test_encoder.py:6-55
+    assert encode("ACGTN", 0, True) == [1, 2, 4, 8, 15]
+    assert encode("acgtn", 0, True) == [1, 2, 4, 8, 15]
+    assert encode("", 0, True) == []
+    assert list(encode("RYSWKMBDHV", 0, True)) == [5, 10, 6, 9, 12, 3, 14, 13, 11, 7]
+    with pytest.raises(CrisprHawkIupacTableError):
+        encode("ACGTXA", 0, True)
+
+
+def _build(fx):
+    reg = synth_region_from_fixture(fx)
+    region = Region(Sequence(fx["region_seq"], True), Coordinate(fx["contig"], fx["bed_start"], fx["bed_stop"], 100))
+    haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
+    if reg.variants:
+        recs = []
+        for v in reg.variants:
+            vr = VariantRecord(True)
+            vr.read_vcf_line(reg.vcf_fields(v), reg.samples, True)
+            recs.append(vr)
+        haps = add_variants_phased(haps, region, reg.samples, recs, True, True)
+    for i, h in enumerate(haps):
+        h.id = f"hap_{i:08d}"
+    return region, haps
+
+
+@pytest.mark.parametrize("case", G3_CASES)
+def test_search_returns_the_reference_guide_list(case):
+    fx = load_golden(f"g3_search_{case}.json.gz")
+    region, haps = _build(fx)
+    assert [h.sequence.sequence for h in haps] == [h["seq"] for h in fx["haplotypes"]]
+    assert [sorted(h.samples.split(",")) for h in haps] == [h["samples"] for h in fx["haplotypes"]]
+    assert [h.variants for h in haps] == [h["variants"] for h in fx["haplotypes"]]
+    pam = PAM(fx["pam"], fx["right"], True)
+    pam.encode(0)
+    assert [list(compute_scan_start_stop(h, region.start, region.stop, len(pam))) for h in haps] == fx["scan"]
+    bits = [encode(h.sequence.sequence, 0, True) for h in haps[:2]]
+    f, r = scan_haplotype(pam, bits[0], fx["scan"][0][0], fx["scan"][0][1], True)
+    assert [f, r] == fx["hits"][0]
+    assert [[f, r] for f, r in pam_search(pam, region, haps, None, 0, True)] == fx["hits"]
+    guides = search(pam, region, haps, None, fx["guidelen"], fx["right"], fx["variants_present"], fx["phased"], 0, True)
+    hidx = {h.id: i for i, h in enumerate(haps)}
+    got = [[g.start, g.stop, g.strand, g.sequence, hidx[g.hapid], g.right] for g in guides]
+    assert got == fx["guides"]
+    for i, pm in fx["guide_posmaps"]:
+        assert [guides[i].posmap[k] for k in range(fx["guidelen"] + len(pam))] == pm
+    guides = reverse_guides(guides, 0)
+    assert [[g.sequence, g.guide, g.pam, g.right] for g in guides] == fx["reversed"]
+    assert scoring._extract_guide_sequences(guides) == fx["kmers"]
+    if "cfdon" in fx:
+        scoring.set_cfd_tables(*synth.cfd_tables())
+        ids = {id(g): i for i, g in enumerate(guides)}
+        scored = scoring.cfdon_score(guides, 0, True)
+        assert [ids[id(g)] for g in scored] == fx["cfdon_order"]
+        for g, want in zip(scored, fx["cfdon"]):
+            assert g.cfdon_score == ("NA" if want is None else str(round(want, 4)))
+
+
+def test_cfd_batch_bit_exact_and_errors():
+    g5 = load_golden("g5_cfd.json.gz")
+    scoring.set_cfd_tables(*synth.cfd_tables(g5["seed"]))
+    by_len = {}
+    for wt, sg, pam, want in g5["cases"]:
+        by_len.setdefault(len(wt), []).append((wt, sg, pam, want))
+    for ln, cases in by_len.items():
+        got = scoring.compute_cfd_batch([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], True)
+        assert got.tolist() == [c[3] for c in cases]
+    with pytest.raises(CrisprHawkCfdScoreError):
+        scoring.compute_cfd_batch(["ACGTN"], ["ACGTA"], ["GG"], True)
+    with pytest.raises(CrisprHawkCfdScoreError):
+        scoring.compute_cfd_batch(["ACGT"], ["ACGT"], ["NG"], True)
