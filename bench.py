@@ -101,11 +101,11 @@ def main():
         step()
     barrier()
     t_start = time.perf_counter()
-    scan_ms, tot_ms, kern = [], [], {"offsets_ms": [], "emit_ms": [], "guides_ms": [], "compact_ms": []}
+    scan_ms, tot_ms, kern = [], [], {"offsets_ms": [], "emit_ms": []}
     tab = None
     for _ in range(args.steps):
         tab = step()
-        scan_ms.append(tab.timing["scan_ms"])
+        scan_ms.append(tab.timing["count_ms"])
         tot_ms.append(tab.timing["total_ms"])
         for k in kern:
             kern[k].append(tab.timing[k])
@@ -137,10 +137,10 @@ def main():
                        "haplotypes_per_gpu": ds.n_hap, "samples_per_gpu": args.samples, "variant_sites": len(reg.variants),
                        "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
                        "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all},
-            "roofline": {"bound": "hbm", "kernel": "k_scan<1>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_search<0>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": scan_avg_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_position": ALGO_BYTES_PER_POS},
-            "kernels_ms": {"scan": scan_avg_ms, **{k[:-3]: float(np.mean(v)) for k, v in kern.items()},
+            "kernels_ms": {"count": scan_avg_ms, **{k[:-3]: float(np.mean(v)) for k, v in kern.items()},
                            "device_total": float(np.mean(tot_ms))},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -52,8 +52,8 @@ class SearchParams(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [
-        ("scan_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("guides_ms", C.c_float),
-        ("compact_ms", C.c_float), ("total_ms", C.c_float), ("scanned_positions", C.c_uint64),
+        ("count_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("total_ms", C.c_float),
+        ("scanned_positions", C.c_uint64),
     ]
 
 

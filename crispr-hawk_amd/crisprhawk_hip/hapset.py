@@ -201,7 +201,7 @@ class DeviceHapSet:
 
 
 class GuideTable:
-    """Columnar guide table of one fused search (rows in (haplotype, strand, position) order)."""
+    """Columnar guide table of one fused search (rows in (haplotype, tile, strand, position) order)."""
 
     def __init__(self, hs: DeviceHapSet, handle, guidelen: int, pamlen: int, right: bool, timing):
         self._hs, self._t = hs, handle
@@ -254,6 +254,12 @@ class GuideTable:
         raw = _CODE2CHAR[code].tobytes()
         return [raw[i * W:(i + 1) * W].decode("ascii") for i in range(n)]
 
+    def emission_order(self) -> np.ndarray:
+        """Row permutation giving the reference's pre-dedup emission order: haplotype, then strand
+        (0 before 1), then ascending PAM position (search_guides.py:530-547).  The device writes rows
+        per 32 768-position tile, so the strands of one haplotype interleave tile by tile."""
+        return np.lexsort((self.pos, self.strand, self.hap))
+
     def reference_order(self) -> np.ndarray:
         """Row permutation reproducing the list order of the reference's search():
         remove_redundant_guides (search_guides.py:340-369) walks a dict keyed by
@@ -261,8 +267,9 @@ class GuideTable:
         n = self.n_rows
         if n == 0:
             return np.zeros(0, dtype=np.int64)
-        key = self.start.astype(np.int64) * 2 + self.strand
+        emit = self.emission_order()
+        key = self.start[emit].astype(np.int64) * 2 + self.strand[emit]
         _, inv = np.unique(key, return_inverse=True)
         first = np.full(inv.max() + 1, n, dtype=np.int64)
         np.minimum.at(first, inv, np.arange(n))
-        return np.lexsort((np.arange(n), first[inv]))
+        return emit[np.lexsort((np.arange(n), first[inv]))]

@@ -61,9 +61,12 @@ struct hawk_hapset {
   int64_t* d_seg_gen;
   int32_t ref_index;
   bool has_meta;
+  uint32_t bph;            // workgroups (tiles of 1024 words) per haplotype row
+  uint32_t* d_tile_seg0;   // [n_hap * bph] first position-map segment each tile needs
+  int64_t ref_startp;
   // workspace reused across searches
-  DevBuf keepF, keepR, counts, aux, offsets, totals, rec, valid, misc, cfd, blocksum, blockoff;
-  DevBuf colsA[8], colsB[8];
+  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial;
+  DevBuf colsA[8];
 };
 
 struct hawk_table {
@@ -160,6 +163,10 @@ int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, h
   HIPCHK(hipMalloc(&hs->d_seg_off, (n_hap + 1) * 4));
   hs->d_seg_rel = nullptr;
   hs->d_seg_gen = nullptr;
+  hs->bph = (hs->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  hs->d_tile_seg0 = nullptr;
+  HIPCHK(hipMalloc(&hs->d_tile_seg0, (size_t)n_hap * hs->bph * 4));
+  hs->ref_startp = 0;
   hs->ref_index = -1;
   hs->has_meta = false;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -176,11 +183,10 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   (void)hipFree(hs->d_scan_stop); (void)hipFree(hs->d_seg_off);
   if (hs->d_seg_rel) (void)hipFree(hs->d_seg_rel);
   if (hs->d_seg_gen) (void)hipFree(hs->d_seg_gen);
-  DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->aux, &hs->offsets, &hs->totals, &hs->rec,
-                    &hs->valid, &hs->misc, &hs->cfd, &hs->blocksum, &hs->blockoff};
+  (void)hipFree(hs->d_tile_seg0);
+  DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
-  for (auto& b : hs->colsB) b.release();
   delete hs;
 }
 
@@ -256,6 +262,22 @@ int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* 
   HIPCHK(hipMemcpyAsync(hs->d_seg_off, seg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(hs->d_seg_rel, seg_rel, (size_t)nseg * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(hs->d_seg_gen, seg_gen, (size_t)nseg * 8, hipMemcpyHostToDevice, ctx->stream));
+  {
+    // first segment each tile needs: the last one starting at or before the tile's first base
+    std::vector<uint32_t> t0((size_t)n * hs->bph);
+    for (uint32_t h = 0; h < n; ++h) {
+      const uint32_t* b = seg_rel + seg_off[h];
+      const uint32_t* e = seg_rel + seg_off[h + 1];
+      for (uint32_t blk = 0; blk < hs->bph; ++blk) {
+        const uint32_t q0 = blk * HAWK_BLOCK * 128u;
+        const uint32_t* it = std::upper_bound(b, e, q0);  // first seg_rel > q0
+        t0[(size_t)h * hs->bph + blk] = (uint32_t)((it - seg_rel) - 1);
+      }
+    }
+    HIPCHK(hipMemcpyAsync(hs->d_tile_seg0, t0.data(), t0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  hs->ref_startp = ref_index >= 0 ? seg_gen[seg_off[ref_index]] : 0;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hs->scan_start.assign(scan_start, scan_start + n);
   hs->scan_stop.assign(scan_stop, scan_stop + n);
@@ -305,7 +327,7 @@ static int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pa
   sp->pam_fwd = pam_fwd; sp->pam_rev = pam_rev;
   sp->pamlen = (int32_t)pamlen; sp->guidelen = (int32_t)guidelen; sp->right = right ? 1 : 0;
   sp->L = (int32_t)(guidelen + pamlen);
-  sp->bph = (hs->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  sp->bph = hs->bph;
   uint32_t need = 0;
   for (uint32_t i = 0; i < pamlen; ++i) {
     const uint32_t a = (uint32_t)(pam_fwd >> (4 * i)) & 15u, b = (uint32_t)(pam_rev >> (4 * i)) & 15u;
@@ -315,6 +337,7 @@ static int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pa
   }
   if (need_v) need |= 16u;
   sp->need = need;
+  { const char* e = getenv("HAWK_DEBUG_MODE"); sp->debug = e ? (uint32_t)atoi(e) : 0u; }
   return HAWK_OK;
 }
 
@@ -329,25 +352,25 @@ int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t 
   if (rc) return rc;
   const HapSetDev d = make_dev(hs);
   const size_t words = (size_t)hs->n_hap * hs->S;
-  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph, naux = (uint64_t)hs->n_hap * sp.bph;
+  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph;  // [strand][haplotype][tile]
   if ((rc = hs->keepF.reserve(words * 4)) || (rc = hs->keepR.reserve(words * 4)) || (rc = hs->counts.reserve(ncnt * 4)) ||
-      (rc = hs->aux.reserve(naux * 2 * 4)) || (rc = hs->offsets.reserve((ncnt + 1) * 8)) ||
-      (rc = hs->totals.reserve(sizeof(ScanTotals))))
+      (rc = hs->offsets.reserve((ncnt + 1) * 8)) || (rc = hs->totals.reserve(sizeof(ScanTotals))) ||
+      (rc = hs->partial.reserve((ncnt / 1024 + 2) * 8)))
     return rc;
-  hawk_launch_scan(ctx->stream, 0, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>(),
-                   hs->aux.as<uint32_t>());
-  hawk_launch_offsets(ctx->stream, hs->counts.as<uint32_t>(), hs->offsets.as<uint64_t>(), ncnt, ncnt / 2,
-                      hs->aux.as<uint32_t>(), naux, hs->totals.as<ScanTotals>());
+  hawk_launch_scan_raw(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>());
+  hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ncnt, hs->partial.as<unsigned long long>(), nullptr,
+                    hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
   HIPCHK(hipGetLastError());
   ScanTotals tot;
   HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
   std::vector<uint64_t> offs(ncnt + 1);
-  HIPCHK(hipMemcpyAsync(offs.data(), hs->offsets.p, (ncnt + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(offs.data(), hs->offsets.p, ncnt * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint64_t nf = tot.n_keep_fwd, nr = tot.n_keep - tot.n_keep_fwd;
+  offs[ncnt] = tot.n_keep;
+  const uint64_t nf = offs[ncnt / 2], nr = tot.n_keep - nf;
   for (uint32_t h = 0; h <= hs->n_hap; ++h) {
-    off_fwd[h] = h < hs->n_hap ? offs[(size_t)h * sp.bph] : nf;
-    off_rev[h] = (h < hs->n_hap ? offs[((size_t)hs->n_hap + h) * sp.bph] : tot.n_keep) - nf;
+    off_fwd[h] = offs[(size_t)h * sp.bph];                           // h == n_hap -> offs[ncnt/2] == nf
+    off_rev[h] = offs[((size_t)hs->n_hap + h) * sp.bph] - nf;        // h == n_hap -> offs[ncnt] - nf == nr
   }
   if (nf > cap_fwd || nr > cap_rev || !hits_fwd || !hits_rev) return (nf || nr) ? HAWK_E_CAPACITY : HAWK_OK;
   uint32_t *d_f = nullptr, *d_r = nullptr;
@@ -380,89 +403,74 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   ScanParams sp;
-  bool any_alt = false;
   int rc = make_scan_params(hs, p->pam_fwd, p->pam_rev, p->pamlen, p->guidelen, p->right, true, &sp);
   if (rc) return rc;
-  (void)any_alt;
   const HapSetDev d = make_dev(hs);
-  const size_t words = (size_t)hs->n_hap * hs->S;
-  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph, naux = (uint64_t)hs->n_hap * sp.bph;
-  if ((rc = hs->keepF.reserve(words * 4)) || (rc = hs->keepR.reserve(words * 4)) || (rc = hs->counts.reserve(ncnt * 4)) ||
-      (rc = hs->aux.reserve(naux * 2 * 4)) || (rc = hs->offsets.reserve((ncnt + 1) * 8)) ||
-      (rc = hs->totals.reserve(sizeof(ScanTotals))) || (rc = hs->misc.reserve(64)) || (rc = hs->cfd.reserve(336 * 8)))
+  const uint64_t ntile = (uint64_t)hs->n_hap * sp.bph;
+  if ((rc = hs->counts.reserve(ntile * 4)) || (rc = hs->offsets.reserve((ntile + 1) * 8)) ||
+      (rc = hs->totals.reserve(sizeof(ScanTotals))) || (rc = hs->misc.reserve(512 * 8 + 64)) ||
+      (rc = hs->cfd.reserve(336 * 8)) || (rc = hs->partial.reserve((ntile / 1024 + 2) * 8)))
     return rc;
   if (p->score_cfdon) {
     HIPCHK(hipMemcpyAsync(hs->cfd.p, p->cfd_mm, 320 * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(hs->cfd.as<double>() + 320, p->cfd_pam, 16 * 8, hipMemcpyHostToDevice, ctx->stream));
   }
-  HIPCHK(hipMemsetAsync(hs->misc.p, 0, 64, ctx->stream));
+  HIPCHK(hipMemsetAsync(hs->misc.p, 0, 512 * 8 + 64, ctx->stream));
+  unsigned long long* d_shards = hs->misc.as<unsigned long long>();          // [256][2] candidate / hit partial sums
+  int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 512 * 8);
+  GuideParams gp;
+  gp.pamlen = sp.pamlen; gp.guidelen = sp.guidelen; gp.right = sp.right; gp.L = sp.L;
+  gp.score_cfdon = p->score_cfdon ? 1 : 0;
+  gp.cfd_mm = hs->cfd.as<double>(); gp.cfd_pam = hs->cfd.as<double>() + 320; gp.bph = sp.bph;
+  RefInfo ri;
+  ri.index = hs->ref_index; ri.startp = hs->ref_startp;
+  for (int s = 0; s < 2; ++s) {
+    ri.lo[s] = 0; ri.hi[s] = 0;
+    if (hs->ref_index >= 0) {  // same arithmetic as the kernel's phase A, for the REF haplotype
+      const bool pamfirst = (sp.right != 0) != (s != 0);
+      const int po = pamfirst ? 0 : sp.guidelen;
+      const int haplen = (int)hs->hap_len[hs->ref_index];
+      ri.lo[s] = std::max(hs->scan_start[hs->ref_index] - po, HAWK_PAD);
+      ri.hi[s] = std::min(hs->scan_stop[hs->ref_index] - po, haplen - sp.L - HAWK_PAD + 1);
+    }
+  }
+  GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  hawk_launch_scan(ctx->stream, 1, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>(),
-                   hs->aux.as<uint32_t>());
+  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
-  hawk_launch_offsets(ctx->stream, hs->counts.as<uint32_t>(), hs->offsets.as<uint64_t>(), ncnt, ncnt,
-                      hs->aux.as<uint32_t>(), naux, hs->totals.as<ScanTotals>());
+  hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
+                    hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
   HIPCHK(hipEventRecord(ev[2], ctx->stream));
   HIPCHK(hipGetLastError());
   ScanTotals tot;
   HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint64_t nrec = tot.n_keep;
+  const uint64_t nrows = tot.n_keep;
   GuideCols ca;
-  if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrec, 1), &ca)) || (rc = hs->rec.reserve(std::max<uint64_t>(nrec, 1) * 8)) ||
-      (rc = hs->valid.reserve(std::max<uint64_t>(nrec, 1))))
-    return rc;
-  GuideParams gp;
-  gp.pamlen = sp.pamlen; gp.guidelen = sp.guidelen; gp.right = sp.right; gp.L = sp.L;
-  gp.score_cfdon = p->score_cfdon ? 1 : 0;
-  gp.cfd_mm = hs->cfd.as<double>(); gp.cfd_pam = hs->cfd.as<double>() + 320; gp.bph = sp.bph;
-  unsigned long long* d_ninv = hs->misc.as<unsigned long long>();
-  int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 16);
+  if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
-  if (nrec) hawk_launch_emit_records(ctx->stream, d, sp.bph, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
-                                     hs->offsets.as<uint64_t>(), hs->rec.as<uint64_t>());
+  if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards,
+                                hs->offsets.as<uint64_t>(), ca, d_status);
   HIPCHK(hipEventRecord(ev[4], ctx->stream));
-  hawk_launch_guides(ctx->stream, d, gp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->rec.as<uint64_t>(), nrec,
-                     ca, hs->valid.as<uint8_t>(), d_ninv, d_status);
-  HIPCHK(hipEventRecord(ev[5], ctx->stream));
   HIPCHK(hipGetLastError());
-  struct { unsigned long long ninv; unsigned long long pad; int status; } fin;
-  HIPCHK(hipMemcpyAsync(&fin, hs->misc.p, sizeof(fin), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  GuideCols final_cols = ca;
-  uint64_t nrows = nrec;
-  HIPCHK(hipEventRecord(ev[6], ctx->stream));
-  if (fin.ninv) {
-    nrows = nrec - fin.ninv;
-    GuideCols cb;
-    const uint64_t nblk = (nrec + HAWK_BLOCK - 1) / HAWK_BLOCK;
-    if ((rc = reserve_cols(hs->colsB, std::max<uint64_t>(nrows, 1), &cb)) || (rc = hs->blocksum.reserve(nblk * 4)) ||
-        (rc = hs->blockoff.reserve((nblk + 1) * 8 + sizeof(ScanTotals))))
-      return rc;
-    hawk_launch_compact(ctx->stream, hs->valid.as<uint8_t>(), nrec, hs->blocksum.as<uint32_t>(), hs->blockoff.as<uint64_t>(),
-                        ca, cb);
-    HIPCHK(hipGetLastError());
-    final_cols = cb;
-  }
-  HIPCHK(hipEventRecord(ev[7], ctx->stream));
+  int status = 0;
+  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (timing) {
     memset(timing, 0, sizeof(*timing));
-    (void)hipEventElapsedTime(&timing->scan_ms, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&timing->count_ms, ev[0], ev[1]);
     (void)hipEventElapsedTime(&timing->offsets_ms, ev[1], ev[2]);
     (void)hipEventElapsedTime(&timing->emit_ms, ev[3], ev[4]);
-    (void)hipEventElapsedTime(&timing->guides_ms, ev[4], ev[5]);
-    (void)hipEventElapsedTime(&timing->compact_ms, ev[6], ev[7]);
-    (void)hipEventElapsedTime(&timing->total_ms, ev[0], ev[7]);
+    (void)hipEventElapsedTime(&timing->total_ms, ev[0], ev[4]);
     uint64_t pos = 0;
     for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
     timing->scanned_positions = pos;
   }
-  if (fin.status) return fin.status;
+  if (status) return status;
   hawk_table* t = new (std::nothrow) hawk_table();
   if (!t) return HAWK_E_INVALID;
-  t->hs = hs; t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = final_cols; t->cap = final_cols.cap;
+  t->hs = hs; t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = ca; t->cap = ca.cap;
   *out = t;
   return HAWK_OK;
 }

@@ -1,0 +1,165 @@
+// hawk_bits.h — device helpers shared by the kernels: funnel shifts over bit-sliced planes,
+// wave64 / workgroup scans, the PAM match and the sliding-window OR.  gfx950, wave = 64.
+#pragma once
+#include "hawk_device.h"
+
+#define WAVE 64
+
+// bits [s, s+32) of the 64-bit value {hi,lo}, 0 <= s < 32 : one v_alignbit_b32
+__device__ __forceinline__ uint32_t fsh(uint32_t lo, uint32_t hi, uint32_t s) {
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+}
+// bits [s, s+32) of the 6-word little-endian bit string a[], starting at word k, 0 <= s < 64
+__device__ __forceinline__ uint32_t shifted(const uint32_t (&a)[6], int k, int s) {
+  return s < 32 ? fsh(a[k], a[k + 1], (uint32_t)s) : fsh(a[k + 1], a[k + 2], (uint32_t)(s - 32));
+}
+// mask of bit positions j (0..31) with lo <= base + j < hi
+__device__ __forceinline__ uint32_t range_mask(int base, int lo, int hi) {
+  int a = lo - base, b = hi - base;
+  a = a < 0 ? 0 : a;
+  b = b > 32 ? 32 : b;
+  if (b <= a) return 0u;
+  uint32_t m = b == 32 ? 0xffffffffu : ((1u << b) - 1u);
+  return m & ~((1u << a) - 1u);
+}
+// DPP lane moves (v_mov_b32_dpp): lanes without a source keep 0
+#define DPP0(v, ctrl, rmask, bmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), (bmask), false))
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHL1 0x130
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+// inclusive prefix sum over the 64 lanes: 16-lane rows by row_shr, then row broadcasts (8 DPP adds)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t v = x + DPP0(x, DPP_ROW_SHR(1), 0xf, 0xf);
+  v += DPP0(x, DPP_ROW_SHR(2), 0xf, 0xf);
+  v += DPP0(x, DPP_ROW_SHR(3), 0xf, 0xf);
+  v += DPP0(v, DPP_ROW_SHR(4), 0xf, 0xe);
+  v += DPP0(v, DPP_ROW_SHR(8), 0xf, 0xc);
+  v += DPP0(v, DPP_ROW_BCAST15, 0xa, 0xf);
+  v += DPP0(v, DPP_ROW_BCAST31, 0xc, 0xf);
+  return v;
+}
+// sum over the 64 lanes, returned in every lane (lane 63 of the inclusive scan, via v_readlane)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), WAVE - 1);
+}
+// exclusive scan over a workgroup of NW wavefronts; *total gets the workgroup sum.
+// s_w: NW words of LDS.  Contains two barriers: every thread of the workgroup must call it.
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  uint32_t inc = wave_incl_scan(v);
+  if (lane == WAVE - 1) s_w[wv] = inc;
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    uint32_t x = s_w[i];
+    if (i < wv) pre += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + inc - v;
+}
+
+// This thread's 4 words of one plane plus 2 look-ahead words (taken from the next lane's
+// registers; the last lane of a wave reads them from memory).  All 64 lanes must call it.
+__device__ __forceinline__ void load6(const uint32_t* __restrict__ row, uint32_t u, uint32_t S, bool active,
+                                      uint32_t (&a)[6]) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (active) v = *reinterpret_cast<const uint4*>(row + 4 * (size_t)u);
+  a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+  uint32_t nx = DPP0(v.x, DPP_WAVE_SHL1, 0xf, 0xf), ny = DPP0(v.y, DPP_WAVE_SHL1, 0xf, 0xf);  // lane i <- lane i+1
+  if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) {
+    nx = 0; ny = 0;
+    if (active && 4 * u + 4 < S) {
+      const uint2 t = *reinterpret_cast<const uint2*>(row + 4 * (size_t)u + 4);  // 16-byte aligned
+      nx = t.x; ny = t.y;
+    }
+  }
+  a[4] = nx; a[5] = ny;
+}
+
+// m[k] bit j  <=>  for every PAM position i: (pam[i] & base[32*(4u+k) + j + po + i]) != 0
+// (search_guides.py:32-46: set intersection per nibble; an N nibble matches any real base).
+__device__ __forceinline__ void pam_match(const uint32_t (&A)[6], const uint32_t (&C)[6], const uint32_t (&G)[6],
+                                          const uint32_t (&T)[6], uint64_t pam, int pamlen, int po, uint32_t (&m)[4]) {
+  m[0] = m[1] = m[2] = m[3] = 0xffffffffu;
+#pragma unroll 1
+  for (int i = 0; i < pamlen; ++i) {
+    const uint32_t nib = (uint32_t)(pam >> (4 * (pamlen - 1 - i))) & 15u;
+    if (nib == 15u) continue;  // wave-uniform: pam is a kernel argument
+    const int s = po + i;
+    // single-base PAM positions (the common case) shift the plane's registers directly
+    if (nib == 1u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] &= shifted(A, k, s);
+    } else if (nib == 2u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] &= shifted(C, k, s);
+    } else if (nib == 4u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] &= shifted(G, k, s);
+    } else if (nib == 8u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] &= shifted(T, k, s);
+    } else {
+      const uint32_t mA = (nib & 1u) ? 0xffffffffu : 0u, mC = (nib & 2u) ? 0xffffffffu : 0u;
+      const uint32_t mG = (nib & 4u) ? 0xffffffffu : 0u, mT = (nib & 8u) ? 0xffffffffu : 0u;
+      uint32_t sel[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sel[k] = (A[k] & mA) | (C[k] & mC) | (G[k] & mG) | (T[k] & mT);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] &= shifted(sel, k, s);
+    }
+  }
+}
+
+// v[k] bit j := OR of the original bits [32k+j, 32k+j+L), valid for k < 4 when L <= 64
+__device__ __forceinline__ void window_or(uint32_t (&v)[6], int L) {
+  int r = 1;
+  while (2 * r <= L && r < 32) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] |= fsh(v[k], v[k + 1], (uint32_t)r);
+    v[5] |= v[5] >> r;
+    r *= 2;
+  }
+  const int rem = L - r;
+  if (rem > 0) {
+    if (rem < 32) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] |= fsh(v[k], v[k + 1], (uint32_t)rem);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] |= v[k + 1];
+    }
+  }
+}
+
+// nbits (<= 64) bits of a plane row starting at bit position bp (row has >= 2 pad words)
+__device__ __forceinline__ uint64_t extract_bits(const uint32_t* __restrict__ row, uint32_t bp, int nbits) {
+  const uint32_t w = bp >> 5, sh = bp & 31u;
+  const uint64_t lo = (uint64_t)row[w] | ((uint64_t)row[w + 1] << 32);
+  uint64_t v = lo >> sh;
+  if (sh) v |= (uint64_t)row[w + 2] << (64 - sh);
+  if (nbits < 64) v &= (1ull << nbits) - 1ull;
+  return v;
+}
+// 4-bit IUPAC code at bit `off` of four core slices
+__device__ __forceinline__ uint32_t code_at(const uint64_t (&c)[4], int off) {
+  return (uint32_t)((c[0] >> off) & 1) | (uint32_t)((c[1] >> off) & 1) << 1 | (uint32_t)((c[2] >> off) & 1) << 2 |
+         (uint32_t)((c[3] >> off) & 1) << 3;
+}
+__device__ __forceinline__ int base_index(uint32_t code) {  // A,C,G,T -> 0..3, anything else -1
+  return (code & (code - 1u)) ? -1 : (code ? __builtin_ctz(code) : -1);
+}
+// haplotype position map (haplotype.py:90-159) as unit-slope segments, global-memory search
+__device__ __forceinline__ int64_t posmap_global(const HapSetDev& hs, uint32_t h, uint32_t rel) {
+  uint32_t lo = hs.seg_off[h], hi = hs.seg_off[h + 1];  // last k in [lo,hi) with seg_rel[k] <= rel
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (hs.seg_rel[mid] <= rel) lo = mid; else hi = mid;
+  }
+  return hs.seg_gen[lo] + (int64_t)(rel - hs.seg_rel[lo]);
+}

@@ -32,6 +32,7 @@ struct ScanParams {
   int32_t L;                  // guidelen + pamlen
   uint32_t bph;               // workgroups per haplotype row
   uint32_t need;              // bit p set: plane p is read by this PAM (bit 4: V plane)
+  uint32_t debug;             // ablation switch for profiling builds (0 in production)
 };
 
 // Totals written by k_offsets.
@@ -62,22 +63,26 @@ struct GuideParams {
   uint32_t bph;
 };
 
-// launch wrappers (hawk_kernels.hip)
+// Where the REF haplotype has candidate windows, per strand (scan range and in-range test of
+// REF expressed on the window start q), and the genomic position of its base 0.
+struct RefInfo {
+  int32_t index;
+  int32_t lo[2], hi[2];
+  int64_t startp;
+};
+
+// launch wrappers
 void hawk_launch_pack(hipStream_t st, const uint8_t* ascii, const uint64_t* seq_off, uint32_t hap0, uint32_t n_hap_batch,
                       uint64_t batch_base, const uint32_t* hap_len, uint32_t S, uint32_t* const* plane,
                       unsigned long long* bad_index);
-void hawk_launch_scan(hipStream_t st, int mode, const HapSetDev& hs, const ScanParams& p, uint32_t* keepF, uint32_t* keepR,
-                      uint32_t* counts, uint32_t* aux);
-void hawk_launch_offsets(hipStream_t st, const uint32_t* counts, uint64_t* offsets, uint64_t n, uint64_t n_first_half,
-                         const uint32_t* aux, uint64_t n_aux, ScanTotals* totals);
-void hawk_launch_emit_records(hipStream_t st, const HapSetDev& hs, uint32_t bph, const uint32_t* keepF, const uint32_t* keepR,
-                              const uint64_t* offsets, uint64_t* rec);
+void hawk_launch_scan_raw(hipStream_t st, const HapSetDev& hs, const ScanParams& p, uint32_t* keepF, uint32_t* keepR,
+                          uint32_t* counts);
 void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, const uint32_t* keepF, const uint32_t* keepR,
                            const uint64_t* offsets, uint64_t n_fwd_total, uint32_t* hits_fwd, uint32_t* hits_rev);
-void hawk_launch_guides(hipStream_t st, const HapSetDev& hs, const GuideParams& gp, const uint32_t* keepF,
-                        const uint32_t* keepR, const uint64_t* rec, uint64_t n_rec, GuideCols cols, uint8_t* valid,
-                        unsigned long long* n_invalid, int* status);
-void hawk_launch_compact(hipStream_t st, const uint8_t* valid, uint64_t n, uint32_t* blocksum, uint64_t* blockoff,
-                         GuideCols src, GuideCols dst);
+void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
+                        const RefInfo& ri, const uint32_t* tile_seg0, uint32_t* counts, unsigned long long* shards,
+                        const uint64_t* offsets, GuideCols out, int* status);
+void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
+                       const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals);
 void hawk_launch_cfd(hipStream_t st, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
                      const double* mm, const double* pamtab, double* out, int* status);

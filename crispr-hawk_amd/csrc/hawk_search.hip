@@ -1,0 +1,483 @@
+// hawk_search.hip — the fused guide-search kernel (K2 + K3 + K4 in one) and its offset scan.
+//
+// k_search<PASS> is launched twice over the same tiles (one workgroup = 1024 plane words =
+// 32 768 positions of one haplotype):
+//   PASS 0  count:  stream the planes, PAM-match both strands, apply scan-range / in-range /
+//                   REF-identical filters, classify the survivors against the REF haplotype
+//                   (remove_redundant_guides) and write ONE count per tile;
+//   (k_mscan1-3: exclusive scan of the tile counts -> row offsets, totals)
+//   PASS 1  emit:   recompute the same bits (cheaper than a keep-bit round trip through HBM:
+//                   0.625 B/position re-read vs 0.25 written + 0.25 read + the window lines),
+//                   and write finished guide rows - coordinates, flags, CFDon, packed window -
+//                   at deterministic offsets, coalesced.
+// Survivors of a tile are first compacted into an LDS list so that row work is spread evenly
+// over the 256 threads regardless of where in the tile the variants cluster; the tile's slice of
+// the haplotype position map sits in LDS next to it.
+//
+// Reference semantics: search_guides.py:32-46 (match), 87-99 (scan), 395-420 (in range),
+// 468-471 (REF-identical skip), 260-280 (coordinates), 340-369 (redundancy), 134-160 (window);
+// scoring.py:352-387 + cfdscore.py:53-95 after annotation.py:27-51 (CFDon).
+#include "hawk_bits.h"
+
+#define CAP 512    // survivors staged per round (2 per thread)
+#define NSEG 64    // position-map segments staged per tile
+#define TILE_WORDS (HAWK_BLOCK * HAWK_WPT)  // 1024 plane words per tile
+#define LDS_OFF 4                            // tile word w lives at s_pl[p][LDS_OFF + w]; word -1 at [3]
+#define LDS_ROW (TILE_WORDS + 8)             // + halo: 1 word before, 2 after (+ pad)
+
+__device__ __forceinline__ int seg_find(const uint32_t* s_rel, int n, uint32_t rel) {
+  int lo = 0, hi = n;  // last j in [0,n) with s_rel[j] <= rel (s_rel[0] <= every rel of the tile)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (s_rel[mid] <= rel) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// A <= 64-bit slice of a plane as two 32-bit words: every operation on it is a full-rate 32-bit
+// VALU op (per-lane variable 64-bit shifts are quarter rate on CDNA and dominated phase C).
+struct W2 { uint32_t lo, hi; };
+// 64 bits starting at tile-relative bit position bp (>= -32) of a staged plane slice
+__device__ __forceinline__ W2 ext_lds(const uint32_t* pl, int bp) {
+  const uint32_t x = (uint32_t)(bp + 32 * LDS_OFF);
+  const uint32_t w = x >> 5, sh = x & 31u;
+  const uint32_t a = pl[w], b = pl[w + 1], c = pl[w + 2];
+  return W2{fsh(a, b, sh), fsh(b, c, sh)};
+}
+// the same from global memory with one 12-byte request (rows are 4-byte aligned)
+struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+__device__ __forceinline__ W2 ext_glb(const uint32_t* __restrict__ row, uint32_t bp) {
+  const uint32_t w = bp >> 5, sh = bp & 31u;
+  const U3 t = *reinterpret_cast<const U3*>(row + w);
+  return W2{fsh(t.a, t.b, sh), fsh(t.b, t.c, sh)};
+}
+// reverse the low L bits of a slice (bit i <-> bit L-1-i), 32 < L <= 64 or L <= 32
+__device__ __forceinline__ W2 rev_bits(W2 v, int L) {
+  const uint32_t rl = __brev(v.hi), rh = __brev(v.lo);  // 64-bit reversal
+  const uint32_t sh = (uint32_t)(64 - L);               // then shift right by 64 - L (0 <= sh < 64)
+  if (sh == 0) return W2{rl, rh};
+  if (sh < 32) return W2{fsh(rl, rh, sh), rh >> sh};
+  return W2{sh == 32 ? rh : rh >> (sh - 32), 0u};
+}
+
+template <int PASS>
+__global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri,
+                                                        const uint32_t* __restrict__ tile_seg0, uint32_t* __restrict__ counts,
+                                                        unsigned long long* __restrict__ shards,
+                                                        const uint64_t* __restrict__ offsets, GuideCols out, int* status) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_pl[HAWK_PLANES][LDS_ROW];
+  __shared__ uint32_t s_list[CAP];
+  __shared__ uint32_t s_segrel[NSEG];
+  __shared__ int64_t s_seggen[NSEG];
+  __shared__ double s_cfd[PASS == 1 ? 336 : 1];
+  __shared__ uint32_t s_w[HAWK_BLOCK / WAVE];
+  __shared__ uint32_t s_acc[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t h = tile / p.bph, blk = tile % p.bph;
+  const uint32_t u = blk * HAWK_BLOCK + tid;
+  const bool active = u < hs.S / 4;
+  const size_t rowbase = (size_t)h * hs.S;
+  const int haplen = (int)hs.hap_len[h];
+  const int ss = hs.scan_start[h], se = hs.scan_stop[h];
+  const bool isref = hs.is_ref[h] != 0;
+  const bool dedup = ri.index >= 0 && !isref;  // rows of this tile can be redundant with REF
+  const bool stage = PASS == 1 || dedup;        // phase C runs if the tile has survivors
+  const uint32_t w0 = blk * TILE_WORDS;         // first plane word of the tile
+  const uint32_t tile_q0 = w0 * 32u;
+  const uint32_t tile_end = tile_q0 + TILE_WORDS * 32u + 64u;  // rel < tile_end can be looked up
+  if (tid < 4) s_acc[tid] = 0;
+
+  // ---- every global load of the tile is issued here, before any of it is consumed -------
+  uint32_t A[6] = {0, 0, 0, 0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0}, G[6] = {0, 0, 0, 0, 0, 0}, Tp[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t E[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0};
+  const uint32_t k0 = stage ? tile_seg0[tile] : 0u, kend = stage ? hs.seg_off[h + 1] : 0u;
+  if ((p.need & 1u) || stage) load6(hs.plane[0] + rowbase, u, hs.S, active, A);
+  if ((p.need & 2u) || stage) load6(hs.plane[1] + rowbase, u, hs.S, active, C);
+  if ((p.need & 4u) || stage) load6(hs.plane[2] + rowbase, u, hs.S, active, G);
+  if ((p.need & 8u) || stage) load6(hs.plane[3] + rowbase, u, hs.S, active, Tp);
+  uint32_t V[4] = {0, 0, 0, 0};
+  if (!isref) {  // workgroup-uniform: REF windows are never filtered
+    load6(hs.plane[4] + rowbase, u, hs.S, active, E);
+    V[0] = E[0]; V[1] = E[1]; V[2] = E[2]; V[3] = E[3];
+  } else if (stage && active) {
+    const uint4 v = *reinterpret_cast<const uint4*>(hs.plane[4] + rowbase + 4 * (size_t)u);
+    V[0] = v.x; V[1] = v.y; V[2] = v.z; V[3] = v.w;
+  }
+  uint32_t halo = 0, seg_r = 0xffffffffu;
+  int64_t seg_g = 0;
+  bool seg_in = false, ovf = false;
+  if (stage) {
+    if (tid < 3 * HAWK_PLANES) {
+      const uint32_t pl = tid / 3, j = tid % 3;  // j: 0 -> word -1, 1 -> word TILE_WORDS, 2 -> TILE_WORDS+1
+      const long long w = j == 0 ? (long long)w0 - 1 : (long long)w0 + TILE_WORDS + (j - 1);
+      if (w >= 0 && w < (long long)hs.S) halo = hs.plane[pl][rowbase + (size_t)w];
+    }
+    if (tid < NSEG) {  // the tile's slice of the position map
+      const uint32_t k = k0 + tid;
+      if (k < kend) {
+        seg_r = hs.seg_rel[k];
+        seg_g = hs.seg_gen[k];
+        seg_in = tid == 0 || seg_r < tile_end;
+      }
+    }
+    ovf = k0 + NSEG < kend && hs.seg_rel[k0 + NSEG] < tile_end;  // rare: > NSEG segments in a tile
+    if (PASS == 1 && gp.score_cfdon) for (uint32_t i = tid; i < 336; i += HAWK_BLOCK) s_cfd[i] = gp.cfd_mm[i];  // mm[320] then pam[16]
+  }
+
+  // ---- phase A: scan + filters on registers; stage the slices phase C reads --------------
+  if (stage) {
+    *reinterpret_cast<uint4*>(&s_pl[0][LDS_OFF + 4 * tid]) = make_uint4(A[0], A[1], A[2], A[3]);
+    *reinterpret_cast<uint4*>(&s_pl[1][LDS_OFF + 4 * tid]) = make_uint4(C[0], C[1], C[2], C[3]);
+    *reinterpret_cast<uint4*>(&s_pl[2][LDS_OFF + 4 * tid]) = make_uint4(G[0], G[1], G[2], G[3]);
+    *reinterpret_cast<uint4*>(&s_pl[3][LDS_OFF + 4 * tid]) = make_uint4(Tp[0], Tp[1], Tp[2], Tp[3]);
+    *reinterpret_cast<uint4*>(&s_pl[4][LDS_OFF + 4 * tid]) = make_uint4(V[0], V[1], V[2], V[3]);
+    if (tid < 3 * HAWK_PLANES) {
+      const uint32_t pl = tid / 3, j = tid % 3;
+      s_pl[pl][j == 0 ? LDS_OFF - 1 : LDS_OFF + TILE_WORDS + (j - 1)] = halo;
+    }
+    if (tid < NSEG) {
+      s_segrel[tid] = seg_in ? seg_r : 0xffffffffu;
+      s_seggen[tid] = seg_g;
+      if (seg_in) atomicAdd(&s_acc[3], 1u);
+    }
+  }
+  uint32_t kF[4], kR[4];
+  uint32_t cand = 0, hits = 0;
+  {
+    if (!isref) window_or(E, p.L);
+    const int poF = p.right ? 0 : p.guidelen, poR = p.right ? p.guidelen : 0;
+    uint32_t mF[4], mR[4];
+    pam_match(A, C, G, Tp, p.pam_fwd, p.pamlen, poF, mF);
+    pam_match(A, C, G, Tp, p.pam_rev, p.pamlen, poR, mR);
+    const int sloF = ss - poF, shiF = se - poF, sloR = ss - poR, shiR = se - poR;
+    const int qmin = HAWK_PAD, qmax = haplen - p.L - HAWK_PAD + 1;  // is_pamhit_in_range on q
+    const int loF = sloF > qmin ? sloF : qmin, hiF = shiF < qmax ? shiF : qmax;
+    const int loR = sloR > qmin ? sloR : qmin, hiR = shiR < qmax ? shiR : qmax;
+    const int base0 = (int)(u * 128u);
+    const bool interior = base0 >= loF && base0 >= loR && base0 + 128 <= hiF && base0 + 128 <= hiR;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t f = mF[k], r = mR[k];
+      if (!interior) {
+        const int b = base0 + 32 * k;
+        f &= range_mask(b, sloF, shiF);
+        r &= range_mask(b, sloR, shiR);
+        hits += __popc(f) + __popc(r);
+        f &= range_mask(b, loF, hiF);
+        r &= range_mask(b, loR, hiR);
+        cand += __popc(f) + __popc(r);
+      } else {
+        cand += __popc(f) + __popc(r);  // interior words: every PAM hit is also in range
+      }
+      kF[k] = active ? (f & E[k]) : 0u;
+      kR[k] = active ? (r & E[k]) : 0u;
+    }
+    if (interior) hits = cand;
+    if (!active) { cand = 0; hits = 0; }
+  }
+  const uint32_t cF = __popc(kF[0]) + __popc(kF[1]) + __popc(kF[2]) + __popc(kF[3]);
+  const uint32_t cR = __popc(kR[0]) + __popc(kR[1]) + __popc(kR[2]) + __popc(kR[3]);
+  // one scan for both strands: per-thread counts <= 128, workgroup totals <= 32768 < 2^16
+  uint32_t TT;
+  const uint32_t exFR = block_excl_scan<HAWK_BLOCK / WAVE>(cF | (cR << 16), s_w, &TT);  // barriers also publish the LDS staging
+  const uint32_t TF = TT & 0xffffu, TR = TT >> 16, exF = exFR & 0xffffu, exR = exFR >> 16;
+  const uint32_t T = TF + TR;
+
+  uint32_t nvalid = 0;  // this thread's share (PASS 0)
+  if (!stage || p.debug == 2) {
+    if (tid == 0) nvalid = T;
+  } else if (T) {  // workgroup-uniform
+    const int nloc = (int)s_acc[3];
+    const size_t refbase = ri.index >= 0 ? (size_t)ri.index * hs.S : 0;
+    uint64_t row_base = PASS == 1 ? offsets[tile] : 0;
+    const int L = p.L;
+    const int W = L + 2 * HAWK_PAD;
+    const uint32_t mlo = L >= 32 ? 0xffffffffu : ((1u << L) - 1u), mhi = L <= 32 ? 0u : ((1u << (L - 32)) - 1u);
+    const uint32_t wlo = 0xffffffffu, whi = W >= 64 ? 0xffffffffu : ((1u << (W - 32)) - 1u);  // W = L + 20 > 32
+    const int ncfd = gp.guidelen < 20 ? gp.guidelen : 20;
+    const uint32_t cfdmask = (1u << ncfd) - 1u;
+
+    for (uint32_t base = 0; base < T; base += CAP) {
+      // ---- phase B: survivors -> LDS list, strand 0 first, each in position order ------
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t idx = s ? TF + exR : exF;
+        const uint32_t cnt = s ? cR : cF;
+        if (cnt && idx < base + CAP && idx + cnt > base) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t x = s ? kR[k] : kF[k];
+            while (x) {
+              const uint32_t j = (uint32_t)__builtin_ctz(x);
+              x &= x - 1;
+              if (idx >= base && idx < base + CAP) s_list[idx - base] = ((uint32_t)s << 31) | ((4 * tid + k) * 32 + j);
+              ++idx;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (p.debug == 1) { if (tid == 0) nvalid += T - base < CAP ? T - base : CAP; __syncthreads(); continue; }
+      const uint32_t n = T - base < CAP ? T - base : CAP;
+      // ---- phase C: one survivor per thread per round ---------------------------------
+#pragma unroll 1
+      for (uint32_t k = 0; k < CAP / HAWK_BLOCK; ++k) {
+        if (k * HAWK_BLOCK >= n) break;  // workgroup-uniform
+        const uint32_t i = tid + k * HAWK_BLOCK;
+        uint32_t valid = 0;
+        uint32_t ql = 0, s = 0;  // ql: window start relative to the tile
+        int64_t start = 0, stop = 0;
+        bool has_ref = false;
+        W2 core[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, rcore[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        if (i < n) {
+          const uint32_t e = s_list[i];
+          s = e >> 31; ql = e & 0x7fffffffu;
+          const uint32_t q = tile_q0 + ql;
+          if (ovf) {
+            start = posmap_global(hs, h, q);
+            if (PASS == 1) stop = posmap_global(hs, h, q + (uint32_t)L);
+          } else {
+            const int j = seg_find(s_segrel, nloc, q);
+            start = s_seggen[j] + (int64_t)(q - s_segrel[j]);
+            if (PASS == 1) {  // search_guides.py:260-280: stop = posmap[q + L]
+              if (j + 1 >= nloc || s_segrel[j + 1] > q + (uint32_t)L) stop = start + L;
+              else { const int j2 = seg_find(s_segrel, nloc, q + (uint32_t)L); stop = s_seggen[j2] + (int64_t)(q + (uint32_t)L - s_segrel[j2]); }
+            }
+          }
+#pragma unroll
+          for (int pl = 0; pl < 4; ++pl) {
+            core[pl] = ext_lds(s_pl[pl], (int)ql);
+            core[pl].lo &= mlo; core[pl].hi &= mhi;
+            rcore[pl] = core[pl];
+          }
+          valid = 1;
+          if (ri.index >= 0) {
+            if (isref) {
+              has_ref = true;
+            } else {
+              // is there a REF guide with the same (start, strand)?  REF's position map is the
+              // identity, so its window starts at qr; it is a guide iff qr lies in REF's candidate
+              // range for this strand and REF's PAM matches there.
+              const int64_t qr = start - ri.startp;
+              if (qr >= ri.lo[s] && qr < ri.hi[s] && p.debug != 5) {
+                W2 rc[4];
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) {
+                  rc[pl] = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
+                  rc[pl].lo &= mlo; rc[pl].hi &= mhi;
+                }
+                // PAM test on REF's slice: for each PAM position the selected planes must have the bit
+                const bool pamfirst = (p.right != 0) != (s != 0);
+                const int po = pamfirst ? 0 : p.guidelen;
+                const uint64_t pam = s ? p.pam_rev : p.pam_fwd;
+                bool ok = true;
+                for (int t = 0; t < p.pamlen; ++t) {
+                  const uint32_t nib = (uint32_t)(pam >> (4 * (p.pamlen - 1 - t))) & 15u;
+                  const int off = po + t;
+                  uint32_t sel = 0;
+                  if (off < 32) {
+                    if (nib & 1u) sel |= rc[0].lo; if (nib & 2u) sel |= rc[1].lo;
+                    if (nib & 4u) sel |= rc[2].lo; if (nib & 8u) sel |= rc[3].lo;
+                  } else {
+                    if (nib & 1u) sel |= rc[0].hi; if (nib & 2u) sel |= rc[1].hi;
+                    if (nib & 4u) sel |= rc[2].hi; if (nib & 8u) sel |= rc[3].hi;
+                  }
+                  ok = ok && ((sel >> (off & 31)) & 1u);
+                }
+                if (ok) {
+                  has_ref = true;
+                  bool same = true;
+#pragma unroll
+                  for (int pl = 0; pl < 4; ++pl) {
+                    rcore[pl] = rc[pl];
+                    same = same && rc[pl].lo == core[pl].lo && rc[pl].hi == core[pl].hi;
+                  }
+                  if (same) valid = 0;  // an alt guide whose upper-cased spacer+PAM equals REF's is redundant
+                }
+              }
+            }
+          }
+        }
+        if (PASS == 0) {
+          nvalid += valid;
+        } else {
+          uint32_t tot;
+          const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(valid, s_w, &tot);
+          if (valid) {
+            const uint64_t o = row_base + ex;
+            if (o >= out.cap) { atomicExch(status, -3 /* HAWK_E_CAPACITY: offsets and counts disagree */); continue; }
+            const bool pamfirst = (p.right != 0) != (s != 0);
+            const uint32_t q = tile_q0 + ql;
+            out.hap[o] = h;
+            out.pos[o] = pamfirst ? q : q + (uint32_t)p.guidelen;
+            out.strand[o] = (uint8_t)s;
+            out.start[o] = start;
+            out.stop[o] = stop;
+            out.flags[o] = has_ref ? 1 : 0;
+#pragma unroll
+            for (int pl = 0; pl < HAWK_PLANES; ++pl) {
+              if (p.debug == 4) continue;
+              W2 w = ext_lds(s_pl[pl], (int)ql - HAWK_PAD);
+              w.lo &= wlo; w.hi &= whi;
+              out.win[(size_t)pl * out.cap + o] = (uint64_t)w.lo | ((uint64_t)w.hi << 32);
+            }
+            // K4: CFDon on the 5'->3' guide.  Strand-1 slices are first turned into the 5'->3' guide
+            // (reverse the L bits, swap A<->T and C<->G planes = reverse complement), after which both
+            // strands read spacer base t at bit t and PAM[-2:] at bits L-2, L-1.  Only positions where
+            // REF and this guide differ contribute, visited in ascending t so the fp64 product is
+            // formed exactly as cfdscore.py:78-95 forms it.
+            double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
+            if (gp.score_cfdon && has_ref && p.debug != 3) {
+              W2 g[4], r[4];
+              if (s) {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) { g[pl] = rev_bits(core[3 - pl], L); r[pl] = rev_bits(rcore[3 - pl], L); }
+              } else {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) { g[pl] = core[pl]; r[pl] = rcore[pl]; }
+              }
+              // spacer positions 0..min(guidelen,20)-1 all sit in the low word
+              uint32_t diff = ((g[0].lo ^ r[0].lo) | (g[1].lo ^ r[1].lo) | (g[2].lo ^ r[2].lo) | (g[3].lo ^ r[3].lo)) & cfdmask;
+              // a lookup needs both bases to be exactly one of A,C,G,T (else KeyError in the reference)
+              const uint32_t g2 = (g[0].lo & g[1].lo) | ((g[0].lo | g[1].lo) & (g[2].lo | g[3].lo)) | (g[2].lo & g[3].lo);
+              const uint32_t r2 = (r[0].lo & r[1].lo) | ((r[0].lo | r[1].lo) & (r[2].lo | r[3].lo)) | (r[2].lo & r[3].lo);
+              bool err = (diff & (g2 | r2)) != 0;
+              const uint32_t gb0 = g[1].lo | g[3].lo, gb1 = g[2].lo | g[3].lo;  // base index bits: A0 C1 G2 T3
+              const uint32_t rb0 = r[1].lo | r[3].lo, rb1 = r[2].lo | r[3].lo;
+              score = 1.0;
+              while (diff && !err) {
+                const uint32_t t = (uint32_t)__builtin_ctz(diff);
+                diff &= diff - 1;
+                const uint32_t a = ((rb0 >> t) & 1u) | (((rb1 >> t) & 1u) << 1);
+                const uint32_t b = ((gb0 >> t) & 1u) | (((gb1 >> t) & 1u) << 1);
+                score *= s_cfd[(t * 4 + a) * 4 + b];
+              }
+              if (!err) {
+                // PAM[-2:] = bits L-2, L-1 (wave-uniform positions)
+                uint32_t c0, c1;
+                {
+                  const int o0 = L - 2, o1 = L - 1;
+                  c0 = ((((o0 < 32 ? g[0].lo : g[0].hi) >> (o0 & 31)) & 1u)) | ((((o0 < 32 ? g[1].lo : g[1].hi) >> (o0 & 31)) & 1u) << 1) |
+                       ((((o0 < 32 ? g[2].lo : g[2].hi) >> (o0 & 31)) & 1u) << 2) | ((((o0 < 32 ? g[3].lo : g[3].hi) >> (o0 & 31)) & 1u) << 3);
+                  c1 = ((((o1 < 32 ? g[0].lo : g[0].hi) >> (o1 & 31)) & 1u)) | ((((o1 < 32 ? g[1].lo : g[1].hi) >> (o1 & 31)) & 1u) << 1) |
+                       ((((o1 < 32 ? g[2].lo : g[2].hi) >> (o1 & 31)) & 1u) << 2) | ((((o1 < 32 ? g[3].lo : g[3].hi) >> (o1 & 31)) & 1u) << 3);
+                }
+                const int p0 = base_index(c0), p1 = base_index(c1);
+                if (p0 < 0 || p1 < 0) err = true;
+                else score *= s_cfd[320 + 4 * p0 + p1];
+              }
+              if (err) { atomicExch(status, -5 /* HAWK_E_CFD */); score = __longlong_as_double(0x7ff8000000000000ll); }
+            }
+            out.cfdon[o] = score;
+          }
+          row_base += tot;
+        }
+      }
+      __syncthreads();  // the list is rewritten by the next round
+    }
+  }
+  if (PASS == 0) {
+    const uint32_t w0s = wave_sum(nvalid), w1s = wave_sum(cand | (hits << 16));  // per-wave sums < 2^16
+    if ((tid & (WAVE - 1)) == 0) {
+      atomicAdd(&s_acc[0], w0s); atomicAdd(&s_acc[1], w1s & 0xffffu); atomicAdd(&s_acc[2], w1s >> 16);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      counts[tile] = s_acc[0];
+      if (s_acc[1] | s_acc[2]) {
+        atomicAdd(&shards[(tile & 255u) * 2 + 0], (unsigned long long)s_acc[1]);
+        atomicAdd(&shards[(tile & 255u) * 2 + 1], (unsigned long long)s_acc[2]);
+      }
+    }
+  }
+}
+
+void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
+                        const RefInfo& ri, const uint32_t* tile_seg0, uint32_t* counts, unsigned long long* shards,
+                        const uint64_t* offsets, GuideCols out, int* status) {
+  const dim3 grid(hs.n_hap * p.bph), block(HAWK_BLOCK);
+  if (pass == 0) hipLaunchKernelGGL(k_search<0>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status);
+  else hipLaunchKernelGGL(k_search<1>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status);
+}
+
+// ---------------------------------------------------------------------------------------
+// multi-workgroup exclusive scan of u32 counts -> u64 offsets (3 small launches)
+// ---------------------------------------------------------------------------------------
+#define MS_TILE 1024  // entries per workgroup (4 per thread)
+
+__global__ __launch_bounds__(HAWK_BLOCK) void k_mscan1(const uint32_t* __restrict__ counts, uint64_t n,
+                                                        unsigned long long* __restrict__ partial) {
+  __shared__ unsigned long long s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const uint64_t i0 = (uint64_t)blockIdx.x * MS_TILE + threadIdx.x * 4;
+  unsigned long long s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (i0 + k < n) s += counts[i0 + k];
+  s = (unsigned long long)wave_sum((uint32_t)s) + ((unsigned long long)wave_sum((uint32_t)(s >> 32)) << 32);
+  if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&s_sum, s);
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_sum;
+}
+
+// single workgroup: exclusive scan of the partials in place, totals, shard sums
+__global__ __launch_bounds__(1024) void k_mscan2(unsigned long long* __restrict__ partial, uint64_t nb,
+                                                  const unsigned long long* __restrict__ shards, ScanTotals* totals) {
+  __shared__ unsigned long long s_part[1024];
+  __shared__ unsigned long long s_aux[2];
+  const uint32_t t = threadIdx.x;
+  if (t < 2) s_aux[t] = 0;
+  unsigned long long carry = 0;
+  for (uint64_t b0 = 0; b0 < nb; b0 += 1024) {
+    const unsigned long long v = b0 + t < nb ? partial[b0 + t] : 0;
+    s_part[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const unsigned long long x = t >= (uint32_t)d ? s_part[t - d] : 0;
+      __syncthreads();
+      s_part[t] += x;
+      __syncthreads();
+    }
+    if (b0 + t < nb) partial[b0 + t] = carry + s_part[t] - v;
+    const unsigned long long tot = s_part[1023];
+    __syncthreads();
+    carry += tot;
+  }
+  if (shards && t < 256) {
+    atomicAdd(&s_aux[0], shards[2 * t]);
+    atomicAdd(&s_aux[1], shards[2 * t + 1]);
+  }
+  __syncthreads();
+  if (t == 0) {
+    totals->n_keep = carry;
+    totals->n_keep_fwd = 0;
+    totals->n_cand = s_aux[0];
+    totals->n_hits = s_aux[1];
+  }
+}
+
+__global__ __launch_bounds__(HAWK_BLOCK) void k_mscan3(const uint32_t* __restrict__ counts, uint64_t n,
+                                                        const unsigned long long* __restrict__ partial_off,
+                                                        uint64_t* __restrict__ offsets) {
+  __shared__ uint32_t s_w[HAWK_BLOCK / WAVE];
+  const uint64_t i0 = (uint64_t)blockIdx.x * MS_TILE + threadIdx.x * 4;
+  uint32_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = i0 + k < n ? counts[i0 + k] : 0u;
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(c[0] + c[1] + c[2] + c[3], s_w, &tot);
+  uint64_t run = partial_off[blockIdx.x] + ex;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < n) offsets[i0 + k] = run;
+    run += c[k];
+  }
+}
+
+void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
+                       const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals) {
+  const uint32_t nb = (uint32_t)((n + MS_TILE - 1) / MS_TILE);
+  hipLaunchKernelGGL(k_mscan1, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial);
+  hipLaunchKernelGGL(k_mscan2, dim3(1), dim3(1024), 0, st, partial, (uint64_t)nb, shards, totals);
+  hipLaunchKernelGGL(k_mscan3, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial, offsets);
+}

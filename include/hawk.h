@@ -104,7 +104,10 @@ typedef struct {
 } hawk_search_params;
 
 typedef struct {          /* kernel times of the last hawk_search (HIP events on the ctx stream), ms */
-  float scan_ms, offsets_ms, emit_ms, guides_ms, compact_ms, total_ms;
+  float count_ms;   /* k_search<0>: scan + filters + redundancy classification -> tile counts */
+  float offsets_ms; /* k_mscan1-3: tile counts -> row offsets */
+  float emit_ms;    /* k_search<1>: re-scan + finished rows (coordinates, windows, CFDon) */
+  float total_ms;   /* first kernel start to last kernel end, including the host round trip for the row count */
   uint64_t scanned_positions; /* sum over haplotypes of (scan_stop - scan_start) */
 } hawk_timing;
 
