@@ -25,6 +25,7 @@ EXPORTS = [
     "hawk_sync", "hawk_hapset_create", "hawk_hapset_destroy", "hawk_hapset_pack_ascii", "hawk_hapset_set_meta",
     "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan",
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
+    "hawk_genome_finalize", "hawk_offtarget_scan",
 ]
 
 
@@ -55,6 +56,16 @@ class Timing(C.Structure):
         ("count_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("total_ms", C.c_float),
         ("scanned_positions", C.c_uint64),
     ]
+
+
+class OtParams(C.Structure):
+    _fields_ = [("pam_fwd", C.c_uint64), ("pam_rev", C.c_uint64), ("pamlen", C.c_uint32), ("guidelen", C.c_uint32),
+                ("right", C.c_uint32), ("max_mm", C.c_uint32)]
+
+
+class OtTiming(C.Structure):
+    _fields_ = [("scan_ms", C.c_float), ("sites_ms", C.c_float), ("match_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_sites", C.c_uint64), ("scanned_positions", C.c_uint64)]
 
 
 _lib: Optional[C.CDLL] = None

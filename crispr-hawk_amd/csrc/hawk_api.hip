@@ -65,7 +65,7 @@ struct hawk_hapset {
   uint32_t* d_tile_seg0;   // [n_hap * bph] first position-map segment each tile needs
   int64_t ref_startp;
   // workspace reused across searches
-  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial;
+  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides;
   DevBuf colsA[8];
 };
 
@@ -184,7 +184,8 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   if (hs->d_seg_rel) (void)hipFree(hs->d_seg_rel);
   if (hs->d_seg_gen) (void)hipFree(hs->d_seg_gen);
   (void)hipFree(hs->d_tile_seg0);
-  DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial};
+  DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
+                    &hs->sites, &hs->hits, &hs->guides};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   delete hs;
@@ -337,6 +338,7 @@ static int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pa
   }
   if (need_v) need |= 16u;
   sp->need = need;
+  sp->poF = 0; sp->poR = 0;
   { const char* e = getenv("HAWK_DEBUG_MODE"); sp->debug = e ? (uint32_t)atoi(e) : 0u; }
   return HAWK_OK;
 }
@@ -519,6 +521,105 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
   if (flags) *flags = c.flags;
   if (cfdon) *cfdon = c.cfdon;
   if (win) *win = c.win;
+  return HAWK_OK;
+}
+
+// ---------------------------------------------------------------------------- K7 off-targets
+int hawk_genome_finalize(hawk_hapset* rows) {
+  if (!rows) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(rows->ctx->device));
+  hawk_launch_ot_onehot(rows->ctx->stream, rows->plane, (uint64_t)rows->n_hap * rows->S);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(rows->ctx->stream));
+  return HAWK_OK;
+}
+
+int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t* guides2, uint32_t n_guides,
+                        uint32_t* out_guide, uint32_t* out_row, uint32_t* out_q, uint8_t* out_strand, uint8_t* out_mm,
+                        uint64_t* out_code, uint32_t* out_nmask, uint64_t cap, uint64_t* n_out, hawk_ot_timing* timing) {
+  if (!hs || !p || !hs->has_meta || !n_out || (n_guides && !guides2)) return HAWK_E_INVALID;
+  if (p->guidelen + p->pamlen > 32 || p->guidelen == 0) return HAWK_E_UNSUPPORTED;  // window code = 2 bits x 32
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  ScanParams sp;
+  int rc = make_scan_params(hs, p->pam_fwd, p->pam_rev, p->pamlen, p->guidelen, p->right, false, &sp);
+  if (rc) return rc;
+  // windows are indexed by their start q: strand 0 stores the + strand as the guide reads it,
+  // strand 1 the mirror image (same convention as the search, search_guides.py:538)
+  sp.poF = p->right ? 0 : (int32_t)p->guidelen;
+  sp.poR = p->right ? (int32_t)p->guidelen : 0;
+  const HapSetDev d = make_dev(hs);
+  const size_t words = (size_t)hs->n_hap * hs->S;
+  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph;
+  if ((rc = hs->keepF.reserve(words * 4)) || (rc = hs->keepR.reserve(words * 4)) || (rc = hs->counts.reserve(ncnt * 4)) ||
+      (rc = hs->offsets.reserve((ncnt + 1) * 8)) || (rc = hs->totals.reserve(sizeof(ScanTotals))) ||
+      (rc = hs->partial.reserve((ncnt / 1024 + 2) * 8)) || (rc = hs->misc.reserve(512 * 8 + 64)) ||
+      (rc = hs->guides.reserve(std::max<size_t>((size_t)n_guides * 8, 16))))
+    return rc;
+  hipEvent_t* ev = ctx->ev;
+  if (n_guides) HIPCHK(hipMemcpyAsync(hs->guides.p, guides2, (size_t)n_guides * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(hs->misc.p, 0, 64, ctx->stream));
+  HIPCHK(hipEventRecord(ev[0], ctx->stream));
+  hawk_launch_scan_raw(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>());
+  hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ncnt, hs->partial.as<unsigned long long>(), nullptr,
+                    hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
+  HIPCHK(hipEventRecord(ev[1], ctx->stream));
+  HIPCHK(hipGetLastError());
+  ScanTotals tot;
+  HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t nsites = tot.n_keep;
+  if ((rc = hs->sites.reserve(std::max<uint64_t>(nsites, 1) * sizeof(OtSite))) ||
+      (rc = hs->hits.reserve(std::max<uint64_t>(cap, 1) * sizeof(OtHit))))
+    return rc;
+  unsigned long long* d_nhits = hs->misc.as<unsigned long long>();
+  HIPCHK(hipEventRecord(ev[2], ctx->stream));
+  if (nsites) hawk_launch_ot_sites(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
+                                   hs->offsets.as<uint64_t>(), hs->sites.as<OtSite>());
+  HIPCHK(hipEventRecord(ev[3], ctx->stream));
+  hawk_launch_ot_match(ctx->stream, hs->sites.as<OtSite>(), nsites, hs->guides.as<uint64_t>(), n_guides, (int)p->guidelen,
+                       p->right ? (int)p->pamlen : 0, (int)p->max_mm, hs->hits.as<OtHit>(), cap, d_nhits);
+  HIPCHK(hipEventRecord(ev[4], ctx->stream));
+  HIPCHK(hipGetLastError());
+  unsigned long long nh = 0;
+  HIPCHK(hipMemcpyAsync(&nh, d_nhits, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n_out = nh;
+  if (timing) {
+    memset(timing, 0, sizeof(*timing));
+    (void)hipEventElapsedTime(&timing->scan_ms, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&timing->sites_ms, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&timing->match_ms, ev[3], ev[4]);
+    (void)hipEventElapsedTime(&timing->total_ms, ev[0], ev[4]);
+    timing->n_sites = nsites;
+    uint64_t pos = 0;
+    for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
+    timing->scanned_positions = pos;
+  }
+  if (nh > cap) return HAWK_E_CAPACITY;
+  if (!nh) return HAWK_OK;
+  std::vector<OtHit> hh(nh);
+  HIPCHK(hipMemcpy(hh.data(), hs->hits.p, nh * sizeof(OtHit), hipMemcpyDeviceToHost));
+  // the hit sites are few: download the site table only when it is small, else fetch hit by hit
+  std::vector<OtSite> ss(nh);
+  if (nsites * sizeof(OtSite) <= (256ull << 20)) {
+    std::vector<OtSite> all(nsites);
+    HIPCHK(hipMemcpy(all.data(), hs->sites.p, nsites * sizeof(OtSite), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < nh; ++i) ss[i] = all[hh[i].site];
+  } else {
+    for (uint64_t i = 0; i < nh; ++i)
+      HIPCHK(hipMemcpyAsync(&ss[i], hs->sites.as<OtSite>() + hh[i].site, sizeof(OtSite), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  for (uint64_t i = 0; i < nh; ++i) {
+    if (out_guide) out_guide[i] = hh[i].guide;
+    if (out_row) out_row[i] = ss[i].row;
+    if (out_q) out_q[i] = ss[i].q & 0x7fffffffu;
+    if (out_strand) out_strand[i] = (uint8_t)(ss[i].q >> 31);
+    if (out_mm) out_mm[i] = (uint8_t)hh[i].mm;
+    if (out_code) out_code[i] = ss[i].code;
+    if (out_nmask) out_nmask[i] = ss[i].nmask;
+  }
   return HAWK_OK;
 }
 

@@ -137,6 +137,16 @@ __device__ __forceinline__ void window_or(uint32_t (&v)[6], int L) {
   }
 }
 
+// A <= 64-bit slice of a plane as two 32-bit words: every operation on it is a full-rate 32-bit
+// VALU op (per-lane variable 64-bit shifts are quarter rate on CDNA and dominated phase C).
+struct W2 { uint32_t lo, hi; };
+// 64 bits of a plane row starting at bit bp, one 12-byte request (rows are 4-byte aligned, >= 2 pad words)
+struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+__device__ __forceinline__ W2 ext_glb(const uint32_t* __restrict__ row, uint32_t bp) {
+  const uint32_t w = bp >> 5, sh = bp & 31u;
+  const U3 t = *reinterpret_cast<const U3*>(row + w);
+  return W2{fsh(t.a, t.b, sh), fsh(t.b, t.c, sh)};
+}
 // nbits (<= 64) bits of a plane row starting at bit position bp (row has >= 2 pad words)
 __device__ __forceinline__ uint64_t extract_bits(const uint32_t* __restrict__ row, uint32_t bp, int nbits) {
   const uint32_t w = bp >> 5, sh = bp & 31u;

@@ -33,6 +33,7 @@ struct ScanParams {
   uint32_t bph;               // workgroups per haplotype row
   uint32_t need;              // bit p set: plane p is read by this PAM (bit 4: V plane)
   uint32_t debug;             // ablation switch for profiling builds (0 in production)
+  int32_t poF, poR;           // raw scan: PAM offset inside the window per strand (0 = index by PAM position)
 };
 
 // Totals written by k_offsets.
@@ -71,7 +72,22 @@ struct RefInfo {
   int64_t startp;
 };
 
+// K7 records
+struct OtSite {   // one PAM-bearing genome window in guide orientation
+  uint64_t code;  // base i of the window at bits 2i,2i+1 (A0 C1 G2 T3)
+  uint32_t nmask; // bit i: base i is ambiguous (N / IUPAC)
+  uint32_t q;     // window start inside the row | strand << 31
+  uint32_t row;
+  uint32_t pad;
+};
+struct OtHit { uint64_t site; uint32_t guide; uint32_t mm; };
+
 // launch wrappers
+void hawk_launch_ot_onehot(hipStream_t st, uint32_t* const* plane, uint64_t nwords);
+void hawk_launch_ot_sites(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const uint32_t* keepF, const uint32_t* keepR,
+                          const uint64_t* offsets, OtSite* sites);
+void hawk_launch_ot_match(hipStream_t st, const OtSite* sites, uint64_t n_sites, const uint64_t* guides, uint32_t n_guides,
+                          int guidelen, int sp0, int max_mm, OtHit* hits, uint64_t cap, unsigned long long* n_hits);
 void hawk_launch_pack(hipStream_t st, const uint8_t* ascii, const uint64_t* seq_off, uint32_t hap0, uint32_t n_hap_batch,
                       uint64_t batch_base, const uint32_t* hap_len, uint32_t S, uint32_t* const* plane,
                       unsigned long long* bad_index);

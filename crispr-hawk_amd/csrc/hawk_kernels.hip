@@ -104,8 +104,8 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_scan_raw(HapSetDev hs, ScanParam
   if (p.need & 4u) load6(hs.plane[2] + rowbase, u, hs.S, active, G);
   if (p.need & 8u) load6(hs.plane[3] + rowbase, u, hs.S, active, T);
   uint32_t mF[4], mR[4];
-  pam_match(A, C, G, T, p.pam_fwd, p.pamlen, 0, mF);
-  pam_match(A, C, G, T, p.pam_rev, p.pamlen, 0, mR);
+  pam_match(A, C, G, T, p.pam_fwd, p.pamlen, p.poF, mF);
+  pam_match(A, C, G, T, p.pam_rev, p.pamlen, p.poR, mR);
   const int base0 = (int)(u * 128u);
   uint32_t cF = 0, cR = 0;
 #pragma unroll

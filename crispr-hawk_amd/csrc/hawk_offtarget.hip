@@ -1,0 +1,145 @@
+// hawk_offtarget.hip — K7: mismatch-tolerant off-target enumeration on the GPU.
+//
+// Replaces the reference's external call `crispritz.py search <index> pam.txt guides.txt -mm M
+// -bDNA 0 -bRNA 0` (offtargets.py:222-293; CRISPRitz 2.6.6 is not vendored, so the semantics
+// are restated from the call site and from the fields the reference consumes, offtarget.py:
+// 77-101): every genome window, both strands, whose PAM positions hold an unambiguous base
+// inside the PAM's IUPAC set and whose spacer differs from a guide in at most `max_mm`
+// positions (an ambiguous genome base counts as a mismatch).
+//
+// The genome is a plane set like the haplotypes (contigs cut into equal rows on the host),
+// made one-hot: A,C,G,T planes keep only unambiguous bases, plane 4 marks ambiguous ones.
+//   k_ot_onehot   planes -> one-hot + ambiguity mask (once per genome)
+//   k_scan_raw    (hawk_kernels.hip) PAM hits of both strands as bitmaps, indexed by window start
+//   k_ot_sites    hit bits -> site records: the guidelen+pamlen window in guide orientation
+//                 (strand 1 reverse-complemented) as a 2-bit code + ambiguity mask
+//   k_ot_match    all pairs site x guide: XOR, fold to one bit per base, popcount, <= max_mm
+//                 survivors appended through a wave-aggregated atomic
+#include "hawk_bits.h"
+
+// reverse the low L (<= 32) bits
+__device__ __forceinline__ uint32_t rev32(uint32_t v, int L) { return __brev(v) >> (32 - L); }
+// spread the 32 bits of x to the even bit positions of a 64-bit word
+__device__ __forceinline__ uint64_t spread(uint32_t x) {
+  uint64_t v = x;
+  v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+  v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+  v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v;
+}
+
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ot_onehot(uint32_t* pA, uint32_t* pC, uint32_t* pG, uint32_t* pT, uint32_t* pV,
+                                                           uint64_t nwords) {
+  const uint64_t i = (uint64_t)blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  if (i >= nwords) return;
+  const uint32_t a = pA[i], c = pC[i], g = pG[i], t = pT[i];
+  const uint32_t multi = (a & c) | ((a | c) & (g | t)) | (g & t);  // two or more planes set: N, R, Y, ...
+  pA[i] = a & ~multi; pC[i] = c & ~multi; pG[i] = g & ~multi; pT[i] = t & ~multi;
+  pV[i] = multi;
+}
+void hawk_launch_ot_onehot(hipStream_t st, uint32_t* const* plane, uint64_t nwords) {
+  if (!nwords) return;
+  hipLaunchKernelGGL(k_ot_onehot, dim3((uint32_t)((nwords + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, plane[0],
+                     plane[1], plane[2], plane[3], plane[4], nwords);
+}
+
+// one workgroup per 1024-word tile of a genome row, as k_emit_hits: bit q of keepF/keepR = a
+// window starting at q has its PAM (strand 0: fwd pattern, strand 1: reverse complement).
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ot_sites(HapSetDev hs, ScanParams p, const uint32_t* __restrict__ keepF,
+                                                          const uint32_t* __restrict__ keepR,
+                                                          const uint64_t* __restrict__ offsets, OtSite* __restrict__ sites) {
+  __shared__ uint32_t s_w[HAWK_BLOCK / WAVE];
+  const uint32_t h = blockIdx.x / p.bph, blk = blockIdx.x % p.bph;
+  const uint32_t u = blk * HAWK_BLOCK + threadIdx.x;
+  const bool active = u < hs.S / 4;
+  const size_t rowbase = (size_t)h * hs.S;
+  const int L = p.L;
+  const uint32_t lmask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const uint32_t* keep = s ? keepR : keepF;
+    uint4 kw = make_uint4(0, 0, 0, 0);
+    if (active) kw = *reinterpret_cast<const uint4*>(keep + rowbase + 4 * (size_t)u);
+    const uint32_t c = __popc(kw.x) + __popc(kw.y) + __popc(kw.z) + __popc(kw.w);
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(c, s_w, &tot);
+    if (tot == 0) continue;  // workgroup-uniform
+    uint64_t o = offsets[((size_t)s * hs.n_hap + h) * p.bph + blk] + ex;
+    const uint32_t w[4] = {kw.x, kw.y, kw.z, kw.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t x = w[k];
+      while (x) {
+        const uint32_t j = (uint32_t)__builtin_ctz(x);
+        x &= x - 1;
+        const uint32_t q = (4 * u + k) * 32 + j;
+        uint32_t a = ext_glb(hs.plane[0] + rowbase, q).lo & lmask, cc = ext_glb(hs.plane[1] + rowbase, q).lo & lmask;
+        uint32_t g = ext_glb(hs.plane[2] + rowbase, q).lo & lmask, t = ext_glb(hs.plane[3] + rowbase, q).lo & lmask;
+        uint32_t nm = ext_glb(hs.plane[4] + rowbase, q).lo & lmask;
+        if (s) {  // guide orientation = reverse complement of the + strand window
+          const uint32_t ra = rev32(t, L), rc = rev32(g, L), rg = rev32(cc, L), rt = rev32(a, L);
+          a = ra; cc = rc; g = rg; t = rt; nm = rev32(nm, L);
+        }
+        (void)a;
+        OtSite st;
+        st.code = spread(cc | t) | (spread(g | t) << 1);  // base i at bits 2i,2i+1: A0 C1 G2 T3
+        st.nmask = nm;
+        st.q = q | ((uint32_t)s << 31);
+        st.row = h;
+        sites[o++] = st;
+      }
+    }
+  }
+}
+void hawk_launch_ot_sites(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const uint32_t* keepF, const uint32_t* keepR,
+                          const uint64_t* offsets, OtSite* sites) {
+  hipLaunchKernelGGL(k_ot_sites, dim3(hs.n_hap * p.bph), dim3(HAWK_BLOCK), 0, st, hs, p, keepF, keepR, offsets, sites);
+}
+
+// All pairs.  Each thread owns one site; the guides stream through LDS in chunks and are read
+// by every lane at the same address (LDS broadcast, conflict-free).  Per pair: XOR the 2-bit
+// codes, fold each base's two bits into one, add the ambiguity bits, popcount.
+#define OT_GCHUNK 1024
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ot_match(const OtSite* __restrict__ sites, uint64_t n_sites,
+                                                          const uint64_t* __restrict__ guides, uint32_t n_guides, int guidelen,
+                                                          int sp0, int max_mm, OtHit* __restrict__ hits, uint64_t cap,
+                                                          unsigned long long* __restrict__ n_hits) {
+  __shared__ uint64_t s_g[OT_GCHUNK];
+  const uint64_t i = (uint64_t)blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  const bool have = i < n_sites;
+  uint64_t code = 0;
+  uint32_t nmsp = 0;
+  const uint64_t smask = guidelen >= 32 ? ~0ull : ((1ull << (2 * guidelen)) - 1ull);
+  bool live = false;
+  if (have) {
+    const OtSite st = sites[i];
+    code = (st.code >> (2 * sp0)) & smask;
+    nmsp = (st.nmask >> sp0) & (guidelen >= 32 ? 0xffffffffu : ((1u << guidelen) - 1u));
+    live = __popc(nmsp) <= max_mm;  // more ambiguous bases than allowed mismatches: no guide can match
+  }
+  const uint64_t nm2 = spread(nmsp);  // ambiguity bits at the even positions, like the folded XOR
+  for (uint32_t g0 = 0; g0 < n_guides; g0 += OT_GCHUNK) {
+    const uint32_t ng = n_guides - g0 < OT_GCHUNK ? n_guides - g0 : OT_GCHUNK;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ng; t += HAWK_BLOCK) s_g[t] = guides[g0 + t];
+    __syncthreads();
+    if (!live) continue;
+    for (uint32_t t = 0; t < ng; ++t) {
+      const uint64_t x = code ^ s_g[t];
+      const uint64_t m = ((x | (x >> 1)) & 0x5555555555555555ull) | nm2;
+      const int mm = __popcll(m);
+      if (mm <= max_mm) {
+        const unsigned long long o = atomicAdd(n_hits, 1ull);  // the compiler aggregates this per wave
+        if (o < cap) { OtHit hh; hh.site = i; hh.guide = g0 + t; hh.mm = (uint32_t)mm; hits[o] = hh; }
+      }
+    }
+  }
+}
+void hawk_launch_ot_match(hipStream_t st, const OtSite* sites, uint64_t n_sites, const uint64_t* guides, uint32_t n_guides,
+                          int guidelen, int sp0, int max_mm, OtHit* hits, uint64_t cap, unsigned long long* n_hits) {
+  if (!n_sites || !n_guides) return;
+  hipLaunchKernelGGL(k_ot_match, dim3((uint32_t)((n_sites + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, sites, n_sites,
+                     guides, n_guides, guidelen, sp0, max_mm, hits, cap, n_hits);
+}

@@ -33,22 +33,12 @@ __device__ __forceinline__ int seg_find(const uint32_t* s_rel, int n, uint32_t r
   }
   return lo;
 }
-// A <= 64-bit slice of a plane as two 32-bit words: every operation on it is a full-rate 32-bit
-// VALU op (per-lane variable 64-bit shifts are quarter rate on CDNA and dominated phase C).
-struct W2 { uint32_t lo, hi; };
 // 64 bits starting at tile-relative bit position bp (>= -32) of a staged plane slice
 __device__ __forceinline__ W2 ext_lds(const uint32_t* pl, int bp) {
   const uint32_t x = (uint32_t)(bp + 32 * LDS_OFF);
   const uint32_t w = x >> 5, sh = x & 31u;
   const uint32_t a = pl[w], b = pl[w + 1], c = pl[w + 2];
   return W2{fsh(a, b, sh), fsh(b, c, sh)};
-}
-// the same from global memory with one 12-byte request (rows are 4-byte aligned)
-struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
-__device__ __forceinline__ W2 ext_glb(const uint32_t* __restrict__ row, uint32_t bp) {
-  const uint32_t w = bp >> 5, sh = bp & 31u;
-  const U3 t = *reinterpret_cast<const U3*>(row + w);
-  return W2{fsh(t.a, t.b, sh), fsh(t.b, t.c, sh)};
 }
 // reverse the low L bits of a slice (bit i <-> bit L-1-i), 32 < L <= 64 or L <= 32
 __device__ __forceinline__ W2 rev_bits(W2 v, int L) {

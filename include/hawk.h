@@ -129,6 +129,25 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
                               void** flags, void** cfdon, void** win);
 
+/* ---- K7: off-target enumeration, replacing the external `crispritz.py search ... -mm M -bDNA 0
+ * -bRNA 0` of offtargets.py:222-293 (CRISPRitz 2.6.6 is a third-party binary the reference shells
+ * out to; semantics restated from the call site and the consumed fields, offtarget.py:77-101).
+ * The genome is a hawk_hapset whose rows are equal-sized contig pieces (made on the host, each
+ * piece overlapping the next by guidelen+pamlen-1 bases; scan_start/scan_stop of a row = the
+ * window starts it owns).  hawk_genome_finalize() turns the planes one-hot once after packing.
+ * guides2: one 64-bit word per guide, spacer base i (5'->3') at bits 2i,2i+1 with A0 C1 G2 T3.
+ * A hit = window whose PAM positions hold unambiguous bases inside the PAM's IUPAC sets and whose
+ * spacer has <= max_mm mismatches (ambiguous genome bases count as mismatches), either strand.
+ * Outputs (cap entries each, any may be NULL): guide index, row, window start in the row, strand,
+ * mismatches, the window in guide orientation as a 2-bit code, its ambiguity mask.  Unordered.
+ * If more than cap hits exist returns HAWK_E_CAPACITY with *n_out = required. */
+typedef struct { uint64_t pam_fwd, pam_rev; uint32_t pamlen, guidelen, right, max_mm; } hawk_ot_params;
+typedef struct { float scan_ms, sites_ms, match_ms, total_ms; uint64_t n_sites, scanned_positions; } hawk_ot_timing;
+int hawk_genome_finalize(hawk_hapset* rows);
+int hawk_offtarget_scan(hawk_hapset* rows, const hawk_ot_params* p, const uint64_t* guides2, uint32_t n_guides,
+                        uint32_t* out_guide, uint32_t* out_row, uint32_t* out_q, uint8_t* out_strand, uint8_t* out_mm,
+                        uint64_t* out_code, uint32_t* out_nmask, uint64_t cap, uint64_t* n_out, hawk_ot_timing* timing);
+
 /* ---- K4 stand-alone: compute_cfd() (scores/cfdscore/cfdscore.py:53-95) on n triples --------
  * wt / sg: n spacers of `len` characters each (host, contiguous, any case, T or U); pam2: n
  * two-character strings (the caller passes guide.pam[-2:], crisprhawk_scores.py:84-86).

@@ -1,0 +1,59 @@
+"""K7 off-target scan vs the oracle's brute force (parity UNPINNED to the reference: it delegates
+this to the external CRISPRitz binary; see oracle/hawk_oracle.c).  Bit-exact row sets."""
+import numpy as np
+import pytest
+
+from crisprhawk_hip import synth
+from crisprhawk_hip.genome import GenomeIndex
+from crisprhawk_hip.pam import PAM
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _plant(rng, genome: list, guide: str, pam_seq: str, right: bool, n: int, max_mm: int):
+    """write mutated copies of guide+PAM (both strands) into the genome so there is something to find"""
+    L = len(guide) + len(pam_seq)
+    for _ in range(n):
+        g = list(guide)
+        for p in rng.integers(0, len(g), size=int(rng.integers(0, max_mm + 2))):
+            g[p] = "ACGT"[rng.integers(0, 4)]
+        w = (pam_seq + "".join(g)) if right else ("".join(g) + pam_seq)
+        if rng.random() < 0.5:
+            w = ora.revcomp(w)
+        pos = int(rng.integers(0, len(genome) - L))
+        genome[pos:pos + L] = list(w)
+
+
+@pytest.mark.parametrize("pam_s,guidelen,right,max_mm,piece", [("NGG", 20, False, 4, 1 << 22), ("TTTV", 23, True, 3, 4096),
+                                                              ("NNGRRT", 21, False, 2, 10000)])
+def test_offtarget_scan_matches_bruteforce(pam_s, guidelen, right, max_mm, piece):
+    rng = np.random.default_rng(77)
+    contigs = {}
+    guides = [synth.random_sequence(rng, guidelen) for _ in range(6)]
+    concrete = {"NGG": "TGG", "TTTV": "TTTA", "NNGRRT": "ACGAGT"}[pam_s]
+    for name, n in (("c1", 60_000), ("c2", 25_001), ("c3", 300)):
+        g = list(synth.random_sequence(rng, n, iupac_frac=0.001))
+        for gd in guides:
+            _plant(rng, g, gd, concrete, right, 12 if n > 1000 else 1, max_mm)
+        if n > 5000:  # an N run: must not produce hits nor blow up
+            g[3000:3400] = "N" * 400
+        contigs[name] = "".join(g)
+    pam = PAM(pam_s, right, True)
+    pam.encode(0)
+    idx = GenomeIndex(contigs, guidelen, len(pam_s), piece=piece)
+    got = idx.scan(guides, pam, right, max_mm, cap=64)  # small cap: exercises the capacity retry
+    want = []
+    for name, seq in contigs.items():
+        for r in ora.offtargets(seq, guides, pam_s, right, max_mm):
+            want.append((int(r["guide"]), name, int(r["pos"]), "-" if r["strand"] else "+", int(r["mm"])))
+    ci = {n: i for i, n in enumerate(contigs)}
+    want.sort(key=lambda t: (t[0], ci[t[1]], t[2], t[3] == "-"))
+    assert len(want) > 20
+    assert [(h.guide, h.contig, h.position, h.strand, h.mm) for h in got] == want
+    # the reported window is the genome window in guide orientation
+    L = guidelen + len(pam_s)
+    for h in got[:200]:
+        w = contigs[h.contig][h.position:h.position + L].upper()
+        w = ora.revcomp(w) if h.strand == "-" else w
+        assert h.window == "".join(c if c in "ACGT" else "N" for c in w)
