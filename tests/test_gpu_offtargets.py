@@ -57,3 +57,43 @@ def test_offtarget_scan_matches_bruteforce(pam_s, guidelen, right, max_mm, piece
         w = contigs[h.contig][h.position:h.position + L].upper()
         w = ora.revcomp(w) if h.strand == "-" else w
         assert h.window == "".join(c if c in "ACGT" else "N" for c in w)
+
+
+def test_offtargets_search_pipeline(tmp_path):
+    """search() -> offtargets_search(): per-guide counts and global CFD 100/(100+sum) as in the
+    reference's annotate_guides_offtargets (offtargets.py:597-627)."""
+    from types import SimpleNamespace
+    from crisprhawk_hip import scoring
+    from crisprhawk_hip.coordinate import Coordinate
+    from crisprhawk_hip.haplotype import Haplotype
+    from crisprhawk_hip.region import Region
+    from crisprhawk_hip.search_guides import search
+    from crisprhawk_hip.annotation import reverse_guides
+    from crisprhawk_hip.search_offtargets import offtargets_search
+    from crisprhawk_hip.sequence import Sequence
+
+    reg = synth.make_region(901, "chrG", 30_000, 10_000, 10_400)
+    region = Region(Sequence(reg.sequence, True), Coordinate("chrG", 10_000, 10_400, 100))
+    hap = Haplotype(Sequence(reg.sequence, True), region.coordinates, False, 0, True)
+    hap.id = "hap_ref"
+    pam = PAM("NGG", False, True)
+    pam.encode(0)
+    guides = reverse_guides(search(pam, region, [hap], None, 20, False, False, False, 0, True), 0)
+    assert len(guides) > 10
+    mm, pt = synth.cfd_tables()
+    scoring.set_cfd_tables(mm, pt)
+    args = SimpleNamespace(verbosity=0, debug=True, crispritz_index={"chrG": reg.contig_seq}, mm=3, bdna=0, brna=0,
+                           guidelen=20, right=False, outdir=str(tmp_path))
+    out = offtargets_search({region: guides}, pam, args)[region]
+    for g in out[:25]:
+        rows = ora.offtargets(reg.contig_seq, [g.guide.upper()], "NGG", False, 3)
+        assert int(g.offtargets) == len(rows) >= 1  # the on-target site itself is always there
+        tot = 0.0
+        for r in rows:
+            w = reg.contig_seq[int(r["pos"]):int(r["pos"]) + 23]
+            w = ora.revcomp(w) if r["strand"] else w
+            tot += round(ora.cfd(g.guide.upper(), w[:20], w[-2:], mm, pt), 4)
+        assert g.cfd == str(round(100 / (100 + tot), 4))
+    tsv = (tmp_path / "offtargets_chrG_10000_10400.tsv").read_text().splitlines()
+    assert tsv[0].split("\t") == ["chrom", "position", "strand", "grna", "spacer", "pam", "mm", "bulge_size", "bulg_type", "cfd", "elevation"]
+    assert len(tsv) - 1 >= len(out)
