@@ -11,10 +11,10 @@ from typing import Dict, List, Optional, Tuple, Union
 import numpy as np
 
 from . import _lib
-from .crisprhawk_error import CrisprHawkCfdScoreError
+from .crisprhawk_error import CrisprHawkCfdScoreError, CrisprHawkDeepCpf1ScoreError
 from .exception_handlers import exception_handler
 from .guide import GUIDESEQPAD, Guide
-from .pam import PAM, SPCAS9, XCAS9
+from .pam import CPF1, PAM, SPCAS9, XCAS9
 from .utils import VERBOSITYLVL, flatten_list, print_verbosity
 
 _CFD_TABLES: Optional[Tuple[np.ndarray, np.ndarray]] = None
@@ -126,11 +126,75 @@ def cfdon_score(guides: List[Guide], verbosity: int, debug: bool) -> List[Guide]
     return flatten_list([members for _, (_, members) in groups.items()])
 
 
+# ---------------------------------------------------------------------------- DeepCpf1 (K6)
+_DEEPCPF1_W: Optional[np.ndarray] = None
+_DC_KEYS = ("conv_w", "conv_b", "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")
+_DC_SHAPES = ((80, 4, 5), (80,), (80, 1200), (80,), (40, 80), (40,), (40, 40), (40,), (1, 40), (1,))
+
+
+def set_deepcpf1_weights(w: Dict[str, np.ndarray]) -> None:
+    """Parameters in the torch layout of the reference's SeqDeepCpf1 (seqdeepcpf1.py:43-56):
+    conv_w (80,4,5), conv_b, w1 (80,1200), b1, w2 (40,80), b2, w3 (40,40), b3, w4 (1,40), b4."""
+    global _DEEPCPF1_W
+    parts = []
+    for k, shp in zip(_DC_KEYS, _DC_SHAPES):
+        a = np.ascontiguousarray(w[k], dtype=np.float32)
+        if a.shape != shp:
+            raise ValueError(f"DeepCpf1 parameter {k} has shape {a.shape}, expected {shp}")
+        parts.append(a.reshape(-1))
+    _DEEPCPF1_W = np.concatenate(parts)
+
+
+def deepcpf1_weights_from_keras(kw: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The Keras arrays of Seq_deepCpf1_weights.h5 -> torch layout, with the transposes / kernel
+    flip of load_deepcpf1_weights (seqdeepcpf1.py:113-124).  Keys: convolution1d_157_W/_b,
+    dense_490.._493 _W/_b (read them with any HDF5 reader; h5py is not a dependency here)."""
+    cw = np.asarray(kw["convolution1d_157_W"], dtype=np.float32)  # (5, 1, 4, 80)
+    cw = np.flip(np.transpose(np.squeeze(cw, 1), (2, 1, 0)), -1)
+    out = {"conv_w": cw, "conv_b": kw["convolution1d_157_b"]}
+    for i, name in enumerate(("dense_490", "dense_491", "dense_492", "dense_493")):
+        out[f"w{i + 1}"] = np.asarray(kw[f"{name}_W"], dtype=np.float32).T
+        out[f"b{i + 1}"] = kw[f"{name}_b"]
+    return out
+
+
+def deepcpf1(guides: List[str], debug: bool = True) -> List[float]:
+    """scores/crisprhawk_scores.py:90-107 on the GPU: 34-mers -> scores."""
+    if _DEEPCPF1_W is None:
+        exception_handler(CrisprHawkDeepCpf1ScoreError, "DeepCpf1 weights not loaded (scoring.set_deepcpf1_weights)",
+                          os.EX_NOINPUT, debug)
+    n = len(guides)
+    if n == 0:
+        return []
+    if any(len(gd) != 34 for gd in guides):
+        exception_handler(CrisprHawkDeepCpf1ScoreError, "DeepCpf1 score calculation failed (34-nt inputs required)",
+                          os.EX_DATAERR, debug)
+    out = np.empty(n, dtype=np.float32)
+    rc = _lib.lib().hawk_deepcpf1(_lib.context(), "".join(guides).encode("ascii"), C.c_uint64(n),
+                                  _DEEPCPF1_W.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    if rc == _lib.HAWK_E_IUPAC:
+        exception_handler(CrisprHawkDeepCpf1ScoreError, "DeepCpf1 score calculation failed", os.EX_DATAERR, debug)
+    _lib.check(rc, "hawk_deepcpf1")
+    return [float(x) for x in out]
+
+
+def deepcpf1_score(guides: List[Guide], threads: int, verbosity: int, debug: bool) -> List[Guide]:
+    """scoring.py:456-497 (one GPU batch; ``threads`` is ignored)."""
+    if not guides:
+        return guides
+    print_verbosity("Computing DeepCpf1 score", verbosity, VERBOSITYLVL[3])
+    for g, s in zip(guides, deepcpf1(_extract_guide_sequences(guides), debug)):
+        g.deepcpf1_score = s
+    return guides
+
+
 def scoring_guides(guides: Dict, pam: PAM, scoring_envs, args) -> Dict:
     """scoring.py:816-867, restricted to the scorers whose parameters can be supplied offline:
-    CFDon for SpCas9/xCas9 PAMs (749-792)."""
+    CFDon for SpCas9/xCas9 PAMs (749-792), DeepCpf1 for Cpf1 PAMs with --right (795-813)."""
     for region, guides_list in guides.items():
         if pam.cas_system in (SPCAS9, XCAS9):
             guides_list = cfdon_score(guides_list, args.verbosity, args.debug)
+        elif pam.cas_system == CPF1 and _DEEPCPF1_W is not None:
+            guides_list = deepcpf1_score(guides_list, args.threads, args.verbosity, args.debug)
         guides[region] = guides_list
     return guides

@@ -649,4 +649,25 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
   return status;
 }
 
+// ---------------------------------------------------------------------------- K6 DeepCpf1
+int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* weights, float* out) {
+  if (!ctx || !weights || (n && (!seqs34 || !out))) return HAWK_E_INVALID;
+  if (!n) return HAWK_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nw = HAWK_DEEPCPF1_NPARAMS;
+  char* d_s = nullptr; float *d_w = nullptr, *d_o = nullptr; int* d_status = nullptr;
+  HIPCHK(hipMalloc(&d_s, n * 34)); HIPCHK(hipMalloc(&d_w, nw * 4)); HIPCHK(hipMalloc(&d_o, n * 4)); HIPCHK(hipMalloc(&d_status, 4));
+  HIPCHK(hipMemcpyAsync(d_s, seqs34, n * 34, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_w, weights, nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream));
+  hawk_launch_deepcpf1(ctx->stream, d_s, n, d_w, d_o, d_status);
+  HIPCHK(hipGetLastError());
+  int status = 0;
+  HIPCHK(hipMemcpyAsync(out, d_o, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_s); (void)hipFree(d_w); (void)hipFree(d_o); (void)hipFree(d_status);
+  return status;
+}
+
 }  // extern "C"

@@ -102,3 +102,4 @@ void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsig
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals);
 void hawk_launch_cfd(hipStream_t st, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
                      const double* mm, const double* pamtab, double* out, int* status);
+void hawk_launch_deepcpf1(hipStream_t st, const char* seqs, uint64_t n, const float* w, float* out, int* status);

@@ -156,6 +156,15 @@ int hawk_offtarget_scan(hawk_hapset* rows, const hawk_ot_params* p, const uint64
 int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
              const double* cfd_mm, const double* cfd_pam, double* out);
 
+/* ---- K6: Seq-DeepCpf1 (scores/deepCpf1/seqdeepcpf1.py:22-92; wrapper scores/crisprhawk_scores.py:
+ * 90-107): n 34-mers (host, contiguous, ACGT any case) -> n fp32 scores.  `weights` is one packed
+ * fp32 block in the torch layout of SeqDeepCpf1: conv.weight[80][4][5], conv.bias[80],
+ * fc1.weight[80][1200], fc1.bias[80], fc2.weight[40][80], fc2.bias[40], fc3.weight[40][40],
+ * fc3.bias[40], output.weight[1][40], output.bias[1].  A non-ACGT base -> HAWK_E_IUPAC (the
+ * reference's KeyError, seqdeepcpf1.py:91). */
+#define HAWK_DEEPCPF1_NPARAMS (1600 + 80 + 96000 + 80 + 3200 + 40 + 1600 + 40 + 40 + 1)
+int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* weights, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,14 @@ def test_cfd_batch_bit_exact_and_errors():
         scoring.compute_cfd_batch(["ACGTN"], ["ACGTA"], ["GG"], True)
     with pytest.raises(CrisprHawkCfdScoreError):
         scoring.compute_cfd_batch(["ACGT"], ["ACGT"], ["NG"], True)
+
+
+def test_deepcpf1_kernel_against_reference_forward():
+    g6 = load_golden("g6_deepcpf1.json.gz")  # SeqDeepCpf1 (torch, fp32) run by the reference, seeded weights
+    scoring.set_deepcpf1_weights(synth.deepcpf1_weights(g6["seed"]))
+    got = np.array(scoring.deepcpf1(g6["seqs"]))
+    assert np.max(np.abs(got - np.array(g6["scores"]))) < 1e-6  # fp32 tolerance stated by north_star
+    assert scoring.deepcpf1([s.lower() for s in g6["seqs"][:3]]) == pytest.approx(g6["scores"][:3], abs=1e-6)
+    from crisprhawk_hip.crisprhawk_error import CrisprHawkDeepCpf1ScoreError
+    with pytest.raises(CrisprHawkDeepCpf1ScoreError):
+        scoring.deepcpf1(["ACGT" * 8 + "NN"])
