@@ -25,7 +25,7 @@ EXPORTS = [
     "hawk_sync", "hawk_hapset_create", "hawk_hapset_destroy", "hawk_hapset_pack_ascii", "hawk_hapset_set_meta",
     "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan",
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
-    "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1",
+    "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth",
 ]
 
 
@@ -56,6 +56,12 @@ class Timing(C.Structure):
         ("count_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("total_ms", C.c_float),
         ("scanned_positions", C.c_uint64),
     ]
+
+
+class GbtModel(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("n_nodes", C.c_uint32), ("tree_off", C.c_void_p), ("feature", C.c_void_p),
+                ("left", C.c_void_p), ("right", C.c_void_p), ("threshold", C.c_void_p), ("value", C.c_void_p),
+                ("init", C.c_double), ("learning_rate", C.c_double)]
 
 
 class OtParams(C.Structure):

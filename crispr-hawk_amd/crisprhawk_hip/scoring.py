@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import numpy as np
 
 from . import _lib
-from .crisprhawk_error import CrisprHawkCfdScoreError, CrisprHawkDeepCpf1ScoreError
+from .crisprhawk_error import CrisprHawkAzimuthScoreError, CrisprHawkCfdScoreError, CrisprHawkDeepCpf1ScoreError
 from .exception_handlers import exception_handler
 from .guide import GUIDESEQPAD, Guide
 from .pam import CPF1, PAM, SPCAS9, XCAS9
@@ -188,11 +188,79 @@ def deepcpf1_score(guides: List[Guide], threads: int, verbosity: int, debug: boo
     return guides
 
 
+# ---------------------------------------------------------------------------- Azimuth (K5)
+_AZIMUTH_MODEL: Optional[Dict] = None
+
+
+def azimuth_model_from_sklearn(gbr) -> Dict:
+    """Flatten a fitted sklearn GradientBoostingRegressor (what the reference unpickles from
+    saved_models/V3_model_nopos.pickle, model_comparison.py:538-550) into the arrays hawk_azimuth takes."""
+    tree_off, feature, left, right, thr, val = [0], [], [], [], [], []
+    for est in gbr.estimators_[:, 0]:
+        t = est.tree_
+        for k in range(t.node_count):
+            leaf = t.children_left[k] == -1
+            feature.append(-1 if leaf else int(t.feature[k]))
+            left.append(0 if leaf else int(t.children_left[k]))
+            right.append(0 if leaf else int(t.children_right[k]))
+            thr.append(float(t.threshold[k]))
+            val.append(float(t.value[k, 0, 0]))
+        tree_off.append(len(feature))
+    init = gbr.init_
+    init_val = float(init.constant_[0, 0]) if hasattr(init, "constant_") else float(np.ravel(init.predict(np.zeros((1, gbr.n_features_in_))))[0])
+    return dict(tree_off=np.array(tree_off, np.int32), feature=np.array(feature, np.int32), left=np.array(left, np.int32),
+                right=np.array(right, np.int32), threshold=np.array(thr, np.float64), value=np.array(val, np.float64),
+                init=init_val, learning_rate=float(gbr.learning_rate))
+
+
+def set_azimuth_model(model) -> None:
+    """A dict of flattened arrays (see azimuth_model_from_sklearn) or a fitted sklearn GBR."""
+    global _AZIMUTH_MODEL
+    _AZIMUTH_MODEL = model if isinstance(model, dict) else azimuth_model_from_sklearn(model)
+
+
+def azimuth(guides, debug: bool = True, return_features: bool = False):
+    """scores/crisprhawk_scores.py:31-44 (azimuth.model_comparison.predict) on the GPU: 30-mers -> scores."""
+    if _AZIMUTH_MODEL is None:
+        exception_handler(CrisprHawkAzimuthScoreError, "Azimuth model not loaded (scoring.set_azimuth_model)", os.EX_NOINPUT, debug)
+    guides = [str(x) for x in guides]
+    n = len(guides)
+    if n == 0:
+        return []
+    if any(len(gd) != 30 for gd in guides):
+        exception_handler(CrisprHawkAzimuthScoreError, "Azimuth score calculation failed (30-nt inputs required)", os.EX_DATAERR, debug)
+    m = _AZIMUTH_MODEL
+    arrs = {k: np.ascontiguousarray(m[k], dtype=(np.float64 if k in ("threshold", "value") else np.int32))
+            for k in ("tree_off", "feature", "left", "right", "threshold", "value")}
+    gm = _lib.GbtModel(len(arrs["tree_off"]) - 1, len(arrs["feature"]), *[arrs[k].ctypes.data for k in
+                       ("tree_off", "feature", "left", "right", "threshold", "value")], float(m["init"]), float(m["learning_rate"]))
+    out = np.empty(n, dtype=np.float64)
+    feats = np.empty((n, 627), dtype=np.float64) if return_features else None
+    rc = _lib.lib().hawk_azimuth(_lib.context(), "".join(guides).encode("ascii"), C.c_uint64(n), C.byref(gm),
+                                 out.ctypes.data_as(C.c_void_p), feats.ctypes.data_as(C.c_void_p) if return_features else None)
+    if rc == _lib.HAWK_E_IUPAC:
+        exception_handler(CrisprHawkAzimuthScoreError, "Azimuth score calculation failed", os.EX_DATAERR, debug)
+    _lib.check(rc, "hawk_azimuth")
+    return (list(out), feats) if return_features else list(out)
+
+
+def azimuth_score(guides: List[Guide], threads: int, verbosity: int, debug: bool) -> List[Guide]:
+    """scoring.py:152-193 (one GPU batch; ``threads`` is ignored)."""
+    if not guides:
+        return guides
+    print_verbosity("Computing Azimuth score", verbosity, VERBOSITYLVL[3])
+    for g, s in zip(guides, azimuth(_extract_guide_sequences(guides), debug)):
+        g.azimuth_score = float(s)
+    return guides
+
+
 def scoring_guides(guides: Dict, pam: PAM, scoring_envs, args) -> Dict:
     """scoring.py:816-867, restricted to the scorers whose parameters can be supplied offline:
-    CFDon for SpCas9/xCas9 PAMs (749-792), DeepCpf1 for Cpf1 PAMs with --right (795-813)."""
+    Azimuth (when a model is set) + CFDon for SpCas9/xCas9 PAMs (749-792), DeepCpf1 for Cpf1 PAMs with --right (795-813)."""
     for region, guides_list in guides.items():
         if pam.cas_system in (SPCAS9, XCAS9):
+            if _AZIMUTH_MODEL is not None:
+                guides_list = azimuth_score(guides_list, args.threads, args.verbosity, args.debug)
             guides_list = cfdon_score(guides_list, args.verbosity, args.debug)
         elif pam.cas_system == CPF1 and _DEEPCPF1_W is not None:
             guides_list = deepcpf1_score(guides_list, args.threads, args.verbosity, args.debug)

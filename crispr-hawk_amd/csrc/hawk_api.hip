@@ -670,4 +670,49 @@ int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* we
   return status;
 }
 
+// ---------------------------------------------------------------------------- K5 Azimuth
+int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_model* m, double* out, double* feats_out) {
+  if (!ctx || !m || !m->tree_off || !m->feature || !m->left || !m->right || !m->threshold || !m->value ||
+      (n && (!seqs30 || !out)))
+    return HAWK_E_INVALID;
+  if (!n) return HAWK_OK;
+  // validate the trees on the host: every child index inside its tree, every feature < 627
+  for (uint32_t t = 0; t < m->n_trees; ++t) {
+    const int32_t lo = m->tree_off[t], hi = m->tree_off[t + 1];
+    if (lo < 0 || hi <= lo || (uint32_t)hi > m->n_nodes) return HAWK_E_INVALID;
+    for (int32_t k = lo; k < hi; ++k) {
+      if (m->feature[k] >= 627) return HAWK_E_INVALID;
+      if (m->feature[k] >= 0 && (m->left[k] <= k - lo || m->right[k] <= k - lo || m->left[k] >= hi - lo || m->right[k] >= hi - lo))
+        return HAWK_E_INVALID;  // children must point forward inside the tree: traversal terminates
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nn = m->n_nodes, nt = m->n_trees;
+  char* d_s = nullptr; int32_t *d_off = nullptr, *d_f = nullptr, *d_l = nullptr, *d_r = nullptr;
+  double *d_th = nullptr, *d_v = nullptr, *d_o = nullptr, *d_fo = nullptr; int* d_status = nullptr;
+  HIPCHK(hipMalloc(&d_s, n * 30)); HIPCHK(hipMalloc(&d_off, (nt + 1) * 4)); HIPCHK(hipMalloc(&d_f, nn * 4));
+  HIPCHK(hipMalloc(&d_l, nn * 4)); HIPCHK(hipMalloc(&d_r, nn * 4)); HIPCHK(hipMalloc(&d_th, nn * 8)); HIPCHK(hipMalloc(&d_v, nn * 8));
+  HIPCHK(hipMalloc(&d_o, n * 8)); HIPCHK(hipMalloc(&d_status, 4));
+  if (feats_out) HIPCHK(hipMalloc(&d_fo, n * 627 * 8));
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(d_s, seqs30, n * 30, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, m->tree_off, (nt + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_f, m->feature, nn * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_l, m->left, nn * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_r, m->right, nn * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_th, m->threshold, nn * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_v, m->value, nn * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_status, 0, 4, st));
+  hawk_launch_azimuth(st, d_s, n, m->n_trees, d_off, d_f, d_l, d_r, d_th, d_v, m->init, m->learning_rate, d_o, d_fo, d_status);
+  HIPCHK(hipGetLastError());
+  int status = 0;
+  HIPCHK(hipMemcpyAsync(out, d_o, n * 8, hipMemcpyDeviceToHost, st));
+  if (feats_out) HIPCHK(hipMemcpyAsync(feats_out, d_fo, n * 627 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  (void)hipFree(d_s); (void)hipFree(d_off); (void)hipFree(d_f); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_th);
+  (void)hipFree(d_v); (void)hipFree(d_o); (void)hipFree(d_status); if (d_fo) (void)hipFree(d_fo);
+  return status;
+}
+
 }  // extern "C"

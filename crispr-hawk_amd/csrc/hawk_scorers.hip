@@ -110,3 +110,113 @@ void hawk_launch_deepcpf1(hipStream_t st, const char* seqs, uint64_t n, const fl
   hipLaunchKernelGGL(k_deepcpf1, dim3((uint32_t)((n + DC_G - 1) / DC_G)), dim3(HAWK_BLOCK), 0, st, seqs, n, cw, cb, w1, b1, w2, b2,
                      w3, b3, w4, b4, out, status);
 }
+
+// ---------------------------------------------------------------------------------------
+// K5: Azimuth (Rule Set 2) = 627 sequence features + gradient-boosted regression trees
+// ---------------------------------------------------------------------------------------
+// One thread per 30-mer.  The sequence is held as 2-bit codes in the Azimuth alphabet order
+// A0 T1 C2 G3 (featurization.py:436-438); features are evaluated on demand where a tree asks for
+// them (a depth-3 tree touches 3 of the 627): one-hots are bit tests, the position-independent
+// counts are XOR/fold/popcount over the packed word, the four melting temperatures are
+// precomputed in fp64 (nearest-neighbour sums + one log each).
+__device__ __forceinline__ int az_code(char c) {
+  switch (c & 0xDF) { case 'A': return 0; case 'T': return 1; case 'C': return 2; case 'G': return 3; default: return -1; }
+}
+__constant__ double c_nnH[16] = {-7.9, -7.2, -8.4, -7.8, -7.2, -7.9, -8.2, -8.5, -8.5, -7.8, -8.0, -10.6, -8.2, -8.4, -9.8, -8.0};
+__constant__ double c_nnS[16] = {-22.2, -20.4, -22.4, -21.0, -21.3, -22.2, -22.2, -22.7, -22.7, -21.0, -19.9, -27.2, -22.2, -22.4, -24.4, -19.9};
+
+// Biopython Tm_NN defaults (DNA_NN3, dnac1 = dnac2 = 25, Na = 50, saltcorr = 5) on codes[lo, lo+n)
+__device__ double az_tm(uint64_t codes, int lo, int n) {
+  double dh = 0.0, ds = 0.0;
+  const int e0 = (int)(codes >> (2 * lo)) & 3, e1 = (int)(codes >> (2 * (lo + n - 1))) & 3;
+  const int at = (e0 < 2) + (e1 < 2), gc = 2 - at;
+  dh += 2.3 * at + 0.1 * gc;
+  ds += 4.1 * at + -2.8 * gc;
+  for (int i = 0; i + 1 < n; ++i) {
+    const int d = (int)(codes >> (2 * (lo + i))) & 15;  // low 2 bits = first base, next 2 = second
+    const int idx = (d & 3) * 4 + (d >> 2);
+    dh += c_nnH[idx]; ds += c_nnS[idx];
+  }
+  const double k = (25.0 - 25.0 / 2.0) * 1e-9, R = 1.987;
+  ds += 0.368 * (n - 1) * log(50.0 * 1e-3);
+  return (1000.0 * dh) / (ds + R * log(k)) - 273.15;
+}
+// number of positions i < npos with the 2-bit code at i equal to c
+__device__ __forceinline__ int az_count1(uint64_t codes, int c, int npos) {
+  const uint64_t x = codes ^ (0x5555555555555555ull * (uint64_t)c);
+  const uint64_t m = ~(x | (x >> 1)) & 0x5555555555555555ull & ((npos >= 32) ? ~0ull : ((1ull << (2 * npos)) - 1ull));
+  return __popcll(m);
+}
+
+__device__ double az_feature(int idx, uint64_t codes, int gc, const double (&tm)[4]) {
+  if (idx < 120) return ((int)(codes >> (2 * (idx >> 2))) & 3) == (idx & 3) ? 1.0 : 0.0;
+  if (idx < 124) return (double)az_count1(codes, idx - 120, 30);
+  if (idx < 588) {
+    const int j = idx - 124, p = j >> 4, a = j & 15;
+    const int d = (int)(codes >> (2 * p)) & 15;
+    return ((d & 3) == (a >> 2) && (d >> 2) == (a & 3)) ? 1.0 : 0.0;
+  }
+  if (idx < 604) {
+    const int a = idx - 588;
+    const uint64_t x1 = codes ^ (0x5555555555555555ull * (uint64_t)(a >> 2));         // first base == a/4
+    const uint64_t x2 = (codes >> 2) ^ (0x5555555555555555ull * (uint64_t)(a & 3));  // next base == a%4
+    const uint64_t m = ~(x1 | (x1 >> 1)) & ~(x2 | (x2 >> 1)) & 0x5555555555555555ull & ((1ull << 58) - 1ull);  // 29 positions
+    return (double)__popcll(m);
+  }
+  if (idx == 604) return gc > 10 ? 1.0 : 0.0;
+  if (idx == 605) return gc < 10 ? 1.0 : 0.0;
+  if (idx == 606) return (double)gc;
+  if (idx < 623) {
+    const int a = idx - 607;
+    return (((int)(codes >> 48) & 3) == (a >> 2) && ((int)(codes >> 54) & 3) == (a & 3)) ? 1.0 : 0.0;  // s[24], s[27]
+  }
+  return tm[idx - 623];
+}
+
+__global__ __launch_bounds__(HAWK_BLOCK) void k_azimuth(const char* __restrict__ seqs, uint64_t n, uint32_t n_trees,
+                                                         const int32_t* __restrict__ tree_off, const int32_t* __restrict__ feature,
+                                                         const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                                         const double* __restrict__ threshold, const double* __restrict__ value,
+                                                         double init, double lr, double* __restrict__ out, double* feats_out,
+                                                         int* status) {
+  const uint64_t i = (uint64_t)blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint64_t codes = 0;
+  bool bad = false;
+  for (int p = 0; p < 30; ++p) {
+    const int c = az_code(seqs[i * 30 + p]);
+    if (c < 0) bad = true;
+    codes |= (uint64_t)(c & 3) << (2 * p);
+  }
+  if (bad) {  // alphabet.index(nucl) raises ValueError in the reference (featurization.py:471)
+    atomicExch(status, -4);
+    out[i] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
+  // GC count of s[4:24]: codes C=2, G=3 have the high bit set
+  const int gc = __popcll((codes >> 8) & 0xAAAAAAAAAAull);
+  double tm[4];
+  tm[0] = az_tm(codes, 0, 30); tm[1] = az_tm(codes, 19, 5); tm[2] = az_tm(codes, 11, 8); tm[3] = az_tm(codes, 6, 5);
+  if (feats_out)
+    for (int f = 0; f < 627; ++f) feats_out[i * 627 + f] = az_feature(f, codes, gc, tm);
+  double acc = init;
+  for (uint32_t t = 0; t < n_trees; ++t) {
+    const int base = tree_off[t];
+    int node = base;
+    int f;
+    while ((f = feature[node]) >= 0) {
+      const double x = (double)(float)az_feature(f, codes, gc, tm);  // sklearn casts X to float32
+      node = base + (x <= threshold[node] ? left[node] : right[node]);
+    }
+    acc += lr * value[node];
+  }
+  out[i] = acc;
+}
+
+void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t n_trees, const int32_t* tree_off,
+                         const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold,
+                         const double* value, double init, double lr, double* out, double* feats_out, int* status) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_azimuth, dim3((uint32_t)((n + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, seqs, n, n_trees,
+                     tree_off, feature, left, right, threshold, value, init, lr, out, feats_out, status);
+}

@@ -165,6 +165,27 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
 #define HAWK_DEEPCPF1_NPARAMS (1600 + 80 + 96000 + 80 + 3200 + 40 + 1600 + 40 + 40 + 1)
 int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* weights, float* out);
 
+/* ---- K5: Azimuth / Rule Set 2 (scoring.py:87-193 -> scores/azimuth/model_comparison.py:507-585):
+ * n 30-mers (4 nt + 20-nt guide + NGG + 3 nt) -> fp64 predictions of a gradient-boosted regression
+ * tree ensemble over the 627 features of features/featurization.py (order-1/2 position-dependent
+ * and -independent nucleotide features, GC features, NGGX, four nearest-neighbour melting
+ * temperatures).  The model is the flattened form of the sklearn GradientBoostingRegressor the
+ * reference unpickles: per tree a node range [tree_off[t], tree_off[t+1]); node k is a leaf iff
+ * feature[k] < 0, else x[feature[k]] (as float32) <= threshold[k] goes to left[k] else right[k]
+ * (indices relative to the tree); prediction = init + learning_rate * sum of leaf values.
+ * feats_out (optional, n*627 doubles) receives the feature matrix.  Non-ACGT -> HAWK_E_IUPAC. */
+typedef struct {
+  uint32_t n_trees, n_nodes;
+  const int32_t* tree_off; /* n_trees + 1 */
+  const int32_t* feature;  /* n_nodes */
+  const int32_t* left;
+  const int32_t* right;
+  const double* threshold;
+  const double* value;
+  double init, learning_rate;
+} hawk_gbt_model;
+int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_model* model, double* out, double* feats_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,26 @@ def offtargets(genome: str, guides: Sequence[str], pam: str, right: bool, max_mm
     if n < 0:
         raise OracleError(int(n))
     return out[:n].copy()
+
+
+def azimuth_features(seqs: Sequence[str]) -> np.ndarray:
+    """[n, 627] feature matrix (Tm columns 623..626: parity unpinned, see hawk_oracle.c)."""
+    out = np.zeros((len(seqs), 627), dtype=np.float64)
+    for i, s in enumerate(seqs):
+        assert len(s) == 30
+        rc = lib().ora_azimuth_features(s.encode("ascii"), _p(out[i]))
+        if rc:
+            raise OracleError(rc)
+    return out
+
+
+def gbt_predict(feats: np.ndarray, model: dict) -> np.ndarray:
+    n, nf = feats.shape
+    out = np.zeros(n, dtype=np.float64)
+    f = np.ascontiguousarray(feats, dtype=np.float64)
+    a = {k: np.ascontiguousarray(model[k]) for k in ("tree_off", "feature", "left", "right", "threshold", "value")}
+    lib().ora_gbt_predict(_p(f), C.c_int64(n), nf, len(a["tree_off"]) - 1, _p(a["tree_off"].astype(np.int32)),
+                          _p(a["feature"].astype(np.int32)), _p(a["left"].astype(np.int32)), _p(a["right"].astype(np.int32)),
+                          _p(a["threshold"].astype(np.float64)), _p(a["value"].astype(np.float64)), C.c_double(model["init"]),
+                          C.c_double(model["learning_rate"]), _p(out))
+    return out

@@ -104,3 +104,50 @@ def test_deepcpf1_kernel_against_reference_forward():
     from crisprhawk_hip.crisprhawk_error import CrisprHawkDeepCpf1ScoreError
     with pytest.raises(CrisprHawkDeepCpf1ScoreError):
         scoring.deepcpf1(["ACGT" * 8 + "NN"])
+
+
+def _random_gbt(rng, n_trees=100, nfeat=627):
+    """depth-3 regression trees in the flattened layout (complete trees, 15 nodes each)"""
+    off, feat, left, right, thr, val = [0], [], [], [], [], []
+    for _ in range(n_trees):
+        for k in range(15):
+            if k < 7:
+                f = int(rng.integers(0, nfeat))
+                feat.append(f); left.append(2 * k + 1); right.append(2 * k + 2)
+                thr.append(float(rng.uniform(-40, 70)) if f >= 623 else (float(rng.integers(0, 20)) + 0.5 if f in (606,) or 120 <= f < 124 or 588 <= f < 604 else 0.5))
+            else:
+                feat.append(-1); left.append(0); right.append(0); thr.append(-2.0)
+            val.append(float(rng.normal()))
+        off.append(len(feat))
+    return dict(tree_off=np.array(off, np.int32), feature=np.array(feat, np.int32), left=np.array(left, np.int32),
+                right=np.array(right, np.int32), threshold=np.array(thr), value=np.array(val), init=0.37, learning_rate=0.1)
+
+
+def test_azimuth_features_and_trees_against_oracle():
+    from oracle import oracle as ora
+    rng = np.random.default_rng(31)
+    seqs = [synth.random_sequence(rng, 30) for _ in range(700)] + ["CCCCAGCTTAGCTAGCTAGCTAGCTAGCCC"]  # reference tests/test_scoring.py:55
+    model = _random_gbt(rng)
+    scoring.set_azimuth_model(model)
+    got, feats = scoring.azimuth(seqs, return_features=True)
+    want_f = ora.azimuth_features(seqs)
+    assert np.array_equal(feats[:, :623], want_f[:, :623])                 # one-hots, counts, GC, NGGX: exact
+    assert np.max(np.abs(feats[:, 623:] - want_f[:, 623:])) < 1e-9         # Tm: fp64, device log vs libm
+    assert np.max(np.abs(np.array(got) - ora.gbt_predict(want_f, model))) < 1e-9
+    from crisprhawk_hip.crisprhawk_error import CrisprHawkAzimuthScoreError
+    with pytest.raises(CrisprHawkAzimuthScoreError):
+        scoring.azimuth(["ACGTN" * 6])
+
+
+def test_azimuth_against_sklearn_gbr():
+    sk = pytest.importorskip("sklearn.ensemble")
+    from oracle import oracle as ora
+    rng = np.random.default_rng(32)
+    train = [synth.random_sequence(rng, 30) for _ in range(400)]
+    X = ora.azimuth_features(train)
+    y = X[:, 606] * 0.03 + X[:, 623] * 0.01 + X[:, 4] - X[:, 130] + rng.normal(0, 0.1, len(train))
+    gbr = sk.GradientBoostingRegressor(n_estimators=100, max_depth=3, learning_rate=0.1, random_state=1).fit(X, y)  # models/ensembles.py:28-30
+    scoring.set_azimuth_model(gbr)
+    test = [synth.random_sequence(rng, 30) for _ in range(300)]
+    got = np.array(scoring.azimuth(test))
+    assert np.max(np.abs(got - gbr.predict(ora.azimuth_features(test)))) < 1e-9
