@@ -217,6 +217,13 @@ class GuideTable:
             self._hs._L.hawk_table_destroy(self._t)
             self._t = None
 
+    def export_to(self, hap: int, pos: int, strand: int, start: int, stop: int, flags: int, cfdon: int, win: int) -> None:
+        """Copy the columns into caller-owned buffers given as raw addresses (host or device, e.g.
+        ``tensor.data_ptr()`` of the send buffers of a collective); 0 skips a column."""
+        ptr = lambda a: C.c_void_p(a) if a else None
+        _lib.check(self._hs._L.hawk_table_download(self._t, ptr(hap), ptr(pos), ptr(strand), ptr(start), ptr(stop),
+                                                   ptr(flags), ptr(cfdon), ptr(win)), "hawk_table_download")
+
     def download(self) -> "GuideTable":
         if self._downloaded:
             return self

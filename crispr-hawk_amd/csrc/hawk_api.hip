@@ -495,16 +495,16 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
   const uint64_t n = t->n_rows;
   if (!n) return HAWK_OK;
   const GuideCols& c = t->cols;
-  if (hap) HIPCHK(hipMemcpyAsync(hap, c.hap, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (pos) HIPCHK(hipMemcpyAsync(pos, c.pos, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (strand) HIPCHK(hipMemcpyAsync(strand, c.strand, n, hipMemcpyDeviceToHost, ctx->stream));
-  if (start) HIPCHK(hipMemcpyAsync(start, c.start, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (stop) HIPCHK(hipMemcpyAsync(stop, c.stop, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (flags) HIPCHK(hipMemcpyAsync(flags, c.flags, n, hipMemcpyDeviceToHost, ctx->stream));
-  if (cfdon) HIPCHK(hipMemcpyAsync(cfdon, c.cfdon, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (hap) HIPCHK(hipMemcpyAsync(hap, c.hap, n * 4, hipMemcpyDefault, ctx->stream));
+  if (pos) HIPCHK(hipMemcpyAsync(pos, c.pos, n * 4, hipMemcpyDefault, ctx->stream));
+  if (strand) HIPCHK(hipMemcpyAsync(strand, c.strand, n, hipMemcpyDefault, ctx->stream));
+  if (start) HIPCHK(hipMemcpyAsync(start, c.start, n * 8, hipMemcpyDefault, ctx->stream));
+  if (stop) HIPCHK(hipMemcpyAsync(stop, c.stop, n * 8, hipMemcpyDefault, ctx->stream));
+  if (flags) HIPCHK(hipMemcpyAsync(flags, c.flags, n, hipMemcpyDefault, ctx->stream));
+  if (cfdon) HIPCHK(hipMemcpyAsync(cfdon, c.cfdon, n * 8, hipMemcpyDefault, ctx->stream));
   if (win)
     for (int p = 0; p < HAWK_PLANES; ++p)
-      HIPCHK(hipMemcpyAsync(win + (size_t)p * n, c.win + (size_t)p * c.cap, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(win + (size_t)p * n, c.win + (size_t)p * c.cap, n * 8, hipMemcpyDefault, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return HAWK_OK;
 }

@@ -117,7 +117,9 @@ void hawk_table_destroy(hawk_table* t);
 /* n_rows: guides after remove_redundant_guides; n_candidates: PAM hits passing
  * is_pamhit_in_range (the bench metric's unit); n_hits: all PAM hits in scan range. */
 int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candidates, uint64_t* n_hits);
-/* Column download (each array n_rows long; any pointer may be NULL).  Rows are ordered by
+/* Column download (each array n_rows long; any pointer may be NULL; destinations may be host or
+ * device memory - the copy kind is inferred, so a table can be exported into buffers a
+ * collective library owns without a host bounce).  Rows are ordered by
  * (haplotype, strand, position) — the reference's pre-dedup emission order.
  *   pos: relative PAM position (what retrieve_guides iterates), start/stop: genomic
  *   (search_guides.py:260-280), strand 0/1, flags bit0 = a REF guide shares (start,strand),
