@@ -54,7 +54,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
                                                         const uint32_t* __restrict__ tile_seg0, uint32_t* __restrict__ counts,
                                                         unsigned long long* __restrict__ shards,
                                                         const uint64_t* __restrict__ offsets, GuideCols out, int* status) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_pl[HAWK_PLANES][LDS_ROW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pl[PASS == 1 ? HAWK_PLANES : 1][PASS == 1 ? LDS_ROW : 8];
   __shared__ uint32_t s_list[CAP];
   __shared__ uint32_t s_segrel[NSEG];
   __shared__ int64_t s_seggen[NSEG];
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   const bool isref = hs.is_ref[h] != 0;
   const bool dedup = ri.index >= 0 && !isref;  // rows of this tile can be redundant with REF
   const bool stage = PASS == 1 || dedup;        // phase C runs if the tile has survivors
+  const bool lds_planes = PASS == 1;            // PASS 0 classifies its few survivors straight from L2/HBM
   const uint32_t w0 = blk * TILE_WORDS;         // first plane word of the tile
   const uint32_t tile_q0 = w0 * 32u;
   const uint32_t tile_end = tile_q0 + TILE_WORDS * 32u + 64u;  // rel < tile_end can be looked up
@@ -81,15 +82,15 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   uint32_t A[6] = {0, 0, 0, 0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0}, G[6] = {0, 0, 0, 0, 0, 0}, Tp[6] = {0, 0, 0, 0, 0, 0};
   uint32_t E[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0};
   const uint32_t k0 = stage ? tile_seg0[tile] : 0u, kend = stage ? hs.seg_off[h + 1] : 0u;
-  if ((p.need & 1u) || stage) load6(hs.plane[0] + rowbase, u, hs.S, active, A);
-  if ((p.need & 2u) || stage) load6(hs.plane[1] + rowbase, u, hs.S, active, C);
-  if ((p.need & 4u) || stage) load6(hs.plane[2] + rowbase, u, hs.S, active, G);
-  if ((p.need & 8u) || stage) load6(hs.plane[3] + rowbase, u, hs.S, active, Tp);
+  if ((p.need & 1u) || lds_planes) load6(hs.plane[0] + rowbase, u, hs.S, active, A);
+  if ((p.need & 2u) || lds_planes) load6(hs.plane[1] + rowbase, u, hs.S, active, C);
+  if ((p.need & 4u) || lds_planes) load6(hs.plane[2] + rowbase, u, hs.S, active, G);
+  if ((p.need & 8u) || lds_planes) load6(hs.plane[3] + rowbase, u, hs.S, active, Tp);
   uint32_t V[4] = {0, 0, 0, 0};
   if (!isref) {  // workgroup-uniform: REF windows are never filtered
     load6(hs.plane[4] + rowbase, u, hs.S, active, E);
     V[0] = E[0]; V[1] = E[1]; V[2] = E[2]; V[3] = E[3];
-  } else if (stage && active) {
+  } else if (lds_planes && active) {
     const uint4 v = *reinterpret_cast<const uint4*>(hs.plane[4] + rowbase + 4 * (size_t)u);
     V[0] = v.x; V[1] = v.y; V[2] = v.z; V[3] = v.w;
   }
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   int64_t seg_g = 0;
   bool seg_in = false, ovf = false;
   if (stage) {
-    if (tid < 3 * HAWK_PLANES) {
+    if (lds_planes && tid < 3 * HAWK_PLANES) {
       const uint32_t pl = tid / 3, j = tid % 3;  // j: 0 -> word -1, 1 -> word TILE_WORDS, 2 -> TILE_WORDS+1
       const long long w = j == 0 ? (long long)w0 - 1 : (long long)w0 + TILE_WORDS + (j - 1);
       if (w >= 0 && w < (long long)hs.S) halo = hs.plane[pl][rowbase + (size_t)w];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   }
 
   // ---- phase A: scan + filters on registers; stage the slices phase C reads --------------
-  if (stage) {
+  if (stage && lds_planes) {
     *reinterpret_cast<uint4*>(&s_pl[0][LDS_OFF + 4 * tid]) = make_uint4(A[0], A[1], A[2], A[3]);
     *reinterpret_cast<uint4*>(&s_pl[1][LDS_OFF + 4 * tid]) = make_uint4(C[0], C[1], C[2], C[3]);
     *reinterpret_cast<uint4*>(&s_pl[2][LDS_OFF + 4 * tid]) = make_uint4(G[0], G[1], G[2], G[3]);
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
       const uint32_t pl = tid / 3, j = tid % 3;
       s_pl[pl][j == 0 ? LDS_OFF - 1 : LDS_OFF + TILE_WORDS + (j - 1)] = halo;
     }
+  }
+  if (stage) {
     if (tid < NSEG) {
       s_segrel[tid] = seg_in ? seg_r : 0xffffffffu;
       s_seggen[tid] = seg_g;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
           }
 #pragma unroll
           for (int pl = 0; pl < 4; ++pl) {
-            core[pl] = ext_lds(s_pl[pl], (int)ql);
+            core[pl] = lds_planes ? ext_lds(s_pl[pl], (int)ql) : ext_glb(hs.plane[pl] + rowbase, q);
             core[pl].lo &= mlo; core[pl].hi &= mhi;
             rcore[pl] = core[pl];
           }
