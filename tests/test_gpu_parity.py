@@ -121,3 +121,44 @@ def test_cfd_error_on_iupac_spacer():
     with pytest.raises(_lib.HawkStatusError) as e:
         ds.search(bits, bitsrc, 3, 20, False, mm, pt)
     assert e.value.status == _lib.HAWK_E_CFD
+
+
+def _oracle_vs_device(reg, pam, guidelen, right, score):
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, len(pam)) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    bits, bitsrc, _, _ = ora.pam_encode(pam)
+    want = ora.search(hs, pam, guidelen, right)
+    mm, pt = synth.cfd_tables() if score else (None, None)
+    tab = device_set(hs).search(bits, bitsrc, len(pam), guidelen, right, mm, pt)
+    assert (tab.n_rows, tab.n_candidates, tab.n_hits) == (len(want.guides), want.n_candidates, want.n_hits)
+    order = tab.reference_order()
+    g = want.guides
+    for col in ("start", "stop", "hap", "pos", "strand"):
+        assert np.array_equal(getattr(tab, col)[order], g[col]), col
+    wins = tab.windows()
+    assert [wins[i] for i in order] == want.windows
+    if score:
+        _, _, _, cfd, _ = ora.reverse_and_cfdon(want, hs.is_ref, guidelen, len(pam), mm, pt)
+        mine = tab.cfdon[order]
+        assert np.array_equal(np.isnan(mine), np.isnan(cfd)) and np.array_equal(mine[~np.isnan(cfd)], cfd[~np.isnan(cfd)])
+    return hs, tab
+
+
+def test_more_than_64_segments_per_tile():
+    # > NSEG position-map segments inside one 32 768-position tile: the kernel's global binary-search fallback
+    reg = synth.make_region(7101, "chrD", 9000, 1500, 7500)
+    synth.add_phased_variants(reg, 7102, 500, 3, frac_snv=0.1, frac_del=0.45, max_indel=5, af_min=0.5, af_max=0.9)
+    hs, _ = _oracle_vs_device(reg, "NGG", 20, False, True)
+    assert max(len(segments_from_posmap(pm)[0]) for pm in hs.posmaps) > 64
+
+
+@pytest.mark.parametrize("region_len", [32768 - 201, 32768 - 200, 65536 - 200 + 1, 4 * 32768 - 200 - 33])
+def test_tile_boundary_lengths(region_len):
+    # haplotype lengths that end exactly on / just past plane-word and tile boundaries; indels move them around
+    reg = synth.make_region(7200 + region_len % 97, "chrB", region_len + 3000, 1200, 1200 + region_len)
+    synth.add_phased_variants(reg, 7201, 60, 2, frac_snv=0.5, frac_del=0.25, af_min=0.3, af_max=0.8)
+    _oracle_vs_device(reg, "NGG", 20, False, True)
+    _oracle_vs_device(reg, "TTTV", 23, True, False)
