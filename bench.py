@@ -138,6 +138,11 @@ def main():
     else:
         cand_all, rows_all, pos_all = cand, rows, positions
 
+    # the PAM-scan kernel on its own (K2, what `pam_search` runs): north_star's >= 40 % of HBM peak target
+    import ctypes as C
+    ps_ms, ps_pos = C.c_float(0), C.c_uint64(0)
+    _lib.check(_lib.lib().hawk_pam_scan_time(ds._h, C.c_uint64(pam.bits), C.c_uint64(pam.bitsrc), len(pam), 20, C.byref(ps_ms),
+                                             C.byref(ps_pos)), "hawk_pam_scan_time")
     gather = None
     if dist is not None and not args.no_gather:
         gather = gather_once(ds, step, dist, rank, world)
@@ -173,6 +178,19 @@ def main():
             "kernels_ms": {"count": scan_avg_ms, **{k[:-3]: float(np.mean(v)) for k, v in kern.items()},
                            "device_total": float(np.mean(tot_ms))},
         }
+        # bytes the scan really moves: one bit per position for each plane the PAM names (NGG/CCN: G and C only)
+        # plus the forward and reverse hit bits; SURVEY.md §8(d) prices the nibble formulation at 0.75 B/position.
+        need = 0
+        for nib in pam.bits_list + [{"A": 1, "C": 2, "G": 4, "T": 8}.get(c, 0) or synth_iupac(c) for c in pam.pamrc.upper()]:
+            if nib != 15:
+                need |= nib
+        ps_bpp = 0.125 * bin(need).count("1") + 0.25
+        ps_bytes = ps_bpp * ps_pos.value
+        out["pam_scan_kernel"] = {"kernel": "k_scan_raw", "launch_ms": ps_ms.value, "bytes_per_position": ps_bpp,
+                                  "bytes_per_launch": ps_bytes, "achieved": ps_bytes / (ps_ms.value * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ps_bytes / (ps_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "survey_algorithmic_bytes_per_position": 0.75,
+                                  "positions_per_s": ps_pos.value / (ps_ms.value * 1e-3)}
         if gather is not None:
             out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
@@ -182,6 +200,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def synth_iupac(c):
+    from crisprhawk_hip.pam import IUPAC_BITS
+    return IUPAC_BITS[c]
 
 
 def gather_once(ds, step, dist, rank, world):

@@ -23,7 +23,7 @@ HAWK_E_UNSUPPORTED = -7
 EXPORTS = [
     "hawk_device_count", "hawk_init", "hawk_destroy", "hawk_strerror", "hawk_last_hip_error", "hawk_stream",
     "hawk_sync", "hawk_hapset_create", "hawk_hapset_destroy", "hawk_hapset_pack_ascii", "hawk_hapset_set_meta",
-    "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan",
+    "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan", "hawk_pam_scan_time",
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth",
 ]

@@ -388,6 +388,36 @@ int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t 
   return HAWK_OK;
 }
 
+int hawk_pam_scan_time(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t reps, float* avg_ms,
+                       uint64_t* scanned_positions) {
+  if (!hs || !hs->has_meta || !avg_ms || !reps) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  ScanParams sp;
+  int rc = make_scan_params(hs, pam_fwd, pam_rev, pamlen, 0, 0, false, &sp);
+  if (rc) return rc;
+  const HapSetDev d = make_dev(hs);
+  const size_t words = (size_t)hs->n_hap * hs->S;
+  const uint64_t ncnt = (uint64_t)hs->n_hap * 2 * sp.bph;
+  if ((rc = hs->keepF.reserve(words * 4)) || (rc = hs->keepR.reserve(words * 4)) || (rc = hs->counts.reserve(ncnt * 4))) return rc;
+  hawk_launch_scan_raw(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>());  // warm-up
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+  for (uint32_t r = 0; r < reps; ++r)
+    hawk_launch_scan_raw(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(), hs->counts.as<uint32_t>());
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  *avg_ms = ms / reps;
+  if (scanned_positions) {
+    uint64_t pos = 0;
+    for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
+    *scanned_positions = pos;
+  }
+  return HAWK_OK;
+}
+
 // ---------------------------------------------------------------------------- fused search
 static int reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   int rc;

@@ -92,6 +92,12 @@ int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes);
 int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t* hits_fwd,
                   uint32_t* hits_rev, uint64_t cap_fwd, uint64_t cap_rev, uint64_t* off_fwd, uint64_t* off_rev);
 
+/* Average duration (HIP events on the context stream) of the K2 PAM-scan kernel alone over `reps`
+ * back-to-back launches on this set: plane codes in, one forward and one reverse hit bit per position
+ * out - the kernel SURVEY.md §8(d) prices at 0.75 B per scanned position. */
+int hawk_pam_scan_time(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t reps, float* avg_ms,
+                       uint64_t* scanned_positions);
+
 /* ---- fused search: search() (search_guides.py:510-548) + the CFDon slice of
  * scoring_guides() (scoring.py:352-387, after annotation.reverse_guides) ------------------- */
 typedef struct {
