@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--right", action="store_true")
     ap.add_argument("--cpu-haps", type=int, default=160, help="haplotypes in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-expand", action="store_true", help="build the haplotype strings on the host and pack them (K1) instead of expanding on the device")
     ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
     args = ap.parse_args()
 
@@ -71,7 +72,7 @@ def main():
     from crisprhawk_hip import _lib, synth
     from crisprhawk_hip.hapset import DeviceHapSet
     from crisprhawk_hip.pam import PAM
-    from crisprhawk_hip.workload import build_phased_haplotypes
+    from crisprhawk_hip.workload import build_phased_haplotypes, expand_on_device
 
     if _lib.device_count() == 0:
         raise _lib.HawkDeviceError("bench.py needs an MI355X: there is no CPU fallback on the product path")
@@ -83,11 +84,20 @@ def main():
     synth.add_phased_variants(reg, 1003_1 + 7919 * rank, args.sites, args.samples)
     pam = PAM(args.pam, args.right, True)
     pam.encode(0)
-    haps, _info = build_phased_haplotypes(reg, len(pam))
-    log(f"workload: {len(haps)} haplotypes x {len(haps[0].seq)} nt, {len(reg.variants)} sites, built in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    ds = DeviceHapSet(haps, device=local)
-    log(f"resident in HBM ({5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes) in {time.time() - t0:.1f}s")
+    expand_ms = None
+    if args.host_expand:
+        haps, _info = build_phased_haplotypes(reg, len(pam))
+        log(f"workload: {len(haps)} haplotypes x {len(haps[0].seq)} nt, {len(reg.variants)} sites, built on the host in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        ds = DeviceHapSet(haps, device=local)
+        region_nt = len(haps[0].seq)
+        log(f"resident in HBM ({5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes) in {time.time() - t0:.1f}s")
+    else:  # the haplotypes are expanded on the device from REF + variant table + genotypes
+        t1 = time.time()
+        ds, _info, expand_ms, _kept = expand_on_device(reg, len(pam), device=local)
+        region_nt = int(ds.hap_len[0])
+        log(f"workload: {ds.n_hap} haplotype rows x {region_nt} nt, {len(reg.variants)} sites; synthesised in {t1 - t0:.1f}s, "
+            f"expanded on the device in {time.time() - t1:.1f}s (kernels {expand_ms:.2f} ms, {5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes)")
     score = (not args.right) and pam.cas_system in (3, 4)  # scoring.py:749-792: CFDon for SpCas9/xCas9 PAMs
     mm, pt = synth.cfd_tables() if score else (None, None)
 
@@ -167,7 +177,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "C3: 1 Mb region x 2504 phased samples (BASELINE.json configs[2])" if (args.samples, args.region_len) == (2504, 1_000_000) else "custom",
-                       "pam": args.pam, "guidelen": args.guidelen, "right": args.right, "region_nt": len(haps[0].seq),
+                       "pam": args.pam, "guidelen": args.guidelen, "right": args.right, "region_nt": region_nt,
                        "haplotypes_per_gpu": ds.n_hap, "samples_per_gpu": args.samples, "variant_sites": len(reg.variants),
                        "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
                        "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all},
@@ -191,10 +201,16 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ps_bytes / (ps_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "survey_algorithmic_bytes_per_position": 0.75,
                                   "positions_per_s": ps_pos.value / (ps_ms.value * 1e-3)}
+        if expand_ms is not None:
+            out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap, "where": "device (hawk_hapset_expand), outside the timed steps"}
         if gather is not None:
             out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(haps, pam, args, mm, pt)
+            if args.host_expand:
+                base_haps = haps
+            else:  # the CPU sample needs strings: build just those haplotypes on the host
+                base_haps, _ = build_phased_haplotypes(reg, len(pam), max_haplotypes=max(2, args.cpu_haps))
+            out["cpu_baseline"] = cpu_baseline(base_haps, pam, args, mm, pt)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -92,6 +92,20 @@ class HostHaplotype:
 
 
 class DeviceHapSet:
+    @classmethod
+    def from_handle(cls, handle, hap_len: np.ndarray, device: Optional[int] = None) -> "DeviceHapSet":
+        """Wrap planes that already exist in HBM (hawk_hapset_expand); set_meta() must follow."""
+        self = cls.__new__(cls)
+        self._L = _lib.lib()
+        self._ctx = _lib.context(device)
+        self._h = handle
+        self.hap_len = np.asarray(hap_len, dtype=np.uint32)
+        self.n_hap = len(self.hap_len)
+        s = C.c_uint32()
+        _lib.check(self._L.hawk_hapset_stride(self._h, C.byref(s)), "hawk_hapset_stride")
+        self.stride = s.value
+        return self
+
     def __init__(self, haps: Sequence[HostHaplotype], device: Optional[int] = None):
         L = _lib.lib()
         self._ctx = _lib.context(device)

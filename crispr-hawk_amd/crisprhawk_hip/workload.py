@@ -73,3 +73,148 @@ def build_phased_haplotypes(reg: SynthRegion, pamlen: int, max_haplotypes: Optio
             if max_haplotypes is not None and len(haps) >= max_haplotypes:
                 return haps, info
     return haps, info
+
+
+# ---------------------------------------------------------------------------------------------
+# the same haplotype set, expanded on the device
+# ---------------------------------------------------------------------------------------------
+_NIB = np.zeros(256, dtype=np.uint8)
+for _c, _v in {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15, "R": 5, "Y": 10, "S": 6, "W": 9, "K": 12, "M": 3, "B": 14, "D": 13,
+               "H": 11, "V": 7}.items():
+    _NIB[ord(_c)] = _v
+    _NIB[ord(_c.lower())] = _v
+
+
+def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None):
+    """build_phased_haplotypes() with the sequence work done by hawk_hapset_expand: the host only
+    prepares index arrays (which variants each chromosome copy carries, prefix sums of their length
+    changes), labels and position-map segments; no haplotype string is ever formed.
+    Returns (DeviceHapSet, [HapInfo] of the kept rows, kernel ms, kept row indices).  Rows that collapse onto an earlier row
+    (haplotypes.py:274-294; homozygous copies, 326-333) stay in HBM with an empty scan range."""
+    import ctypes as C
+    from . import _lib
+    from .expand import HaplotypeBuildError
+    from .hapset import DeviceHapSet, _p
+
+    seq = reg.sequence
+    startp, stopp, n_ref = reg.startp, reg.stopp, len(reg.sequence)
+    ref_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
+    ref_seg = PosSegments.identity(startp, n_ref)
+    ref_set = DeviceHapSet([HostHaplotype(ref_u8, ref_seg, True, scan_bounds(ref_seg, startp, stopp, pamlen))], device)
+    nv = len(reg.variants)
+    if nv == 0:
+        ref_set.alias = np.zeros(1, dtype=np.int64)
+        return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
+    r0 = np.array([v.pos - startp for v in reg.variants], dtype=np.int64)
+    reflen = np.array([len(v.ref) for v in reg.variants], dtype=np.int64)
+    altlen = np.array([len(v.alt) for v in reg.variants], dtype=np.int64)
+    order = np.argsort(r0, kind="stable")
+    if np.any(order != np.arange(nv)):
+        raise HaplotypeBuildError("variants must be sorted by position")
+    # replaced span as the reference computes it (haplotype.py:197-201): |chain|+1 for deletions, else 1
+    chain = altlen - reflen
+    span = np.where(chain < 0, -chain + 1, 1)
+    if np.any((chain < 0) & (altlen != 1)) or np.any((chain == 0) & (reflen != 1)):
+        raise HaplotypeBuildError("device expansion handles SNVs, deletions (alt of one base) and insertions")
+    if np.any(r0[1:] < r0[:-1] + span[:-1]) or np.any(r0 < 0) or np.any(r0 + span > n_ref):
+        raise HaplotypeBuildError("overlapping variants / variant outside the region")
+    for v, a, sp in zip(reg.variants, r0, span):  # REF allele must match (haplotype.py:203-208)
+        if seq[a:a + sp] != v.ref[:sp] if len(v.ref) >= sp else True:
+            raise HaplotypeBuildError(f"Mismatching reference alleles at position {v.pos}")
+    alt_blob = "".join(v.alt for v in reg.variants).encode("ascii")
+    alt_codes = _NIB[np.frombuffer(alt_blob, dtype=np.uint8)]
+    alt_off = np.zeros(nv, dtype=np.int64)
+    alt_off[1:] = np.cumsum(altlen)[:-1]
+    # rows: REF, then every chromosome copy that carries at least one variant, in (sample, copy) order
+    G = np.stack([v.gt.reshape(-1) for v in reg.variants])  # [site, 2*sample]
+    cols, sites = np.nonzero(G.T)                             # sorted by column, then site
+    counts = np.bincount(cols, minlength=G.shape[1])
+    live = np.flatnonzero(counts)
+    n_hap = 1 + len(live)
+    hv_off = np.zeros(n_hap + 1, dtype=np.uint64)
+    hv_off[2:] = np.cumsum(counts[live])
+    hv_idx = sites.astype(np.uint32)
+    c = chain[hv_idx]
+    excl = np.cumsum(c) - c
+    row_of = np.repeat(np.arange(len(live)), counts[live])
+    starts = hv_off[1:-1].astype(np.int64)
+    excl -= excl[starts][row_of] if len(starts) else 0
+    hv_o = (r0[hv_idx] + excl).astype(np.int32)
+    tot = np.zeros(n_hap, dtype=np.int64)
+    np.add.at(tot, row_of + 1, c)
+    hap_len = (n_ref + tot).astype(np.uint32)
+    if np.any(hv_o.astype(np.int64) + span[hv_idx] > n_ref):  # the reference's clamp (haplotype.py:199-201) would fire
+        raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
+    L = _lib.lib()
+    handle = C.c_void_p()
+    hashes = np.zeros((n_hap, 2), dtype=np.uint64)
+    ms = C.c_float(0)
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
+    arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(alt_codes), hv_off, hv_idx, hv_o, hap_len]
+    _lib.check(L.hawk_hapset_expand(ref_set._h, nv, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), len(alt_codes),
+                                    n_hap, _p(hv_off), _p(hv_idx), _p(hv_o), _p(hap_len), C.byref(handle), _p(hashes), C.byref(ms)),
+               "hawk_hapset_expand")
+    ds = DeviceHapSet.from_handle(handle, hap_len, device)
+    # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes) ----------------
+    key = [bytes(hashes[i]) for i in range(n_hap)]
+    col_of_row = np.concatenate(([-1], live))
+    first: Dict[bytes, int] = {key[0]: 0}
+    info: List[Optional[HapInfo]] = [HapInfo(["REF"], ())] + [None] * (n_hap - 1)
+    alias = np.arange(n_hap)
+    row_of_col = {int(cc): i + 1 for i, cc in enumerate(live)}
+    for si in range(len(reg.samples)):
+        rows = [row_of_col.get(2 * si), row_of_col.get(2 * si + 1)]
+        if rows[0] is None and rows[1] is None:
+            continue
+        keys = [key[r] if r is not None else key[0] for r in rows]  # a copy without variants is the REF sequence
+        name = reg.samples[si]
+        if keys[0] == keys[1]:
+            entries = [(rows[0], f"{name}:1|1")]
+            if rows[1] is not None and rows[0] is not None:
+                alias[rows[1]] = rows[0]
+        else:
+            entries = [(rows[0], f"{name}:1|0"), (rows[1], f"{name}:0|1")]
+        for r, label in entries:
+            if r is None:
+                continue  # collapses onto REF, which keeps samples == "REF" (haplotypes.py:255-258)
+            j = first.get(key[r])
+            if j is None:
+                first[key[r]] = r
+                info[r] = HapInfo([label], tuple(int(x) for x in hv_idx[int(hv_off[r]):int(hv_off[r + 1])]))
+            else:
+                alias[r] = j
+                if j != 0:
+                    info[j].samples.append(label)
+    # ---- position-map segments + scan bounds per row ------------------------------------------
+    haps = []
+    for r in range(n_hap):
+        if alias[r] != r:
+            haps.append(HostHaplotype(b"", PosSegments.identity(startp, int(hap_len[r])), False, (0, 0)))
+            continue
+        a, b = int(hv_off[r]), int(hv_off[r + 1])
+        vi = hv_idx[a:b]
+        ch = chain[vi]
+        ind = np.flatnonzero(ch != 0)
+        if len(ind) == 0:
+            seg = PosSegments.identity(startp, int(hap_len[r]))
+        else:
+            o = hv_o[a:b][ind].astype(np.int64)
+            pos = r0[vi][ind] + startp
+            chi = ch[ind]
+            rel, gen = [np.zeros(1, np.int64)], [np.array([startp], np.int64)]
+            dele = chi < 0
+            rel.append(o[dele] + 1); gen.append(pos[dele] + 1 - chi[dele])
+            for k in np.flatnonzero(~dele):
+                n = int(chi[k])
+                rel.append(o[k] + 1 + np.arange(n + 1)); gen.append(np.concatenate((np.full(n, pos[k]), [pos[k] + 1])))
+            rel, gen = np.concatenate(rel), np.concatenate(gen)
+            srt = np.argsort(rel, kind="stable")
+            rel, gen = rel[srt], gen[srt]
+            keep = rel < int(hap_len[r])
+            seg = PosSegments(rel[keep].astype(np.uint32), gen[keep], int(hap_len[r]))
+        haps.append(HostHaplotype(b"", seg, r == 0, scan_bounds(seg, startp, stopp, pamlen)))
+    ds.set_meta(haps)
+    ds.alias = alias
+    ds.host_meta = haps
+    kept = [i for i in range(n_hap) if alias[i] == i]
+    return ds, [info[i] for i in kept], float(ms.value), kept

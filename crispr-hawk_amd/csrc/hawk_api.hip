@@ -679,6 +679,73 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
   return status;
 }
 
+// ---------------------------------------------------------------------------- f1 haplotype expansion
+int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                       const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
+                       uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
+                       const uint32_t* hap_len, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms) {
+  if (!ref_set || !out || !n_hap || !hv_off || !hap_len || (n_var && (!v_r0 || !v_span || !v_alt_off || !v_alt_len || !alt_codes)))
+    return HAWK_E_INVALID;
+  hawk_ctx* ctx = ref_set->ctx;
+  const uint32_t ref_len = ref_set->hap_len[0];
+  const uint64_t ncar = hv_off[n_hap];
+  if (ncar && (!hv_idx || !hv_o)) return HAWK_E_INVALID;
+  // validate everything the kernel will index with, on the host
+  for (uint32_t i = 0; i < n_var; ++i) {
+    if ((uint64_t)v_r0[i] + v_span[i] > ref_len || v_span[i] == 0 || v_alt_len[i] == 0) return HAWK_E_INVALID;
+    if ((uint64_t)v_alt_off[i] + v_alt_len[i] > alt_codes_len) return HAWK_E_INVALID;
+    if (i && v_r0[i] < v_r0[i - 1] + v_span[i - 1]) return HAWK_E_INVALID;  // sorted, non-overlapping
+  }
+  for (uint32_t h = 0; h < n_hap; ++h) {
+    if (hv_off[h + 1] < hv_off[h]) return HAWK_E_INVALID;
+    int64_t off = 0;
+    uint32_t prev = 0;
+    for (uint64_t k = hv_off[h]; k < hv_off[h + 1]; ++k) {
+      const uint32_t vi = hv_idx[k];
+      if (vi >= n_var || (k > hv_off[h] && vi <= prev)) return HAWK_E_INVALID;
+      if ((int64_t)hv_o[k] != (int64_t)v_r0[vi] + off) return HAWK_E_INVALID;  // exclusive prefix of the length changes
+      off += (int64_t)v_alt_len[vi] - (int64_t)v_span[vi];
+      prev = vi;
+    }
+    if ((int64_t)hap_len[h] != (int64_t)ref_len + off) return HAWK_E_INVALID;
+  }
+  hawk_hapset* hs = nullptr;
+  int rc = hawk_hapset_create(ctx, n_hap, hap_len, &hs);
+  if (rc) return rc;
+  uint32_t *d_r0 = nullptr, *d_span = nullptr, *d_ao = nullptr, *d_al = nullptr, *d_idx = nullptr;
+  uint8_t* d_codes = nullptr; uint64_t* d_off = nullptr; int32_t* d_o = nullptr; unsigned long long* d_hash = nullptr;
+  const size_t nv = std::max<size_t>(n_var, 1), nc = std::max<size_t>(ncar, 1);
+  HIPCHK(hipMalloc(&d_r0, nv * 4)); HIPCHK(hipMalloc(&d_span, nv * 4)); HIPCHK(hipMalloc(&d_ao, nv * 4)); HIPCHK(hipMalloc(&d_al, nv * 4));
+  HIPCHK(hipMalloc(&d_codes, std::max<size_t>(alt_codes_len, 1))); HIPCHK(hipMalloc(&d_off, (size_t)(n_hap + 1) * 8));
+  HIPCHK(hipMalloc(&d_idx, nc * 4)); HIPCHK(hipMalloc(&d_o, nc * 4)); HIPCHK(hipMalloc(&d_hash, (size_t)n_hap * 16));
+  hipStream_t st = ctx->stream;
+  if (n_var) {
+    HIPCHK(hipMemcpyAsync(d_r0, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_span, v_span, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ao, v_alt_off, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_al, v_alt_len, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_codes, alt_codes, alt_codes_len, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipMemcpyAsync(d_off, hv_off, (size_t)(n_hap + 1) * 8, hipMemcpyHostToDevice, st));
+  if (ncar) {
+    HIPCHK(hipMemcpyAsync(d_idx, hv_idx, ncar * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_o, hv_o, ncar * 4, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipMemsetAsync(d_hash, 0, (size_t)n_hap * 16, st));
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  hawk_launch_hx_build(st, ref_set->plane, d_r0, d_span, d_ao, d_al, d_codes, d_off, d_idx, d_o, hs->d_hap_len, n_hap, hs->S, hs->plane);
+  hawk_launch_hx_hash(st, hs->plane, n_hap, hs->S, d_hash);
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  HIPCHK(hipGetLastError());
+  if (hash_out) HIPCHK(hipMemcpyAsync(hash_out, d_hash, (size_t)n_hap * 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
+  (void)hipFree(d_r0); (void)hipFree(d_span); (void)hipFree(d_ao); (void)hipFree(d_al); (void)hipFree(d_codes); (void)hipFree(d_off);
+  (void)hipFree(d_idx); (void)hipFree(d_o); (void)hipFree(d_hash);
+  *out = hs;
+  return HAWK_OK;
+}
+
 // ---------------------------------------------------------------------------- K6 DeepCpf1
 int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* weights, float* out) {
   if (!ctx || !weights || (n && (!seqs34 || !out))) return HAWK_E_INVALID;

@@ -106,3 +106,8 @@ void hawk_launch_deepcpf1(hipStream_t st, const char* seqs, uint64_t n, const fl
 void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t n_trees, const int32_t* tree_off,
                          const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold,
                          const double* value, double init, double lr, double* out, double* feats_out, int* status);
+void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
+                          const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
+                          const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,
+                          uint32_t* const* plane);
+void hawk_launch_hx_hash(hipStream_t st, uint32_t* const* plane, uint32_t n_hap, uint32_t S, unsigned long long* hash);

@@ -84,6 +84,21 @@ int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words);
 /* Upload planes computed elsewhere (5 * n_hap * stride words, plane-major). */
 int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes);
 
+/* ---- haplotype expansion on the device, replacing Haplotype.add_variants_phased
+ * (haplotype.py:214-252) per chromosome copy.  ref_set: a one-row hapset holding the REF region.
+ * Variant table (position-sorted, non-overlapping): v_r0 = position in the region, v_span = REF bases
+ * replaced (SNV 1, deletion len(ref), insertion 1), alt allele = v_alt_len IUPAC codes (encoder.py
+ * nibbles, one per byte) at alt_codes + v_alt_off.  Row h of the new set carries variants
+ * hv_idx[hv_off[h] .. hv_off[h+1]) (ascending) whose output start positions hv_o are the exclusive
+ * prefix sums r0 + sum of earlier (alt_len - span); hap_len[h] = region length + its total change
+ * (all verified on the host before launch).  Alt bases are written with the V plane set, exactly as
+ * the reference lower-cases them.  hash_out (optional, 2 words per row): content hash for
+ * collapse_haplotypes (haplotypes.py:274-294).  The caller finishes with hawk_hapset_set_meta. */
+int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                       const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
+                       uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
+                       const uint32_t* hap_len, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms);
+
 /* ---- K2: pam_search() (search_guides.py:102-131) ---------------------------------------
  * Raw PAM hits of every haplotype inside its [scan_start, scan_stop): ascending relative
  * positions per haplotype, forward-PAM hits in hits_fwd and reverse-complement-PAM hits in

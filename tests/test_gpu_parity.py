@@ -162,3 +162,49 @@ def test_tile_boundary_lengths(region_len):
     synth.add_phased_variants(reg, 7201, 60, 2, frac_snv=0.5, frac_del=0.25, af_min=0.3, af_max=0.8)
     _oracle_vs_device(reg, "NGG", 20, False, True)
     _oracle_vs_device(reg, "TTTV", 23, True, False)
+
+
+@pytest.mark.parametrize("case", ["phased4", "phased16", "cpf1", "indel_dense", "tiny"])
+def test_device_haplotype_expansion_vs_reference_vectors(case):
+    """planes written by hawk_hapset_expand == planes packed from the haplotype
+    strings the reference built; labels, position maps and scan bounds too; then the search."""
+    from crisprhawk_hip.workload import expand_on_device
+    from util import synth_region_from_fixture, posmap_from_breaks
+    fx = load_golden(f"g3_search_{case}.json.gz")
+    reg = synth_region_from_fixture(fx)
+    ds, info, _ms, kept = expand_on_device(reg, len(fx["pam"]))
+    assert len(kept) == len(fx["haplotypes"])
+    want = device_set(hapset_from_golden(fx))
+    pw, pg = want.planes(), ds.planes()
+    for j, r in enumerate(kept):
+        n = (len(fx["haplotypes"][j]["seq"]) + 31) // 32
+        assert np.array_equal(pg[:, r, :n], pw[:, j, :n]), (case, j)
+        assert not pg[:, r, n:].any()
+        assert sorted(info[j].samples) == fx["haplotypes"][j]["samples"]
+        seg = ds.host_meta[r].seg
+        assert np.array_equal(seg.full(), posmap_from_breaks(fx["haplotypes"][j]["posmap_breaks"], fx["haplotypes"][j]["posmap_len"]))
+        assert list(ds.host_meta[r].scan) == fx["scan"][j]
+    bits, bitsrc, _, _ = ora.pam_encode(fx["pam"])
+    tab = ds.search(bits, bitsrc, len(fx["pam"]), fx["guidelen"], fx["right"])
+    rowmap = {r: j for j, r in enumerate(kept)}
+    order = tab.reference_order()
+    wins = tab.windows()
+    got = [[int(tab.start[i]), int(tab.stop[i]), int(tab.strand[i]), wins[i], rowmap[int(tab.hap[i])], bool(tab.right_as_stored()[i])]
+           for i in order]
+    assert got == fx["guides"]
+
+
+def test_device_expansion_matches_host_expansion_200kb():
+    from crisprhawk_hip.workload import build_phased_haplotypes, expand_on_device
+    reg = synth.make_region(7301, "chrH", 260_000, 30_000, 230_000)
+    synth.add_phased_variants(reg, 7302, 6000, 12, af_min=0.02, af_max=0.5)
+    haps, info_h = build_phased_haplotypes(reg, 3)
+    ds, info_d, ms, kept = expand_on_device(reg, 3)
+    assert len(kept) == len(haps) and [sorted(i.samples) for i in info_d] == [sorted(i.samples) for i in info_h]
+    want = DeviceHapSet(haps).planes()
+    got = ds.planes()
+    for j, r in enumerate(kept):
+        n = (len(haps[j].seq) + 31) // 32
+        assert np.array_equal(got[:, r, :n], want[:, j, :n])
+        assert np.array_equal(ds.host_meta[r].seg.rel, haps[j].seg.rel) and np.array_equal(ds.host_meta[r].seg.gen, haps[j].seg.gen)
+        assert ds.host_meta[r].scan == haps[j].scan
