@@ -339,7 +339,6 @@ static int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pa
   if (need_v) need |= 16u;
   sp->need = need;
   sp->poF = 0; sp->poR = 0;
-  { const char* e = getenv("HAWK_DEBUG_MODE"); sp->debug = e ? (uint32_t)atoi(e) : 0u; }
   return HAWK_OK;
 }
 
@@ -540,7 +539,7 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
 }
 
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
-                              void** flags, void** cfdon, void** win) {
+                              void** flags, void** cfdon, void** win, uint64_t* win_plane_stride) {
   if (!t) return HAWK_E_INVALID;
   const GuideCols& c = t->cols;
   if (hap) *hap = c.hap;
@@ -551,6 +550,7 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
   if (flags) *flags = c.flags;
   if (cfdon) *cfdon = c.cfdon;
   if (win) *win = c.win;
+  if (win_plane_stride) *win_plane_stride = c.cap;  // plane p of the window slices starts at win + p * stride
   return HAWK_OK;
 }
 

@@ -147,20 +147,6 @@ __device__ __forceinline__ W2 ext_glb(const uint32_t* __restrict__ row, uint32_t
   const U3 t = *reinterpret_cast<const U3*>(row + w);
   return W2{fsh(t.a, t.b, sh), fsh(t.b, t.c, sh)};
 }
-// nbits (<= 64) bits of a plane row starting at bit position bp (row has >= 2 pad words)
-__device__ __forceinline__ uint64_t extract_bits(const uint32_t* __restrict__ row, uint32_t bp, int nbits) {
-  const uint32_t w = bp >> 5, sh = bp & 31u;
-  const uint64_t lo = (uint64_t)row[w] | ((uint64_t)row[w + 1] << 32);
-  uint64_t v = lo >> sh;
-  if (sh) v |= (uint64_t)row[w + 2] << (64 - sh);
-  if (nbits < 64) v &= (1ull << nbits) - 1ull;
-  return v;
-}
-// 4-bit IUPAC code at bit `off` of four core slices
-__device__ __forceinline__ uint32_t code_at(const uint64_t (&c)[4], int off) {
-  return (uint32_t)((c[0] >> off) & 1) | (uint32_t)((c[1] >> off) & 1) << 1 | (uint32_t)((c[2] >> off) & 1) << 2 |
-         (uint32_t)((c[3] >> off) & 1) << 3;
-}
 __device__ __forceinline__ int base_index(uint32_t code) {  // A,C,G,T -> 0..3, anything else -1
   return (code & (code - 1u)) ? -1 : (code ? __builtin_ctz(code) : -1);
 }

@@ -32,7 +32,6 @@ struct ScanParams {
   int32_t L;                  // guidelen + pamlen
   uint32_t bph;               // workgroups per haplotype row
   uint32_t need;              // bit p set: plane p is read by this PAM (bit 4: V plane)
-  uint32_t debug;             // ablation switch for profiling builds (0 in production)
   int32_t poF, poR;           // raw scan: PAM offset inside the window per strand (0 = index by PAM position)
 };
 

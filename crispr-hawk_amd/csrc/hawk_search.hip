@@ -177,7 +177,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   const uint32_t T = TF + TR;
 
   uint32_t nvalid = 0;  // this thread's share (PASS 0)
-  if (!stage || p.debug == 2) {
+  if (!stage) {
     if (tid == 0) nvalid = T;
   } else if (T) {  // workgroup-uniform
     const int nloc = (int)s_acc[3];
@@ -210,7 +210,6 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
         }
       }
       __syncthreads();
-      if (p.debug == 1) { if (tid == 0) nvalid += T - base < CAP ? T - base : CAP; __syncthreads(); continue; }
       const uint32_t n = T - base < CAP ? T - base : CAP;
       // ---- phase C: one survivor per thread per round ---------------------------------
 #pragma unroll 1
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
               // identity, so its window starts at qr; it is a guide iff qr lies in REF's candidate
               // range for this strand and REF's PAM matches there.
               const int64_t qr = start - ri.startp;
-              if (qr >= ri.lo[s] && qr < ri.hi[s] && p.debug != 5) {
+              if (qr >= ri.lo[s] && qr < ri.hi[s]) {
                 W2 rc[4];
 #pragma unroll
                 for (int pl = 0; pl < 4; ++pl) {
@@ -309,7 +308,6 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
             out.flags[o] = has_ref ? 1 : 0;
 #pragma unroll
             for (int pl = 0; pl < HAWK_PLANES; ++pl) {
-              if (p.debug == 4) continue;
               W2 w = ext_lds(s_pl[pl], (int)ql - HAWK_PAD);
               w.lo &= wlo; w.hi &= whi;
               out.win[(size_t)pl * out.cap + o] = (uint64_t)w.lo | ((uint64_t)w.hi << 32);
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
             // REF and this guide differ contribute, visited in ascending t so the fp64 product is
             // formed exactly as cfdscore.py:78-95 forms it.
             double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
-            if (gp.score_cfdon && has_ref && p.debug != 3) {
+            if (gp.score_cfdon && has_ref) {
               W2 g[4], r[4];
               if (s) {
 #pragma unroll

@@ -148,9 +148,10 @@ int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candida
  *   A,C,G,T,V for the guidelen+pamlen+20-nt window, bit 0 = leftmost base. */
 int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
                         uint8_t* flags, double* cfdon, uint64_t* win);
-/* Device pointers of the same columns (for a collective over xGMI without a host bounce). */
+/* Device pointers of the same columns (valid until the next hawk_search on the same set);
+ * plane p of the window slices starts at win + p * win_plane_stride (in uint64 elements). */
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
-                              void** flags, void** cfdon, void** win);
+                              void** flags, void** cfdon, void** win, uint64_t* win_plane_stride);
 
 /* ---- K7: off-target enumeration, replacing the external `crispritz.py search ... -mm M -bDNA 0
  * -bRNA 0` of offtargets.py:222-293 (CRISPRitz 2.6.6 is a third-party binary the reference shells
