@@ -192,6 +192,24 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
 
     for (uint32_t base = 0; base < T; base += CAP) {
       // ---- phase B: survivors -> LDS list, strand 0 first, each in position order ------
+      if (PASS == 0 && T <= CAP) {  // the common case: the whole tile fits one round, no range checks per survivor
+        // (count pass only: in the emit pass the second copy of the loop costs registers and occupancy)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          uint32_t idx = s ? TF + exR : exF;
+          if (s ? cR : cF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              uint32_t x = s ? kR[k] : kF[k];
+              const uint32_t tag = ((uint32_t)s << 31) | ((4 * tid + k) * 32);
+              while (x) {
+                s_list[idx++] = tag | (uint32_t)__builtin_ctz(x);
+                x &= x - 1;
+              }
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         uint32_t idx = s ? TF + exR : exF;
@@ -208,6 +226,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
             }
           }
         }
+      }
       }
       __syncthreads();
       const uint32_t n = T - base < CAP ? T - base : CAP;
@@ -236,13 +255,35 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
               else { const int j2 = seg_find(s_segrel, nloc, q + (uint32_t)L); stop = s_seggen[j2] + (int64_t)(q + (uint32_t)L - s_segrel[j2]); }
             }
           }
+          valid = 1;
+          if (PASS == 0) {
+            // count pass: only the verdict is needed.  The survivor is redundant iff a REF window with the
+            // same genomic start lies in REF's candidate range and equals it on all four code planes (equal
+            // cores have equal PAM bits, so REF's PAM test is implied).  Compare the planes the scan just
+            // streamed (L2-hot) first; the others are fetched only when those agree (e.g. an A<->T SNV).
+            const int64_t qr = start - ri.startp;
+            if (qr >= ri.lo[s] && qr < ri.hi[s]) {
+              bool same = true;
+#pragma unroll
+              for (int round = 0; round < 2; ++round) {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) {
+                  const bool hot = ((p.need >> pl) & 1u) != 0;
+                  if (same && hot == (round == 0)) {
+                    const W2 a = ext_glb(hs.plane[pl] + rowbase, q), b = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
+                    same = ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
+                  }
+                }
+              }
+              if (same) valid = 0;
+            }
+          } else {
 #pragma unroll
           for (int pl = 0; pl < 4; ++pl) {
-            core[pl] = lds_planes ? ext_lds(s_pl[pl], (int)ql) : ext_glb(hs.plane[pl] + rowbase, q);
+            core[pl] = ext_lds(s_pl[pl], (int)ql);
             core[pl].lo &= mlo; core[pl].hi &= mhi;
             rcore[pl] = core[pl];
           }
-          valid = 1;
           if (ri.index >= 0) {
             if (isref) {
               has_ref = true;
@@ -288,6 +329,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
                 }
               }
             }
+          }
           }
         }
         if (PASS == 0) {
