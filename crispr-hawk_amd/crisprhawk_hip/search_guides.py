@@ -5,22 +5,26 @@ scan / filter / coordinate / redundancy work done by the HIP kernels through the
 (hawk_search) and materialises ``Guide`` objects in the reference's list order.  The
 ``haplotypes_bits`` argument is accepted for signature compatibility; the planes are the
 encoded form and are built once per call for all haplotypes together.
-Unphased VCFs (IUPAC expansion, search_guides.py:163-257, 473-480) are not covered: BASELINE's
-configurations are phased or variant-free."""
+With an unphased VCF the candidates come from the same device pass (the PAM match is a set
+intersection, so IUPAC-encoded haplotypes need no special casing) and are then expanded on the
+host through ``resolve_guide`` exactly as search_guides.py:163-257, 473-480 does: that step is a
+Cartesian product over a handful of ambiguous positions per window, string work by nature."""
 import os
 from collections import defaultdict
 from typing import DefaultDict, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 
-from .crisprhawk_error import CrisprHawkCfdScoreError
+from itertools import product
+
+from .crisprhawk_error import CrisprHawkCfdScoreError, CrisprHawkIupacTableError
 from .exception_handlers import exception_handler
 from .guide import GUIDESEQPAD, Guide
 from .hapset import DeviceHapSet, GuideTable, HostHaplotype, PosSegments
 from .haplotype import Haplotype
 from .pam import PAM
 from .region import Region
-from .utils import VERBOSITYLVL, print_verbosity
+from .utils import IUPACTABLE, VERBOSITYLVL, print_verbosity
 
 PADDING = 100  # region_constructor.py:21
 
@@ -87,6 +91,39 @@ def extract_guide_sequence(haplotype: Haplotype, position: int, pamlen: int, gui
     if right:
         return "".join(haplotype[position - GUIDESEQPAD: position + guidelen + pamlen + GUIDESEQPAD])
     return "".join(haplotype[position - guidelen - GUIDESEQPAD: position + pamlen + GUIDESEQPAD])
+
+
+def _valid_guide(pamguide: str, pam: PAM, direction: int, right: bool, debug: bool) -> bool:
+    """search_guides.py:163-169: does the resolved PAM slice still match the PAM pattern?"""
+    p = PAM(pamguide, right, debug)
+    p.encode(0)
+    pat = pam.bits if direction == 0 else pam.bitsrc
+    n = len(pam)
+    for i, nib in enumerate(p.bits_list):  # match() on nibbles (search_guides.py:32-46)
+        pn = (pat >> (4 * (n - 1 - i))) & 0xF
+        if pn and not (pn & nib):
+            return False
+    return True
+
+
+def _decode_iupac(nt: str, pos: int, h: Haplotype, debug: bool) -> str:
+    """search_guides.py:175-213"""
+    try:
+        ntiupac = IUPACTABLE[nt.upper()]
+    except KeyError as e:
+        exception_handler(CrisprHawkIupacTableError, f"Invalid IUPAC character ({nt})", os.EX_DATAERR, debug, e)
+    if len(ntiupac) == 1:
+        return ntiupac.lower() if nt.islower() else ntiupac
+    return "".join(n if n == alleles[0] else n.lower() for n in list(ntiupac) for alleles in h.variant_alleles[pos])
+
+
+def resolve_guide(guideseq: str, pam: PAM, direction: int, right: bool, pos: int, guidelen: int, h: Haplotype,
+                  debug: bool) -> List[str]:
+    """search_guides.py:216-257: all allele combinations of an IUPAC-encoded window whose PAM still matches."""
+    p = pos - GUIDESEQPAD if right else pos - guidelen - GUIDESEQPAD
+    alts = ["".join(g) for g in product(*[list(_decode_iupac(nt, p + i, h, debug)) for i, nt in enumerate(guideseq)])]
+    idx = GUIDESEQPAD if right else (len(guideseq) - GUIDESEQPAD - len(pam))
+    return [g for g in alts if _valid_guide(g[idx: idx + len(pam)], pam, direction, right, debug)]
 
 
 def adjust_guide_position(posmap, posrel: int, guidelen: int, pamlen: int, right: bool) -> Tuple[int, int]:
@@ -160,9 +197,33 @@ def search(pam: PAM, region: Region, haplotypes: List[Haplotype], haplotypes_bit
     """search_guides.py:510-548.  ``cfd_tables=(mm, pam)`` additionally scores CFDon in the same
     device pass (kept on each Guide for scoring.cfdon_score)."""
     print_verbosity(f"Searching guide candidates in {region.coordinates}", verbosity, VERBOSITYLVL[3])
-    if variants_present and not phased:
-        raise NotImplementedError("unphased (IUPAC-resolved) search is outside the GPU path's scope (DESIGN.md §8)")
     ds = _device_set(region, haplotypes, len(pam))
     mm, pt = cfd_tables if cfd_tables is not None else (None, None)
+    if variants_present and not phased:
+        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right)
+        return _resolve_unphased(tab, haplotypes, pam, guidelen, right, debug)
     tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt)
     return guides_from_table(tab, haplotypes, debug)
+
+
+def _resolve_unphased(tab: GuideTable, haplotypes: List[Haplotype], pam: PAM, guidelen: int, right: bool, debug: bool) -> List[Guide]:
+    """retrieve_guides' unphased branch (search_guides.py:473-480) over the device rows, in the
+    reference's emission order, then remove_redundant_guides on the resolved sequences."""
+    tab.download()
+    wins = tab.windows()
+    ras = tab.right_as_stored()
+    L = guidelen + len(pam)
+    guides: List[Guide] = []
+    for i in tab.emission_order():
+        h = haplotypes[int(tab.hap[i])]
+        r, pos, strand = bool(ras[i]), int(tab.pos[i]), int(tab.strand[i])
+        if not is_pamhit_valid(pos, len(h), guidelen, len(pam), r):
+            continue
+        pivot = pos if r else pos - guidelen
+        for seq in resolve_guide(wins[i], pam, strand, r, pos, guidelen, h, debug):
+            def _pm(seg=h.segments, pivot=pivot):
+                g = seg.lookup(np.arange(pivot, pivot + L))
+                return {k: int(g[k]) for k in range(L)}
+            guides.append(Guide(int(tab.start[i]), int(tab.stop[i]), seq, guidelen, len(pam), strand, h.samples, h.variants,
+                                h.afs, _pm, debug, r, h.id))
+    return remove_redundant_guides(guides, debug)

@@ -141,7 +141,10 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_hash(const uint32_t* pA, cons
       b += fmix64(key * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
     }
   }
-  atomicAdd(&s_h[0], a); atomicAdd(&s_h[1], b);
+  // wave sums first (64-bit as two 32-bit halves with carry-free 64-bit shuffles), then one LDS atomic per wave
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+  if ((threadIdx.x & (WAVE - 1)) == 0) { atomicAdd(&s_h[0], a); atomicAdd(&s_h[1], b); }
   __syncthreads();
   if (threadIdx.x == 0 && (s_h[0] | s_h[1])) { atomicAdd(&hash[2 * h], s_h[0]); atomicAdd(&hash[2 * h + 1], s_h[1]); }
 }

@@ -17,6 +17,8 @@ reference computed for them.
 Fixtures:
   g1_tables.json.gz     nibble table, PAM bits / bitsrc / cas_system for every listed PAM
   g2_scan.json.gz       scan_haplotype hit lists (IUPAC-bearing sequences, 5 PAMs, edge ranges)
+  g4_unphased.json.gz   unphased VCF: IUPAC-encoded haplotypes + indel windows built by the reference and
+                        its search() output (resolve_guide expansion)
   g3_search_*.json.gz   haplotype construction + pam_search + search() + reverse_guides +
                         scorer input k-mers + CFDon (synthetic tables) for several regions
   g5_cfd.json.gz        compute_cfd on random (wt, sg, pam) triples, synthetic tables
@@ -293,6 +295,52 @@ def g3_all():
     g3_search("ngn", synth.make_region(3061, "chrX", 4000, 300, 3300), "NGN", 20, False)
 
 
+# ---------------------------------------------------------------------------- G4 (unphased)
+def g4_unphased():
+    """Unphased VCF: the reference encodes heterozygous SNVs as lower-case IUPAC letters, builds one
+    200-bp window haplotype per indel, and search() expands every candidate through resolve_guide
+    (search_guides.py:163-257, 473-480).  The haplotypes are built by the reference's own
+    add_variants_unphased body (haplotypes.py:672-712, VCF object replaced by its sample list)."""
+    reg = synth.make_region(4001, "chrU", 5000, 1000, 4000)
+    synth.add_phased_variants(reg, 4002, 40, 3, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.2, af_max=0.6)
+    region = _ref_region(reg)
+    haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
+    records = []
+    for v in reg.variants:
+        vr = VariantRecord(True)
+        fields = reg.vcf_fields(v)
+        fields[9:] = [g.replace("|", "/") for g in fields[9:]]
+        vr.read_vcf_line(fields, reg.samples, False)
+        records.append(vr)
+    variants = flatten_list([r.split() for r in records])
+    snvs, indels = R_haps.classify_variants(variants)
+    if snvs:
+        haps.extend(R_haps.compute_snvs_haplotype_unphased(snvs, reg.samples, region.sequence.sequence, region.coordinates, False, True))
+    for indel in indels:
+        if region.coordinates.startp <= indel.position < region.coordinates.stopp:
+            haps.extend(R_haps.create_indels_haplotype_unphased(indel, snvs, region, False, True))
+    for i, h in enumerate(haps):
+        h.id = f"hap_{i:08d}"
+    pam_s, guidelen, right = "NGG", 20, False
+    pam = R_pam.PAM(pam_s, right, True)
+    pam.encode(0)
+    bits = [R_encoder.encode(h.sequence.sequence, 0, True) for h in haps]
+    scan = [list(R_search.compute_scan_start_stop(h, region.start, region.stop, len(pam))) for h in haps]
+    hits = R_search.pam_search(pam, region, haps, bits, 0, True)
+    guides = R_search.search(pam, region, haps, bits, guidelen, right, True, False, 0, True)
+    hapidx = {h.id: i for i, h in enumerate(haps)}
+    out_haps = [dict(seq=h.sequence.sequence, samples=h.samples, variants=h.variants, contig=h.contig,
+                     coord=[h.coordinates.startp, h.coordinates.stopp, h.coordinates.start, h.coordinates.stop],
+                     posmap_breaks=_posmap_breaks(h.posmap), posmap_len=len(h.posmap),
+                     variant_alleles={str(k): [list(t) for t in v] for k, v in h.variant_alleles.items()}) for h in haps]
+    dump("g4_unphased.json.gz", dict(
+        contig=reg.contig, bed_start=reg.bed_start, bed_stop=reg.bed_stop, startp=region.start, stopp=region.stop,
+        region_seq=reg.sequence, pam=pam_s, guidelen=guidelen, right=right, haplotypes=out_haps, scan=scan,
+        hits=[[list(f), list(r)] for f, r in hits],
+        guides=[[g.start, g.stop, g.strand, g.sequence, hapidx[g.hapid], bool(g.right), g.samples] for g in guides]))
+    print(f"   unphased: {len(haps)} haplotypes, {sum(len(f)+len(r) for f, r in hits)} hits, {len(guides)} guides")
+
+
 # ---------------------------------------------------------------------------- G5
 def g5_cfd():
     rng = np.random.default_rng(5005)
@@ -335,13 +383,15 @@ def g6_deepcpf1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     if "g1" in which:
         g1_tables()
     if "g2" in which:
         g2_scan()
     if "g3" in which:
         g3_all()
+    if "g4" in which:
+        g4_unphased()
     if "g5" in which:
         g5_cfd()
     if "g6" in which:

@@ -151,3 +151,30 @@ def test_azimuth_against_sklearn_gbr():
     test = [synth.random_sequence(rng, 30) for _ in range(300)]
     got = np.array(scoring.azimuth(test))
     assert np.max(np.abs(got - gbr.predict(ora.azimuth_features(test)))) < 1e-9
+
+
+def test_unphased_search_resolves_iupac_like_the_reference():
+    """haplotypes built by the reference from an unphased VCF (lower-case IUPAC letters at
+    heterozygous SNVs, one window haplotype per indel) -> search() with resolve_guide expansion."""
+    from util import posmap_from_breaks
+    fx = load_golden("g4_unphased.json.gz")
+    region = Region(Sequence(fx["region_seq"], True), Coordinate(fx["contig"], fx["bed_start"], fx["bed_stop"], 100))
+    haps = []
+    for i, gh in enumerate(fx["haplotypes"]):
+        sp, ep, s0, e0 = gh["coord"]  # window haplotypes carry their own coordinates (padding 0)
+        coord = Coordinate(gh["contig"], sp, ep, sp - s0)
+        assert (coord.start, coord.stop) == (s0, e0)
+        h = Haplotype(Sequence(gh["seq"], True, allow_lower_case=True), coord, False, 0, True)
+        h.samples, h.variants = gh["samples"], gh["variants"]
+        h.set_posmap({k: int(v) for k, v in enumerate(posmap_from_breaks(gh["posmap_breaks"], gh["posmap_len"]))})
+        h.set_variant_alleles({int(k): [tuple(t) for t in v] for k, v in gh["variant_alleles"].items()})
+        h.id = f"hap_{i:08d}"
+        haps.append(h)
+    pam = PAM(fx["pam"], fx["right"], True)
+    pam.encode(0)
+    assert [list(compute_scan_start_stop(h, region.start, region.stop, len(pam))) for h in haps] == fx["scan"]
+    assert [[f, r] for f, r in pam_search(pam, region, haps, None, 0, True)] == fx["hits"]
+    guides = search(pam, region, haps, None, fx["guidelen"], fx["right"], True, False, 0, True)
+    hidx = {h.id: i for i, h in enumerate(haps)}
+    got = [[g.start, g.stop, g.strand, g.sequence, hidx[g.hapid], g.right, g.samples] for g in guides]
+    assert got == fx["guides"]
