@@ -65,7 +65,7 @@ struct hawk_hapset {
   uint32_t* d_tile_seg0;   // [n_hap * bph] first position-map segment each tile needs
   int64_t ref_startp;
   // workspace reused across searches
-  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides;
+  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf colsA[8];
 };
 
@@ -442,6 +442,14 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
       (rc = hs->totals.reserve(sizeof(ScanTotals))) || (rc = hs->misc.reserve(512 * 8 + 64)) ||
       (rc = hs->cfd.reserve(336 * 8)) || (rc = hs->partial.reserve((ntile / 1024 + 2) * 8)))
     return rc;
+  // hand-over lists (2 KB per tile): the count pass leaves each small tile's valid survivors for the emit pass.
+  // HAWK_LIST_EMIT=0 keeps the recompute-everything emit pass (A/B measurements).
+  static const bool list_emit = [] { const char* e = getenv("HAWK_LIST_EMIT"); return !(e && e[0] == '0'); }();
+  uint32_t* d_lists = nullptr;
+  if (list_emit) {
+    if ((rc = hs->lists.reserve(ntile * HAWK_LIST_CAP * 4))) return rc;
+    d_lists = hs->lists.as<uint32_t>();
+  }
   if (p->score_cfdon) {
     HIPCHK(hipMemcpyAsync(hs->cfd.p, p->cfd_mm, 320 * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(hs->cfd.as<double>() + 320, p->cfd_pam, 16 * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -468,7 +476,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status);
+  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
   hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
                     hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
@@ -482,7 +490,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
   if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards,
-                                hs->offsets.as<uint64_t>(), ca, d_status);
+                                hs->offsets.as<uint64_t>(), ca, d_status, d_lists);
   HIPCHK(hipEventRecord(ev[4], ctx->stream));
   HIPCHK(hipGetLastError());
   int status = 0;

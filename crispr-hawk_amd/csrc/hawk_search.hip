@@ -24,6 +24,7 @@
 #define TILE_WORDS (HAWK_BLOCK * HAWK_WPT)  // 1024 plane words per tile
 #define LDS_OFF 4                            // tile word w lives at s_pl[p][LDS_OFF + w]; word -1 at [3]
 #define LDS_ROW (TILE_WORDS + 8)             // + halo: 1 word before, 2 after (+ pad)
+#define LIST_CAP 512                         // valid survivors a tile may hand from the count pass to the emit pass
 
 __device__ __forceinline__ int seg_find(const uint32_t* s_rel, int n, uint32_t rel) {
   int lo = 0, hi = n;  // last j in [0,n) with s_rel[j] <= rel (s_rel[0] <= every rel of the tile)
@@ -49,11 +50,57 @@ __device__ __forceinline__ W2 rev_bits(W2 v, int L) {
   return W2{sh == 32 ? rh : rh >> (sh - 32), 0u};
 }
 
+// K4: CFDon on the 5'->3' guide.  Strand-1 slices are first turned into the 5'->3' guide (reverse the L
+// bits, swap A<->T and C<->G planes = reverse complement), after which both strands read spacer base t at
+// bit t and PAM[-2:] at bits L-2, L-1.  Only positions where REF and this guide differ contribute, visited
+// in ascending t so the fp64 product is formed exactly as cfdscore.py:78-95 forms it.
+__device__ __forceinline__ double cfdon_from_slices(const W2 (&core)[4], const W2 (&rcore)[4], uint32_t s, int L,
+                                                    uint32_t cfdmask, const double* s_cfd, bool& err) {
+  W2 g[4], r[4];
+  if (s) {
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) { g[pl] = rev_bits(core[3 - pl], L); r[pl] = rev_bits(rcore[3 - pl], L); }
+  } else {
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) { g[pl] = core[pl]; r[pl] = rcore[pl]; }
+  }
+  // spacer positions 0..min(guidelen,20)-1 all sit in the low word
+  uint32_t diff = ((g[0].lo ^ r[0].lo) | (g[1].lo ^ r[1].lo) | (g[2].lo ^ r[2].lo) | (g[3].lo ^ r[3].lo)) & cfdmask;
+  // a lookup needs both bases to be exactly one of A,C,G,T (else KeyError in the reference)
+  const uint32_t g2 = (g[0].lo & g[1].lo) | ((g[0].lo | g[1].lo) & (g[2].lo | g[3].lo)) | (g[2].lo & g[3].lo);
+  const uint32_t r2 = (r[0].lo & r[1].lo) | ((r[0].lo | r[1].lo) & (r[2].lo | r[3].lo)) | (r[2].lo & r[3].lo);
+  err = (diff & (g2 | r2)) != 0;
+  const uint32_t gb0 = g[1].lo | g[3].lo, gb1 = g[2].lo | g[3].lo;  // base index bits: A0 C1 G2 T3
+  const uint32_t rb0 = r[1].lo | r[3].lo, rb1 = r[2].lo | r[3].lo;
+  double score = 1.0;
+  while (diff && !err) {
+    const uint32_t t = (uint32_t)__builtin_ctz(diff);
+    diff &= diff - 1;
+    const uint32_t a = ((rb0 >> t) & 1u) | (((rb1 >> t) & 1u) << 1);
+    const uint32_t b = ((gb0 >> t) & 1u) | (((gb1 >> t) & 1u) << 1);
+    score *= s_cfd[(t * 4 + a) * 4 + b];
+  }
+  if (!err) {
+    const int o0 = L - 2, o1 = L - 1;  // PAM[-2:] (wave-uniform positions)
+    uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      c0 |= (((o0 < 32 ? g[pl].lo : g[pl].hi) >> (o0 & 31)) & 1u) << pl;
+      c1 |= (((o1 < 32 ? g[pl].lo : g[pl].hi) >> (o1 & 31)) & 1u) << pl;
+    }
+    const int p0 = base_index(c0), p1 = base_index(c1);
+    if (p0 < 0 || p1 < 0) err = true;
+    else score *= s_cfd[320 + 4 * p0 + p1];
+  }
+  return err ? __longlong_as_double(0x7ff8000000000000ll) : score;
+}
+
 template <int PASS>
 __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri,
                                                         const uint32_t* __restrict__ tile_seg0, uint32_t* __restrict__ counts,
                                                         unsigned long long* __restrict__ shards,
-                                                        const uint64_t* __restrict__ offsets, GuideCols out, int* status) {
+                                                        const uint64_t* __restrict__ offsets, GuideCols out, int* status,
+                                                        uint32_t* __restrict__ lists) {
   __shared__ __attribute__((aligned(16))) uint32_t s_pl[PASS == 1 ? HAWK_PLANES : 1][PASS == 1 ? LDS_ROW : 8];
   __shared__ uint32_t s_list[CAP];
   __shared__ uint32_t s_segrel[NSEG];
@@ -63,6 +110,10 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   __shared__ uint32_t s_acc[4];
   const uint32_t tid = threadIdx.x;
   const uint32_t tile = blockIdx.x;
+  // list mode: the count pass hands the valid survivors of small tiles to k_emit_list; this kernel's emit
+  // pass then only serves the tiles whose list did not fit (REF tiles, very dense tiles)
+  const bool list_mode = PASS == 0 && lists != nullptr;
+  if (PASS == 1 && lists != nullptr && counts[tile] <= LIST_CAP) return;
   const uint32_t h = tile / p.bph, blk = tile % p.bph;
   const uint32_t u = blk * HAWK_BLOCK + tid;
   const bool active = u < hs.S / 4;
@@ -71,7 +122,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   const int ss = hs.scan_start[h], se = hs.scan_stop[h];
   const bool isref = hs.is_ref[h] != 0;
   const bool dedup = ri.index >= 0 && !isref;  // rows of this tile can be redundant with REF
-  const bool stage = PASS == 1 || dedup;        // phase C runs if the tile has survivors
+  const bool stage = PASS == 1 || dedup || list_mode;  // phase C runs if the tile has survivors
   const bool lds_planes = PASS == 1;            // PASS 0 classifies its few survivors straight from L2/HBM
   const uint32_t w0 = blk * TILE_WORDS;         // first plane word of the tile
   const uint32_t tile_q0 = w0 * 32u;
@@ -177,8 +228,9 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   const uint32_t T = TF + TR;
 
   uint32_t nvalid = 0;  // this thread's share (PASS 0)
-  if (!stage) {
-    if (tid == 0) nvalid = T;
+  uint32_t lrun = 0;  // valid survivors listed so far (list mode)
+  if (!stage || (PASS == 0 && !dedup && (!list_mode || T > LIST_CAP))) {
+    if (tid == 0) nvalid = T;  // nothing can be redundant here and no list is wanted: the count is the survivor count
   } else if (T) {  // workgroup-uniform
     const int nloc = (int)s_acc[3];
     const size_t refbase = ri.index >= 0 ? (size_t)ri.index * hs.S : 0;
@@ -257,25 +309,58 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
           }
           valid = 1;
           if (PASS == 0) {
-            // count pass: only the verdict is needed.  The survivor is redundant iff a REF window with the
-            // same genomic start lies in REF's candidate range and equals it on all four code planes (equal
-            // cores have equal PAM bits, so REF's PAM test is implied).  Compare the planes the scan just
-            // streamed (L2-hot) first; the others are fetched only when those agree (e.g. an A<->T SNV).
-            const int64_t qr = start - ri.startp;
-            if (qr >= ri.lo[s] && qr < ri.hi[s]) {
-              bool same = true;
+            // count pass: the verdict (and, for the hand-over list, whether a REF guide shares the key).
+            // A REF guide exists at (start, strand) iff the window start qr = start - startp lies in REF's
+            // candidate range and REF's PAM matches there (tested on the planes the PAM names, which the scan
+            // just streamed: L2-hot).  The survivor is redundant iff additionally the four code planes agree:
+            // compare the hot planes first, the others are fetched only when those agree (e.g. an A<->T SNV).
+            if (ri.index >= 0) {
+              if (isref) {
+                has_ref = true;
+              } else {
+                const int64_t qr = start - ri.startp;
+                if (qr >= ri.lo[s] && qr < ri.hi[s]) {
+                  W2 rc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
-              for (int round = 0; round < 2; ++round) {
+                  for (int pl = 0; pl < 4; ++pl)
+                    if ((p.need >> pl) & 1u) { rc[pl] = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr); rc[pl].lo &= mlo; rc[pl].hi &= mhi; }
+                  const bool pamfirst = (p.right != 0) != (s != 0);
+                  const int po = pamfirst ? 0 : p.guidelen;
+                  const uint64_t pam = s ? p.pam_rev : p.pam_fwd;
+                  bool ok = true;
+                  for (int t = 0; t < p.pamlen; ++t) {
+                    const uint32_t nib = (uint32_t)(pam >> (4 * (p.pamlen - 1 - t))) & 15u;
+                    const int off = po + t;
+                    uint32_t sel = 0;
+                    if (off < 32) {
+                      if (nib & 1u) sel |= rc[0].lo; if (nib & 2u) sel |= rc[1].lo;
+                      if (nib & 4u) sel |= rc[2].lo; if (nib & 8u) sel |= rc[3].lo;
+                    } else {
+                      if (nib & 1u) sel |= rc[0].hi; if (nib & 2u) sel |= rc[1].hi;
+                      if (nib & 4u) sel |= rc[2].hi; if (nib & 8u) sel |= rc[3].hi;
+                    }
+                    ok = ok && (nib == 15u || ((sel >> (off & 31)) & 1u));
+                  }
+                  if (ok) {
+                    has_ref = true;
+                    bool same = true;
 #pragma unroll
-                for (int pl = 0; pl < 4; ++pl) {
-                  const bool hot = ((p.need >> pl) & 1u) != 0;
-                  if (same && hot == (round == 0)) {
-                    const W2 a = ext_glb(hs.plane[pl] + rowbase, q), b = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
-                    same = ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
+                    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+                      for (int pl = 0; pl < 4; ++pl) {
+                        const bool hot = ((p.need >> pl) & 1u) != 0;
+                        if (same && hot == (round == 0)) {
+                          const W2 a = ext_glb(hs.plane[pl] + rowbase, q);
+                          W2 b = rc[pl];
+                          if (!hot) b = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
+                          same = ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
+                        }
+                      }
+                    }
+                    if (same) valid = 0;
                   }
                 }
               }
-              if (same) valid = 0;
             }
           } else {
 #pragma unroll
@@ -333,7 +418,15 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
           }
         }
         if (PASS == 0) {
-          nvalid += valid;
+          if (list_mode) {  // compact the valid survivors into the tile's hand-over list
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(valid, s_w, &tot);
+            if (valid && lrun + ex < LIST_CAP) lists[(size_t)tile * LIST_CAP + lrun + ex] = ql | (s << 15) | ((uint32_t)has_ref << 16);
+            lrun += tot;
+            if (tid == 0) nvalid += tot;
+          } else {
+            nvalid += valid;
+          }
         } else {
           uint32_t tot;
           const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(valid, s_w, &tot);
@@ -354,52 +447,11 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
               w.lo &= wlo; w.hi &= whi;
               out.win[(size_t)pl * out.cap + o] = (uint64_t)w.lo | ((uint64_t)w.hi << 32);
             }
-            // K4: CFDon on the 5'->3' guide.  Strand-1 slices are first turned into the 5'->3' guide
-            // (reverse the L bits, swap A<->T and C<->G planes = reverse complement), after which both
-            // strands read spacer base t at bit t and PAM[-2:] at bits L-2, L-1.  Only positions where
-            // REF and this guide differ contribute, visited in ascending t so the fp64 product is
-            // formed exactly as cfdscore.py:78-95 forms it.
             double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
             if (gp.score_cfdon && has_ref) {
-              W2 g[4], r[4];
-              if (s) {
-#pragma unroll
-                for (int pl = 0; pl < 4; ++pl) { g[pl] = rev_bits(core[3 - pl], L); r[pl] = rev_bits(rcore[3 - pl], L); }
-              } else {
-#pragma unroll
-                for (int pl = 0; pl < 4; ++pl) { g[pl] = core[pl]; r[pl] = rcore[pl]; }
-              }
-              // spacer positions 0..min(guidelen,20)-1 all sit in the low word
-              uint32_t diff = ((g[0].lo ^ r[0].lo) | (g[1].lo ^ r[1].lo) | (g[2].lo ^ r[2].lo) | (g[3].lo ^ r[3].lo)) & cfdmask;
-              // a lookup needs both bases to be exactly one of A,C,G,T (else KeyError in the reference)
-              const uint32_t g2 = (g[0].lo & g[1].lo) | ((g[0].lo | g[1].lo) & (g[2].lo | g[3].lo)) | (g[2].lo & g[3].lo);
-              const uint32_t r2 = (r[0].lo & r[1].lo) | ((r[0].lo | r[1].lo) & (r[2].lo | r[3].lo)) | (r[2].lo & r[3].lo);
-              bool err = (diff & (g2 | r2)) != 0;
-              const uint32_t gb0 = g[1].lo | g[3].lo, gb1 = g[2].lo | g[3].lo;  // base index bits: A0 C1 G2 T3
-              const uint32_t rb0 = r[1].lo | r[3].lo, rb1 = r[2].lo | r[3].lo;
-              score = 1.0;
-              while (diff && !err) {
-                const uint32_t t = (uint32_t)__builtin_ctz(diff);
-                diff &= diff - 1;
-                const uint32_t a = ((rb0 >> t) & 1u) | (((rb1 >> t) & 1u) << 1);
-                const uint32_t b = ((gb0 >> t) & 1u) | (((gb1 >> t) & 1u) << 1);
-                score *= s_cfd[(t * 4 + a) * 4 + b];
-              }
-              if (!err) {
-                // PAM[-2:] = bits L-2, L-1 (wave-uniform positions)
-                uint32_t c0, c1;
-                {
-                  const int o0 = L - 2, o1 = L - 1;
-                  c0 = ((((o0 < 32 ? g[0].lo : g[0].hi) >> (o0 & 31)) & 1u)) | ((((o0 < 32 ? g[1].lo : g[1].hi) >> (o0 & 31)) & 1u) << 1) |
-                       ((((o0 < 32 ? g[2].lo : g[2].hi) >> (o0 & 31)) & 1u) << 2) | ((((o0 < 32 ? g[3].lo : g[3].hi) >> (o0 & 31)) & 1u) << 3);
-                  c1 = ((((o1 < 32 ? g[0].lo : g[0].hi) >> (o1 & 31)) & 1u)) | ((((o1 < 32 ? g[1].lo : g[1].hi) >> (o1 & 31)) & 1u) << 1) |
-                       ((((o1 < 32 ? g[2].lo : g[2].hi) >> (o1 & 31)) & 1u) << 2) | ((((o1 < 32 ? g[3].lo : g[3].hi) >> (o1 & 31)) & 1u) << 3);
-                }
-                const int p0 = base_index(c0), p1 = base_index(c1);
-                if (p0 < 0 || p1 < 0) err = true;
-                else score *= s_cfd[320 + 4 * p0 + p1];
-              }
-              if (err) { atomicExch(status, -5 /* HAWK_E_CFD */); score = __longlong_as_double(0x7ff8000000000000ll); }
+              bool err;
+              score = cfdon_from_slices(core, rcore, s, L, cfdmask, s_cfd, err);
+              if (err) atomicExch(status, -5 /* HAWK_E_CFD */);
             }
             out.cfdon[o] = score;
           }
@@ -425,12 +477,157 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_emit_list — the emit pass for tiles whose valid survivors fit the hand-over list.
+//
+// The count pass already did the PAM match, the range / variant-window filters and the REF
+// classification, and left (window start, strand, has-REF) per valid survivor in `lists`.  What is
+// left is row assembly: stage the tile's five plane slices and its position-map slice in LDS, then
+// one thread per row looks up the coordinates, cuts the padded window and the spacer+PAM core out
+// of LDS, fetches REF's core when a REF guide shares the key, scores CFDon and stores the row at
+// offsets[tile] + i.  No scans, no list building, no barriers after the staging one.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri,
+                                                          const uint32_t* __restrict__ tile_seg0,
+                                                          const uint32_t* __restrict__ counts,
+                                                          const uint64_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ lists, GuideCols out, int* status) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_pl[HAWK_PLANES][LDS_ROW];
+  __shared__ uint32_t s_segrel[NSEG];
+  __shared__ int64_t s_seggen[NSEG];
+  __shared__ double s_cfd[336];
+  __shared__ uint32_t s_nloc;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t n = counts[tile];
+  if (n == 0 || n > LIST_CAP) return;  // workgroup-uniform
+  const uint32_t h = tile / p.bph, blk = tile % p.bph;
+  const uint32_t u = blk * HAWK_BLOCK + tid;
+  const bool active = u < hs.S / 4;
+  const size_t rowbase = (size_t)h * hs.S;
+  const bool isref = hs.is_ref[h] != 0;
+  const uint32_t w0 = blk * TILE_WORDS;
+  const uint32_t tile_q0 = w0 * 32u;
+  const uint32_t tile_end = tile_q0 + TILE_WORDS * 32u + 64u;
+  if (tid == 0) s_nloc = 0;
+
+  // the survivor entries first: their latency hides behind the staging
+  const uint32_t e0 = tid < n ? lists[(size_t)tile * LIST_CAP + tid] : 0u;
+  const uint32_t e1 = tid + HAWK_BLOCK < n ? lists[(size_t)tile * LIST_CAP + tid + HAWK_BLOCK] : 0u;
+  uint4 v[HAWK_PLANES];
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl)
+    v[pl] = active ? *reinterpret_cast<const uint4*>(hs.plane[pl] + rowbase + 4 * (size_t)u) : make_uint4(0, 0, 0, 0);
+  uint32_t halo = 0;
+  if (tid < 3 * HAWK_PLANES) {
+    const uint32_t pl = tid / 3, j = tid % 3;  // j: 0 -> word -1, 1 -> word TILE_WORDS, 2 -> TILE_WORDS+1
+    const long long w = j == 0 ? (long long)w0 - 1 : (long long)w0 + TILE_WORDS + (j - 1);
+    if (w >= 0 && w < (long long)hs.S) halo = hs.plane[pl][rowbase + (size_t)w];
+  }
+  const uint32_t k0 = tile_seg0[tile], kend = hs.seg_off[h + 1];
+  uint32_t seg_r = 0xffffffffu;
+  int64_t seg_g = 0;
+  bool seg_in = false;
+  if (tid < NSEG) {
+    const uint32_t k = k0 + tid;
+    if (k < kend) {
+      seg_r = hs.seg_rel[k];
+      seg_g = hs.seg_gen[k];
+      seg_in = tid == 0 || seg_r < tile_end;
+    }
+  }
+  const bool ovf = k0 + NSEG < kend && hs.seg_rel[k0 + NSEG] < tile_end;
+  if (gp.score_cfdon) for (uint32_t i = tid; i < 336; i += HAWK_BLOCK) s_cfd[i] = gp.cfd_mm[i];
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) *reinterpret_cast<uint4*>(&s_pl[pl][LDS_OFF + 4 * tid]) = v[pl];
+  if (tid < 3 * HAWK_PLANES) {
+    const uint32_t pl = tid / 3, j = tid % 3;
+    s_pl[pl][j == 0 ? LDS_OFF - 1 : LDS_OFF + TILE_WORDS + (j - 1)] = halo;
+  }
+  if (tid < NSEG) {
+    s_segrel[tid] = seg_in ? seg_r : 0xffffffffu;
+    s_seggen[tid] = seg_g;
+    if (seg_in) atomicAdd(&s_nloc, 1u);
+  }
+  __syncthreads();
+  const int nloc = (int)s_nloc;
+  const size_t refbase = ri.index >= 0 ? (size_t)ri.index * hs.S : 0;
+  const int L = p.L;
+  const int W = L + 2 * HAWK_PAD;
+  const uint32_t mlo = L >= 32 ? 0xffffffffu : ((1u << L) - 1u), mhi = L <= 32 ? 0u : ((1u << (L - 32)) - 1u);
+  const uint32_t whi = W >= 64 ? 0xffffffffu : ((1u << (W - 32)) - 1u);  // W = L + 20 > 32
+  const int ncfd = gp.guidelen < 20 ? gp.guidelen : 20;
+  const uint32_t cfdmask = (1u << ncfd) - 1u;
+  const uint64_t row0 = offsets[tile];
+
+#pragma unroll 1
+  for (uint32_t k = 0; k < LIST_CAP / HAWK_BLOCK; ++k) {
+    const uint32_t i = tid + k * HAWK_BLOCK;
+    if (i >= n) break;
+    const uint32_t e = k ? e1 : e0;
+    const uint32_t ql = e & 0x7fffu, s = (e >> 15) & 1u;
+    const bool has_ref = ((e >> 16) & 1u) != 0;
+    const uint32_t q = tile_q0 + ql;
+    int64_t start, stop;
+    if (ovf) {
+      start = posmap_global(hs, h, q);
+      stop = posmap_global(hs, h, q + (uint32_t)L);
+    } else {  // search_guides.py:260-280: start = posmap[q], stop = posmap[q + L]
+      const int j = seg_find(s_segrel, nloc, q);
+      start = s_seggen[j] + (int64_t)(q - s_segrel[j]);
+      if (j + 1 >= nloc || s_segrel[j + 1] > q + (uint32_t)L) stop = start + L;
+      else { const int j2 = seg_find(s_segrel, nloc, q + (uint32_t)L); stop = s_seggen[j2] + (int64_t)(q + (uint32_t)L - s_segrel[j2]); }
+    }
+    const uint64_t o = row0 + i;
+    if (o >= out.cap) { atomicExch(status, -3 /* HAWK_E_CAPACITY: offsets and counts disagree */); continue; }
+    const bool pamfirst = (p.right != 0) != (s != 0);
+    out.hap[o] = h;
+    out.pos[o] = pamfirst ? q : q + (uint32_t)p.guidelen;
+    out.strand[o] = (uint8_t)s;
+    out.start[o] = start;
+    out.stop[o] = stop;
+    out.flags[o] = has_ref ? 1 : 0;
+    W2 core[4], rcore[4];
+#pragma unroll
+    for (int pl = 0; pl < HAWK_PLANES; ++pl) {
+      W2 w = ext_lds(s_pl[pl], (int)ql - HAWK_PAD);
+      w.hi &= whi;
+      out.win[(size_t)pl * out.cap + o] = (uint64_t)w.lo | ((uint64_t)w.hi << 32);
+      if (pl < 4) {  // the spacer+PAM core is the window without its pads
+        core[pl].lo = fsh(w.lo, w.hi, HAWK_PAD) & mlo;
+        core[pl].hi = (w.hi >> HAWK_PAD) & mhi;
+        rcore[pl] = core[pl];
+      }
+    }
+    double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
+    if (gp.score_cfdon && has_ref) {
+      if (!isref) {
+        const uint32_t qr = (uint32_t)(start - ri.startp);  // REF's position map is the identity
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+          rcore[pl] = ext_glb(hs.plane[pl] + refbase, qr);
+          rcore[pl].lo &= mlo; rcore[pl].hi &= mhi;
+        }
+      }
+      bool err;
+      score = cfdon_from_slices(core, rcore, s, L, cfdmask, s_cfd, err);
+      if (err) atomicExch(status, -5 /* HAWK_E_CFD */);
+    }
+    out.cfdon[o] = score;
+  }
+}
+
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const uint32_t* tile_seg0, uint32_t* counts, unsigned long long* shards,
-                        const uint64_t* offsets, GuideCols out, int* status) {
+                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists) {
   const dim3 grid(hs.n_hap * p.bph), block(HAWK_BLOCK);
-  if (pass == 0) hipLaunchKernelGGL(k_search<0>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status);
-  else hipLaunchKernelGGL(k_search<1>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status);
+  if (pass == 0) {
+    hipLaunchKernelGGL(k_search<0>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status, lists);
+  } else {
+    // lists != nullptr: small tiles are assembled from their hand-over lists, the rest recompute
+    if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, offsets, lists, out, status);
+    hipLaunchKernelGGL(k_search<1>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status, lists);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
