@@ -62,7 +62,7 @@ struct hawk_hapset {
   int32_t ref_index;
   bool has_meta;
   uint32_t bph;            // workgroups (tiles of 1024 words) per haplotype row
-  uint32_t* d_tile_seg0;   // [n_hap * bph] first position-map segment each tile needs
+  TileMeta* d_tile_meta;   // [n_hap * bph] per-tile record (haplotype scalars + first position-map segment)
   int64_t ref_startp;
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
@@ -164,8 +164,8 @@ int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, h
   hs->d_seg_rel = nullptr;
   hs->d_seg_gen = nullptr;
   hs->bph = (hs->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
-  hs->d_tile_seg0 = nullptr;
-  HIPCHK(hipMalloc(&hs->d_tile_seg0, (size_t)n_hap * hs->bph * 4));
+  hs->d_tile_meta = nullptr;
+  HIPCHK(hipMalloc(&hs->d_tile_meta, (size_t)n_hap * hs->bph * sizeof(TileMeta)));
   hs->ref_startp = 0;
   hs->ref_index = -1;
   hs->has_meta = false;
@@ -183,7 +183,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   (void)hipFree(hs->d_scan_stop); (void)hipFree(hs->d_seg_off);
   if (hs->d_seg_rel) (void)hipFree(hs->d_seg_rel);
   if (hs->d_seg_gen) (void)hipFree(hs->d_seg_gen);
-  (void)hipFree(hs->d_tile_seg0);
+  (void)hipFree(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides};
   for (auto* b : bufs) b->release();
@@ -265,17 +265,20 @@ int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* 
   HIPCHK(hipMemcpyAsync(hs->d_seg_gen, seg_gen, (size_t)nseg * 8, hipMemcpyHostToDevice, ctx->stream));
   {
     // first segment each tile needs: the last one starting at or before the tile's first base
-    std::vector<uint32_t> t0((size_t)n * hs->bph);
+    std::vector<TileMeta> t0((size_t)n * hs->bph);
     for (uint32_t h = 0; h < n; ++h) {
       const uint32_t* b = seg_rel + seg_off[h];
       const uint32_t* e = seg_rel + seg_off[h + 1];
       for (uint32_t blk = 0; blk < hs->bph; ++blk) {
         const uint32_t q0 = blk * HAWK_BLOCK * 128u;
         const uint32_t* it = std::upper_bound(b, e, q0);  // first seg_rel > q0
-        t0[(size_t)h * hs->bph + blk] = (uint32_t)((it - seg_rel) - 1);
+        TileMeta& t = t0[(size_t)h * hs->bph + blk];
+        t.h = h; t.blk = blk; t.hap_len = hs->hap_len[h];
+        t.scan_start = scan_start[h]; t.scan_stop = scan_stop[h]; t.is_ref = is_ref[h] ? 1u : 0u;
+        t.seg0 = (uint32_t)((it - seg_rel) - 1); t.seg_end = seg_off[h + 1];
       }
     }
-    HIPCHK(hipMemcpyAsync(hs->d_tile_seg0, t0.data(), t0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs->d_tile_meta, t0.data(), t0.size() * sizeof(TileMeta), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   hs->ref_startp = ref_index >= 0 ? seg_gen[seg_off[ref_index]] : 0;
@@ -476,7 +479,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists);
+  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
   hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
                     hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
@@ -489,7 +492,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   GuideCols ca;
   if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
-  if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_seg0, hs->counts.as<uint32_t>(), d_shards,
+  if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
                                 hs->offsets.as<uint64_t>(), ca, d_status, d_lists);
   HIPCHK(hipEventRecord(ev[4], ctx->stream));
   HIPCHK(hipGetLastError());

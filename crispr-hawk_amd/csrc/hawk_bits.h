@@ -64,21 +64,33 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 }
 
 // This thread's 4 words of one plane plus 2 look-ahead words (taken from the next lane's
-// registers; the last lane of a wave reads them from memory).  All 64 lanes must call it.
+// registers; the last lane of a wave reads them from memory).  Split in two so that a kernel can
+// put every plane's loads in flight (load6_issue) before the first use waits for any of them
+// (load6_finish): with the DPP right behind the load the compiler serialises the planes, one full
+// memory round trip each.  All 64 lanes must call both halves.
+struct Ld6 {
+  uint4 v;
+  uint2 t;
+};
+__device__ __forceinline__ void load6_issue(const uint32_t* __restrict__ row, uint32_t u, uint32_t S, bool active, Ld6& r) {
+  r.v = make_uint4(0, 0, 0, 0);
+  r.t = make_uint2(0, 0);
+  if (active) r.v = *reinterpret_cast<const uint4*>(row + 4 * (size_t)u);
+  if ((threadIdx.x & (WAVE - 1)) == WAVE - 1 && active && 4 * u + 4 < S)
+    r.t = *reinterpret_cast<const uint2*>(row + 4 * (size_t)u + 4);  // 16-byte aligned
+}
+__device__ __forceinline__ void load6_finish(const Ld6& r, uint32_t (&a)[6]) {
+  a[0] = r.v.x; a[1] = r.v.y; a[2] = r.v.z; a[3] = r.v.w;
+  const uint32_t nx = DPP0(r.v.x, DPP_WAVE_SHL1, 0xf, 0xf), ny = DPP0(r.v.y, DPP_WAVE_SHL1, 0xf, 0xf);  // lane i <- lane i+1
+  const bool last = (threadIdx.x & (WAVE - 1)) == WAVE - 1;
+  a[4] = last ? r.t.x : nx;
+  a[5] = last ? r.t.y : ny;
+}
 __device__ __forceinline__ void load6(const uint32_t* __restrict__ row, uint32_t u, uint32_t S, bool active,
                                       uint32_t (&a)[6]) {
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (active) v = *reinterpret_cast<const uint4*>(row + 4 * (size_t)u);
-  a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-  uint32_t nx = DPP0(v.x, DPP_WAVE_SHL1, 0xf, 0xf), ny = DPP0(v.y, DPP_WAVE_SHL1, 0xf, 0xf);  // lane i <- lane i+1
-  if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) {
-    nx = 0; ny = 0;
-    if (active && 4 * u + 4 < S) {
-      const uint2 t = *reinterpret_cast<const uint2*>(row + 4 * (size_t)u + 4);  // 16-byte aligned
-      nx = t.x; ny = t.y;
-    }
-  }
-  a[4] = nx; a[5] = ny;
+  Ld6 r;
+  load6_issue(row, u, S, active, r);
+  load6_finish(r, a);
 }
 
 // m[k] bit j  <=>  for every PAM position i: (pam[i] & base[32*(4u+k) + j + po + i]) != 0

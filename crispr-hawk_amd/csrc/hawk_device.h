@@ -26,6 +26,16 @@ struct HapSetDev {
   int32_t ref_index;
 };
 
+// Everything a search workgroup needs to know about its tile, in one 32-byte record so that a single scalar
+// load (instead of a chain of dependent ones) stands between the kernel arguments and the plane loads.
+struct TileMeta {
+  uint32_t h, blk;       // haplotype row, tile index within the row
+  uint32_t hap_len;
+  int32_t scan_start, scan_stop;
+  uint32_t is_ref;
+  uint32_t seg0, seg_end;  // first position-map segment the tile needs; end of the haplotype's segments
+};
+
 struct ScanParams {
   uint64_t pam_fwd, pam_rev;  // PAM.bits / PAM.bitsrc: first PAM base in the most significant nibble
   int32_t pamlen, guidelen, right;
@@ -95,7 +105,7 @@ void hawk_launch_scan_raw(hipStream_t st, const HapSetDev& hs, const ScanParams&
 void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, const uint32_t* keepF, const uint32_t* keepR,
                            const uint64_t* offsets, uint64_t n_fwd_total, uint32_t* hits_fwd, uint32_t* hits_rev);
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
-                        const RefInfo& ri, const uint32_t* tile_seg0, uint32_t* counts, unsigned long long* shards,
+                        const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists);
 #define HAWK_LIST_CAP 512  // entries per tile in the count pass -> emit pass hand-over list (hawk_search.hip LIST_CAP)
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,

@@ -97,7 +97,7 @@ __device__ __forceinline__ double cfdon_from_slices(const W2 (&core)[4], const W
 
 template <int PASS>
 __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri,
-                                                        const uint32_t* __restrict__ tile_seg0, uint32_t* __restrict__ counts,
+                                                        const TileMeta* __restrict__ tmeta, uint32_t* __restrict__ counts,
                                                         unsigned long long* __restrict__ shards,
                                                         const uint64_t* __restrict__ offsets, GuideCols out, int* status,
                                                         uint32_t* __restrict__ lists) {
@@ -114,13 +114,14 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   // pass then only serves the tiles whose list did not fit (REF tiles, very dense tiles)
   const bool list_mode = PASS == 0 && lists != nullptr;
   if (PASS == 1 && lists != nullptr && counts[tile] <= LIST_CAP) return;
-  const uint32_t h = tile / p.bph, blk = tile % p.bph;
+  const TileMeta tm = tmeta[tile];  // one scalar load: every haplotype / tile scalar the workgroup needs
+  const uint32_t h = tm.h, blk = tm.blk;
   const uint32_t u = blk * HAWK_BLOCK + tid;
   const bool active = u < hs.S / 4;
   const size_t rowbase = (size_t)h * hs.S;
-  const int haplen = (int)hs.hap_len[h];
-  const int ss = hs.scan_start[h], se = hs.scan_stop[h];
-  const bool isref = hs.is_ref[h] != 0;
+  const int haplen = (int)tm.hap_len;
+  const int ss = tm.scan_start, se = tm.scan_stop;
+  const bool isref = tm.is_ref != 0;
   const bool dedup = ri.index >= 0 && !isref;  // rows of this tile can be redundant with REF
   const bool stage = PASS == 1 || dedup || list_mode;  // phase C runs if the tile has survivors
   const bool lds_planes = PASS == 1;            // PASS 0 classifies its few survivors straight from L2/HBM
@@ -132,19 +133,17 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   // ---- every global load of the tile is issued here, before any of it is consumed -------
   uint32_t A[6] = {0, 0, 0, 0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0}, G[6] = {0, 0, 0, 0, 0, 0}, Tp[6] = {0, 0, 0, 0, 0, 0};
   uint32_t E[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0};
-  const uint32_t k0 = stage ? tile_seg0[tile] : 0u, kend = stage ? hs.seg_off[h + 1] : 0u;
-  if ((p.need & 1u) || lds_planes) load6(hs.plane[0] + rowbase, u, hs.S, active, A);
-  if ((p.need & 2u) || lds_planes) load6(hs.plane[1] + rowbase, u, hs.S, active, C);
-  if ((p.need & 4u) || lds_planes) load6(hs.plane[2] + rowbase, u, hs.S, active, G);
-  if ((p.need & 8u) || lds_planes) load6(hs.plane[3] + rowbase, u, hs.S, active, Tp);
-  uint32_t V[4] = {0, 0, 0, 0};
-  if (!isref) {  // workgroup-uniform: REF windows are never filtered
-    load6(hs.plane[4] + rowbase, u, hs.S, active, E);
-    V[0] = E[0]; V[1] = E[1]; V[2] = E[2]; V[3] = E[3];
-  } else if (lds_planes && active) {
-    const uint4 v = *reinterpret_cast<const uint4*>(hs.plane[4] + rowbase + 4 * (size_t)u);
-    V[0] = v.x; V[1] = v.y; V[2] = v.z; V[3] = v.w;
-  }
+  const uint32_t k0 = tm.seg0, kend = tm.seg_end;
+  const uint32_t ldmask = lds_planes ? 15u : p.need;
+  Ld6 la, lc, lg, lt, lv;
+  la.v = lc.v = lg.v = lt.v = lv.v = make_uint4(0, 0, 0, 0);
+  la.t = lc.t = lg.t = lt.t = lv.t = make_uint2(0, 0);
+  if (ldmask & 1u) load6_issue(hs.plane[0] + rowbase, u, hs.S, active, la);
+  if (ldmask & 2u) load6_issue(hs.plane[1] + rowbase, u, hs.S, active, lc);
+  if (ldmask & 4u) load6_issue(hs.plane[2] + rowbase, u, hs.S, active, lg);
+  if (ldmask & 8u) load6_issue(hs.plane[3] + rowbase, u, hs.S, active, lt);
+  if (!isref) load6_issue(hs.plane[4] + rowbase, u, hs.S, active, lv);  // workgroup-uniform: REF windows are never filtered
+  else if (lds_planes && active) lv.v = *reinterpret_cast<const uint4*>(hs.plane[4] + rowbase + 4 * (size_t)u);
   uint32_t halo = 0, seg_r = 0xffffffffu;
   int64_t seg_g = 0;
   bool seg_in = false, ovf = false;
@@ -167,6 +166,9 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   }
 
   // ---- phase A: scan + filters on registers; stage the slices phase C reads --------------
+  load6_finish(la, A); load6_finish(lc, C); load6_finish(lg, G); load6_finish(lt, Tp);
+  uint32_t V[4] = {lv.v.x, lv.v.y, lv.v.z, lv.v.w};
+  if (!isref) load6_finish(lv, E);
   if (stage && lds_planes) {
     *reinterpret_cast<uint4*>(&s_pl[0][LDS_OFF + 4 * tid]) = make_uint4(A[0], A[1], A[2], A[3]);
     *reinterpret_cast<uint4*>(&s_pl[1][LDS_OFF + 4 * tid]) = make_uint4(C[0], C[1], C[2], C[3]);
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
 // offsets[tile] + i.  No scans, no list building, no barriers after the staging one.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri,
-                                                          const uint32_t* __restrict__ tile_seg0,
+                                                          const TileMeta* __restrict__ tmeta,
                                                           const uint32_t* __restrict__ counts,
                                                           const uint64_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ lists, GuideCols out, int* status) {
@@ -501,11 +503,12 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
   const uint32_t tile = blockIdx.x;
   const uint32_t n = counts[tile];
   if (n == 0 || n > LIST_CAP) return;  // workgroup-uniform
-  const uint32_t h = tile / p.bph, blk = tile % p.bph;
+  const TileMeta tm = tmeta[tile];
+  const uint32_t h = tm.h, blk = tm.blk;
   const uint32_t u = blk * HAWK_BLOCK + tid;
   const bool active = u < hs.S / 4;
   const size_t rowbase = (size_t)h * hs.S;
-  const bool isref = hs.is_ref[h] != 0;
+  const bool isref = tm.is_ref != 0;
   const uint32_t w0 = blk * TILE_WORDS;
   const uint32_t tile_q0 = w0 * 32u;
   const uint32_t tile_end = tile_q0 + TILE_WORDS * 32u + 64u;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
     const long long w = j == 0 ? (long long)w0 - 1 : (long long)w0 + TILE_WORDS + (j - 1);
     if (w >= 0 && w < (long long)hs.S) halo = hs.plane[pl][rowbase + (size_t)w];
   }
-  const uint32_t k0 = tile_seg0[tile], kend = hs.seg_off[h + 1];
+  const uint32_t k0 = tm.seg0, kend = tm.seg_end;
   uint32_t seg_r = 0xffffffffu;
   int64_t seg_g = 0;
   bool seg_in = false;
@@ -618,15 +621,15 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
 }
 
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
-                        const RefInfo& ri, const uint32_t* tile_seg0, uint32_t* counts, unsigned long long* shards,
+                        const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists) {
   const dim3 grid(hs.n_hap * p.bph), block(HAWK_BLOCK);
   if (pass == 0) {
-    hipLaunchKernelGGL(k_search<0>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status, lists);
+    hipLaunchKernelGGL(k_search<0>, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, offsets, out, status, lists);
   } else {
     // lists != nullptr: small tiles are assembled from their hand-over lists, the rest recompute
-    if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, offsets, lists, out, status);
-    hipLaunchKernelGGL(k_search<1>, grid, block, 0, st, hs, p, gp, ri, tile_seg0, counts, shards, offsets, out, status, lists);
+    if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, lists, out, status);
+    hipLaunchKernelGGL(k_search<1>, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, offsets, out, status, lists);
   }
 }
 
