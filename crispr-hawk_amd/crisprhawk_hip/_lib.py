@@ -9,7 +9,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhawk_hip.so")
+LIB_PATH = os.environ.get("CRISPRHAWK_HIP_LIB", os.path.join(_HERE, "libhawk_hip.so"))
 
 HAWK_OK = 0
 HAWK_E_INVALID = -1

@@ -488,7 +488,9 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   ScanTotals tot;
   HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint64_t nrows = tot.n_keep;
+  uint64_t nrows = tot.n_keep;
+  static const bool count_only = [] { const char* e = getenv("HAWK_COUNT_ONLY"); return e && e[0] == '1'; }();
+  if (count_only) nrows = 0;  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
   GuideCols ca;
   if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
   HIPCHK(hipEventRecord(ev[3], ctx->stream));

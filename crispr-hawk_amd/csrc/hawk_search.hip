@@ -24,6 +24,9 @@
 #define TILE_WORDS (HAWK_BLOCK * HAWK_WPT)  // 1024 plane words per tile
 #define LDS_OFF 4                            // tile word w lives at s_pl[p][LDS_OFF + w]; word -1 at [3]
 #define LDS_ROW (TILE_WORDS + 8)             // + halo: 1 word before, 2 after (+ pad)
+#ifndef COUNT_WAVES
+#define COUNT_WAVES 7
+#endif
 #define LIST_CAP 512                         // valid survivors a tile may hand from the count pass to the emit pass
 
 __device__ __forceinline__ int seg_find(const uint32_t* s_rel, int n, uint32_t rel) {
@@ -96,11 +99,11 @@ __device__ __forceinline__ double cfdon_from_slices(const W2 (&core)[4], const W
 }
 
 template <int PASS>
-__global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri,
-                                                        const TileMeta* __restrict__ tmeta, uint32_t* __restrict__ counts,
-                                                        unsigned long long* __restrict__ shards,
-                                                        const uint64_t* __restrict__ offsets, GuideCols out, int* status,
-                                                        uint32_t* __restrict__ lists) {
+__device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParams& p, const GuideParams& gp, const RefInfo& ri,
+                                            const TileMeta* __restrict__ tmeta, uint32_t* __restrict__ counts,
+                                            unsigned long long* __restrict__ shards,
+                                            const uint64_t* __restrict__ offsets, const GuideCols& out, int* status,
+                                            uint32_t* __restrict__ lists) {
   __shared__ __attribute__((aligned(16))) uint32_t s_pl[PASS == 1 ? HAWK_PLANES : 1][PASS == 1 ? LDS_ROW : 8];
   __shared__ uint32_t s_list[CAP];
   __shared__ uint32_t s_segrel[NSEG];
@@ -231,7 +234,10 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
 
   uint32_t nvalid = 0;  // this thread's share (PASS 0)
   uint32_t lrun = 0;  // valid survivors listed so far (list mode)
-  if (!stage || (PASS == 0 && !dedup && (!list_mode || T > LIST_CAP))) {
+#ifndef ABL
+#define ABL 0
+#endif
+  if (!stage || (PASS == 0 && !dedup && (!list_mode || T > LIST_CAP)) || (PASS == 0 && ABL == 1)) {
     if (tid == 0) nvalid = T;  // nothing can be redundant here and no list is wanted: the count is the survivor count
   } else if (T) {  // workgroup-uniform
     const int nloc = (int)s_acc[3];
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
             // candidate range and REF's PAM matches there (tested on the planes the PAM names, which the scan
             // just streamed: L2-hot).  The survivor is redundant iff additionally the four code planes agree:
             // compare the hot planes first, the others are fetched only when those agree (e.g. an A<->T SNV).
-            if (ri.index >= 0) {
+            if (ri.index >= 0 && ABL != 2) {
               if (isref) {
                 has_ref = true;
               } else {
@@ -479,6 +485,21 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_search(HapSetDev hs, ScanParams 
   }
 }
 
+// The two passes as kernels.  The count pass is latency- and issue-bound, so it is held to the
+// register budget of 8 waves per SIMD; the emit pass is bounded by its LDS staging (6 workgroups per CU).
+__global__ __launch_bounds__(HAWK_BLOCK) __attribute__((amdgpu_waves_per_eu(COUNT_WAVES, 8)))
+void k_search_count(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri, const TileMeta* __restrict__ tmeta,
+                    uint32_t* __restrict__ counts, unsigned long long* __restrict__ shards, int* status,
+                    uint32_t* __restrict__ lists) {
+  search_tile<0>(hs, p, gp, ri, tmeta, counts, shards, nullptr, GuideCols{}, status, lists);
+}
+__global__ __launch_bounds__(HAWK_BLOCK)
+void k_search_emit(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri, const TileMeta* __restrict__ tmeta,
+                   uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets, GuideCols out, int* status,
+                   uint32_t* __restrict__ lists) {
+  search_tile<1>(hs, p, gp, ri, tmeta, counts, nullptr, offsets, out, status, lists);
+}
+
 // ---------------------------------------------------------------------------------------
 // k_emit_list — the emit pass for tiles whose valid survivors fit the hand-over list.
 //
@@ -625,11 +646,11 @@ void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const Sca
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists) {
   const dim3 grid(hs.n_hap * p.bph), block(HAWK_BLOCK);
   if (pass == 0) {
-    hipLaunchKernelGGL(k_search<0>, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, offsets, out, status, lists);
+    hipLaunchKernelGGL(k_search_count, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, status, lists);
   } else {
     // lists != nullptr: small tiles are assembled from their hand-over lists, the rest recompute
     if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, lists, out, status);
-    hipLaunchKernelGGL(k_search<1>, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, offsets, out, status, lists);
+    hipLaunchKernelGGL(k_search_emit, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, out, status, lists);
   }
 }
 
