@@ -521,7 +521,10 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
   __shared__ double s_cfd[336];
   __shared__ uint32_t s_nloc;
   const uint32_t tid = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin, each XCD with its own L2: give every XCD a contiguous
+  // run of tiles, so that the rows of neighbouring tiles (which share cache lines at their seams) meet in one L2.
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t tile = blockIdx.x < per * 8u ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t n = counts[tile];
   if (n == 0 || n > LIST_CAP) return;  // workgroup-uniform
   const TileMeta tm = tmeta[tile];
