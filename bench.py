@@ -9,10 +9,14 @@ configuration the metric is quoted on.
 
     python bench.py [--gpus N --steps K --warmup W]        # N > 1 via torch.distributed.run
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the longer of the two fused
-k_search passes) with its algorithmic bytes - 0.625 B read per scanned haplotype position, plus 74 B
-per guide row written for the emit pass - against the 8 TB/s HBM peak, using its HIP-event duration
-measured on the stream it runs on.  `cpu_baseline` times the
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the longer of k_search_count
+and k_emit_list) with its algorithmic bytes against the 8 TB/s HBM peak, using its HIP-event duration
+measured on the stream it runs on:
+  k_emit_list     0.625 B read per scanned haplotype position (five bit planes) + 74 B written and 4 B
+                  of hand-over list read per guide row;
+  k_search_count  one bit per position for each plane the PAM names plus the variant plane
+                  (NGG/CCN: 0.375 B) + 4 B of hand-over list written per guide row.
+`cpu_baseline` times the
 C oracle (a port of the reference's algorithm, oracle/hawk_oracle.c) on a bounded sample of the
 same workload on the host cores (rank 0, N == 1 only).
 """
@@ -35,6 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the emit pass additionally writes each guide row once (74 B: K3 record + packed window + K4 score).
 READ_BYTES_PER_POS = 0.625
 ROW_BYTES = 74
+LIST_BYTES = 4  # one u32 hand-over entry per guide row (count pass writes it, k_emit_list reads it)
 
 
 def log(msg):
@@ -126,7 +131,7 @@ def main():
         step()
     barrier()
     t_start = time.perf_counter()
-    scan_ms, tot_ms, kern = [], [], {"offsets_ms": [], "emit_ms": []}
+    scan_ms, tot_ms, kern = [], [], {"offsets_ms": [], "emit_ms": [], "emit_list_ms": []}
     tab = None
     for _ in range(args.steps):
         tab = step()
@@ -161,11 +166,24 @@ def main():
     if rank == 0:
         scan_avg_ms = float(np.mean(scan_ms))
         emit_avg_ms = float(np.mean(kern["emit_ms"]))
-        # dominant kernel = the longer of the two fused passes
-        if emit_avg_ms >= scan_avg_ms:
-            dom, dom_ms, algo_bytes = "k_search<1>", emit_avg_ms, READ_BYTES_PER_POS * positions + ROW_BYTES * rows
+        # dominant kernel = the longer of the count pass and the list-driven emit pass, each priced with the
+        # bytes it has to move
+        need = 0
+        for nib in pam.bits_list + [{"A": 1, "C": 2, "G": 4, "T": 8}.get(c, 0) or synth_iupac(c) for c in pam.pamrc.upper()]:
+            if nib != 15:
+                need |= nib
+        count_bpp = 0.125 * (bin(need).count("1") + 1)
+        emit_list_avg_ms = float(np.mean(kern["emit_list_ms"]))
+        if emit_list_avg_ms == 0.0:  # HAWK_LIST_EMIT=0: the recompute-everything emit pass
+            emit_name, emit_ms_, emit_bytes = "k_search_emit", emit_avg_ms, READ_BYTES_PER_POS * positions + ROW_BYTES * rows
+            count_bytes = count_bpp * positions
         else:
-            dom, dom_ms, algo_bytes = "k_search<0>", scan_avg_ms, READ_BYTES_PER_POS * positions
+            emit_name, emit_ms_, emit_bytes = "k_emit_list", emit_list_avg_ms, READ_BYTES_PER_POS * positions + (ROW_BYTES + LIST_BYTES) * rows
+            count_bytes = count_bpp * positions + LIST_BYTES * rows
+        if emit_ms_ >= scan_avg_ms:
+            dom, dom_ms, algo_bytes, bpp = emit_name, emit_ms_, emit_bytes, READ_BYTES_PER_POS
+        else:
+            dom, dom_ms, algo_bytes, bpp = "k_search_count", scan_avg_ms, count_bytes, count_bpp
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -183,8 +201,12 @@ def main():
                        "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": dom_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes, "read_bytes_per_position": READ_BYTES_PER_POS,
-                         "row_bytes": ROW_BYTES},
+                         "algorithmic_bytes_per_launch": algo_bytes, "read_bytes_per_position": bpp,
+                         "row_bytes": ROW_BYTES, "list_bytes_per_row": LIST_BYTES,
+                         "other_kernel": {"kernel": "k_search_count" if dom != "k_search_count" else emit_name,
+                                          "launch_ms": scan_avg_ms if dom != "k_search_count" else emit_ms_,
+                                          "algorithmic_bytes_per_launch": count_bytes if dom != "k_search_count" else emit_bytes,
+                                          "frac": (count_bytes / (scan_avg_ms * 1e-3) if dom != "k_search_count" else emit_bytes / (emit_ms_ * 1e-3)) / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms": {"count": scan_avg_ms, **{k[:-3]: float(np.mean(v)) for k, v in kern.items()},
                            "device_total": float(np.mean(tot_ms))},
         }

@@ -54,7 +54,7 @@ class SearchParams(C.Structure):
 class Timing(C.Structure):
     _fields_ = [
         ("count_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("total_ms", C.c_float),
-        ("scanned_positions", C.c_uint64),
+        ("scanned_positions", C.c_uint64), ("emit_list_ms", C.c_float), ("reserved", C.c_float),
     ]
 
 

@@ -495,7 +495,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
   if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                                hs->offsets.as<uint64_t>(), ca, d_status, d_lists);
+                                hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
   HIPCHK(hipEventRecord(ev[4], ctx->stream));
   HIPCHK(hipGetLastError());
   int status = 0;
@@ -506,6 +506,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     (void)hipEventElapsedTime(&timing->count_ms, ev[0], ev[1]);
     (void)hipEventElapsedTime(&timing->offsets_ms, ev[1], ev[2]);
     (void)hipEventElapsedTime(&timing->emit_ms, ev[3], ev[4]);
+    if (nrows && d_lists) (void)hipEventElapsedTime(&timing->emit_list_ms, ev[3], ev[5]);
     (void)hipEventElapsedTime(&timing->total_ms, ev[0], ev[4]);
     uint64_t pos = 0;
     for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);

@@ -106,7 +106,7 @@ void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, co
                            const uint64_t* offsets, uint64_t n_fwd_total, uint32_t* hits_fwd, uint32_t* hits_rev);
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
-                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists);
+                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, hipEvent_t mid = nullptr);
 #define HAWK_LIST_CAP 512  // entries per tile in the count pass -> emit pass hand-over list (hawk_search.hip LIST_CAP)
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals);

@@ -646,13 +646,14 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
 
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
-                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists) {
+                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, hipEvent_t mid) {
   const dim3 grid(hs.n_hap * p.bph), block(HAWK_BLOCK);
   if (pass == 0) {
     hipLaunchKernelGGL(k_search_count, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, status, lists);
   } else {
     // lists != nullptr: small tiles are assembled from their hand-over lists, the rest recompute
     if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, lists, out, status);
+    if (mid) (void)hipEventRecord(mid, st);  // timing: k_emit_list ends here
     hipLaunchKernelGGL(k_search_emit, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, out, status, lists);
   }
 }

@@ -125,11 +125,13 @@ typedef struct {
 } hawk_search_params;
 
 typedef struct {          /* kernel times of the last hawk_search (HIP events on the ctx stream), ms */
-  float count_ms;   /* k_search<0>: scan + filters + redundancy classification -> tile counts */
+  float count_ms;   /* k_search_count: scan + filters + redundancy classification -> tile counts + hand-over lists */
   float offsets_ms; /* k_mscan1-3: tile counts -> row offsets */
-  float emit_ms;    /* k_search<1>: re-scan + finished rows (coordinates, windows, CFDon) */
+  float emit_ms;    /* k_emit_list + k_search_emit: finished rows (coordinates, windows, CFDon) */
   float total_ms;   /* first kernel start to last kernel end, including the host round trip for the row count */
   uint64_t scanned_positions; /* sum over haplotypes of (scan_stop - scan_start) */
+  float emit_list_ms; /* k_emit_list alone (0 when the hand-over lists are switched off) */
+  float reserved;
 } hawk_timing;
 
 /* Runs the whole device pipeline; the guide table stays in HBM. `timing` may be NULL. */
