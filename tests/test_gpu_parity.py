@@ -208,3 +208,76 @@ def test_device_expansion_matches_host_expansion_200kb():
         assert np.array_equal(got[:, r, :n], want[:, j, :n])
         assert np.array_equal(ds.host_meta[r].seg.rel, haps[j].seg.rel) and np.array_equal(ds.host_meta[r].seg.gen, haps[j].seg.gen)
         assert ds.host_meta[r].scan == haps[j].scan
+
+
+def _dense_region(seed, sites, samples):
+    reg = synth.make_region(seed, "chrX", 75_000, 2_000, 72_000)
+    synth.add_phased_variants(reg, seed + 1, sites, samples, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.6, af_max=0.95)
+    return reg
+
+
+def test_tiles_with_more_rows_than_the_handover_list():
+    # a variant every ~12 nt carried by most haplotypes: alt tiles keep thousands of rows, far more than the
+    # 512-entry hand-over list of the count pass, so they take the recompute emit pass next to list-driven tiles
+    reg = _dense_region(7301, 6000, 3)
+    hs, tab = _oracle_vs_device(reg, "NGG", 20, False, True)
+    per_tile = np.bincount((tab.hap.astype(np.int64) * 8 + tab.pos // 32768)[~np.asarray(hs.is_ref)[tab.hap]])
+    assert per_tile.max() > 512 and (per_tile[per_tile > 0] <= 512).any()
+    _oracle_vs_device(reg, "TTTV", 23, True, False)
+
+
+def test_search_without_a_ref_haplotype():
+    # no REF row in the set: nothing is redundant, no CFDon partner exists (every score is NA)
+    reg = synth.make_region(7401, "chrN", 50_000, 1_000, 48_000)
+    synth.add_phased_variants(reg, 7402, 400, 4, af_min=0.2, af_max=0.7)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = [h for h in oracle_haplotypes(fx) if h["samples"] != ["REF"]]
+    assert haps
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, 3) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [False] * len(haps), scan)
+    bits, bitsrc, _, _ = ora.pam_encode("NGG")
+    want = ora.search(hs, "NGG", 20, False)
+    mm, pt = synth.cfd_tables()
+    tab = device_set(hs).search(bits, bitsrc, 3, 20, False, mm, pt)
+    assert (tab.n_rows, tab.n_candidates, tab.n_hits) == (len(want.guides), want.n_candidates, want.n_hits)
+    order = tab.reference_order()
+    for col in ("start", "stop", "hap", "pos", "strand"):
+        assert np.array_equal(getattr(tab, col)[order], want.guides[col]), col
+    wins = tab.windows()
+    assert [wins[i] for i in order] == want.windows
+    assert np.isnan(tab.cfdon).all() and not tab.flags.any()
+
+
+def test_recompute_emit_pass_matches_list_driven_emit():
+    # HAWK_LIST_EMIT=0 switches the hand-over lists off (read once per process, hence the child): both emit
+    # paths must produce the same table, compared here through a digest of every column
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path[:0] = [%r, %r, %r]
+from crisprhawk_hip import synth
+from oracle import oracle as ora
+import test_gpu_parity as T
+reg = T._dense_region(7301, 1500, 3)
+hs, tab = T._oracle_vs_device(reg, "NGG", 20, False, True)
+h = hashlib.sha256()
+for col in ("hap", "pos", "strand", "start", "stop", "flags"):
+    h.update(np.ascontiguousarray(getattr(tab, col)).tobytes())
+h.update(np.nan_to_num(tab.cfdon, nan=-1.0).tobytes())
+h.update(np.ascontiguousarray(tab.win).tobytes())
+print("DIGEST", tab.n_rows, h.hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "tests"), os.path.join(root, "crispr-hawk_amd"), root)
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, HAWK_LIST_EMIT=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert outs[0] == outs[1]
