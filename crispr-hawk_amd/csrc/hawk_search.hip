@@ -1,15 +1,16 @@
 // hawk_search.hip — the fused guide-search kernel (K2 + K3 + K4 in one) and its offset scan.
 //
-// k_search<PASS> is launched twice over the same tiles (one workgroup = 1024 plane words =
-// 32 768 positions of one haplotype):
-//   PASS 0  count:  stream the planes, PAM-match both strands, apply scan-range / in-range /
-//                   REF-identical filters, classify the survivors against the REF haplotype
-//                   (remove_redundant_guides) and write ONE count per tile;
+// Three kernels over the same tiles (one workgroup = 1024 plane words = 32 768 positions of one
+// haplotype):
+//   k_search_count  stream the planes the PAM names + V, PAM-match both strands, apply scan-range /
+//                   in-range / REF-identical filters, classify the survivors against the REF
+//                   haplotype (remove_redundant_guides); write ONE count per tile and the tile's
+//                   hand-over list of valid survivors (window start, strand, has-REF; <= 512);
 //   (k_mscan1-3: exclusive scan of the tile counts -> row offsets, totals)
-//   PASS 1  emit:   recompute the same bits (cheaper than a keep-bit round trip through HBM:
-//                   0.625 B/position re-read vs 0.25 written + 0.25 read + the window lines),
-//                   and write finished guide rows - coordinates, flags, CFDon, packed window -
-//                   at deterministic offsets, coalesced.
+//   k_emit_list     stage the tile's five plane slices in LDS and assemble one finished row per
+//                   list entry - coordinates, flags, CFDon, packed window - at deterministic
+//                   offsets, coalesced;
+//   k_search_emit   tiles beyond the list (REF tiles): recompute the bits and emit (search_tile<1>).
 // Survivors of a tile are first compacted into an LDS list so that row work is spread evenly
 // over the 256 threads regardless of where in the tile the variants cluster; the tile's slice of
 // the haplotype position map sits in LDS next to it.
