@@ -26,6 +26,7 @@ EXPORTS = [
     "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan", "hawk_pam_scan_time",
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
+    "hawk_table_collapse", "hawk_table_collapse_download",
 ]
 
 

@@ -193,7 +193,9 @@ class DeviceHapSet:
 
     def search(self, pam_bits: int, pam_bitsrc: int, pamlen: int, guidelen: int, right: bool,
                cfd_mm: Optional[np.ndarray] = None, cfd_pam: Optional[np.ndarray] = None,
-               download: bool = True) -> "GuideTable":
+               download: bool = True, collapse: bool = False) -> "GuideTable":
+        """One fused search.  `collapse` additionally groups the rows the report merges (GuideTable.collapse)
+        while the table is still in HBM."""
         L = self._L
         sp = _lib.SearchParams()
         sp.pam_fwd, sp.pam_rev, sp.pamlen, sp.guidelen, sp.right = pam_bits, pam_bitsrc, pamlen, guidelen, int(bool(right))
@@ -209,6 +211,8 @@ class DeviceHapSet:
         del keep
         self.last_timing = tm
         tab = GuideTable(self, t, guidelen, pamlen, bool(right), tm)
+        if collapse:
+            tab.collapse()
         if download:
             tab.download()
         return tab
@@ -237,6 +241,23 @@ class GuideTable:
         ptr = lambda a: C.c_void_p(a) if a else None
         _lib.check(self._hs._L.hawk_table_download(self._t, ptr(hap), ptr(pos), ptr(strand), ptr(start), ptr(stop),
                                                    ptr(flags), ptr(cfdon), ptr(win)), "hawk_table_download")
+
+    def collapse(self) -> "GuideTable":
+        """Group the rows the guide report merges (reports.py:958-1008) on the device, before download():
+        `group_perm` (row indices ordered by (start, strand, group)), `group_off` (CSR into it),
+        `gc_num / gc_den` per group (gc_content of the spacer, annotation.py:513-541), `collapse_ms`."""
+        if self._t is None:
+            raise RuntimeError("collapse() needs the device-resident table: call it before download()")
+        ng, ms = C.c_uint64(), C.c_float()
+        _lib.check(self._hs._L.hawk_table_collapse(self._t, C.byref(ng), C.byref(ms)), "hawk_table_collapse")
+        self.n_groups, self.collapse_ms = ng.value, ms.value
+        self.group_perm = np.empty(self.n_rows, np.uint32)
+        self.group_off = np.zeros(self.n_groups + 1, np.uint64)
+        self.gc_num = np.empty(self.n_groups, np.uint8)
+        self.gc_den = np.empty(self.n_groups, np.uint8)
+        _lib.check(self._hs._L.hawk_table_collapse_download(self._t, _p(self.group_perm), _p(self.group_off), _p(self.gc_num),
+                                                            _p(self.gc_den)), "hawk_table_collapse_download")
+        return self
 
     def download(self) -> "GuideTable":
         if self._downloaded:

@@ -64,8 +64,10 @@ struct hawk_hapset {
   uint32_t bph;            // workgroups (tiles of 1024 words) per haplotype row
   TileMeta* d_tile_meta;   // [n_hap * bph] per-tile record (haplotype scalars + first position-map segment)
   int64_t ref_startp;
+  int64_t min_gen, max_gen;  // range of genomic positions the position maps reach (collapse sort key)
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
+  DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt;  // hawk_table_collapse
   DevBuf colsA[8];
 };
 
@@ -73,6 +75,9 @@ struct hawk_table {
   hawk_hapset* hs;
   uint64_t n_rows, n_cand, n_hits, cap;
   GuideCols cols;  // points into hs->colsA or colsB
+  uint32_t guidelen, pamlen, right;
+  uint64_t n_groups;  // valid after hawk_table_collapse
+  bool collapsed;
 };
 
 extern "C" {
@@ -185,7 +190,8 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   if (hs->d_seg_gen) (void)hipFree(hs->d_seg_gen);
   (void)hipFree(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
-                    &hs->sites, &hs->hits, &hs->guides};
+                    &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
+                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   delete hs;
@@ -282,6 +288,13 @@ int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* 
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   hs->ref_startp = ref_index >= 0 ? seg_gen[seg_off[ref_index]] : 0;
+  hs->min_gen = INT64_MAX; hs->max_gen = INT64_MIN;
+  for (uint32_t h = 0; h < n; ++h)
+    for (uint32_t k = seg_off[h]; k < seg_off[h + 1]; ++k) {
+      const uint32_t end = k + 1 < seg_off[h + 1] ? seg_rel[k + 1] : hs->hap_len[h];
+      hs->min_gen = std::min(hs->min_gen, seg_gen[k]);
+      hs->max_gen = std::max(hs->max_gen, seg_gen[k] + (int64_t)(end - seg_rel[k]));
+    }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hs->scan_start.assign(scan_start, scan_start + n);
   hs->scan_stop.assign(scan_stop, scan_stop + n);
@@ -516,6 +529,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   hawk_table* t = new (std::nothrow) hawk_table();
   if (!t) return HAWK_E_INVALID;
   t->hs = hs; t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = ca; t->cap = ca.cap;
+  t->guidelen = p->guidelen; t->pamlen = p->pamlen; t->right = p->right ? 1 : 0; t->n_groups = 0; t->collapsed = false;
   *out = t;
   return HAWK_OK;
 }
@@ -565,6 +579,66 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
   if (cfdon) *cfdon = c.cfdon;
   if (win) *win = c.win;
   if (win_plane_stride) *win_plane_stride = c.cap;  // plane p of the window slices starts at win + p * stride
+  return HAWK_OK;
+}
+
+int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
+  if (!t || !n_groups) return HAWK_E_INVALID;
+  hawk_hapset* hs = t->hs;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t n = t->n_rows;
+  t->collapsed = false;
+  *n_groups = 0;
+  if (kernel_ms) *kernel_ms = 0.f;
+  if (n == 0) { t->n_groups = 0; t->collapsed = true; return HAWK_OK; }
+  if (n > 0xffffffffull || hs->max_gen - hs->min_gen > 0xffffffffll) return HAWK_E_UNSUPPORTED;
+  unsigned end_bit = 32;
+  while (end_bit < 64 && ((uint64_t)(hs->max_gen - hs->min_gen) >> (end_bit - 32)) != 0) ++end_bit;
+  const size_t temp_bytes = hawk_collapse_temp_bytes(n, end_bit);
+  int rc;
+  if ((rc = hs->ckeys.reserve(2 * n * 8)) || (rc = hs->cvals.reserve(2 * n * 4)) || (rc = hs->cflags.reserve(n * 4)) ||
+      (rc = hs->cgidx.reserve(n * 4)) || (rc = hs->ctemp.reserve(temp_bytes + 16)) || (rc = hs->cgoff.reserve((n + 1) * 8)) ||
+      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(16)))
+    return rc;
+  unsigned long long cnt[2] = {0, 0};
+  for (int attempt = 0; attempt < 4; ++attempt) {  // a new seed whenever two different rows collide in the hash bits
+    HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 16, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (hawk_launch_collapse(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)t->right, hs->min_gen,
+                             end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p, temp_bytes, hs->ckeys.as<uint64_t>(),
+                             hs->cvals.as<uint32_t>(), hs->cflags.as<uint32_t>(), hs->cgidx.as<uint32_t>(),
+                             hs->ccnt.as<unsigned long long>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(),
+                             hs->cgc.as<uint8_t>() + n))
+      return HAWK_E_HIP;
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(cnt, hs->ccnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); *kernel_ms += ms; }
+    if (cnt[0] == cnt[1]) break;
+  }
+  if (cnt[0] != cnt[1]) return HAWK_E_UNSUPPORTED;
+  const uint64_t ng = cnt[1];
+  HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  t->n_groups = ng; t->collapsed = true;
+  *n_groups = ng;
+  return HAWK_OK;
+}
+
+int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den) {
+  if (!t || !t->collapsed) return HAWK_E_INVALID;
+  hawk_hapset* hs = t->hs;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t n = t->n_rows, ng = t->n_groups;
+  if (n == 0) { if (group_off) group_off[0] = 0; return HAWK_OK; }
+  if (perm) HIPCHK(hipMemcpyAsync(perm, hs->cvals.as<uint32_t>() + n, n * 4, hipMemcpyDefault, ctx->stream));
+  if (group_off) HIPCHK(hipMemcpyAsync(group_off, hs->cgoff.p, (ng + 1) * 8, hipMemcpyDefault, ctx->stream));
+  if (gc_num) HIPCHK(hipMemcpyAsync(gc_num, hs->cgc.p, ng, hipMemcpyDefault, ctx->stream));
+  if (gc_den) HIPCHK(hipMemcpyAsync(gc_den, hs->cgc.as<uint8_t>() + n, ng, hipMemcpyDefault, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return HAWK_OK;
 }
 

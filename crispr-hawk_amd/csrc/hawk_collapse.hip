@@ -1,0 +1,136 @@
+// hawk_collapse.hip — f2: which guide rows the report merges (reports.py:958-1008
+// `_collapse_report_entries`: a pandas groupby over chr, start, stop, sgRNA_sequence, pam, strand,
+// scores, gc_content, origin).  Scores and GC are functions of the sequence and of the REF guide at
+// the same (start, strand), so two rows merge iff they agree in start, stop, strand, origin (REF
+// haplotype or not) and in the case-preserving spacer+PAM — on the device: the five L-bit core
+// slices of the window planes (the V plane is the case).  Equality of the stored (+ strand) cores is
+// equality of the reverse-complemented guides the report prints.
+//
+//   k_collapse_keys   row -> 64-bit sort key  (start - base) << 32 | strand << 31 | hash31(core, stop, origin)
+//   rocprim::radix_sort_pairs (key, row id); stable, so equal keys keep table order (haplotype ascending)
+//   k_collapse_heads  neighbours in sorted order are compared on the FULL row key (not the hash): head flags;
+//                     counts heads by key and heads by full key - if they differ, two different rows of one
+//                     (start, strand) collided in the 31 hash bits and may interleave: the host layer re-runs
+//                     with another seed, so the grouping is exact, never probabilistic
+//   rocprim::exclusive_scan of the flags, k_collapse_groups: CSR offsets + GC counts of each group's guide
+//                     (annotation.py:513-541: gc_fraction(guide.guide); Biopython's default drops ambiguous bases)
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "hawk_device.h"
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+struct RowKey {
+  int64_t start, stop;
+  uint64_t core[HAWK_PLANES];
+  uint32_t sr;  // strand | origin << 1
+};
+__device__ __forceinline__ RowKey row_key(const GuideCols& c, const uint8_t* __restrict__ is_ref, uint64_t i, uint64_t mask) {
+  RowKey k;
+  k.start = c.start[i];
+  k.stop = c.stop[i];
+  k.sr = (uint32_t)c.strand[i] | ((uint32_t)(is_ref[c.hap[i]] != 0) << 1);
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) k.core[pl] = (c.win[(size_t)pl * c.cap + i] >> HAWK_PAD) & mask;
+  return k;
+}
+__device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
+  bool s = a.start == b.start && a.stop == b.stop && a.sr == b.sr;
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) s = s && a.core[pl] == b.core[pl];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, uint64_t mask,
+                                                       int64_t base, uint64_t seed, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const RowKey k = row_key(c, is_ref, i, mask);
+  uint64_t h = seed;
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) h = mix64(h ^ k.core[pl]);
+  h = mix64(h ^ (uint64_t)k.stop ^ ((uint64_t)(k.sr >> 1) << 63));
+  keys[i] = ((uint64_t)(k.start - base) << 32) | ((uint64_t)(k.sr & 1u) << 31) | (h >> 33);
+  vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_collapse_heads(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, uint64_t mask,
+                                                        const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                        uint32_t* __restrict__ flags, unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t hk = 0, hf = 0;
+  if (j < n) {
+    if (j == 0) {
+      hk = hf = 1;
+    } else {
+      hk = keys[j] != keys[j - 1];
+      hf = hk || !same_row(row_key(c, is_ref, vals[j], mask), row_key(c, is_ref, vals[j - 1], mask));
+    }
+    flags[j] = hf;
+  }
+  const unsigned long long bk = __ballot(hk), bf = __ballot(hf);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt[0], (uint32_t)__popcll(bk)); atomicAdd(&s_cnt[1], (uint32_t)__popcll(bf)); }
+  __syncthreads();
+  if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// flags (0/1) and their exclusive scan gidx: a head at sorted position j opens group gidx[j]
+__global__ __launch_bounds__(256) void k_collapse_groups(GuideCols c, uint64_t n, const uint32_t* __restrict__ vals,
+                                                         const uint32_t* __restrict__ flags, const uint32_t* __restrict__ gidx,
+                                                         int guidelen, int pamlen, int right, uint64_t* __restrict__ group_off,
+                                                         uint8_t* __restrict__ gc_num, uint8_t* __restrict__ gc_den) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || !flags[j]) return;
+  const uint32_t g = gidx[j];
+  group_off[g] = j;
+  const uint64_t r = vals[j];
+  // the spacer inside the stored (+ strand) core: behind the PAM when the PAM comes first (right ^ strand)
+  const bool pamfirst = (right != 0) != (c.strand[r] != 0);
+  const int sh = HAWK_PAD + (pamfirst ? pamlen : 0);
+  const uint64_t m = guidelen >= 64 ? ~0ull : ((1ull << guidelen) - 1ull);
+  const uint64_t A = (c.win[r] >> sh) & m, C = (c.win[c.cap + r] >> sh) & m, G = (c.win[2 * c.cap + r] >> sh) & m,
+                 T = (c.win[3 * c.cap + r] >> sh) & m;
+  const uint64_t gc = (C | G) & ~(A | T);  // C, G, S
+  const uint64_t at = (A | T) & ~(C | G);  // A, T, W
+  gc_num[g] = (uint8_t)__popcll(gc);
+  gc_den[g] = (uint8_t)__popcll(gc | at);
+}
+
+size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit) {
+  size_t a = 0, b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
+                                  end_bit, (hipStream_t)0);
+  (void)rocprim::exclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  return a > b ? a : b;
+}
+
+// keys/vals: [2][n] ping-pong; flags, gidx: [n]; counters: [2], zeroed by the caller; group_off must hold
+// n + 1 entries (the number of groups is only known afterwards)
+int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
+                         int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
+                         uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
+                         uint8_t* gc_den) {
+  const int L = guidelen + pamlen;
+  const uint64_t mask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, mask, base, seed, keys, vals);
+  size_t tb = temp_bytes;
+  if (rocprim::radix_sort_pairs(temp, tb, keys, keys + n, vals, vals + n, n, 0, end_bit, st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, c, is_ref, n, mask, keys + n, vals + n, flags, counters);
+  tb = temp_bytes;
+  if (rocprim::exclusive_scan(temp, tb, flags, gidx, 0u, n, rocprim::plus<uint32_t>(), st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_collapse_groups, grid, block, 0, st, c, n, vals + n, flags, gidx, guidelen, pamlen, right, group_off, gc_num,
+                     gc_den);
+  return 0;
+}

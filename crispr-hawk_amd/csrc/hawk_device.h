@@ -107,6 +107,11 @@ void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, co
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, hipEvent_t mid = nullptr);
+size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit);
+int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
+                         int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
+                         uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
+                         uint8_t* gc_den);
 #define HAWK_LIST_CAP 512  // entries per tile in the count pass -> emit pass hand-over list (hawk_search.hip LIST_CAP)
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals);

@@ -155,6 +155,21 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
                               void** flags, void** cfdon, void** win, uint64_t* win_plane_stride);
 
+/* ---- f2: which rows the guide report merges.  Replaces the pandas groupby of
+ * `_collapse_report_entries` (reports.py:958-1008; group columns chr, start, stop, sgRNA_sequence, pam,
+ * strand, scores, gc_content, origin): two rows merge iff they agree in start, stop, strand, origin
+ * (REF haplotype or not) and in the case-preserving spacer+PAM; scores and GC are functions of those.
+ * hawk_table_collapse sorts and groups in HBM (results stay in the set's workspace until the next
+ * search or collapse); hawk_table_collapse_download copies them out (host or device destinations,
+ * any pointer may be NULL):
+ *   perm[n_rows]         row indices ordered by (start, strand, group); rows of one group are contiguous
+ *                        and keep table order (haplotype ascending)
+ *   group_off[n_groups+1] CSR offsets into perm
+ *   gc_num, gc_den[n_groups]  G/C/S and A/C/G/T/S/W base counts of the group's spacer: gc_content =
+ *                        gc_num / gc_den (annotation.py:513-541 -> Biopython gc_fraction, ambiguous bases dropped) */
+int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms);
+int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den);
+
 /* ---- K7: off-target enumeration, replacing the external `crispritz.py search ... -mm M -bDNA 0
  * -bRNA 0` of offtargets.py:222-293 (CRISPRitz 2.6.6 is a third-party binary the reference shells
  * out to; semantics restated from the call site and the consumed fields, offtarget.py:77-101).

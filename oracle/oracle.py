@@ -286,3 +286,24 @@ def gbt_predict(feats: np.ndarray, model: dict) -> np.ndarray:
                           _p(a["threshold"].astype(np.float64)), _p(a["value"].astype(np.float64)), C.c_double(model["init"]),
                           C.c_double(model["learning_rate"]), _p(out))
     return out
+
+
+def collapse_rows(start, stop, strand, is_ref_row, windows: Sequence[str], guidelen: int, pamlen: int, right: bool):
+    """Groups of guide rows the report merges (reports.py:958-1008 `_collapse_report_entries`: groupby over
+    chr, start, stop, sgRNA_sequence, pam, strand, scores, gc_content, origin — scores and GC are functions of
+    the rest).  Rows are given as search() leaves them (windows on the + strand, 10-nt pads, case preserved);
+    equality of the + strand spacer+PAM is equality of the reverse-complemented guide the report prints
+    (annotation.py:27-51).  Returns ({key: [row indices ascending]}, {key: (gc_num, gc_den)}) with
+    gc_content = gc_num / gc_den of the spacer (annotation.py:513-541 -> Biopython `gc_fraction`, default
+    ambiguous="remove": C, G, S over A, C, G, T, S, W, U; parity unpinned - Biopython is absent here)."""
+    groups, gc = {}, {}
+    for i, w in enumerate(windows):
+        core = w[10:-10]
+        key = (int(start[i]), int(stop[i]), int(strand[i]), bool(is_ref_row[i]), core)
+        groups.setdefault(key, []).append(i)
+        if key not in gc:
+            pamfirst = bool(right) != bool(strand[i])
+            spacer = core[pamlen:] if pamfirst else core[:guidelen]
+            num = sum(spacer.count(c) for c in "CGScgs")
+            gc[key] = (num, num + sum(spacer.count(c) for c in "ATWUatwu"))
+    return groups, gc

@@ -281,3 +281,47 @@ print("DIGEST", tab.n_rows, h.hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
     assert outs[0] == outs[1]
+
+
+def _check_collapse(hs, tab, guidelen, pamlen, right):
+    """GuideTable.collapse() (device sort + group) against the oracle's dictionary grouping."""
+    wins = tab.windows()
+    isref_row = np.asarray(hs.is_ref)[tab.hap]
+    want, want_gc = ora.collapse_rows(tab.start, tab.stop, tab.strand, isref_row, wins, guidelen, pamlen, right)
+    assert tab.n_groups == len(want)
+    perm, off = tab.group_perm.astype(np.int64), tab.group_off.astype(np.int64)
+    assert sorted(perm.tolist()) == list(range(tab.n_rows)) and off[0] == 0 and off[-1] == tab.n_rows
+    assert (np.diff(tab.start[perm]) >= 0).all()  # ordered by start: the report's primary sort key
+    seen = set()
+    for g in range(tab.n_groups):
+        rows = perm[off[g]:off[g + 1]]
+        assert len(rows) and (np.diff(rows) > 0).all()  # members keep table order
+        r = int(rows[0])
+        key = (int(tab.start[r]), int(tab.stop[r]), int(tab.strand[r]), bool(isref_row[r]), wins[r][10:-10])
+        assert key not in seen and want[key] == rows.tolist()
+        seen.add(key)
+        assert (int(tab.gc_num[g]), int(tab.gc_den[g])) == want_gc[key]
+
+
+@pytest.mark.parametrize("pam,guidelen,right", [("NGG", 20, False), ("TTTV", 23, True)])
+def test_collapse_groups_against_oracle(pam, guidelen, right):
+    # 12 haplotypes over common variants: most alt rows are shared by several haplotypes
+    reg = synth.make_region(7501, "chrC", 40_000, 1_000, 38_000)
+    synth.add_phased_variants(reg, 7502, 300, 6, af_min=0.3, af_max=0.8)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, len(pam)) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    bits, bitsrc, _, _ = ora.pam_encode(pam)
+    tab = device_set(hs).search(bits, bitsrc, len(pam), guidelen, right, collapse=True)
+    assert tab.n_groups < tab.n_rows
+    _check_collapse(hs, tab, guidelen, len(pam), right)
+
+
+def test_collapse_empty_and_single():
+    seq = "ACGT" * 100
+    ds = DeviceHapSet([HostHaplotype(seq, PosSegments.identity(1, len(seq)), True, (100, 300))])
+    bits, bitsrc, _, _ = ora.pam_encode("NGG")
+    tab = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
+    assert tab.n_rows == 0 and tab.n_groups == 0 and tab.group_off.tolist() == [0]
