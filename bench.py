@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--cpu-haps", type=int, default=160, help="haplotypes in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-expand", action="store_true", help="build the haplotype strings on the host and pack them (K1) instead of expanding on the device")
+    ap.add_argument("--no-collapse", action="store_true", help="skip the one-off report-row collapse after the timed loop")
     ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
     args = ap.parse_args()
 
@@ -158,6 +159,15 @@ def main():
     ps_ms, ps_pos = C.c_float(0), C.c_uint64(0)
     _lib.check(_lib.lib().hawk_pam_scan_time(ds._h, C.c_uint64(pam.bits), C.c_uint64(pam.bitsrc), len(pam), 20, C.byref(ps_ms),
                                              C.byref(ps_pos)), "hawk_pam_scan_time")
+    # f2 (outside the timed steps): which rows the report merges, sorted and grouped in HBM
+    collapse = None
+    if rank == 0 and not args.no_collapse:
+        tc = step(keep=True) if dist is None else ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+        ng, cms = C.c_uint64(), C.c_float()
+        _lib.check(_lib.lib().hawk_table_collapse(tc._t, C.byref(ng), C.byref(cms)), "hawk_table_collapse")
+        collapse = {"kernels_ms": cms.value, "rows": tc.n_rows, "groups": ng.value,
+                    "what": "k_collapse_keys + rocprim radix sort (key, row) + k_collapse_heads + scan + k_collapse_groups"}
+        tc.close()
     gather = None
     if dist is not None and not args.no_gather:
         gather = gather_once(ds, step, dist, rank, world)
@@ -225,6 +235,8 @@ def main():
                                   "positions_per_s": ps_pos.value / (ps_ms.value * 1e-3)}
         if expand_ms is not None:
             out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap, "where": "device (hawk_hapset_expand), outside the timed steps"}
+        if collapse is not None:
+            out["collapse"] = collapse
         if gather is not None:
             out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:

@@ -23,6 +23,10 @@ Fixtures:
                         scorer input k-mers + CFDon (synthetic tables) for several regions
   g5_cfd.json.gz        compute_cfd on random (wt, sg, pam) triples, synthetic tables
   g6_deepcpf1.json.gz   SeqDeepCpf1 forward on random 34-mers, seeded synthetic weights
+  g7_report_*.json.gz   the guide report: search -> _annotate_variants -> annotate_variants_afs ->
+                        reverse_guides -> gc -> CFDon -> reports._process_data -> _collapse_report_entries ->
+                        _format_report, stored as the TSV text the reference would write.  gc_content comes from
+                        a restatement of Biopython's gc_fraction (Biopython is absent: that column is unpinned)
 """
 
 import gzip
@@ -63,6 +67,16 @@ def _install_standins():
     ps.tabix_index = lambda *a, **k: None
     sys.modules["pysam"] = ps
     sys.modules["pysam.utils"] = psu
+    bio = types.ModuleType("Bio")  # annotation.py imports gc_fraction at module level; never called through the stand-in
+    bsu = types.ModuleType("Bio.SeqUtils")
+
+    def _absent(*a, **k):
+        raise NotImplementedError("Biopython is not installed here")
+
+    bsu.gc_fraction = _absent
+    bio.SeqUtils = bsu
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.SeqUtils"] = bsu
     h5 = types.ModuleType("h5py")  # only load_deepcpf1_weights touches it; never called
     h5.File = object
     sys.modules["h5py"] = h5
@@ -295,6 +309,83 @@ def g3_all():
     g3_search("ngn", synth.make_region(3061, "chrX", 4000, 300, 3300), "NGN", 20, False)
 
 
+# ---------------------------------------------------------------------------- G7 (guide report)
+def _gc_fraction_restated(seq: str) -> float:
+    """Biopython 1.83 SeqUtils.gc_fraction(seq) with its default ambiguous="remove": (C+G+S) / (A+C+G+T+S+W+U),
+    0 for an empty denominator.  Restated because Biopython is not installed: gc_content is unpinned."""
+    gc = sum(seq.count(c) for c in "CGScgs")
+    n = gc + sum(seq.count(c) for c in "ATWUatwu")
+    return gc / n if n else 0.0
+
+
+def g7_report(name, reg, pam_s, guidelen, right, cfd=True):
+    from crisprhawk import annotation as R_ann
+    from crisprhawk import reports as R_rep
+    import math
+    region = _ref_region(reg)
+    haps, variants_present, phased = _ref_haplotypes(reg, region)
+    for i, h in enumerate(haps):
+        h.id = f"hap_{i:08d}"
+    pam = R_pam.PAM(pam_s, right, True)
+    pam.encode(0)
+    bits = [R_encoder.encode(h.sequence.sequence, 0, True) for h in haps]
+    guides = R_search.search(pam, region, haps, bits, guidelen, right, variants_present, phased, 0, True)
+    # annotation.annotate_guides (annotation.py:545-600) without the BED annotations
+    guides = R_ann._annotate_variants(guides, 0, True)
+    guides = R_ann.annotate_variants_afs(guides, 0)
+    guides = R_ann.reverse_guides(guides, 0)
+    for g in guides:
+        g.gc = _gc_fraction_restated(g.guide)  # annotation.gc_content with the restated gc_fraction
+    if cfd:  # scoring.cfdon_score (scoring.py:352-387) with the synthetic tables; guides leave in group order
+        mm, pt = synth.cfd_tables()
+        mmd, pamd = synth.cfd_tables_as_dicts(mm, pt)
+        groups = R_search.group_guides_position(guides, True)
+        out = []
+        for _, grp in groups.items():
+            gref, members = grp[0], grp[1]
+            for sg in members:
+                sg.cfdon_score = float("nan") if gref is None else float(
+                    R_cfd.compute_cfd(gref.guide, sg.guide, sg.pam[-2:], mmd, pamd, True))
+                out.append(sg)
+        guides = out
+    df = R_rep._process_data(region, guides, pam, [], [], [], [], False, False)
+    n_rows = len(df)
+    df = R_rep._collapse_report_entries(df, pam, [], [], False)
+    df = R_rep._format_report(df, pam, right, [], [], False)
+    tsv = df.to_csv(sep="\t", index=False)
+    obj = dict(
+        contig=reg.contig, bed_start=reg.bed_start, bed_stop=reg.bed_stop, startp=region.start, stopp=region.stop,
+        region_seq=reg.sequence, samples=reg.samples,
+        variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants],
+        pam=pam_s, guidelen=guidelen, right=right, cfd=cfd, target=str(region.coordinates),
+        haplotypes=[dict(id=h.id, samples=h.samples, variants=h.variants,
+                         afs={k: (None if v != v else v) for k, v in h.afs.items()}) for h in haps],
+        rows_before_collapse=n_rows, report_tsv=tsv,
+    )
+    dump(f"g7_report_{name}.json.gz", obj)
+    print(f"   {name}: {len(haps)} haplotypes, {n_rows} guide rows -> {len(df)} report rows")
+
+
+def g7_all():
+    reg = synth.make_region(3001, "chrP", 6000, 1500, 4500)
+    synth.add_phased_variants(reg, 3002, 60, 4, frac_snv=0.6, frac_del=0.2, af_min=0.15, af_max=0.6)
+    g7_report("phased4", reg, "NGG", 20, False)
+    reg = synth.make_region(3011, "chrQ", 40000, 5000, 35000)
+    synth.add_phased_variants(reg, 3012, 400, 8, af_min=0.05, af_max=0.5)
+    g7_report("phased16", reg, "NGG", 20, False)
+    reg = synth.make_region(3021, "chrC", 12000, 2000, 10000)
+    synth.add_phased_variants(reg, 3022, 120, 4, frac_snv=0.7, frac_del=0.15, af_min=0.1, af_max=0.6)
+    g7_report("cpf1", reg, "TTTV", 23, True, cfd=False)
+    reg = synth.make_region(3041, "chrE", 3000, 700, 1500)
+    synth.add_phased_variants(reg, 3042, 80, 3, frac_snv=0.2, frac_del=0.4, max_indel=6, af_min=0.2, af_max=0.7, edge_margin=1)
+    g7_report("indel_dense", reg, "NGG", 20, False)
+    g7_report("c1", synth.config_c1(), "NGG", 20, False)
+    # SaCas9: no efficiency score columns at all
+    reg = synth.make_region(3071, "chrS", 8000, 1000, 7000)
+    synth.add_phased_variants(reg, 3072, 90, 3, af_min=0.2, af_max=0.6)
+    g7_report("sacas9", reg, "NNGRRT", 21, False, cfd=False)
+
+
 # ---------------------------------------------------------------------------- G4 (unphased, SURVEY row a10)
 def g4_unphased():
     """Unphased VCF: the reference encodes heterozygous SNVs as lower-case IUPAC letters, builds one
@@ -383,7 +474,7 @@ def g6_deepcpf1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     if "g1" in which:
         g1_tables()
     if "g2" in which:
@@ -396,3 +487,5 @@ if __name__ == "__main__":
         g5_cfd()
     if "g6" in which:
         g6_deepcpf1()
+    if "g7" in which:
+        g7_all()

@@ -1,0 +1,79 @@
+"""the guide report (annotate -> score -> collapse -> sort) against the TSV text the reference
+produced for the same inputs (tests/golden/g7_report_*.json.gz, built by tests/golden/make_golden.py through
+the reference's own annotation.py / reports.py).  The CPU test feeds the report assembler from the oracle's
+rows and groups; the GPU test feeds it from the device table and hawk_table_collapse."""
+import numpy as np
+import pytest
+
+from crisprhawk_hip import reports, synth
+from crisprhawk_hip.hapset import PosSegments, segments_from_posmap
+from crisprhawk_hip.pam import PAM
+from oracle import oracle as ora
+from util import load_golden, oracle_haplotypes
+
+CASES = ["phased4", "phased16", "cpf1", "indel_dense", "c1", "sacas9"]
+
+
+class _Hap:
+    def __init__(self, label, posmap, n):
+        self.samples, self.variants, self.id = label["samples"], label["variants"], label["id"]
+        self.afs = {k: (float("nan") if v is None else v) for k, v in label["afs"].items()}
+        rel, gen = segments_from_posmap(posmap)
+        self.segments = PosSegments(rel, gen, n)
+
+
+def _oracle_side(fx):
+    pam_s, guidelen, right = fx["pam"], fx["guidelen"], fx["right"]
+    haps = oracle_haplotypes(fx)
+    assert len(haps) == len(fx["haplotypes"])
+    scan = [ora.scan_bounds(h["posmap"], fx["startp"], fx["stopp"], len(pam_s)) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    labels = [_Hap(lb, h["posmap"], len(h["seq"])) for lb, h in zip(fx["haplotypes"], haps)]
+    return hs, labels
+
+
+def _pam(fx):
+    pam = PAM(fx["pam"], fx["right"], True)
+    pam.encode(0)
+    return pam
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_report_from_oracle_rows_matches_reference_tsv(case):
+    fx = load_golden(f"g7_report_{case}.json.gz")
+    hs, labels = _oracle_side(fx)
+    pam_s, guidelen, right = fx["pam"], fx["guidelen"], fx["right"]
+    res = ora.search(hs, pam_s, guidelen, right)
+    g = res.guides
+    assert len(g["start"]) == fx["rows_before_collapse"]
+    cfd = None
+    if fx["cfd"]:
+        mm, pt = synth.cfd_tables()
+        _, _, _, cfd, _ = ora.reverse_and_cfdon(res, hs.is_ref, guidelen, len(pam_s), mm, pt)
+    isref_row = np.asarray(hs.is_ref)[g["hap"]]
+    groups, gc = ora.collapse_rows(g["start"], g["stop"], g["strand"], isref_row, res.windows, guidelen, len(pam_s), right)
+    perm, off, num, den = [], [0], [], []
+    for key, rows in groups.items():
+        perm += rows
+        off.append(len(perm))
+        num.append(gc[key][0]); den.append(gc[key][1])
+    inp = reports.ReportInput(g["start"], g["stop"], g["strand"], g["hap"], g["pos"], res.windows, cfd, np.array(perm), np.array(off),
+                              np.array(num), np.array(den), guidelen, len(pam_s), right)
+    df = reports.report_frame(inp, labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
+    assert reports.to_tsv(df) == fx["report_tsv"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_report_from_device_table_matches_reference_tsv(case):
+    from crisprhawk_hip.hapset import DeviceHapSet, HostHaplotype
+    fx = load_golden(f"g7_report_{case}.json.gz")
+    hs, labels = _oracle_side(fx)
+    pam_s, guidelen, right = fx["pam"], fx["guidelen"], fx["right"]
+    ds = DeviceHapSet([HostHaplotype(seq, lb.segments, r, sc) for seq, lb, r, sc in zip(hs.seqs, labels, hs.is_ref, hs.scan)])
+    bits, bitsrc, _, _ = ora.pam_encode(pam_s)
+    mm, pt = synth.cfd_tables() if fx["cfd"] else (None, None)
+    tab = ds.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, collapse=True)
+    assert tab.n_rows == fx["rows_before_collapse"]
+    df = reports.report_frame(reports.ReportInput.from_table(tab), labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
+    assert reports.to_tsv(df) == fx["report_tsv"]
