@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--cpu-haps", type=int, default=160, help="haplotypes in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-expand", action="store_true", help="build the haplotype strings on the host and pack them (K1) instead of expanding on the device")
+    ap.add_argument("--report", action="store_true", help="also assemble the guide report (f2) of the whole workload once and time it")
     ap.add_argument("--no-collapse", action="store_true", help="skip the one-off report-row collapse after the timed loop")
     ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
     args = ap.parse_args()
@@ -167,6 +168,20 @@ def main():
         _lib.check(_lib.lib().hawk_table_collapse(tc._t, C.byref(ng), C.byref(cms)), "hawk_table_collapse")
         collapse = {"kernels_ms": cms.value, "rows": tc.n_rows, "groups": ng.value,
                     "what": "k_collapse_keys + rocprim radix sort (key, row) + k_collapse_heads + scan + k_collapse_groups"}
+        if args.report and not args.host_expand:
+            from crisprhawk_hip import reports as hip_reports
+            from crisprhawk_hip.workload import row_labels
+            t0 = time.perf_counter()
+            tc.collapse()
+            t1 = time.perf_counter()
+            inp = hip_reports.ReportInput.from_table(tc)
+            t2 = time.perf_counter()
+            df = hip_reports.report_frame(inp, row_labels(reg, ds, _info, _kept), pam, reg.contig, f"{reg.contig}:{reg.bed_start}-{reg.bed_stop}")
+            t3 = time.perf_counter()
+            collapse["report"] = {"report_rows": int(len(df)), "collapse_and_download_group_arrays_s": t1 - t0,
+                                  "table_download_and_decode_s": t2 - t1, "assemble_s": t3 - t2,
+                                  "what": "crisprhawk_hip.reports.report_frame: one pass per report row (variants, AFs, samples, order)"}
+            log(f"report: {len(df)} rows from {tc.n_rows} guide rows in {t3 - t0:.1f}s")
         tc.close()
     gather = None
     if dist is not None and not args.no_gather:

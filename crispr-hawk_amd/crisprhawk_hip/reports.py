@@ -150,6 +150,7 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
     L = inp.guidelen + inp.pamlen
     pamclass = compute_pam_class(pam)
     parsed_cache: Dict[int, Dict[int, List]] = {}
+    member_cache: Dict[bytes, tuple] = {}
     recs = []
     perm = np.asarray(inp.group_perm, dtype=np.int64)
     off = np.asarray(inp.group_off, dtype=np.int64)
@@ -198,12 +199,17 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
         den = int(inp.gc_den[g])
         rec["gc_content"] = str(int(inp.gc_num[g]) / den if den else 0.0)
         rec["origin"] = "ref" if h.samples == "REF" else "alt"
-        members = [haplotypes[int(x)] for x in inp.hap[rows]]
-        rec["samples"] = collapse_samples([m.samples for m in members])
+        mkey = np.ascontiguousarray(inp.hap[rows]).tobytes()  # guides around one variant share their carriers
+        agg = member_cache.get(mkey)
+        if agg is None:
+            members = [haplotypes[int(x)] for x in inp.hap[rows]]
+            agg = (collapse_samples([m.samples for m in members]), collapse_haplotype_ids([m.id for m in members]))
+            member_cache[mkey] = agg
+        rec["samples"] = agg[0]
         rec["variant_id"] = ",".join(sorted(set(variant_id.split(",")))) if variant_id else ""  # _check_variant_ids
         rec["af"] = af
         rec["target"] = target
-        rec["haplotype_id"] = collapse_haplotype_ids([m.id for m in members])
+        rec["haplotype_id"] = agg[1]
         recs.append(rec)
     if not recs:
         return pd.DataFrame({c: [] for c in cols})
@@ -224,3 +230,18 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
 def to_tsv(df) -> str:
     """What _store_report writes (reports.py:739)."""
     return df.to_csv(sep="\t", index=False)
+
+
+def report_filename(contig: str, bed_start: int, bed_stop: int, pam: PAM, guidelen: int) -> str:
+    """reports.py:1042-1047: crisprhawk_guides__{contig}_{BEDstart}_{BEDstop}_{PAM}_{guidelen}.tsv"""
+    return f"crisprhawk_guides__{contig}_{bed_start}_{bed_stop}_{pam}_{guidelen}.tsv"
+
+
+def report_table(tab, haplotypes, pam: PAM, contig: str, bed_start: int, bed_stop: int, outdir: str, scores=None,
+                 with_cfdon: bool = True) -> str:
+    """report_guides for one region from a collapsed GuideTable: assemble, write the TSV, return its path."""
+    import os
+    df = report_frame(ReportInput.from_table(tab), haplotypes, pam, contig, f"{contig}:{bed_start}-{bed_stop}", scores, with_cfdon)
+    path = os.path.join(outdir, report_filename(contig, bed_start, bed_stop, pam, tab.guidelen))
+    df.to_csv(path, sep="\t", index=False)
+    return path

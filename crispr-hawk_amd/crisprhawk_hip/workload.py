@@ -218,3 +218,25 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     ds.host_meta = haps
     kept = [i for i in range(n_hap) if alias[i] == i]
     return ds, [info[i] for i in kept], float(ms.value), kept
+
+
+class RowLabel:
+    """What the report needs to know about one device haplotype row (the Haplotype fields of guide.py:64-118)."""
+
+    __slots__ = ("samples", "variants", "afs", "id", "segments")
+
+    def __init__(self, samples: str, variants: str, afs, hid: str, segments):
+        self.samples, self.variants, self.afs, self.id, self.segments = samples, variants, afs, hid, segments
+
+
+def row_labels(reg: SynthRegion, ds, info: List[HapInfo], kept: List[int]) -> List[Optional[RowLabel]]:
+    """Labels per device row of an expand_on_device() set (None for rows collapsed onto another row): samples
+    joined as collapse_haplotypes does, variant ids `chr-pos-ref/alt`, allele frequencies by id."""
+    vid = [f"{reg.contig}-{v.pos}-{v.ref}/{v.alt}" for v in reg.variants]
+    af = {vid[i]: float(v.af) for i, v in enumerate(reg.variants)}
+    out: List[Optional[RowLabel]] = [None] * ds.n_hap
+    for r, inf in zip(kept, info):
+        ids = [vid[i] for i in inf.variant_idx]
+        out[r] = RowLabel(",".join(inf.samples), ",".join(ids) if ids else "NA", {k: af[k] for k in ids}, f"hap_{r:08d}",
+                          ds.host_meta[r].seg)
+    return out
