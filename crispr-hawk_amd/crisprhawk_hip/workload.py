@@ -180,38 +180,47 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
             j = first.get(key[r])
             if j is None:
                 first[key[r]] = r
-                info[r] = HapInfo([label], tuple(int(x) for x in hv_idx[int(hv_off[r]):int(hv_off[r + 1])]))
+                info[r] = HapInfo([label], hv_idx[int(hv_off[r]):int(hv_off[r + 1])])
             else:
                 alias[r] = j
                 if j != 0:
                     info[j].samples.append(label)
     # ---- position-map segments + scan bounds per row ------------------------------------------
+    # all rows at once: every carried deletion opens one segment behind it, every carried insertion of n bases
+    # opens n + 1 (the inserted bases all map to the anchor position, haplotype.py:106-159)
+    ch_all = chain[hv_idx]
+    ind = np.flatnonzero(ch_all != 0)
+    row_all = row_of + 1  # device row of every list entry (row 0 is REF)
+    o_i = hv_o[ind].astype(np.int64)
+    pos_i = r0[hv_idx[ind]] + startp
+    ch_i = ch_all[ind]
+    row_i = row_all[ind]
+    nseg_i = np.where(ch_i < 0, 1, ch_i + 1)
+    rep = np.repeat(np.arange(len(ind)), nseg_i)
+    first_of = np.cumsum(nseg_i) - nseg_i
+    k_in = np.arange(len(rep)) - first_of[rep]           # 0..n within an insertion's run, 0 for a deletion
+    is_del = ch_i[rep] < 0
+    seg_rel_all = o_i[rep] + 1 + k_in
+    seg_gen_all = np.where(is_del, pos_i[rep] + 1 - ch_i[rep], np.where(k_in < ch_i[rep], pos_i[rep], pos_i[rep] + 1))
+    seg_row_all = row_i[rep]
+    keep = seg_rel_all < hap_len[seg_row_all].astype(np.int64)
+    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[keep], seg_gen_all[keep], seg_row_all[keep]
+    srt = np.lexsort((seg_rel_all, seg_row_all))        # rows are already ascending; order each row by rel
+    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[srt], seg_gen_all[srt], seg_row_all[srt]
+    seg_cnt = np.bincount(seg_row_all, minlength=n_hap)
+    seg_start = np.concatenate(([0], np.cumsum(seg_cnt)))
     haps = []
+    zero_rel, first_gen = np.zeros(1, np.uint32), np.array([startp], np.int64)
     for r in range(n_hap):
         if alias[r] != r:
             haps.append(HostHaplotype(b"", PosSegments.identity(startp, int(hap_len[r])), False, (0, 0)))
             continue
-        a, b = int(hv_off[r]), int(hv_off[r + 1])
-        vi = hv_idx[a:b]
-        ch = chain[vi]
-        ind = np.flatnonzero(ch != 0)
-        if len(ind) == 0:
+        a, b = int(seg_start[r]), int(seg_start[r + 1])
+        if a == b:
             seg = PosSegments.identity(startp, int(hap_len[r]))
         else:
-            o = hv_o[a:b][ind].astype(np.int64)
-            pos = r0[vi][ind] + startp
-            chi = ch[ind]
-            rel, gen = [np.zeros(1, np.int64)], [np.array([startp], np.int64)]
-            dele = chi < 0
-            rel.append(o[dele] + 1); gen.append(pos[dele] + 1 - chi[dele])
-            for k in np.flatnonzero(~dele):
-                n = int(chi[k])
-                rel.append(o[k] + 1 + np.arange(n + 1)); gen.append(np.concatenate((np.full(n, pos[k]), [pos[k] + 1])))
-            rel, gen = np.concatenate(rel), np.concatenate(gen)
-            srt = np.argsort(rel, kind="stable")
-            rel, gen = rel[srt], gen[srt]
-            keep = rel < int(hap_len[r])
-            seg = PosSegments(rel[keep].astype(np.uint32), gen[keep], int(hap_len[r]))
+            seg = PosSegments(np.concatenate((zero_rel, seg_rel_all[a:b].astype(np.uint32))),
+                              np.concatenate((first_gen, seg_gen_all[a:b])), int(hap_len[r]))
         haps.append(HostHaplotype(b"", seg, r == 0, scan_bounds(seg, startp, stopp, pamlen)))
     ds.set_meta(haps)
     ds.alias = alias
