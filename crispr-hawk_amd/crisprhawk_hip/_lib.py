@@ -26,7 +26,8 @@ EXPORTS = [
     "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan", "hawk_pam_scan_time",
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
-    "hawk_table_collapse", "hawk_table_collapse_download",
+    "hawk_table_collapse", "hawk_table_collapse_download", "hawk_gt_parse", "hawk_gt_destroy", "hawk_gt_codes", "hawk_gt_lists",
+    "hawk_gt_lists_download",
 ]
 
 
@@ -97,6 +98,7 @@ def lib() -> C.CDLL:
         L.hawk_destroy.restype = None
         L.hawk_hapset_destroy.restype = None
         L.hawk_table_destroy.restype = None
+        L.hawk_gt_destroy.restype = None
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is C.c_int:

@@ -85,89 +85,81 @@ for _c, _v in {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15, "R": 5, "Y": 10, "S": 6,
     _NIB[ord(_c.lower())] = _v
 
 
-def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None):
-    """build_phased_haplotypes() with the sequence work done by hawk_hapset_expand: the host only
-    prepares index arrays (which variants each chromosome copy carries, prefix sums of their length
-    changes), labels and position-map segments; no haplotype string is ever formed.
-    Returns (DeviceHapSet, [HapInfo] of the kept rows, kernel ms, kept row indices).  Rows that collapse onto an earlier row
-    (haplotypes.py:274-294; homozygous copies, 326-333) stay in HBM with an empty scan range."""
-    import ctypes as C
-    from . import _lib
+def _variant_table(pos: np.ndarray, refs: List[str], alts: List[str], seq: str, startp: int):
+    """Per-variant arrays the expansion kernels index with (validated against the reference string)."""
     from .expand import HaplotypeBuildError
-    from .hapset import DeviceHapSet, _p
-
-    seq = reg.sequence
-    startp, stopp, n_ref = reg.startp, reg.stopp, len(reg.sequence)
-    ref_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
-    ref_seg = PosSegments.identity(startp, n_ref)
-    ref_set = DeviceHapSet([HostHaplotype(ref_u8, ref_seg, True, scan_bounds(ref_seg, startp, stopp, pamlen))], device)
-    nv = len(reg.variants)
-    if nv == 0:
-        ref_set.alias = np.zeros(1, dtype=np.int64)
-        return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
-    r0 = np.array([v.pos - startp for v in reg.variants], dtype=np.int64)
-    reflen = np.array([len(v.ref) for v in reg.variants], dtype=np.int64)
-    altlen = np.array([len(v.alt) for v in reg.variants], dtype=np.int64)
-    order = np.argsort(r0, kind="stable")
-    if np.any(order != np.arange(nv)):
+    n_ref = len(seq)
+    nv = len(refs)
+    r0 = np.asarray(pos, dtype=np.int64) - startp
+    reflen = np.array([len(x) for x in refs], dtype=np.int64)
+    altlen = np.array([len(x) for x in alts], dtype=np.int64)
+    if np.any(np.diff(r0) < 0):
         raise HaplotypeBuildError("variants must be sorted by position")
     # replaced span as the reference computes it (haplotype.py:197-201): |chain|+1 for deletions, else 1
     chain = altlen - reflen
     span = np.where(chain < 0, -chain + 1, 1)
     if np.any((chain < 0) & (altlen != 1)) or np.any((chain == 0) & (reflen != 1)):
         raise HaplotypeBuildError("device expansion handles SNVs, deletions (alt of one base) and insertions")
-    if np.any(r0[1:] < r0[:-1] + span[:-1]) or np.any(r0 < 0) or np.any(r0 + span > n_ref):
-        raise HaplotypeBuildError("overlapping variants / variant outside the region")
-    for v, a, sp in zip(reg.variants, r0, span):  # REF allele must match (haplotype.py:203-208)
-        if seq[a:a + sp] != v.ref[:sp] if len(v.ref) >= sp else True:
-            raise HaplotypeBuildError(f"Mismatching reference alleles at position {v.pos}")
-    alt_blob = "".join(v.alt for v in reg.variants).encode("ascii")
-    alt_codes = _NIB[np.frombuffer(alt_blob, dtype=np.uint8)]
+    if np.any(r0 < 0) or np.any(r0 + span > n_ref):
+        raise HaplotypeBuildError("variant outside the region")
+    for i in range(nv):  # REF allele must match (haplotype.py:203-208)
+        a, sp = int(r0[i]), int(span[i])
+        if len(refs[i]) < sp or seq[a:a + sp].upper() != refs[i][:sp].upper():
+            raise HaplotypeBuildError(f"Mismatching reference alleles at position {int(pos[i])}")
+    alt_blob = "".join(alts).encode("ascii")
+    alt_codes = _NIB[np.frombuffer(alt_blob, dtype=np.uint8)] if alt_blob else np.zeros(0, np.uint8)
     alt_off = np.zeros(nv, dtype=np.int64)
-    alt_off[1:] = np.cumsum(altlen)[:-1]
-    # rows: REF, then every chromosome copy that carries at least one variant, in (sample, copy) order
-    G = np.stack([v.gt.reshape(-1) for v in reg.variants])  # [site, 2*sample]
-    cols, sites = np.nonzero(G.T)                             # sorted by column, then site
-    counts = np.bincount(cols, minlength=G.shape[1])
-    live = np.flatnonzero(counts)
+    if nv:
+        alt_off[1:] = np.cumsum(altlen)[:-1]
+    return r0, span, chain, altlen, alt_off, alt_codes
+
+
+def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, samples: List[str], tab, live: np.ndarray,
+                 counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device):
+    """Common tail of the device expansions: rows = REF + every chromosome copy (column) with a non-empty carried
+    list, in column order.  Calls hawk_hapset_expand, then labels / homozygous merge / collapse on the 16-byte
+    content hashes (haplotypes.py:232-368) and the position-map segments + scan bounds of every kept row."""
+    import ctypes as C
+    from . import _lib
+    from .expand import HaplotypeBuildError
+    from .hapset import DeviceHapSet, _p
+    r0, span, chain, altlen, alt_off, alt_codes = tab
+    n_ref, nv = len(seq), len(r0)
     n_hap = 1 + len(live)
     hv_off = np.zeros(n_hap + 1, dtype=np.uint64)
-    hv_off[2:] = np.cumsum(counts[live])
-    hv_idx = sites.astype(np.uint32)
-    c = chain[hv_idx]
-    excl = np.cumsum(c) - c
-    row_of = np.repeat(np.arange(len(live)), counts[live])
-    starts = hv_off[1:-1].astype(np.int64)
-    excl -= excl[starts][row_of] if len(starts) else 0
-    hv_o = (r0[hv_idx] + excl).astype(np.int32)
-    tot = np.zeros(n_hap, dtype=np.int64)
-    np.add.at(tot, row_of + 1, c)
-    hap_len = (n_ref + tot).astype(np.uint32)
-    if np.any(hv_o.astype(np.int64) + span[hv_idx] > n_ref):  # the reference's clamp (haplotype.py:199-201) would fire
-        raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
+    hv_off[2:] = np.cumsum(counts_live)
+    hv_idx = np.ascontiguousarray(hv_idx, dtype=np.uint32)
+    hv_o = np.ascontiguousarray(hv_o, dtype=np.int32)
+    row_of = np.repeat(np.arange(len(live)), counts_live)
+    hap_len = np.concatenate(([n_ref], n_ref + np.asarray(tot_live, dtype=np.int64))).astype(np.uint32)
+    if len(hv_idx):
+        if np.any(hv_o.astype(np.int64) + span[hv_idx] > n_ref):  # the reference's clamp (haplotype.py:199-201) would fire
+            raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
+        same_row = row_of[1:] == row_of[:-1]
+        if np.any(same_row & (r0[hv_idx[1:]] < r0[hv_idx[:-1]] + span[hv_idx[:-1]])):
+            raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
     L = _lib.lib()
     handle = C.c_void_p()
     hashes = np.zeros((n_hap, 2), dtype=np.uint64)
     ms = C.c_float(0)
     u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
-    arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(alt_codes), hv_off, hv_idx, hv_o, hap_len]
+    arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(alt_codes)]
     _lib.check(L.hawk_hapset_expand(ref_set._h, nv, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), len(alt_codes),
                                     n_hap, _p(hv_off), _p(hv_idx), _p(hv_o), _p(hap_len), C.byref(handle), _p(hashes), C.byref(ms)),
                "hawk_hapset_expand")
     ds = DeviceHapSet.from_handle(handle, hap_len, device)
     # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes) ----------------
     key = [bytes(hashes[i]) for i in range(n_hap)]
-    col_of_row = np.concatenate(([-1], live))
     first: Dict[bytes, int] = {key[0]: 0}
     info: List[Optional[HapInfo]] = [HapInfo(["REF"], ())] + [None] * (n_hap - 1)
     alias = np.arange(n_hap)
     row_of_col = {int(cc): i + 1 for i, cc in enumerate(live)}
-    for si in range(len(reg.samples)):
+    for si in range(len(samples)):
         rows = [row_of_col.get(2 * si), row_of_col.get(2 * si + 1)]
         if rows[0] is None and rows[1] is None:
             continue
         keys = [key[r] if r is not None else key[0] for r in rows]  # a copy without variants is the REF sequence
-        name = reg.samples[si]
+        name = samples[si]
         if keys[0] == keys[1]:
             entries = [(rows[0], f"{name}:1|1")]
             if rows[1] is not None and rows[0] is not None:
@@ -229,6 +221,128 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     return ds, [info[i] for i in kept], float(ms.value), kept
 
 
+def _ref_only_set(seq: str, startp: int, stopp: int, pamlen: int, device):
+    from .hapset import DeviceHapSet
+    ref_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
+    ref_seg = PosSegments.identity(startp, len(seq))
+    return DeviceHapSet([HostHaplotype(ref_u8, ref_seg, True, scan_bounds(ref_seg, startp, stopp, pamlen))], device)
+
+
+def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None):
+    """build_phased_haplotypes() with the sequence work done by hawk_hapset_expand: the host only
+    prepares index arrays (which variants each chromosome copy carries, prefix sums of their length
+    changes), labels and position-map segments; no haplotype string is ever formed.
+    Returns (DeviceHapSet, [HapInfo] of the kept rows, kernel ms, kept row indices).  Rows that collapse onto an earlier row
+    (haplotypes.py:274-294; homozygous copies, 326-333) stay in HBM with an empty scan range."""
+    seq, startp, stopp = reg.sequence, reg.startp, reg.stopp
+    ref_set = _ref_only_set(seq, startp, stopp, pamlen, device)
+    if not reg.variants:
+        ref_set.alias = np.zeros(1, dtype=np.int64)
+        return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
+    tab = _variant_table(np.array([v.pos for v in reg.variants]), [v.ref for v in reg.variants], [v.alt for v in reg.variants], seq, startp)
+    r0, span, chain = tab[0], tab[1], tab[2]
+    # which variants each chromosome copy carries, from the in-memory genotype matrix
+    G = np.stack([v.gt.reshape(-1) for v in reg.variants])  # [site, 2*sample]
+    cols, sites = np.nonzero(G.T)                             # sorted by column, then site
+    counts = np.bincount(cols, minlength=G.shape[1])
+    live = np.flatnonzero(counts)
+    hv_idx = sites.astype(np.uint32)
+    c = chain[hv_idx]
+    excl = np.cumsum(c) - c
+    row_of = np.repeat(np.arange(len(live)), counts[live])
+    starts = (np.cumsum(counts[live]) - counts[live]).astype(np.int64)
+    excl -= excl[starts][row_of] if len(starts) else 0
+    hv_o = (r0[hv_idx] + excl).astype(np.int32)
+    tot = np.zeros(len(live), dtype=np.int64)
+    np.add.at(tot, row_of, c)
+    return _expand_rows(ref_set, seq, startp, stopp, pamlen, reg.samples, tab, live, counts[live], hv_idx, hv_o, tot, device)
+
+
+class VcfVariants:
+    """The variant table of a VCF block after VariantRecord.split() (variant.py:313-331): one entry per ALT allele,
+    alleles and position adjusted like adjust_multiallelic, ids like _compute_id, AF from INFO."""
+
+    def __init__(self, block, contig: Optional[str] = None):
+        from .variant import adjust_multiallelic
+        pos, ref, alt, vid, af, line, allele = [], [], [], [], [], [], []
+        for i, f in enumerate(block.fixed):
+            chrom, p, r, alts, info = f[0], int(f[1]), f[3], f[4].split(","), f[7]
+            afs = [float("nan")] * len(alts)
+            k = info.find("AF=")
+            if k != -1:  # variant.py:188-206
+                e = info.find(";", k + 3)
+                afs = [float(x) for x in info[k + 3: len(info) if e == -1 else e].split(",")]
+                if len(afs) != len(alts):
+                    raise ValueError(f"AF number does not match the alleles number ({len(afs)} - {len(alts)})")
+            for a, al in enumerate(alts):
+                r_, a_, p_ = adjust_multiallelic(r, al, p)
+                pos.append(p_); ref.append(r_); alt.append(a_); af.append(afs[a])
+                vid.append(f"{chrom}-{p}-{r}/{al}")
+                line.append(i); allele.append(a + 1)
+        order = np.argsort(np.asarray(pos, dtype=np.int64), kind="stable")
+        pick = lambda xs: [xs[int(j)] for j in order]
+        self.pos = np.asarray(pos, dtype=np.int64)[order]
+        self.ref, self.alt, self.id, self.af = pick(ref), pick(alt), pick(vid), pick(af)
+        self.line = np.asarray(line, dtype=np.uint32)[order]
+        self.allele = np.asarray(allele, dtype=np.uint8)[order]
+
+    def __len__(self) -> int:
+        return len(self.pos)
+
+
+def expand_from_vcf(region_seq: str, startp: int, stopp: int, block, samples: List[str], pamlen: int, phased: bool = True,
+                    device: Optional[int] = None):
+    """f3 -> f1: the records of a VCF block (readers.VCF.fetch_block) straight to device haplotypes.  The sample
+    columns are parsed on the device (hawk_gt_parse) and inverted into carried-variant lists there
+    (hawk_gt_lists); the host handles the fixed columns of the records only.
+    Returns (DeviceHapSet, [HapInfo], kernel ms {parse, lists, expand}, kept rows, VcfVariants)."""
+    import ctypes as C
+    from . import _lib
+    from .hapset import _p
+    if not phased:
+        raise ValueError("expand_from_vcf builds phased haplotypes; unphased VCFs go through haplotypes.py")
+    ref_set = _ref_only_set(region_seq, startp, stopp, pamlen, device)
+    vt = VcfVariants(block)
+    if len(vt) == 0:
+        ref_set.alias = np.zeros(1, dtype=np.int64)
+        return ref_set, [HapInfo(["REF"], ())], {"parse": 0.0, "lists": 0.0, "expand": 0.0}, [0], vt
+    tab = _variant_table(vt.pos, vt.ref, vt.alt, region_seq, startp)
+    r0, chain = tab[0], tab[2]
+    L = _lib.lib()
+    g = C.c_void_p()
+    ms_parse, ms_lists = C.c_float(0), C.c_float(0)
+    text = np.ascontiguousarray(block.text)
+    _lib.check(L.hawk_gt_parse(ref_set._ctx, _p(text), C.c_uint64(len(text)), _p(block.line_off), _p(block.gt_off),
+                               C.c_uint64(len(block)), len(samples), C.byref(g), C.byref(ms_parse)), "hawk_gt_parse")
+    try:
+        flags = np.zeros(len(block), dtype=np.uint8)
+        _lib.check(L.hawk_gt_codes(g, None, _p(flags)), "hawk_gt_codes")
+        if np.any(flags & 2):
+            raise ValueError(f"VCF record {int(np.flatnonzero(flags & 2)[0])} does not have one genotype per sample")
+        if np.any(flags & 1):  # variant.py:489-506: a phased VCF must hold a|b everywhere
+            raise ValueError("Phased genotypes cannot have more than one allele on each copy")
+        if np.any(flags & 4):
+            raise ValueError(f"Malformed genotype in VCF record {int(np.flatnonzero(flags & 4)[0])}")
+        n_cols = 2 * len(samples)
+        col_off = np.zeros(n_cols + 1, dtype=np.uint64)
+        col_delta = np.zeros(n_cols, dtype=np.int64)
+        _lib.check(L.hawk_gt_lists(g, _p(vt.line), _p(vt.allele), _p(np.ascontiguousarray(r0, dtype=np.int32)),
+                                   _p(np.ascontiguousarray(chain, dtype=np.int32)), len(vt), _p(col_off), _p(col_delta),
+                                   C.byref(ms_lists)), "hawk_gt_lists")
+        ne = int(col_off[-1])
+        hv_idx = np.zeros(max(ne, 1), dtype=np.uint32)
+        hv_o = np.zeros(max(ne, 1), dtype=np.int32)
+        _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
+        hv_idx, hv_o = hv_idx[:ne], hv_o[:ne]
+    finally:
+        L.hawk_gt_destroy(g)
+    counts = np.diff(col_off.astype(np.int64))
+    live = np.flatnonzero(counts)
+    ds, info, ms_expand, kept = _expand_rows(ref_set, region_seq, startp, stopp, pamlen, samples, tab, live, counts[live], hv_idx,
+                                             hv_o, col_delta[live], device)
+    return ds, info, {"parse": float(ms_parse.value), "lists": float(ms_lists.value), "expand": ms_expand}, kept, vt
+
+
 class RowLabel:
     """What the report needs to know about one device haplotype row (the Haplotype fields of guide.py:64-118)."""
 
@@ -244,8 +358,10 @@ def row_labels(reg: SynthRegion, ds, info: List[HapInfo], kept: List[int]) -> Li
     vid = [f"{reg.contig}-{v.pos}-{v.ref}/{v.alt}" for v in reg.variants]
     af = {vid[i]: float(v.af) for i, v in enumerate(reg.variants)}
     out: List[Optional[RowLabel]] = [None] * ds.n_hap
+    is_indel = [len(v.ref) != len(v.alt) for v in reg.variants]
     for r, inf in zip(kept, info):
-        ids = [vid[i] for i in inf.variant_idx]
+        idx = [int(i) for i in inf.variant_idx]
+        ids = [vid[i] for i in idx if not is_indel[i]] + [vid[i] for i in idx if is_indel[i]]  # haplotype.py:234-242
         out[r] = RowLabel(",".join(inf.samples), ",".join(ids) if ids else "NA", {k: af[k] for k in ids}, f"hap_{r:08d}",
                           ds.host_meta[r].seg)
     return out

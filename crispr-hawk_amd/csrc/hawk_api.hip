@@ -782,7 +782,7 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
   for (uint32_t i = 0; i < n_var; ++i) {
     if ((uint64_t)v_r0[i] + v_span[i] > ref_len || v_span[i] == 0 || v_alt_len[i] == 0) return HAWK_E_INVALID;
     if ((uint64_t)v_alt_off[i] + v_alt_len[i] > alt_codes_len) return HAWK_E_INVALID;
-    if (i && v_r0[i] < v_r0[i - 1] + v_span[i - 1]) return HAWK_E_INVALID;  // sorted, non-overlapping
+    if (i && v_r0[i] < v_r0[i - 1]) return HAWK_E_INVALID;  // sorted by position (alleles of one site may share it)
   }
   for (uint32_t h = 0; h < n_hap; ++h) {
     if (hv_off[h + 1] < hv_off[h]) return HAWK_E_INVALID;
@@ -790,7 +790,7 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
     uint32_t prev = 0;
     for (uint64_t k = hv_off[h]; k < hv_off[h + 1]; ++k) {
       const uint32_t vi = hv_idx[k];
-      if (vi >= n_var || (k > hv_off[h] && vi <= prev)) return HAWK_E_INVALID;
+      if (vi >= n_var || (k > hv_off[h] && (vi <= prev || v_r0[vi] < v_r0[prev] + v_span[prev]))) return HAWK_E_INVALID;  // ascending, non-overlapping within a row
       if ((int64_t)hv_o[k] != (int64_t)v_r0[vi] + off) return HAWK_E_INVALID;  // exclusive prefix of the length changes
       off += (int64_t)v_alt_len[vi] - (int64_t)v_span[vi];
       prev = vi;
@@ -831,6 +831,141 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
   (void)hipFree(d_r0); (void)hipFree(d_span); (void)hipFree(d_ao); (void)hipFree(d_al); (void)hipFree(d_codes); (void)hipFree(d_off);
   (void)hipFree(d_idx); (void)hipFree(d_o); (void)hipFree(d_hash);
   *out = hs;
+  return HAWK_OK;
+}
+
+// ---------------------------------------------------------------------------- f3: VCF genotypes
+struct hawk_gt {
+  hawk_ctx* ctx;
+  uint64_t n_lines;
+  uint32_t n_samples, n_var;
+  uint8_t* d_codes;   // [n_lines][2 * n_samples]
+  uint8_t* d_flags;   // [n_lines]
+  uint64_t n_entries; // carried-variant entries over all columns (valid after hawk_gt_lists)
+  uint64_t* d_col_off; uint32_t* d_idx; int32_t* d_o; int64_t* d_delta;
+};
+
+int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const uint64_t* line_off, const uint64_t* gt_off,
+                  uint64_t n_lines, uint32_t n_samples, hawk_gt** out, float* kernel_ms) {
+  if (!ctx || !out || !n_samples || (n_lines && (!text || !line_off || !gt_off))) return HAWK_E_INVALID;
+  // every offset the kernel dereferences is checked here
+  for (uint64_t i = 0; i < n_lines; ++i)
+    if (line_off[i + 1] > text_len || line_off[i] >= line_off[i + 1] || gt_off[i] < line_off[i] || gt_off[i] > line_off[i + 1])
+      return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  hawk_gt* g = new (std::nothrow) hawk_gt();
+  if (!g) return HAWK_E_INVALID;
+  g->ctx = ctx; g->n_lines = n_lines; g->n_samples = n_samples; g->n_var = 0; g->n_entries = 0;
+  g->d_codes = nullptr; g->d_flags = nullptr; g->d_col_off = nullptr; g->d_idx = nullptr; g->d_o = nullptr; g->d_delta = nullptr;
+  if (kernel_ms) *kernel_ms = 0.f;
+  const size_t ncode = std::max<size_t>((size_t)n_lines * 2 * n_samples, 1);
+  HIPCHK(hipMalloc(&g->d_codes, ncode)); HIPCHK(hipMalloc(&g->d_flags, std::max<size_t>(n_lines, 1)));
+  if (n_lines) {
+    uint8_t* d_text = nullptr; uint64_t *d_lo = nullptr, *d_go = nullptr;
+    HIPCHK(hipMalloc(&d_text, text_len)); HIPCHK(hipMalloc(&d_lo, (n_lines + 1) * 8)); HIPCHK(hipMalloc(&d_go, n_lines * 8));
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemcpyAsync(d_text, text, text_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_lo, line_off, (n_lines + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_go, gt_off, n_lines * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(g->d_codes, 0xff, ncode, st));  // samples a short record does not reach read as missing
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    hawk_launch_gt_parse(st, d_text, d_lo, d_go, n_lines, n_samples, g->d_codes, g->d_flags);
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
+    (void)hipFree(d_text); (void)hipFree(d_lo); (void)hipFree(d_go);
+  }
+  *out = g;
+  return HAWK_OK;
+}
+
+void hawk_gt_destroy(hawk_gt* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipFree(g->d_codes); (void)hipFree(g->d_flags);
+  if (g->d_col_off) (void)hipFree(g->d_col_off);
+  if (g->d_idx) (void)hipFree(g->d_idx);
+  if (g->d_o) (void)hipFree(g->d_o);
+  if (g->d_delta) (void)hipFree(g->d_delta);
+  delete g;
+}
+
+int hawk_gt_codes(hawk_gt* g, uint8_t* codes, uint8_t* line_flags) {
+  if (!g) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  if (codes && g->n_lines) HIPCHK(hipMemcpyAsync(codes, g->d_codes, (size_t)g->n_lines * 2 * g->n_samples, hipMemcpyDefault, g->ctx->stream));
+  if (line_flags && g->n_lines) HIPCHK(hipMemcpyAsync(line_flags, g->d_flags, g->n_lines, hipMemcpyDefault, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return HAWK_OK;
+}
+
+int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allele, const int32_t* var_r0, const int32_t* var_chain,
+                  uint32_t n_var, uint64_t* col_off, int64_t* col_delta, float* kernel_ms) {
+  if (!g || !col_off || (n_var && (!var_line || !var_allele || !var_r0 || !var_chain))) return HAWK_E_INVALID;
+  for (uint32_t j = 0; j < n_var; ++j)
+    if (var_line[j] >= g->n_lines || var_allele[j] == 0 || var_allele[j] == 255) return HAWK_E_INVALID;
+  hawk_ctx* ctx = g->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t n_cols = 2 * g->n_samples, n_chunk = (n_var + 63u) / 64u;
+  hipStream_t st = ctx->stream;
+  if (g->d_col_off) { (void)hipFree(g->d_col_off); g->d_col_off = nullptr; }
+  if (g->d_idx) { (void)hipFree(g->d_idx); g->d_idx = nullptr; }
+  if (g->d_o) { (void)hipFree(g->d_o); g->d_o = nullptr; }
+  if (g->d_delta) { (void)hipFree(g->d_delta); g->d_delta = nullptr; }
+  g->n_var = n_var; g->n_entries = 0;
+  if (kernel_ms) *kernel_ms = 0.f;
+  std::vector<uint64_t> off(n_cols + 1, 0);
+  if (n_var == 0) {
+    memcpy(col_off, off.data(), (n_cols + 1) * 8);
+    if (col_delta) memset(col_delta, 0, (size_t)n_cols * 8);
+    return HAWK_OK;
+  }
+  uint32_t *d_vl = nullptr, *d_cnt = nullptr; uint8_t* d_va = nullptr; int32_t *d_r0 = nullptr, *d_ch = nullptr;
+  unsigned long long* d_bal = nullptr;
+  HIPCHK(hipMalloc(&d_vl, (size_t)n_var * 4)); HIPCHK(hipMalloc(&d_va, n_var)); HIPCHK(hipMalloc(&d_r0, (size_t)n_var * 4));
+  HIPCHK(hipMalloc(&d_ch, (size_t)n_var * 4)); HIPCHK(hipMalloc(&d_cnt, (size_t)n_cols * 4));
+  HIPCHK(hipMalloc(&d_bal, (size_t)n_cols * n_chunk * 8));
+  HIPCHK(hipMalloc(&g->d_col_off, (size_t)(n_cols + 1) * 8)); HIPCHK(hipMalloc(&g->d_delta, (size_t)n_cols * 8));
+  HIPCHK(hipMemcpyAsync(d_vl, var_line, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_va, var_allele, n_var, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_r0, var_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_ch, var_chain, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  hawk_launch_gt_count(st, g->d_codes, n_cols, d_vl, d_va, n_var, d_bal, d_cnt);
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  std::vector<uint32_t> cnt(n_cols);
+  HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n_cols * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (uint32_t c = 0; c < n_cols; ++c) off[c + 1] = off[c] + cnt[c];  // 2 * n_samples values: a host prefix sum
+  const uint64_t ne = off[n_cols];
+  HIPCHK(hipMalloc(&g->d_idx, std::max<size_t>(ne, 1) * 4)); HIPCHK(hipMalloc(&g->d_o, std::max<size_t>(ne, 1) * 4));
+  HIPCHK(hipMemcpyAsync(g->d_col_off, off.data(), (size_t)(n_cols + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(ctx->ev[2], st));
+  hawk_launch_gt_fill(st, n_cols, d_r0, d_ch, n_var, d_bal, g->d_col_off, g->d_idx, g->d_o, g->d_delta);
+  HIPCHK(hipEventRecord(ctx->ev[3], st));
+  HIPCHK(hipGetLastError());
+  if (col_delta) HIPCHK(hipMemcpyAsync(col_delta, g->d_delta, (size_t)n_cols * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (kernel_ms) {
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]); (void)hipEventElapsedTime(&b, ctx->ev[2], ctx->ev[3]);
+    *kernel_ms = a + b;
+  }
+  memcpy(col_off, off.data(), (size_t)(n_cols + 1) * 8);
+  g->n_entries = ne;
+  (void)hipFree(d_vl); (void)hipFree(d_va); (void)hipFree(d_r0); (void)hipFree(d_ch); (void)hipFree(d_cnt); (void)hipFree(d_bal);
+  return HAWK_OK;
+}
+
+int hawk_gt_lists_download(hawk_gt* g, uint32_t* hv_idx, int32_t* hv_o) {
+  if (!g) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  if (g->n_entries) {
+    if (hv_idx) HIPCHK(hipMemcpyAsync(hv_idx, g->d_idx, g->n_entries * 4, hipMemcpyDefault, g->ctx->stream));
+    if (hv_o) HIPCHK(hipMemcpyAsync(hv_o, g->d_o, g->n_entries * 4, hipMemcpyDefault, g->ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
   return HAWK_OK;
 }
 

@@ -112,6 +112,12 @@ int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_r
                          int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
                          uint8_t* gc_den);
+void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* line_off, const uint64_t* gt_off, uint64_t n_lines,
+                          uint32_t n_samples, uint8_t* codes, uint8_t* flags);
+void hawk_launch_gt_count(hipStream_t st, const uint8_t* codes, uint32_t n_cols, const uint32_t* var_line, const uint8_t* var_allele,
+                          uint32_t n_var, unsigned long long* ballots, uint32_t* col_count);
+void hawk_launch_gt_fill(hipStream_t st, uint32_t n_cols, const int32_t* var_r0, const int32_t* var_chain, uint32_t n_var,
+                         const unsigned long long* ballots, const uint64_t* col_off, uint32_t* hv_idx, int32_t* hv_o, int64_t* col_delta);
 #define HAWK_LIST_CAP 512  // entries per tile in the count pass -> emit pass hand-over list (hawk_search.hip LIST_CAP)
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals);

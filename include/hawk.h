@@ -170,6 +170,30 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
 int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms);
 int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den);
 
+/* ---- f3: VCF sample columns -> allele codes -> carried-variant lists.  Replaces the per-sample Python work of
+ * VariantRecord.read_vcf_line -> _genotypes_to_samples (variant.py:286-311, 558-619) and the inversion into
+ * per-sample variant lists of compute_haplotypes_phased (haplotypes.py:132-159).
+ * hawk_gt_parse: text = the raw bytes of n_lines VCF records ('\n'-terminated), record i =
+ *   text[line_off[i], line_off[i+1]), its first sample column starts at gt_off[i] (host arrays).  The device
+ *   keeps codes[n_lines][2*n_samples]: allele carried by copy 0 / copy 1 of each sample (0 REF, k = k-th ALT,
+ *   255 missing or absent), and a flag byte per record: 1 = a genotype without '|' (unphased or haploid),
+ *   2 = field count != n_samples, 4 = unexpected character.  hawk_gt_codes downloads both (NULL skips).
+ * hawk_gt_lists: variants j = (record var_line[j], allele var_allele[j] >= 1), ascending; var_r0[j] = offset of
+ *   the variant in the reference region, var_chain[j] = alt length - replaced length.  Per chromosome copy
+ *   (column c = 2*sample + copy) the ascending list of carried variants is built on the device; col_off[2*n_samples+1]
+ *   (host) receives the CSR offsets, col_delta (host, may be NULL) the summed length change per column.
+ *   hawk_gt_lists_download copies hv_idx and hv_o = var_r0 + exclusive running sum of var_chain within the
+ *   column (host or device destinations) - the inputs of hawk_hapset_expand for the rows "columns with a
+ *   non-empty list, in column order". */
+typedef struct hawk_gt hawk_gt;
+int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const uint64_t* line_off, const uint64_t* gt_off,
+                  uint64_t n_lines, uint32_t n_samples, hawk_gt** out, float* kernel_ms);
+void hawk_gt_destroy(hawk_gt* g);
+int hawk_gt_codes(hawk_gt* g, uint8_t* codes, uint8_t* line_flags);
+int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allele, const int32_t* var_r0, const int32_t* var_chain,
+                  uint32_t n_var, uint64_t* col_off, int64_t* col_delta, float* kernel_ms);
+int hawk_gt_lists_download(hawk_gt* g, uint32_t* hv_idx, int32_t* hv_o);
+
 /* ---- K7: off-target enumeration, replacing the external `crispritz.py search ... -mm M -bDNA 0
  * -bRNA 0` of offtargets.py:222-293 (CRISPRitz 2.6.6 is a third-party binary the reference shells
  * out to; semantics restated from the call site and the consumed fields, offtarget.py:77-101).

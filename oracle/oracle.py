@@ -307,3 +307,49 @@ def collapse_rows(start, stop, strand, is_ref_row, windows: Sequence[str], guide
             num = sum(spacer.count(c) for c in "CGScgs")
             gc[key] = (num, num + sum(spacer.count(c) for c in "ATWUatwu"))
     return groups, gc
+
+
+def vcf_genotype_codes(records: Sequence[Sequence[str]], n_samples: int):
+    """Allele codes of the sample columns of tab-split VCF records, the way _genotypes_to_samples reads them
+    (variant.py:558-619): the genotype is the part before the first ':', alleles are separated by '|' (phased) or
+    '/'; '0' = REF, '.' = missing, k = k-th ALT.  Returns codes[n, 2*n_samples] (255 = missing / absent) and flags
+    (1: a genotype without '|', 2: field count != n_samples, 4: malformed)."""
+    n = len(records)
+    codes = np.full((n, 2 * n_samples), 255, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8)
+    for i, rec in enumerate(records):
+        gts = list(rec[9:])
+        if len(gts) != n_samples:
+            flags[i] |= 2
+        for s, gt in enumerate(gts[:n_samples]):
+            g = gt.split(":")[0]
+            sep = "|" if "|" in g else ("/" if "/" in g else None)
+            parts = g.split(sep) if sep else [g]
+            if sep != "|" or len(parts) != 2:
+                flags[i] |= 1
+            for c, a in enumerate(parts[:2]):
+                if a == ".":
+                    codes[i, 2 * s + c] = 255
+                elif a.isdigit():
+                    codes[i, 2 * s + c] = min(int(a), 254)
+                else:
+                    flags[i] |= 4
+    return codes, flags
+
+
+def carried_lists(codes: np.ndarray, var_line, var_allele, var_r0, var_chain):
+    """Per chromosome copy (column) the ascending list of carried variants, and per entry r0 + the running sum of
+    the length changes of the variants before it (haplotypes.py:132-159 inverted; haplotype.py:185-252 offsets)."""
+    n_cols = codes.shape[1]
+    col_off = np.zeros(n_cols + 1, dtype=np.uint64)
+    idx, off, delta = [], [], np.zeros(n_cols, dtype=np.int64)
+    for c in range(n_cols):
+        run = 0
+        for j in range(len(var_line)):
+            if codes[var_line[j], c] == var_allele[j]:
+                idx.append(j)
+                off.append(int(var_r0[j]) + run)
+                run += int(var_chain[j])
+        col_off[c + 1] = len(idx)
+        delta[c] = run
+    return col_off, np.array(idx, dtype=np.uint32), np.array(off, dtype=np.int32), delta

@@ -23,6 +23,8 @@ Fixtures:
                         scorer input k-mers + CFDon (synthetic tables) for several regions
   g5_cfd.json.gz        compute_cfd on random (wt, sg, pam) triples, synthetic tables
   g6_deepcpf1.json.gz   SeqDeepCpf1 forward on random 34-mers, seeded synthetic weights
+  g8_vcf_lines.json.gz  VariantRecord.read_vcf_line / split() on multi-allelic, missing-allele and
+                        extra-FORMAT records
   g7_report_*.json.gz   the guide report: search -> _annotate_variants -> annotate_variants_afs ->
                         reverse_guides -> gc -> CFDon -> reports._process_data -> _collapse_report_entries ->
                         _format_report, stored as the TSV text the reference would write.  gc_content comes from
@@ -473,8 +475,58 @@ def g6_deepcpf1():
     dump("g6_deepcpf1.json.gz", dict(seed=2002, seqs=seqs, scores=scores))
 
 
+# ---------------------------------------------------------------------------- G8 (VCF records)
+def g8_vcf_lines():
+    """VariantRecord.read_vcf_line / split() (variant.py:286-331) on hand-made and random records: multi-allelic
+    sites, multi-digit allele indices, missing alleles, extra FORMAT fields, no AF."""
+    rng = np.random.default_rng(8008)
+    samples = [f"S{i:03d}" for i in range(37)]
+    recs = []
+
+    def gts(n_alt, p_missing=0.05, extra=False):
+        out = []
+        for _ in samples:
+            a = [("." if rng.random() < p_missing else str(int(rng.integers(0, n_alt + 1)))) for _ in range(2)]
+            g = "|".join(a)
+            if extra:
+                g += f":{int(rng.integers(1, 99))}:{rng.random():.2f}"
+            out.append(g)
+        return out
+
+    pos = 1000
+    for i in range(60):
+        pos += int(rng.integers(1, 40))
+        kind = i % 6
+        if kind == 0:
+            ref, alts, info = "A", ["G"], "AF=0.25"
+        elif kind == 1:
+            ref, alts, info = "ACG", ["A"], "AC=3;AF=0.0125;AN=10"
+        elif kind == 2:
+            ref, alts, info = "T", ["TGA", "C"], "AF=0.1,0.2"
+        elif kind == 3:
+            ref, alts, info = "C", ["A", "G", "T"], "DP=10"
+        elif kind == 4:
+            ref, alts, info = "GT", ["G", "GTT", "AT"], "AF=0.01,0.02,0.5;DB"
+        else:
+            ref, alts = "A", [c * (1 + j % 3) for j, c in enumerate("CGTCGTCGTCGT")]  # 12 ALT alleles: two-digit indices
+            info = "AF=" + ",".join(f"{0.001 * (j + 1):.3f}" for j in range(12))
+        fmt = "GT:DP:GQ" if i % 4 == 1 else "GT"
+        recs.append(["chrV", str(pos), ".", ref, ",".join(alts), "50", "PASS" if i % 5 else "q10", info, fmt]
+                    + gts(len(alts), extra=(fmt != "GT")))
+    out = []
+    for fields in recs:
+        vr = VariantRecord(True)
+        vr.read_vcf_line(fields, samples, True)
+        out.append(dict(
+            fields=fields, alt=vr.alt, vtype=vr.vtype, afs=[None if a != a else a for a in vr.afs], ids=vr.id, filter=vr.filter,
+            samples=[[sorted(s0), sorted(s1)] for s0, s1 in vr.samples],
+            split=[[v.position, v.ref, v.alt[0], v.id[0], v.vtype[0]] for v in vr.split()],
+        ))
+    dump("g8_vcf_lines.json.gz", dict(samples=samples, records=out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_tables()
     if "g2" in which:
@@ -489,3 +541,5 @@ if __name__ == "__main__":
         g6_deepcpf1()
     if "g7" in which:
         g7_all()
+    if "g8" in which:
+        g8_vcf_lines()
