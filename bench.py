@@ -46,6 +46,40 @@ def log(msg):
     print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def time_vcf_ingest(reg, ds_ref, pamlen, device):
+    """f3 at workload scale: the VCF text of the region's records (what readers.VCF.fetch_block returns) ->
+    hawk_gt_parse -> hawk_gt_lists -> hawk_hapset_expand, compared with the planes of the in-memory path."""
+    from crisprhawk_hip.readers import VcfBlock
+    from crisprhawk_hip.workload import expand_from_vcf
+    t0 = time.perf_counter()
+    ns = len(reg.samples)
+    parts, fixed, line_len = [], [], []
+    sep = np.array([ord("|")], np.uint8)
+    for v in reg.variants:
+        head = f"{reg.contig}\t{v.pos}\t.\t{v.ref}\t{v.alt}\t.\tPASS\tAF={v.af:.6g}\tGT\t".encode()
+        g = np.empty((ns, 4), np.uint8)
+        g[:, 0] = v.gt[:, 0] + 48; g[:, 1] = sep; g[:, 2] = v.gt[:, 1] + 48; g[:, 3] = 9
+        body = g.reshape(-1).tobytes()[:-1] + b"\n"
+        parts.append(head); parts.append(body)
+        fixed.append(head.decode().rstrip("\t").split("\t"))
+        line_len.append((len(head), len(head) + len(body)))
+    text = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    ll = np.array(line_len, dtype=np.uint64)
+    line_off = np.zeros(len(ll) + 1, dtype=np.uint64)
+    line_off[1:] = np.cumsum(ll[:, 1])
+    gt_off = line_off[:-1] + ll[:, 0]
+    blk = VcfBlock(text, line_off, gt_off, fixed)
+    t1 = time.perf_counter()
+    ds2, info2, ms, kept2, vt = expand_from_vcf(reg.sequence, reg.startp, reg.stopp, blk, reg.samples, pamlen, True, device)
+    t2 = time.perf_counter()
+    same = bool(ds2.n_hap == ds_ref.n_hap and np.array_equal(ds2.planes(), ds_ref.planes()))
+    log(f"vcf ingest: {len(text) / 1e6:.0f} MB of records -> {ds2.n_hap} haplotype rows in {t2 - t1:.2f}s "
+        f"(parse {ms['parse']:.2f} ms, lists {ms['lists']:.2f} ms, expand {ms['expand']:.2f} ms); planes identical: {same}")
+    return {"text_bytes": int(len(text)), "records": len(blk), "samples": ns, "make_text_s": t1 - t0, "ingest_wall_s": t2 - t1,
+            "kernels_ms": ms, "parse_GBps": len(text) / (ms["parse"] * 1e-3) / 1e9 if ms["parse"] else None,
+            "planes_identical_to_in_memory_path": same}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +94,7 @@ def main():
     ap.add_argument("--cpu-haps", type=int, default=160, help="haplotypes in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-expand", action="store_true", help="build the haplotype strings on the host and pack them (K1) instead of expanding on the device")
+    ap.add_argument("--vcf", action="store_true", help="also time the VCF-text ingest of the workload (f3: device genotype parser + carried lists)")
     ap.add_argument("--report", action="store_true", help="also assemble the guide report (f2) of the whole workload once and time it")
     ap.add_argument("--no-collapse", action="store_true", help="skip the one-off report-row collapse after the timed loop")
     ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
@@ -183,6 +218,9 @@ def main():
                                   "what": "crisprhawk_hip.reports.report_frame: one pass per report row (variants, AFs, samples, order)"}
             log(f"report: {len(df)} rows from {tc.n_rows} guide rows in {t3 - t0:.1f}s")
         tc.close()
+    vcf_ingest = None
+    if rank == 0 and args.vcf and not args.host_expand:
+        vcf_ingest = time_vcf_ingest(reg, ds, len(pam), local)
     gather = None
     if dist is not None and not args.no_gather:
         gather = gather_once(ds, step, dist, rank, world)
@@ -252,6 +290,8 @@ def main():
             out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap, "where": "device (hawk_hapset_expand), outside the timed steps"}
         if collapse is not None:
             out["collapse"] = collapse
+        if vcf_ingest is not None:
+            out["vcf_ingest"] = vcf_ingest
         if gather is not None:
             out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
