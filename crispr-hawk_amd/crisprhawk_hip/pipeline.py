@@ -1,0 +1,70 @@
+"""Files in, guide reports out: the path of `crisprhawk_search` (`crisprhawk.py:121-138`) for phased or variant-free
+inputs, with every stage on the device path of this package.
+
+    FASTA + BED (+ VCF)  --readers-->  region string, VCF record text
+                         --hawk_gt_parse / hawk_gt_lists / hawk_hapset_expand-->  haplotype planes in HBM
+                         --hawk_search (+ CFDon)-->  guide table in HBM
+                         --hawk_table_collapse-->  report groups
+                         --reports.report_frame-->  crisprhawk_guides__*.tsv
+
+Only what the reference's search sub-command does between reading its inputs and writing the guide report is covered;
+BED/gene annotations, the non-CFDon scorers (model files) and the off-target stage have their own entry points
+(`scoring.py`, `offtargets.py`).
+"""
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import reports
+from .pam import PAM, SPCAS9, XCAS9
+from .readers import VCF, Bed, Fasta
+from .workload import HapInfo, RowLabel, expand_from_vcf
+
+PADDING = 100  # region_constructor.py:21
+
+
+def _labels(ds, info: List[HapInfo], kept: List[int], vt) -> List[Optional[RowLabel]]:
+    """RowLabel per device row: samples joined as collapse_haplotypes does, variant ids in the reference's order
+    (SNVs by position, then indels: haplotype.py:234-242), allele frequencies by id, ids hap_<k> in list order."""
+    out: List[Optional[RowLabel]] = [None] * ds.n_hap
+    for k, (r, inf) in enumerate(zip(kept, info)):
+        idx = [int(i) for i in inf.variant_idx]
+        snv = [i for i in idx if len(vt.ref[i]) == len(vt.alt[i])]
+        indel = [i for i in idx if len(vt.ref[i]) != len(vt.alt[i])]
+        ids = [vt.id[i] for i in snv + indel]
+        out[r] = RowLabel(",".join(inf.samples), ",".join(ids) if ids else "NA", {vt.id[i]: float(vt.af[i]) for i in idx},
+                          f"hap_{k:08d}", ds.host_meta[r].seg)
+    return out
+
+
+def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidelen: int, right: bool, outdir: str,
+                 cfd_tables=None, device: Optional[int] = None, debug: bool = True) -> Dict[str, str]:
+    """One report per BED interval; returns {str(coordinate): path}.  `cfd_tables = (mm[20,4,4], pam[16])` adds the
+    CFDon column for SpCas9-class PAMs (scoring.py:352-387)."""
+    pam = PAM(pam_seq, right, debug)
+    pam.encode(0)
+    fa = Fasta(fasta, 0, debug)
+    fastas = {fa.contig: fa}
+    vcf_by_contig = {}
+    for f in vcfs or []:
+        v = VCF(f, 0, debug)
+        vcf_by_contig[v.contig] = v
+    score = cfd_tables is not None and pam.cas_system in (SPCAS9, XCAS9) and not right
+    mm, pt = cfd_tables if score else (None, None)
+    os.makedirs(outdir, exist_ok=True)
+    paths = {}
+    for coord in Bed(bedfile, PADDING, debug):
+        seq = fastas[coord.contig].fetch(coord).sequence
+        v = vcf_by_contig.get(coord.contig)
+        if v is not None and not v.phased:
+            raise ValueError("search_files handles phased VCFs; unphased inputs go through search_guides.search")
+        from .readers import VcfBlock
+        blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
+        samples = v.samples if v is not None else []
+        ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device)
+        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt, download=False, collapse=True)
+        labels = _labels(ds, info, kept, vt)
+        bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041
+        paths[str(coord)] = reports.report_table(tab, labels, pam, coord.contig, bed_start, bed_stop, outdir, None, score)
+    return paths

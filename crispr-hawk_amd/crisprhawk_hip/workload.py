@@ -225,7 +225,10 @@ def _ref_only_set(seq: str, startp: int, stopp: int, pamlen: int, device):
     from .hapset import DeviceHapSet
     ref_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
     ref_seg = PosSegments.identity(startp, len(seq))
-    return DeviceHapSet([HostHaplotype(ref_u8, ref_seg, True, scan_bounds(ref_seg, startp, stopp, pamlen))], device)
+    meta = HostHaplotype(ref_u8, ref_seg, True, scan_bounds(ref_seg, startp, stopp, pamlen))
+    ds = DeviceHapSet([meta], device)
+    ds.host_meta = [meta]
+    return ds
 
 
 def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None):

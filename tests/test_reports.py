@@ -2,6 +2,8 @@
 produced for the same inputs (tests/golden/g7_report_*.json.gz, built by tests/golden/make_golden.py through
 the reference's own annotation.py / reports.py).  The CPU test feeds the report assembler from the oracle's
 rows and groups; the GPU test feeds it from the device table and hawk_table_collapse."""
+import os
+
 import numpy as np
 import pytest
 
@@ -77,3 +79,27 @@ def test_report_from_device_table_matches_reference_tsv(case):
     assert tab.n_rows == fx["rows_before_collapse"]
     df = reports.report_frame(reports.ReportInput.from_table(tab), labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     assert reports.to_tsv(df) == fx["report_tsv"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_files_to_report_matches_reference_tsv(tmp_path, case):
+    """FASTA + BED + VCF files -> pipeline.search_files -> the TSV the reference wrote for the same inputs."""
+    from crisprhawk_hip import pipeline, readers
+    fx = load_golden(f"g7_report_{case}.json.gz")
+    contig_seq = "N" * (fx["startp"] - 1) + fx["region_seq"] + "ACGT" * 10
+    fa, bed, vcf = str(tmp_path / "g.fa"), str(tmp_path / "r.bed"), str(tmp_path / "v.vcf.gz")
+    readers.write_fasta(fa, fx["contig"], contig_seq, 80)
+    with open(bed, "w") as f:
+        f.write(f"{fx['contig']}\t{fx['bed_start']}\t{fx['bed_stop']}\n")
+    vcfs = []
+    if fx["variants"]:
+        rows = [[fx["contig"], str(p), ".", r, a, ".", "PASS", f"AF={af:.6g}", "GT"] + [f"{g[0]}|{g[1]}" for g in gts]
+                for p, r, a, af, gts in fx["variants"]]
+        readers.write_vcf(vcf, fx["contig"], fx["samples"], rows, True)
+        vcfs = [vcf]
+    paths = pipeline.search_files(fa, bed, vcfs, fx["pam"], fx["guidelen"], fx["right"], str(tmp_path / "out"),
+                                  cfd_tables=synth.cfd_tables() if fx["cfd"] else None)
+    (path,) = paths.values()
+    assert os.path.basename(path) == f"crisprhawk_guides__{fx['contig']}_{fx['bed_start']}_{fx['bed_stop']}_{fx['pam']}_{fx['guidelen']}.tsv"
+    assert open(path).read() == fx["report_tsv"]
