@@ -503,7 +503,10 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   uint64_t nrows = tot.n_keep;
   static const bool count_only = [] { const char* e = getenv("HAWK_COUNT_ONLY"); return e && e[0] == '1'; }();
-  if (count_only) nrows = 0;  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
+  if (count_only) {  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
+    if (getenv("HAWK_COUNT_VERBOSE")) fprintf(stderr, "[hawk] count pass: n_keep=%llu n_cand=%llu n_hits=%llu\n", (unsigned long long)tot.n_keep, (unsigned long long)tot.n_cand, (unsigned long long)tot.n_hits);
+    nrows = 0;
+  }
   GuideCols ca;
   if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
