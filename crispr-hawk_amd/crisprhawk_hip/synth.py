@@ -139,6 +139,8 @@ def add_phased_variants(
     for k in range(n_sites):
         pos = int(lo + slots[k] * span + jitter[k])
         refb = seq[pos - 1]
+        if refb not in "ACGT":
+            continue  # no variant on an ambiguous reference base
         gt = gt_all[k].reshape(n_samples, 2)
         if kinds[k] < frac_snv:
             altb = "ACGT"[("ACGT".index(refb) + int(alt_pick[k])) % 4]

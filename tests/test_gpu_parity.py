@@ -325,3 +325,23 @@ def test_collapse_empty_and_single():
     bits, bitsrc, _, _ = ora.pam_encode("NGG")
     tab = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
     assert tab.n_rows == 0 and tab.n_groups == 0 and tab.group_off.tolist() == [0]
+
+
+_FUZZ = [  # (seed, pam, guidelen, right, sites, samples, frac_snv, frac_del, max_indel)
+    (1, "NGG", 17, False, 120, 3, 0.7, 0.15, 4), (2, "NGG", 24, False, 200, 2, 0.3, 0.35, 8), (3, "NAG", 20, True, 80, 4, 0.9, 0.05, 2),
+    (4, "TTTV", 20, True, 150, 3, 0.5, 0.25, 6), (5, "TTN", 25, True, 60, 2, 0.6, 0.2, 3), (6, "NNGRRT", 22, False, 100, 3, 0.5, 0.25, 5),
+    (7, "NNNRRT", 21, True, 90, 2, 0.8, 0.1, 3), (8, "TTCN", 20, True, 110, 3, 0.6, 0.2, 4), (9, "NGK", 20, False, 140, 5, 0.4, 0.3, 7),
+    (10, "NNG", 18, False, 70, 2, 0.7, 0.15, 2), (11, "YTTV", 23, True, 130, 4, 0.5, 0.25, 5), (12, "NGNNNNNNNNNNNNGN", 28, False, 60, 2, 0.6, 0.2, 3),
+    (13, "N", 20, False, 40, 2, 0.7, 0.15, 2), (14, "NRG", 41, False, 50, 2, 0.6, 0.2, 3),
+]
+
+
+@pytest.mark.parametrize("cfg", _FUZZ, ids=[f"{c[1]}-{c[2]}-{'R' if c[3] else 'L'}" for c in _FUZZ])
+def test_search_parameter_sweep_against_oracle(cfg):
+    # PAM shapes (single base, IUPAC sets, all-N, 16 long), guide lengths up to the 44-nt core limit, both guide sides,
+    # SNV- to indel-heavy variant mixes; a region that spans two tiles with an IUPAC-bearing reference
+    seed, pam, guidelen, right, sites, samples, fs, fd, mi = cfg
+    reg = synth.make_region(7600 + seed, "chrZ", 41_000, 1_500, 39_500, iupac_frac=0.002 if seed % 3 == 0 else 0.0)
+    synth.add_phased_variants(reg, 7700 + seed, sites, samples, frac_snv=fs, frac_del=fd, max_indel=mi, af_min=0.2, af_max=0.8)
+    score = (not right) and reg.sequence.upper().count("N") == 0 and seed % 3 != 0 and len(pam) >= 2
+    _oracle_vs_device(reg, pam, guidelen, right, score)
