@@ -103,19 +103,19 @@ __device__ __forceinline__ void pam_match(const uint32_t (&A)[6], const uint32_t
     const uint32_t nib = (uint32_t)(pam >> (4 * (pamlen - 1 - i))) & 15u;
     if (nib == 15u) continue;  // wave-uniform: pam is a kernel argument
     const int s = po + i;
-    // single-base PAM positions (the common case) shift the plane's registers directly
+    // single-base PAM positions (the common case) shift the plane's registers directly; the word the shift starts
+    // in is a wave-uniform branch, not a per-word select
+#define PAM_AND_PLANE(X)                                                                    \
+    if (s < 32) { _Pragma("unroll") for (int k = 0; k < 4; ++k) m[k] &= fsh(X[k], X[k + 1], (uint32_t)s); } \
+    else { _Pragma("unroll") for (int k = 0; k < 4; ++k) m[k] &= fsh(X[k + 1], X[k + 2], (uint32_t)(s - 32)); }
     if (nib == 1u) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] &= shifted(A, k, s);
+      PAM_AND_PLANE(A)
     } else if (nib == 2u) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] &= shifted(C, k, s);
+      PAM_AND_PLANE(C)
     } else if (nib == 4u) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] &= shifted(G, k, s);
+      PAM_AND_PLANE(G)
     } else if (nib == 8u) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] &= shifted(T, k, s);
+      PAM_AND_PLANE(T)
     } else {
       const uint32_t mA = (nib & 1u) ? 0xffffffffu : 0u, mC = (nib & 2u) ? 0xffffffffu : 0u;
       const uint32_t mG = (nib & 4u) ? 0xffffffffu : 0u, mT = (nib & 8u) ? 0xffffffffu : 0u;
@@ -126,6 +126,7 @@ __device__ __forceinline__ void pam_match(const uint32_t (&A)[6], const uint32_t
       for (int k = 0; k < 4; ++k) m[k] &= shifted(sel, k, s);
     }
   }
+#undef PAM_AND_PLANE
 }
 
 // v[k] bit j := OR of the original bits [32k+j, 32k+j+L), valid for k < 4 when L <= 64

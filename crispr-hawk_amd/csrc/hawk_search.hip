@@ -471,7 +471,10 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
     }
   }
   if (PASS == 0) {
-    const uint32_t w0s = wave_sum(nvalid), w1s = wave_sum(cand | (hits << 16));  // per-wave sums < 2^16
+    const uint32_t w1s = wave_sum(cand | (hits << 16));  // per-wave sums < 2^16
+    // in list mode (and whenever phase C did not run) thread 0 alone holds the tile's count
+    const bool spread = stage && !list_mode && T != 0 && !(PASS == 0 && !dedup);
+    const uint32_t w0s = spread ? wave_sum(nvalid) : nvalid;  // workgroup-uniform choice
     if ((tid & (WAVE - 1)) == 0) {
       atomicAdd(&s_acc[0], w0s); atomicAdd(&s_acc[1], w1s & 0xffffu); atomicAdd(&s_acc[2], w1s >> 16);
     }
