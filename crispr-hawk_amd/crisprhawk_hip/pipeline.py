@@ -17,7 +17,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import reports
-from .pam import PAM, SPCAS9, XCAS9
+from . import scoring
+from .pam import CPF1, PAM, SPCAS9, XCAS9
 from .readers import VCF, Bed, Fasta
 from .workload import HapInfo, RowLabel, expand_from_vcf
 
@@ -66,5 +67,22 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt, download=False, collapse=True)
         labels = _labels(ds, info, kept, vt)
         bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041
-        paths[str(coord)] = reports.report_table(tab, labels, pam, coord.contig, bed_start, bed_stop, outdir, None, score)
+        inp = reports.ReportInput.from_table(tab)
+        # model-based scorers run once per report row, on the group representatives (scoring.py:749-813); they are
+        # on only when the caller has supplied their parameters (scoring.set_azimuth_model / set_deepcpf1_weights)
+        scores = {}
+        if tab.n_rows:
+            rows, kmers = reports.scorer_kmers(inp)
+            def _col(vals):
+                a = np.full(tab.n_rows, np.nan)
+                a[rows] = vals
+                return a
+            if pam.cas_system in (SPCAS9, XCAS9) and scoring._AZIMUTH_MODEL is not None:
+                scores["score_azimuth"] = _col(scoring.azimuth(kmers, debug))
+            if pam.cas_system == CPF1 and scoring._DEEPCPF1_W is not None:
+                scores["score_deepcpf1"] = _col(scoring.deepcpf1(kmers, debug))
+        df = reports.report_frame(inp, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score)
+        path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
+        df.to_csv(path, sep="\t", index=False)
+        paths[str(coord)] = path
     return paths

@@ -140,6 +140,21 @@ class ReportInput:
                    tab.gc_den, tab.guidelen, tab.pamlen, tab.right)
 
 
+def scorer_kmers(inp: ReportInput):
+    """Scorer inputs of the group representatives: `guide.sequence[6:-7].upper()` after reverse_guides
+    (scoring.py:50-67) - 30-mers for 20+3 Cas9 guides, 34-mers for 23+4 Cpf1 guides.  Returns (rows, kmers)."""
+    perm = np.asarray(inp.group_perm, dtype=np.int64)
+    off = np.asarray(inp.group_off, dtype=np.int64)
+    rows = perm[off[:-1]]
+    out = []
+    for r in rows.tolist():
+        w = inp.windows[r]
+        if int(inp.strand[r]) == 1:
+            w = w[::-1].translate(_RC_TRANS)
+        out.append(w[6:-7].upper())
+    return rows, out
+
+
 def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
                  with_cfdon: bool = True):
     """The collapsed, sorted report of one region as a pandas DataFrame (what reports.report_guides hands to

