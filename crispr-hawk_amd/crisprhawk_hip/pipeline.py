@@ -40,9 +40,16 @@ def _labels(ds, info: List[HapInfo], kept: List[int], vt) -> List[Optional[RowLa
 
 
 def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidelen: int, right: bool, outdir: str,
-                 cfd_tables=None, device: Optional[int] = None, debug: bool = True) -> Dict[str, str]:
+                 cfd_tables=None, azimuth_model=None, deepcpf1_weights=None, device: Optional[int] = None,
+                 debug: bool = True) -> Dict[str, str]:
     """One report per BED interval; returns {str(coordinate): path}.  `cfd_tables = (mm[20,4,4], pam[16])` adds the
-    CFDon column for SpCas9-class PAMs (scoring.py:352-387)."""
+    CFDon column for SpCas9-class PAMs (scoring.py:352-387); `azimuth_model` (a fitted sklearn GBR or the flattened
+    dict of scoring.azimuth_model_from_sklearn) and `deepcpf1_weights` (scoring.set_deepcpf1_weights layout) switch
+    their score columns on - the reference reads those parameters from files it downloads."""
+    if azimuth_model is not None:
+        scoring.set_azimuth_model(azimuth_model)
+    if deepcpf1_weights is not None:
+        scoring.set_deepcpf1_weights(deepcpf1_weights)
     pam = PAM(pam_seq, right, debug)
     pam.encode(0)
     fa = Fasta(fasta, 0, debug)
@@ -68,8 +75,8 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         labels = _labels(ds, info, kept, vt)
         bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041
         inp = reports.ReportInput.from_table(tab)
-        # model-based scorers run once per report row, on the group representatives (scoring.py:749-813); they are
-        # on only when the caller has supplied their parameters (scoring.set_azimuth_model / set_deepcpf1_weights)
+        # model-based scorers run once per report row, on the group representatives (scoring.py:749-813), when the
+        # caller has supplied their parameters
         scores = {}
         if tab.n_rows:
             rows, kmers = reports.scorer_kmers(inp)
@@ -77,9 +84,9 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
                 a = np.full(tab.n_rows, np.nan)
                 a[rows] = vals
                 return a
-            if pam.cas_system in (SPCAS9, XCAS9) and scoring._AZIMUTH_MODEL is not None:
+            if pam.cas_system in (SPCAS9, XCAS9) and azimuth_model is not None:
                 scores["score_azimuth"] = _col(scoring.azimuth(kmers, debug))
-            if pam.cas_system == CPF1 and scoring._DEEPCPF1_W is not None:
+            if pam.cas_system == CPF1 and deepcpf1_weights is not None:
                 scores["score_deepcpf1"] = _col(scoring.deepcpf1(kmers, debug))
         df = reports.report_frame(inp, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score)
         path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))

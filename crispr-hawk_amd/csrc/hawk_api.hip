@@ -67,7 +67,7 @@ struct hawk_hapset {
   int64_t min_gen, max_gen;  // range of genomic positions the position maps reach (collapse sort key)
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
-  DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt;  // hawk_table_collapse
+  DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
   DevBuf colsA[8];
 };
 
@@ -191,7 +191,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   (void)hipFree(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
-                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt};
+                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   delete hs;
@@ -602,7 +602,7 @@ int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
   int rc;
   if ((rc = hs->ckeys.reserve(2 * n * 8)) || (rc = hs->cvals.reserve(2 * n * 4)) || (rc = hs->cflags.reserve(n * 4)) ||
       (rc = hs->cgidx.reserve(n * 4)) || (rc = hs->ctemp.reserve(temp_bytes + 16)) || (rc = hs->cgoff.reserve((n + 1) * 8)) ||
-      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(16)))
+      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(16)) || (rc = hs->cfull.reserve(hawk_collapse_full_bytes(n))))
     return rc;
   unsigned long long cnt[2] = {0, 0};
   for (int attempt = 0; attempt < 4; ++attempt) {  // a new seed whenever two different rows collide in the hash bits
@@ -612,7 +612,7 @@ int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
                              end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p, temp_bytes, hs->ckeys.as<uint64_t>(),
                              hs->cvals.as<uint32_t>(), hs->cflags.as<uint32_t>(), hs->cgidx.as<uint32_t>(),
                              hs->ccnt.as<unsigned long long>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(),
-                             hs->cgc.as<uint8_t>() + n))
+                             hs->cgc.as<uint8_t>() + n, hs->cfull.p))
       return HAWK_E_HIP;
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(hipGetLastError());

@@ -8,7 +8,8 @@
 //
 //   k_collapse_keys   row -> 64-bit sort key  (start - base) << 32 | strand << 31 | hash31(core, stop, origin)
 //   rocprim::radix_sort_pairs (key, row id); stable, so equal keys keep table order (haplotype ascending)
-//   k_collapse_heads  neighbours in sorted order are compared on the FULL row key (not the hash): head flags;
+//   k_collapse_heads  neighbours in sorted order are compared on the FULL row key (not the hash; 64-byte records
+//                     written by k_collapse_keys): head flags;
 //                     counts heads by key and heads by full key - if they differ, two different rows of one
 //                     (start, strand) collided in the 31 hash bits and may interleave: the host layer re-runs
 //                     with another seed, so the grouping is exact, never probabilistic
@@ -50,10 +51,14 @@ __device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
 
 __global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, uint64_t mask,
                                                        int64_t base, uint64_t seed, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals) {
+                                                       uint32_t* __restrict__ vals, ulonglong4* __restrict__ full) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const RowKey k = row_key(c, is_ref, i, mask);
+  // the full key as one 64-byte record: the head pass compares neighbours of the SORTED order, i.e. rows scattered
+  // over the table - one line per row here instead of nine (one per column) there
+  full[2 * i] = make_ulonglong4((unsigned long long)k.start, (unsigned long long)k.stop, (unsigned long long)k.sr, k.core[0]);
+  full[2 * i + 1] = make_ulonglong4(k.core[1], k.core[2], k.core[3], k.core[4]);
   uint64_t h = seed;
 #pragma unroll
   for (int pl = 0; pl < HAWK_PLANES; ++pl) h = mix64(h ^ k.core[pl]);
@@ -62,7 +67,10 @@ __global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_
   vals[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void k_collapse_heads(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, uint64_t mask,
+__device__ __forceinline__ bool same4(const ulonglong4& a, const ulonglong4& b) {
+  return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+}
+__global__ __launch_bounds__(256) void k_collapse_heads(const ulonglong4* __restrict__ full, uint64_t n,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                         uint32_t* __restrict__ flags, unsigned long long* __restrict__ counters) {
   __shared__ uint32_t s_cnt[2];
@@ -75,7 +83,12 @@ __global__ __launch_bounds__(256) void k_collapse_heads(GuideCols c, const uint8
       hk = hf = 1;
     } else {
       hk = keys[j] != keys[j - 1];
-      hf = hk || !same_row(row_key(c, is_ref, vals[j], mask), row_key(c, is_ref, vals[j - 1], mask));
+      if (!hk) {
+        const uint64_t a = vals[j], b = vals[j - 1];
+        hf = !(same4(full[2 * a], full[2 * b]) && same4(full[2 * a + 1], full[2 * b + 1]));
+      } else {
+        hf = 1;
+      }
     }
     flags[j] = hf;
   }
@@ -107,6 +120,9 @@ __global__ __launch_bounds__(256) void k_collapse_groups(GuideCols c, uint64_t n
   gc_den[g] = (uint8_t)__popcll(gc | at);
 }
 
+// bytes of the full-key records (64 per row)
+size_t hawk_collapse_full_bytes(uint64_t n) { return (size_t)n * 64; }
+
 size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit) {
   size_t a = 0, b = 0;
   (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
@@ -120,14 +136,14 @@ size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit) {
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
                          int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
-                         uint8_t* gc_den) {
+                         uint8_t* gc_den, void* full) {
   const int L = guidelen + pamlen;
   const uint64_t mask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, mask, base, seed, keys, vals);
+  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, mask, base, seed, keys, vals, (ulonglong4*)full);
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, keys, keys + n, vals, vals + n, n, 0, end_bit, st) != hipSuccess) return -2;
-  hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, c, is_ref, n, mask, keys + n, vals + n, flags, counters);
+  hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, (const ulonglong4*)full, n, keys + n, vals + n, flags, counters);
   tb = temp_bytes;
   if (rocprim::exclusive_scan(temp, tb, flags, gidx, 0u, n, rocprim::plus<uint32_t>(), st) != hipSuccess) return -2;
   hipLaunchKernelGGL(k_collapse_groups, grid, block, 0, st, c, n, vals + n, flags, gidx, guidelen, pamlen, right, group_off, gc_num,

@@ -111,7 +111,8 @@ size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit);
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
                          int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
-                         uint8_t* gc_den);
+                         uint8_t* gc_den, void* full);
+size_t hawk_collapse_full_bytes(uint64_t n);
 void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* line_off, const uint64_t* gt_off, uint64_t n_lines,
                           uint32_t n_samples, uint8_t* codes, uint8_t* flags);
 void hawk_launch_gt_count(hipStream_t st, const uint8_t* codes, uint32_t n_cols, const uint32_t* var_line, const uint8_t* var_allele,

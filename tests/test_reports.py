@@ -121,11 +121,8 @@ def test_pipeline_model_scorers_fill_their_columns(tmp_path):
     rows = [[fx["contig"], str(p), ".", r, a, ".", "PASS", f"AF={af:.6g}", "GT"] + [f"{g[0]}|{g[1]}" for g in gts]
             for p, r, a, af, gts in fx["variants"]]
     readers.write_vcf(vcf, fx["contig"], fx["samples"], rows, False)
-    scoring.set_deepcpf1_weights(synth.deepcpf1_weights())
-    try:
-        (path,) = pipeline.search_files(fa, bed, [vcf], fx["pam"], fx["guidelen"], fx["right"], str(tmp_path / "out")).values()
-    finally:
-        scoring._DEEPCPF1_W = None
+    (path,) = pipeline.search_files(fa, bed, [vcf], fx["pam"], fx["guidelen"], fx["right"], str(tmp_path / "out"),
+                                    deepcpf1_weights=synth.deepcpf1_weights()).values()
     got = pd.read_csv(path, sep="\t", dtype=str, keep_default_na=False)
     want = pd.read_csv(io.StringIO(fx["report_tsv"]), sep="\t", dtype=str, keep_default_na=False)
     assert list(got.columns) == list(want.columns) and len(got) == len(want)
@@ -133,11 +130,4 @@ def test_pipeline_model_scorers_fill_their_columns(tmp_path):
         if c != "score_deepcpf1":
             assert (got[c] == want[c]).all(), c
     # the report groups on the score column, so equal order also means the scores did not split or reorder groups
-    w = synth.deepcpf1_weights()
-    scoring.set_deepcpf1_weights(w)
-    try:
-        for _, r in got.head(40).iterrows():
-            sg, pam_s = r["sgRNA_sequence"], r["pam"]
-            assert r["score_deepcpf1"] != "NA" and abs(float(r["score_deepcpf1"])) < 1e6
-    finally:
-        scoring._DEEPCPF1_W = None
+    assert (got["score_deepcpf1"] != "NA").all() and np.isfinite(got["score_deepcpf1"].astype(float)).all()
