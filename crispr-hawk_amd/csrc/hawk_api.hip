@@ -65,6 +65,7 @@ struct hawk_hapset {
   TileMeta* d_tile_meta;   // [n_hap * bph] per-tile record (haplotype scalars + first position-map segment)
   int64_t ref_startp;
   int64_t min_gen, max_gen;  // range of genomic positions the position maps reach (collapse sort key)
+  uint64_t cols_cap = 0;      // rows the guide-table columns currently hold (0: never reserved)
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
@@ -499,24 +500,48 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   HIPCHK(hipEventRecord(ev[2], ctx->stream));
   HIPCHK(hipGetLastError());
   ScanTotals tot;
-  HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  uint64_t nrows = tot.n_keep;
   static const bool count_only = [] { const char* e = getenv("HAWK_COUNT_ONLY"); return e && e[0] == '1'; }();
+  GuideCols ca;
+  int status = 0;
+  uint64_t nrows = 0;
+  bool emitted = false;
+  if (hs->cols_cap && !count_only) {
+    // Columns from an earlier search on this set are still reserved: launch the emit pass straight behind the offset
+    // scan instead of waiting for the row count to cross PCIe (the kernels take their offsets from HBM and refuse to
+    // write past the capacity).  If the table turns out larger, the normal path below runs after a reserve.
+    if ((rc = reserve_cols(hs->colsA, hs->cols_cap, &ca))) return rc;
+    HIPCHK(hipEventRecord(ev[3], ctx->stream));
+    hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
+                       hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
+    HIPCHK(hipEventRecord(ev[4], ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    nrows = tot.n_keep;
+    emitted = nrows <= hs->cols_cap;
+    if (!emitted) { status = 0; HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream)); }
+  } else {
+    HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    nrows = tot.n_keep;
+  }
   if (count_only) {  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
     if (getenv("HAWK_COUNT_VERBOSE")) fprintf(stderr, "[hawk] count pass: n_keep=%llu n_cand=%llu n_hits=%llu\n", (unsigned long long)tot.n_keep, (unsigned long long)tot.n_cand, (unsigned long long)tot.n_hits);
     nrows = 0;
   }
-  GuideCols ca;
-  if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(nrows, 1), &ca))) return rc;
-  HIPCHK(hipEventRecord(ev[3], ctx->stream));
-  if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                                hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
-  HIPCHK(hipEventRecord(ev[4], ctx->stream));
-  HIPCHK(hipGetLastError());
-  int status = 0;
-  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!emitted) {
+    const uint64_t want = std::max<uint64_t>(nrows, 1);
+    if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(want, hs->cols_cap), &ca))) return rc;
+    hs->cols_cap = ca.cap;
+    HIPCHK(hipEventRecord(ev[3], ctx->stream));
+    if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
+                                  hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
+    HIPCHK(hipEventRecord(ev[4], ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   if (timing) {
     memset(timing, 0, sizeof(*timing));
     (void)hipEventElapsedTime(&timing->count_ms, ev[0], ev[1]);

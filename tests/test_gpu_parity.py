@@ -345,3 +345,34 @@ def test_search_parameter_sweep_against_oracle(cfg):
     synth.add_phased_variants(reg, 7700 + seed, sites, samples, frac_snv=fs, frac_del=fd, max_indel=mi, af_min=0.2, af_max=0.8)
     score = (not right) and reg.sequence.upper().count("N") == 0 and seed % 3 != 0 and len(pam) >= 2
     _oracle_vs_device(reg, pam, guidelen, right, score)
+
+
+def test_repeated_searches_on_one_set_grow_and_shrink_the_table():
+    # the second and later searches launch their emit pass before the row count is known (columns already reserved):
+    # a bigger table than ever before must fall back to reserve-and-relaunch, a smaller one must not see stale rows
+    reg = synth.make_region(7801, "chrG", 45_000, 1_200, 43_000)
+    synth.add_phased_variants(reg, 7802, 250, 4, af_min=0.2, af_max=0.7)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    sizes = []
+    ds = None
+    for pam in ("NGG", "NNG", "TTTV", "N", "NGG"):
+        scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, len(pam)) for h in haps]
+        hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+        if ds is None:
+            ds = device_set(hs)
+        else:  # same planes, new scan bounds for this PAM length
+            ds.set_meta([HostHaplotype(seq, PosSegments(*segments_from_posmap(pm), len(seq)), r, sc)
+                         for seq, pm, r, sc in zip(hs.seqs, hs.posmaps, hs.is_ref, hs.scan)])
+        bits, bitsrc, _, _ = ora.pam_encode(pam)
+        want = ora.search(hs, pam, 20, False)
+        tab = ds.search(bits, bitsrc, len(pam), 20, False)
+        assert (tab.n_rows, tab.n_candidates) == (len(want.guides["start"]), want.n_candidates)
+        order = tab.reference_order()
+        for col in ("start", "stop", "hap", "pos", "strand"):
+            assert np.array_equal(getattr(tab, col)[order], want.guides[col]), (pam, col)
+        wins = tab.windows()
+        assert [wins[i] for i in order] == want.windows
+        sizes.append(tab.n_rows)
+    assert sizes[1] > sizes[0] and sizes[3] > sizes[1] and sizes[4] == sizes[0]
