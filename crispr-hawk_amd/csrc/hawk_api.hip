@@ -66,6 +66,7 @@ struct hawk_hapset {
   int64_t ref_startp;
   int64_t min_gen, max_gen;  // range of genomic positions the position maps reach (collapse sort key)
   uint64_t cols_cap = 0;      // rows the guide-table columns currently hold (0: never reserved)
+  std::vector<double> cfd_host;  // the CFD tables resident in `cfd`
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
@@ -467,9 +468,15 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     if ((rc = hs->lists.reserve(ntile * HAWK_LIST_CAP * 4))) return rc;
     d_lists = hs->lists.as<uint32_t>();
   }
-  if (p->score_cfdon) {
-    HIPCHK(hipMemcpyAsync(hs->cfd.p, p->cfd_mm, 320 * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hs->cfd.as<double>() + 320, p->cfd_pam, 16 * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (p->score_cfdon) {  // the tables go up once; later searches with the same tables find them in HBM
+    if (hs->cfd_host.size() != 336 || memcmp(hs->cfd_host.data(), p->cfd_mm, 320 * 8) != 0 ||
+        memcmp(hs->cfd_host.data() + 320, p->cfd_pam, 16 * 8) != 0) {
+      hs->cfd_host.assign(336, 0.0);
+      memcpy(hs->cfd_host.data(), p->cfd_mm, 320 * 8);
+      memcpy(hs->cfd_host.data() + 320, p->cfd_pam, 16 * 8);
+      HIPCHK(hipMemcpyAsync(hs->cfd.p, hs->cfd_host.data(), 336 * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
   }
   HIPCHK(hipMemsetAsync(hs->misc.p, 0, 512 * 8 + 64, ctx->stream));
   unsigned long long* d_shards = hs->misc.as<unsigned long long>();          // [256][2] candidate / hit partial sums
