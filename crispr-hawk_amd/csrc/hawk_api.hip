@@ -837,10 +837,13 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
   if (rc) return rc;
   uint32_t *d_r0 = nullptr, *d_span = nullptr, *d_ao = nullptr, *d_al = nullptr, *d_idx = nullptr;
   uint8_t* d_codes = nullptr; uint64_t* d_off = nullptr; int32_t* d_o = nullptr; unsigned long long* d_hash = nullptr;
+  int32_t* d_wk0 = nullptr; uint32_t* d_wn = nullptr;
+  const size_t nwg = (size_t)n_hap * ((hs->S + HAWK_BLOCK - 1) / HAWK_BLOCK);
   const size_t nv = std::max<size_t>(n_var, 1), nc = std::max<size_t>(ncar, 1);
   HIPCHK(hipMalloc(&d_r0, nv * 4)); HIPCHK(hipMalloc(&d_span, nv * 4)); HIPCHK(hipMalloc(&d_ao, nv * 4)); HIPCHK(hipMalloc(&d_al, nv * 4));
   HIPCHK(hipMalloc(&d_codes, std::max<size_t>(alt_codes_len, 1))); HIPCHK(hipMalloc(&d_off, (size_t)(n_hap + 1) * 8));
   HIPCHK(hipMalloc(&d_idx, nc * 4)); HIPCHK(hipMalloc(&d_o, nc * 4)); HIPCHK(hipMalloc(&d_hash, (size_t)n_hap * 16));
+  HIPCHK(hipMalloc(&d_wk0, nwg * 4)); HIPCHK(hipMalloc(&d_wn, nwg * 4));
   hipStream_t st = ctx->stream;
   if (n_var) {
     HIPCHK(hipMemcpyAsync(d_r0, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
@@ -856,7 +859,7 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
   }
   HIPCHK(hipMemsetAsync(d_hash, 0, (size_t)n_hap * 16, st));
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hawk_launch_hx_build(st, ref_set->plane, d_r0, d_span, d_ao, d_al, d_codes, d_off, d_idx, d_o, hs->d_hap_len, n_hap, hs->S, hs->plane);
+  hawk_launch_hx_build(st, ref_set->plane, d_r0, d_span, d_ao, d_al, d_codes, d_off, d_idx, d_o, hs->d_hap_len, n_hap, hs->S, hs->plane, d_wk0, d_wn);
   hawk_launch_hx_hash(st, hs->plane, n_hap, hs->S, d_hash);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   HIPCHK(hipGetLastError());
@@ -864,7 +867,7 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
   HIPCHK(hipStreamSynchronize(st));
   if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
   (void)hipFree(d_r0); (void)hipFree(d_span); (void)hipFree(d_ao); (void)hipFree(d_al); (void)hipFree(d_codes); (void)hipFree(d_off);
-  (void)hipFree(d_idx); (void)hipFree(d_o); (void)hipFree(d_hash);
+  (void)hipFree(d_idx); (void)hipFree(d_o); (void)hipFree(d_hash); (void)hipFree(d_wk0); (void)hipFree(d_wn);
   *out = hs;
   return HAWK_OK;
 }

@@ -131,5 +131,5 @@ void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t 
 void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
                           const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
                           const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,
-                          uint32_t* const* plane);
+                          uint32_t* const* plane, int32_t* wg_k0, uint32_t* wg_n);
 void hawk_launch_hx_hash(hipStream_t st, uint32_t* const* plane, uint32_t n_hap, uint32_t S, unsigned long long* hash);

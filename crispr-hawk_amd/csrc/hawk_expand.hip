@@ -19,6 +19,29 @@
 
 struct HxVar { int32_t o; uint32_t r0; uint32_t span; uint32_t alt_len; uint32_t alt_off; };
 
+// Which of a row's carried variants a workgroup of k_hx_build needs: the last one starting at or before the
+// workgroup's first output position (its alt allele / the copy behind it may reach in) and every one starting
+// inside its 8192 positions.  One thread per (row, workgroup): the two binary searches are dependent global
+// loads, cheap when 6 x 10^5 of them run side by side, but 5 us of serial latency when lane 0 of every
+// k_hx_build workgroup does them with 255 lanes waiting (the first version: 2.4 ms instead of 0.9 ms).
+__global__ __launch_bounds__(256) void k_hx_index(const uint64_t* __restrict__ hv_off, const int32_t* __restrict__ hv_o, uint32_t n_hap,
+                                                  uint32_t wpr, int32_t* __restrict__ wg_k0, uint32_t* __restrict__ wg_n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (uint64_t)n_hap * wpr) return;
+  const uint32_t h = (uint32_t)(i / wpr), wb = (uint32_t)(i % wpr);
+  const uint64_t lo = hv_off[h];
+  const int K = (int)(hv_off[h + 1] - lo);
+  const int32_t p_lo = (int32_t)(wb * HAWK_BLOCK * 32u), p_hi = p_lo + HAWK_BLOCK * 32;
+  int a = 0, b = K;  // first index with o > p_lo
+  while (a < b) { const int m = (a + b) >> 1; if (hv_o[lo + m] <= p_lo) a = m + 1; else b = m; }
+  int c = a, d = K;  // first index with o >= p_hi
+  while (c < d) { const int m = (c + d) >> 1; if (hv_o[lo + m] < p_hi) c = m + 1; else d = m; }
+  const int first = a - 1 < 0 ? 0 : a - 1;
+  int n = c - first;
+  wg_k0[i] = a - 1;
+  wg_n[i] = (uint32_t)(n < 0 ? 0 : (n > HX_MAXV ? HX_MAXV : n));
+}
+
 __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restrict__ refA, const uint32_t* __restrict__ refC,
                                                           const uint32_t* __restrict__ refG, const uint32_t* __restrict__ refT,
                                                           const uint32_t* __restrict__ v_r0, const uint32_t* __restrict__ v_span,
@@ -26,29 +49,17 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restr
                                                           const uint8_t* __restrict__ alt_codes, const uint64_t* __restrict__ hv_off,
                                                           const uint32_t* __restrict__ hv_idx, const int32_t* __restrict__ hv_o,
                                                           const uint32_t* __restrict__ hap_len, uint32_t S, uint32_t wpr /*workgroups per row*/,
+                                                          const int32_t* __restrict__ wg_k0, const uint32_t* __restrict__ wg_n,
                                                           uint32_t* pA, uint32_t* pC, uint32_t* pG, uint32_t* pT, uint32_t* pV) {
   __shared__ HxVar s_v[HX_MAXV];
-  __shared__ int s_n, s_k0;
   const uint32_t h = blockIdx.x / wpr, wb = blockIdx.x % wpr;
   const uint32_t w = wb * HAWK_BLOCK + threadIdx.x;
   const uint64_t lo = hv_off[h], hi = hv_off[h + 1];
   const int K = (int)(hi - lo);
   const int32_t p_lo = (int32_t)(wb * HAWK_BLOCK * 32u), p_hi = p_lo + HAWK_BLOCK * 32;
   const int32_t len = (int32_t)hap_len[h];
-  // first relevant variant: the last one starting at or before p_lo (its alt / the copy after it may reach in)
-  if (threadIdx.x == 0) {
-    int a = 0, b = K;  // first index with o > p_lo
-    while (a < b) { const int m = (a + b) >> 1; if (hv_o[lo + m] <= p_lo) a = m + 1; else b = m; }
-    s_k0 = a - 1;
-    int n = 0;
-    for (int k = a - 1 < 0 ? 0 : a - 1; k < K && n < HX_MAXV; ++k) {
-      const int32_t o = hv_o[lo + k];
-      if (o >= p_hi) break;
-      ++n;
-    }
-    s_n = n;
-  }
-  __syncthreads();
+  const int s_k0 = wg_k0[blockIdx.x];  // k_hx_index
+  const int s_n = (int)wg_n[blockIdx.x];
   const int k0 = s_k0 < 0 ? 0 : s_k0, n = s_n;
   for (int i = threadIdx.x; i < n; i += HAWK_BLOCK) {
     const uint32_t vi = hv_idx[lo + k0 + i];
@@ -111,10 +122,13 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restr
 void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
                           const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
                           const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,
-                          uint32_t* const* plane) {
+                          uint32_t* const* plane, int32_t* wg_k0, uint32_t* wg_n) {
   const uint32_t wpr = (S + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  const uint64_t nwg = (uint64_t)n_hap * wpr;
+  hipLaunchKernelGGL(k_hx_index, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, hv_off, hv_o, n_hap, wpr, wg_k0, wg_n);
   hipLaunchKernelGGL(k_hx_build, dim3(n_hap * wpr), dim3(HAWK_BLOCK), 0, st, ref[0], ref[1], ref[2], ref[3], v_r0, v_span, v_alt_off,
-                     v_alt_len, alt_codes, hv_off, hv_idx, hv_o, hap_len, S, wpr, plane[0], plane[1], plane[2], plane[3], plane[4]);
+                     v_alt_len, alt_codes, hv_off, hv_idx, hv_o, hap_len, S, wpr, wg_k0, wg_n, plane[0], plane[1], plane[2], plane[3],
+                     plane[4]);
 }
 
 __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
