@@ -106,7 +106,11 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
                                             const uint64_t* __restrict__ offsets, const GuideCols& out, int* status,
                                             uint32_t* __restrict__ lists) {
   __shared__ __attribute__((aligned(16))) uint32_t s_pl[PASS == 1 ? HAWK_PLANES : 1][PASS == 1 ? LDS_ROW : 8];
-  __shared__ uint32_t s_list[CAP];
+  __shared__ uint32_t s_list[PASS == 1 ? CAP : 1];
+  // count pass: every thread's survivor bits (4 words per strand) and packed exclusive offsets, so that phase C
+  // can find "survivor number i of the tile" by search instead of every thread looping over its own bits
+  __shared__ __attribute__((aligned(16))) uint32_t s_kw[PASS == 0 ? 2 : 1][PASS == 0 ? HAWK_BLOCK * 4 : 4];
+  __shared__ uint32_t s_ex[PASS == 0 ? HAWK_BLOCK : 1];
   __shared__ uint32_t s_segrel[NSEG];
   __shared__ int64_t s_seggen[NSEG];
   __shared__ double s_cfd[PASS == 1 ? 336 : 1];
@@ -227,9 +231,14 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
   }
   const uint32_t cF = __popc(kF[0]) + __popc(kF[1]) + __popc(kF[2]) + __popc(kF[3]);
   const uint32_t cR = __popc(kR[0]) + __popc(kR[1]) + __popc(kR[2]) + __popc(kR[3]);
+  if (PASS == 0) {
+    *reinterpret_cast<uint4*>(&s_kw[0][4 * tid]) = make_uint4(kF[0], kF[1], kF[2], kF[3]);
+    *reinterpret_cast<uint4*>(&s_kw[1][4 * tid]) = make_uint4(kR[0], kR[1], kR[2], kR[3]);
+  }
   // one scan for both strands: per-thread counts <= 128, workgroup totals <= 32768 < 2^16
   uint32_t TT;
   const uint32_t exFR = block_excl_scan<HAWK_BLOCK / WAVE>(cF | (cR << 16), s_w, &TT);  // barriers also publish the LDS staging
+  if (PASS == 0) s_ex[tid] = exFR;  // published by the barrier in front of phase C
   const uint32_t TF = TT & 0xffffu, TR = TT >> 16, exF = exFR & 0xffffu, exR = exFR >> 16;
   const uint32_t T = TF + TR;
 
@@ -252,25 +261,9 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
     const uint32_t cfdmask = (1u << ncfd) - 1u;
 
     for (uint32_t base = 0; base < T; base += CAP) {
-      // ---- phase B: survivors -> LDS list, strand 0 first, each in position order ------
-      if (PASS == 0 && T <= CAP) {  // the common case: the whole tile fits one round, no range checks per survivor
-        // (count pass only: in the emit pass the second copy of the loop costs registers and occupancy)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          uint32_t idx = s ? TF + exR : exF;
-          if (s ? cR : cF) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              uint32_t x = s ? kR[k] : kF[k];
-              const uint32_t tag = ((uint32_t)s << 31) | ((4 * tid + k) * 32);
-              while (x) {
-                s_list[idx++] = tag | (uint32_t)__builtin_ctz(x);
-                x &= x - 1;
-              }
-            }
-          }
-        }
-      } else {
+      // ---- phase B (emit pass): survivors -> LDS list, strand 0 first, each in position order ------
+      // (the count pass needs no list: its phase C looks survivor number i up in s_ex / s_kw)
+      if (PASS == 1) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         uint32_t idx = s ? TF + exR : exF;
@@ -302,8 +295,31 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
         bool has_ref = false;
         W2 core[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, rcore[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         if (i < n) {
-          const uint32_t e = s_list[i];
-          s = e >> 31; ql = e & 0x7fffffffu;
+          if (PASS == 0) {
+            // survivor number g of the tile (strand 0 in position order, then strand 1): the thread that found it
+            // is the last one whose exclusive offset is <= the survivor's rank within its strand
+            const uint32_t g = base + i;
+            s = g >= TF ? 1u : 0u;
+            const uint32_t target = s ? g - TF : g;
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t step = HAWK_BLOCK / 2; step; step >>= 1) {
+              const uint32_t v = s ? s_ex[lo + step] >> 16 : s_ex[lo + step] & 0xffffu;
+              if (v <= target) lo += step;
+            }
+            uint32_t j = target - (s ? s_ex[lo] >> 16 : s_ex[lo] & 0xffffu);  // its rank among that thread's bits
+            const uint4 w4 = *reinterpret_cast<const uint4*>(&s_kw[s][4 * lo]);
+            uint32_t x = w4.x, kw = 0;
+            uint32_t c = (uint32_t)__popc(w4.x);
+            if (j >= c) { j -= c; x = w4.y; kw = 1; c = (uint32_t)__popc(w4.y);
+              if (j >= c) { j -= c; x = w4.z; kw = 2; c = (uint32_t)__popc(w4.z);
+                if (j >= c) { j -= c; x = w4.w; kw = 3; } } }
+            for (; j; --j) x &= x - 1;  // clusters are short: a few iterations at most
+            ql = (4 * lo + kw) * 32 + (uint32_t)__builtin_ctz(x);
+          } else {
+            const uint32_t e = s_list[i];
+            s = e >> 31; ql = e & 0x7fffffffu;
+          }
           const uint32_t q = tile_q0 + ql;
           if (ovf) {
             start = posmap_global(hs, h, q);
