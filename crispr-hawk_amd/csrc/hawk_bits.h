@@ -63,6 +63,25 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
   return pre + inc - v;
 }
 
+// rank of this thread among the threads of the workgroup with `flag` set, and their number; two barriers
+template <int NW>
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_w, uint32_t* total) {
+  const unsigned long long b = __ballot(flag);
+  const int wv = threadIdx.x / WAVE;
+  if ((threadIdx.x & (WAVE - 1)) == 0) s_w[wv] = (uint32_t)__popcll(b);
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t x = s_w[i];
+    if (i < wv) pre += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
+
 // This thread's 4 words of one plane plus 2 look-ahead words (taken from the next lane's
 // registers; the last lane of a wave reads them from memory).  Split in two so that a kernel can
 // put every plane's loads in flight (load6_issue) before the first use waits for any of them

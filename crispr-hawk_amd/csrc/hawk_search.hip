@@ -445,7 +445,7 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
         if (PASS == 0) {
           if (list_mode) {  // compact the valid survivors into the tile's hand-over list
             uint32_t tot;
-            const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(valid, s_w, &tot);
+            const uint32_t ex = block_rank<HAWK_BLOCK / WAVE>(valid != 0, s_w, &tot);
             if (valid && lrun + ex < LIST_CAP) lists[(size_t)tile * LIST_CAP + lrun + ex] = ql | (s << 15) | ((uint32_t)has_ref << 16);
             lrun += tot;
             if (tid == 0) nvalid += tot;
