@@ -9,12 +9,13 @@ from typing import Dict, List, Tuple, Union
 import numpy as np
 
 from .coordinate import Coordinate
-from .crisprhawk_error import CrisprHawkHaplotypeError
+from .crisprhawk_error import CrisprHawkHaplotypeError, CrisprHawkIupacTableError
 from .exception_handlers import exception_handler
 from .expand import HaplotypeBuildError, expand_haplotype
 from .hapset import PosSegments
 from .region import Region
 from .sequence import Sequence
+from .utils import IUPAC_ENCODER, IUPACTABLE, match_iupac
 from .variant import VTYPES, VariantRecord
 
 
@@ -95,6 +96,59 @@ class Haplotype(Region):
         suffix = "1|0" if self._chromcopy == 0 else "0|1"
         self._sequence = Sequence(arr.tobytes().decode("ascii"), self._debug, allow_lower_case=True)
         self._samples = f"{sample}:{suffix}" if self._phased else sample
+        self._variants = ",".join(v.id[0] for v in variants)
+        self._afs = {v.id[0]: v.afs[0] for v in variants}
+
+    def add_variants_unphased(self, variants: List[VariantRecord], sample: str) -> None:
+        """haplotype.py:254-316: heterozygous-agnostic encoding of an unphased sample - every SNV becomes the
+        lower-case IUPAC letter of {reference base(s), alt}, indels are applied as in the phased case, and
+        `variant_alleles` remembers (ref, alt, position) per final relative position for resolve_guide."""
+        variants = _sort_variants(variants)
+        start = self._coordinates.start
+        cur: Dict[int, str] = {}        # SNV letter written so far, by genomic position
+        sites = []
+        va: Dict[int, List[Tuple[str, str, int]]] = {}
+        off = 0                          # length change of the indels already applied (they come last, by position)
+        deleted: List[Tuple[int, int]] = []
+        for v in variants:
+            pos, ref, alt = v.position, v.ref, v.alt[0]
+            if any(a < pos <= b for a, b in deleted):
+                continue                 # position removed by a previous deletion (haplotype.py:262-265)
+            chain = len(alt) - len(ref)
+            posrel = pos - start + off
+            stop = posrel + abs(chain) + 1 if chain < 0 else posrel + 1
+            ref_seq = self._sequence.sequence
+            refnt = "".join(cur.get(pos + i, ref_seq[pos - start + i: pos - start + i + 1]) for i in range(stop - posrel))
+            if not match_iupac(ref, refnt):
+                raise ValueError(f"Mismatching reference alleles in VCF and reference sequence at position {pos} ({refnt} - {ref})")
+            if posrel in va:
+                if pos == va[posrel][0][2]:
+                    va[posrel].append((ref, alt, pos))
+            else:
+                va[posrel] = [(ref, alt, pos)]
+            if v.vtype[0] == VTYPES[0]:
+                try:
+                    letter = IUPAC_ENCODER["".join({IUPACTABLE[refnt.upper()], alt})]
+                except KeyError as e:
+                    exception_handler(CrisprHawkIupacTableError, f"An error occurred while encoding {refnt}>{alt} at position {pos} as IUPAC character",
+                                      os.EX_DATAERR, self._debug, e)
+                cur[pos] = letter.lower()
+                sites = [x for x in sites if x[0] != pos] + [(pos, ref.encode(), letter.encode())]
+            else:
+                va = {p_: a_ for p_, a_ in va.items() if p_ <= posrel or p_ >= stop}
+                va = {(p_ + chain if p_ > posrel else p_): a_ for p_, a_ in va.items()}
+                sites.append((pos, ref.encode(), alt.encode()))
+                if chain < 0:
+                    deleted.append((pos, pos - chain))
+                off += chain
+        try:
+            arr, seg = expand_haplotype(self._arr, start, sites)
+        except HaplotypeBuildError as e:
+            raise ValueError(str(e)) from e
+        self._arr, self._seg = arr, seg
+        self._sequence = Sequence(arr.tobytes().decode("ascii"), self._debug, allow_lower_case=True)
+        self._variant_alleles = va
+        self._samples = sample
         self._variants = ",".join(v.id[0] for v in variants)
         self._afs = {v.id[0]: v.afs[0] for v in variants}
 

@@ -178,3 +178,22 @@ def test_unphased_search_resolves_iupac_like_the_reference():
     hidx = {h.id: i for i, h in enumerate(haps)}
     got = [[g.start, g.stop, g.strand, g.sequence, hidx[g.hapid], g.right, g.samples] for g in guides]
     assert got == fx["guides"]
+
+
+def test_unphased_vcf_records_to_guides_end_to_end():
+    """Unphased VCF records -> haplotypes.add_variants_unphased (mirror) -> device search -> resolve_guide: the
+    guide list the reference produced from its own haplotypes for the same records (g4_unphased)."""
+    from test_host_objects import _unphased_inputs
+    from crisprhawk_hip import haplotypes as H
+    fx = load_golden("g4_unphased.json.gz")
+    reg, region, recs = _unphased_inputs()
+    haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
+    haps = H.add_variants_unphased(haps, region, reg.samples, recs, False, True)
+    for i, h in enumerate(haps):
+        h.id = f"hap_{i:08d}"
+    pam = PAM(fx["pam"], fx["right"], True)
+    pam.encode(0)
+    guides = search(pam, region, haps, None, fx["guidelen"], fx["right"], True, False, 0, True)
+    got = sorted([g.start, g.stop, g.strand, g.sequence, ",".join(sorted(g.samples.split(","))), g.right] for g in guides)
+    want = sorted([g[0], g[1], g[2], g[3], ",".join(sorted(g[6].split(","))), g[5]] for g in fx["guides"])
+    assert got == want

@@ -115,3 +115,54 @@ def test_variant_record():  # test_variant.py:6-99
     a, b = v.split()
     assert (a.alt, b.alt, b.position) == (["G"], ["AT"], 100) and b.samples == [({"s3"}, {"s2"})]
     assert v.split("snp")[0].id == ["chr1-100-A/G"]
+
+
+def _unphased_inputs():
+    """The inputs tests/golden/make_golden.py:g4_unphased fed the reference (same seeds)."""
+    from crisprhawk_hip import synth
+    from crisprhawk_hip.coordinate import Coordinate
+    from crisprhawk_hip.region import Region
+    from crisprhawk_hip.sequence import Sequence
+    from crisprhawk_hip.variant import VariantRecord
+    reg = synth.make_region(4001, "chrU", 5000, 1000, 4000)
+    synth.add_phased_variants(reg, 4002, 40, 3, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.2, af_max=0.6)
+    region = Region(Sequence(reg.sequence, True), Coordinate(reg.contig, reg.bed_start, reg.bed_stop, synth.PADDING))
+    recs = []
+    for v in reg.variants:
+        f = reg.vcf_fields(v)
+        f[9:] = [g.replace("|", "/") for g in f[9:]]
+        r = VariantRecord(True)
+        r.read_vcf_line(f, reg.samples, False)
+        recs.append(r)
+    return reg, region, recs
+
+
+def test_unphased_haplotype_construction_matches_reference_fixture():
+    """haplotypes.add_variants_unphased (IUPAC-encoded SNV haplotypes per sample + one window haplotype set per
+    indel, haplotypes.py:370-712) against the haplotypes the reference built for the same VCF records
+    (g4_unphased): sequences, coordinates, samples, variants, position maps and variant_alleles.  The reference
+    walks the indel carriers in set (hash) order; the mirror sorts them, so haplotypes are matched by content."""
+    from crisprhawk_hip import haplotypes as H
+    from crisprhawk_hip.haplotype import Haplotype
+    from crisprhawk_hip.hapset import segments_from_posmap
+    from crisprhawk_hip.sequence import Sequence
+    from util import load_golden
+    fx = load_golden("g4_unphased.json.gz")
+    reg, region, recs = _unphased_inputs()
+    assert reg.sequence == fx["region_seq"]
+    haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
+    haps = H.add_variants_unphased(haps, region, reg.samples, recs, False, True)
+
+    def sig(seq, coord, samples, variants, breaks, n, va):
+        return (seq, tuple(coord), tuple(sorted(samples.split(","))), tuple(sorted(variants.split(","))),
+                tuple(map(tuple, breaks)), n, tuple(sorted((int(k), tuple(map(tuple, v))) for k, v in va.items())))
+
+    got = []
+    for h in haps:
+        pm = h.segments.full()
+        c = h.coordinates
+        got.append(sig(h.sequence.sequence, [c.startp, c.stopp, c.start, c.stop], h.samples, h.variants,
+                       [[int(a), int(b)] for a, b in zip(*segments_from_posmap(pm))], len(pm), h.variant_alleles))
+    want = [sig(w["seq"], w["coord"], w["samples"], w["variants"], w["posmap_breaks"], w["posmap_len"], w["variant_alleles"])
+            for w in fx["haplotypes"]]
+    assert len(got) == len(want) and got[:13] == want[:13] and sorted(got) == sorted(want)
