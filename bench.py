@@ -104,12 +104,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("HAWK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 control flow without RCCL
+    cdev = "cuda" if backend == "nccl" else "cpu"           # where the small collective tensors live
     if world > 1:
         import torch
         import torch.distributed as dist  # RCCL ("nccl") process group: barrier, timing reduce, table gather
 
+        if os.environ.get("HAWK_BENCH_ONE_GPU") == "1":  # rehearsal: every rank on GPU 0 of a one-GPU box
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from crisprhawk_hip import _lib, synth
     from crisprhawk_hip.hapset import DeviceHapSet
@@ -146,12 +153,12 @@ def main():
     counts_all = None
     if dist is not None:
         import torch
-        counts_all = torch.zeros(2 * world, dtype=torch.int64, device="cuda")
+        counts_all = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
 
     def step(keep=False):
         tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
         if dist is not None:  # the table directory every rank needs before any exchange: rows + candidates per rank
-            mine = torch.tensor([tab.n_rows, tab.n_candidates], dtype=torch.int64, device="cuda")
+            mine = torch.tensor([tab.n_rows, tab.n_candidates], dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(counts_all, mine)
         if not keep:
             tab.close()
@@ -181,10 +188,10 @@ def main():
     cand, rows, positions = tab.n_candidates, tab.n_rows, tab.timing["scanned_positions"]
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cand, rows, positions], dtype=torch.int64, device="cuda")
+        c = torch.tensor([cand, rows, positions], dtype=torch.int64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         cand_all, rows_all, pos_all = (int(x) for x in c.tolist())
     else:
@@ -222,7 +229,7 @@ def main():
     if rank == 0 and args.vcf and not args.host_expand:
         vcf_ingest = time_vcf_ingest(reg, ds, len(pam), local)
     gather = None
-    if dist is not None and not args.no_gather:
+    if dist is not None and not args.no_gather and backend == "nccl":
         gather = gather_once(ds, step, dist, rank, world)
 
     out = None
