@@ -71,3 +71,75 @@ def gather_tables(cols: Dict[str, np.ndarray], hap_offset: int, group=None, devi
         dt = send[k].dtype
         out[k] = raw.view(dt).reshape((-1,) + send[k].shape[1:])
     return out
+
+
+def _gather_var(arr: np.ndarray, group, dev, dst: int):
+    """Variable-length gather of a [n, ...] array to `dst`: list of per-rank arrays there, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = len(arr)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    a2 = np.ascontiguousarray(arr).reshape(n, -1).view(np.uint8).reshape(n, -1)
+    width = a2.shape[1] if n else int(np.prod(arr.shape[1:], dtype=np.int64)) * arr.dtype.itemsize
+    buf = torch.zeros((nmax, max(width, 1)), dtype=torch.uint8, device=dev)
+    if n:
+        buf[:n, :width] = torch.from_numpy(a2).to(dev)
+    recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [recv[r][: counts[r], :width].cpu().numpy().view(arr.dtype).reshape((-1,) + arr.shape[1:]) for r in range(world)]
+
+
+def gather_collapsed(cols: Dict[str, np.ndarray], group_perm: np.ndarray, group_off: np.ndarray, is_ref_row: np.ndarray,
+                     hap_offset: int, guidelen: int, pamlen: int, group=None, device: Optional[str] = None, dst: int = 0):
+    """The exchange after a per-rank `GuideTable.collapse()` (SURVEY §8 f2 x §8e): instead of every row, each rank
+    sends one representative row per group of report-identical rows plus the group's member haplotype ids
+    (4 B per row instead of 74 B: C3 moves ~130 MB per rank instead of 2.1 GB).  Rank `dst` merges groups that
+    occur on several ranks (the same guide carried by samples of different ranks; REF rows, present on every rank)
+    by their full key - start, stop, strand, origin, the five core slices - and returns
+    ({column: representative rows}, member_off[n_groups + 1], members[global haplotype ids, ascending per group]);
+    other ranks return None.  `cols`: table_columns(tab); `is_ref_row`: whether each row is from the REF haplotype."""
+    import torch
+    dev = torch.device(device) if device else torch.device("cpu")
+    perm = np.asarray(group_perm, dtype=np.int64)
+    off = np.asarray(group_off, dtype=np.int64)
+    reps = perm[off[:-1]]
+    hap = cols["hap"].astype(np.int64)
+    ghap = np.where(hap == 0, 0, hap + hap_offset)  # local haplotype 0 is REF on every rank
+    parts = {k: _gather_var(np.ascontiguousarray(cols[k][reps]), group, dev, dst) for k in cols}
+    origin = _gather_var(np.ascontiguousarray(is_ref_row[reps].astype(np.uint8)), group, dev, dst)
+    sizes = _gather_var(np.diff(off), group, dev, dst)
+    members = _gather_var(ghap[perm].astype(np.uint32), group, dev, dst)
+    if parts["hap"] is None:
+        return None
+    rep = {k: np.concatenate(v) for k, v in parts.items()}
+    origin, sizes, members = np.concatenate(origin), np.concatenate(sizes), np.concatenate(members)
+    # second-level merge on the full key
+    L = guidelen + pamlen
+    mask = np.uint64((1 << L) - 1) if L < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    core = (rep["win"] >> np.uint64(10)) & mask
+    key = np.zeros(len(sizes), dtype=[("start", np.int64), ("strand", np.uint8), ("stop", np.int64), ("origin", np.uint8),
+                                      ("c0", np.uint64), ("c1", np.uint64), ("c2", np.uint64), ("c3", np.uint64), ("c4", np.uint64)])
+    key["start"], key["strand"], key["stop"], key["origin"] = rep["start"], rep["strand"], rep["stop"], origin
+    for p in range(5):
+        key[f"c{p}"] = core[:, p]
+    _, first, inv = np.unique(key, return_index=True, return_inverse=True)  # sorted by (start, strand, ...)
+    inv = inv.reshape(-1)
+    n_groups = len(first)
+    grp_of_member = np.repeat(inv, sizes)
+    order = np.lexsort((members, grp_of_member))
+    gm, mm = grp_of_member[order], members[order]
+    keep = np.ones(len(mm), dtype=bool)
+    keep[1:] = (gm[1:] != gm[:-1]) | (mm[1:] != mm[:-1])  # REF (0) arrives once per rank
+    gm, mm = gm[keep], mm[keep]
+    member_off = np.zeros(n_groups + 1, dtype=np.int64)
+    np.add.at(member_off, gm + 1, 1)
+    member_off = np.cumsum(member_off)
+    out = {k: v[first] for k, v in rep.items()}
+    out["hap"] = mm[member_off[:-1]].astype(np.uint32)  # a representative's haplotype: the group's first member
+    return out, member_off, mm.astype(np.uint32)

@@ -58,3 +58,92 @@ def test_gather_tables_world2_gloo(tmp_path):
                                    for p, o in zip(parts, off)])
         assert np.array_equal(got[k], want), k
     assert len(got["hap"]) == sum(sizes)
+
+
+def _rank_rows(rank, world):
+    """Oracle guide rows of this rank's sample block (REF + its samples' haplotypes), as table columns."""
+    from crisprhawk_hip import synth
+    from oracle import oracle as ora
+    from util import oracle_haplotypes
+    reg = synth.make_region(8801, "chrM", 20_000, 1_000, 19_000)
+    synth.add_phased_variants(reg, 8802, 150, 8, af_min=0.3, af_max=0.8)
+    lo, hi = shard_range(len(reg.samples), rank, world) if world else (0, len(reg.samples))
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples[lo:hi],
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt[lo:hi]]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, 3) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    res = ora.search(hs, "NGG", 20, False)
+    g = res.guides
+    n = len(g["start"])
+    win = np.zeros((n, 5), dtype=np.uint64)
+    code = {c: i for i, c in enumerate("ACGT")}
+    for i, w in enumerate(res.windows):  # planes A, C, G, T, V of the 43-nt window, bit j = base j
+        for j, ch in enumerate(w):
+            win[i, code[ch.upper()]] |= np.uint64(1) << np.uint64(j)
+            if ch.islower():
+                win[i, 4] |= np.uint64(1) << np.uint64(j)
+    cols = dict(hap=g["hap"].astype(np.uint32), pos=g["pos"].astype(np.uint32), strand=g["strand"].astype(np.uint8),
+                start=g["start"].astype(np.int64), stop=g["stop"].astype(np.int64), flags=np.zeros(n, np.uint8),
+                cfdon=np.full(n, np.nan), win=win)
+    isref_row = np.asarray(hs.is_ref)[g["hap"]]
+    groups, _ = ora.collapse_rows(g["start"], g["stop"], g["strand"], isref_row, res.windows, 20, 3, False)
+    perm, off = [], [0]
+    for rows in groups.values():
+        perm += rows
+        off.append(len(perm))
+    labels = [h["samples"] for h in haps]
+    return cols, np.array(perm), np.array(off), isref_row, labels, res.windows
+
+
+def _worker_collapsed(rank, world, port, out_dir):
+    import sys
+    sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+    import torch.distributed as dist
+    from crisprhawk_hip.parallel import gather_collapsed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cols, perm, off, isref_row, labels, _ = _rank_rows(rank, world)
+    res = gather_collapsed(cols, perm, off, isref_row, hap_offset=1000 * rank, guidelen=20, pamlen=3)
+    if rank == 0:
+        rep, moff, members = res
+        np.savez(os.path.join(out_dir, "collapsed.npz"), moff=moff, members=members, **rep)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_collapsed_world2_gloo(tmp_path):
+    """Two ranks with half of the samples each: representatives + member lists gathered to rank 0 and merged there
+    must equal the grouping of the two tables laid side by side."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_collapsed, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "collapsed.npz")
+    want = {}
+    for r in range(2):
+        cols, perm, off, isref_row, labels, wins = _rank_rows(r, 2)
+        for i in range(len(cols["hap"])):
+            key = (int(cols["start"][i]), int(cols["stop"][i]), int(cols["strand"][i]), bool(isref_row[i]), wins[i][10:-10])
+            h = int(cols["hap"][i])
+            want.setdefault(key, set()).add(0 if h == 0 else h + 1000 * r)
+    moff, members = got["moff"], got["members"]
+    assert len(moff) - 1 == len(want) and (np.diff(got["start"]) >= 0).all()
+    mask = np.uint64((1 << 23) - 1)
+    letters = np.array(list("ACGT"))
+    seen = set()
+    for g in range(len(moff) - 1):
+        core = (got["win"][g] >> np.uint64(10)) & mask
+        seq = ""
+        for j in range(23):
+            bits = [(int(core[p]) >> j) & 1 for p in range(5)]
+            ch = letters[bits[:4].index(1)]
+            seq += ch.lower() if bits[4] else ch
+        mem = set(int(x) for x in members[moff[g]:moff[g + 1]])
+        origin = mem == {0}
+        key = (int(got["start"][g]), int(got["stop"][g]), int(got["strand"][g]), origin, seq)
+        assert key in want and want[key] == mem and key not in seen, key
+        assert sorted(mem) == [int(x) for x in members[moff[g]:moff[g + 1]]]
+        seen.add(key)
