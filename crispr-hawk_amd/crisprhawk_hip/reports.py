@@ -43,7 +43,17 @@ def adjust_multiallelic(ref: str, alt: str, pos: int):  # variant.py:456-486
     return ref[-1], alt[len(ref) - 1:], pos + len(ref) - 1
 
 
+_PARSED: Dict[str, tuple] = {}  # variant id -> (adjusted position, ref, alt): ids repeat across thousands of haplotypes
+
+
 def _parse_variant(variant_id: str):  # annotation.py:53-62
+    hit = _PARSED.get(variant_id)
+    if hit is None:
+        hit = _PARSED[variant_id] = _parse_variant_uncached(variant_id)
+    return hit
+
+
+def _parse_variant_uncached(variant_id: str):
     parts = variant_id.split("-")
     ref, alt = parts[2].split("/")
     ref_, alt_, pos_ = adjust_multiallelic(ref, alt, int(parts[1]))
@@ -117,6 +127,44 @@ def select_reportcols(pam: PAM, right: bool) -> List[str]:
     return cols + REPORTCOLS[15:20] + REPORTCOLS[20:22]
 
 
+class _SampleIndex:
+    """collapse_samples over many member sets without re-splitting the label strings every time: every distinct
+    `sample:genotype` entry gets its rank in string order once; a member set is then a union of small rank arrays, and
+    because entries of one sample are neighbours in that order, _polish_samples_phased's per-sample maxima are a
+    reduceat."""
+
+    def __init__(self, haplotypes):
+        entries = sorted({e for h in haplotypes if h is not None for e in h.samples.split(",")})
+        rank = {e: i for i, e in enumerate(entries)}
+        self.phased = any("|" in e for e in entries)
+        self.entries = entries
+        names = [e.split(":")[0] for e in entries]
+        uniq: Dict[str, int] = {}
+        self.sample_id = np.array([uniq.setdefault(n, len(uniq)) for n in names], dtype=np.int64)
+        self.names = list(uniq)
+        if self.phased:
+            gts = [(e.split(":")[1].split("|") if ":" in e and "|" in e else ["0", "0"]) for e in entries]
+            self.a1 = np.array([int(g[0]) for g in gts], dtype=np.int64)
+            self.a2 = np.array([int(g[1]) for g in gts], dtype=np.int64)
+            self.odd = np.array([":" not in e or "|" not in e for e in entries])  # "REF" / unphased labels among phased ones
+        self.ranks = [None if h is None else np.array(sorted({rank[e] for e in h.samples.split(",")}), dtype=np.int64)
+                      for h in haplotypes]
+        self._fmt: Dict[tuple, str] = {}
+
+    def collapse(self, hap_ids: np.ndarray, haplotypes) -> str:
+        if not self.phased:
+            return collapse_samples([haplotypes[int(x)].samples for x in hap_ids])
+        r = np.unique(np.concatenate([self.ranks[int(x)] for x in hap_ids]))
+        if self.odd[r].any():  # e.g. the REF haplotype's group: the plain path
+            return collapse_samples([haplotypes[int(x)].samples for x in hap_ids])
+        sid = self.sample_id[r]
+        starts = np.flatnonzero(np.concatenate(([True], sid[1:] != sid[:-1])))
+        m1 = np.maximum.reduceat(self.a1[r], starts)
+        m2 = np.maximum.reduceat(self.a2[r], starts)
+        names = self.names
+        return ",".join([f"{names[i]}:{a}|{b}" for i, a, b in zip(sid[starts].tolist(), m1.tolist(), m2.tolist())])
+
+
 class ReportInput:
     """The columns the report needs, from a GuideTable (device rows + device groups) or from any other source
     of the same arrays (tests build it from the CPU oracle)."""
@@ -166,6 +214,7 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
     pamclass = compute_pam_class(pam)
     parsed_cache: Dict[int, Dict[int, List]] = {}
     member_cache: Dict[bytes, tuple] = {}
+    sample_index = _SampleIndex(haplotypes)
     recs = []
     perm = np.asarray(inp.group_perm, dtype=np.int64)
     off = np.asarray(inp.group_off, dtype=np.int64)
@@ -218,7 +267,7 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
         agg = member_cache.get(mkey)
         if agg is None:
             members = [haplotypes[int(x)] for x in inp.hap[rows]]
-            agg = (collapse_samples([m.samples for m in members]), collapse_haplotype_ids([m.id for m in members]))
+            agg = (sample_index.collapse(inp.hap[rows], haplotypes), collapse_haplotype_ids([m.id for m in members]))
             member_cache[mkey] = agg
         rec["samples"] = agg[0]
         rec["variant_id"] = ",".join(sorted(set(variant_id.split(",")))) if variant_id else ""  # _check_variant_ids
