@@ -213,3 +213,67 @@ def test_files_to_device_haplotypes_equal_in_memory_path(tmp_path, compress):
     for col in ("hap", "pos", "strand", "start", "stop", "flags", "win"):
         assert np.array_equal(getattr(t0, col), getattr(t1, col)), col
     assert np.array_equal(np.nan_to_num(t0.cfdon, nan=-1), np.nan_to_num(t1.cfdon, nan=-1))
+
+
+@pytest.mark.gpu
+def test_multiallelic_sites_expand_like_the_host_builder(tmp_path):
+    """Records with several ALT alleles: every chromosome copy carries at most one allele of a site, so the split
+    variants (VariantRecord.split, variant.py:313-331) never overlap within a row although they share a position in
+    the table.  Device expansion from the record text against the host mirror of solve_haplotypes_phased."""
+    from crisprhawk_hip import haplotypes as H
+    from crisprhawk_hip.haplotype import Haplotype
+    from crisprhawk_hip.region import Region
+    from crisprhawk_hip.sequence import Sequence
+    from crisprhawk_hip.workload import expand_from_vcf
+    rng = np.random.default_rng(9401)
+    reg = synth.make_region(9402, "chrM", 9_000, 1_000, 8_000)
+    seq, startp = reg.sequence, reg.startp
+    samples = [f"S{i}" for i in range(6)]
+    rows, pos = [], startp + 150
+    others = lambda b: [x for x in "ACGT" if x != b]
+    while pos < reg.stopp - 200:
+        ref = seq[pos - startp]
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            alts = others(ref)[:2]                                   # two SNV alleles
+        elif kind == 1:
+            alts = [others(ref)[0], ref + "GA"]                      # SNV + insertion at one site
+        elif kind == 2:
+            alts = [seq[pos - startp: pos - startp + 1], ref + "T"]  # placeholder, fixed below: deletion + insertion
+            alts[0] = ref
+        else:
+            alts = others(ref)                                       # three SNV alleles
+        vref = ref
+        if kind == 2:  # REF = 3 bases, alleles: deletion to 1 base, and insertion behind the first base
+            vref = seq[pos - startp: pos - startp + 3]
+            alts = [vref[0], vref[0] + "C" + vref[1:]]
+        gts = ["|".join(str(int(rng.integers(0, len(alts) + 1))) for _ in range(2)) for _ in samples]
+        rows.append(["chrM", str(pos), ".", vref, ",".join(alts), ".", "PASS", "AF=" + ",".join(["0.1"] * len(alts)), "GT"] + gts)
+        pos += int(rng.integers(40, 160))
+    vcf = str(tmp_path / "m.vcf")
+    readers.write_vcf(vcf, "chrM", samples, rows)
+    v = readers.VCF(vcf)
+    coord = Coordinate("chrM", reg.bed_start, reg.bed_stop, synth.PADDING)
+    blk = v.fetch_block(coord)
+    ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, v.samples, 3, v.phased)
+    # host mirror: records -> split -> per-sample copies -> collapse
+    region = Region(Sequence(seq, True), coord)
+    want = H.add_variants_phased([Haplotype(Sequence(seq, True), coord, False, 0, True)], region, v.samples, v.fetch(coord), True, True)
+    got_seqs = []
+    nib2chr = {}
+    from crisprhawk_hip.pam import IUPAC_BITS
+    for ch, b in IUPAC_BITS.items():
+        nib2chr[b] = ch
+    nibbles = {r: ds.nibbles(r) for r in kept}
+    vplane = ds.planes()[4]
+    for r in kept:
+        n = int(ds.hap_len[r])
+        bits = ((vplane[r][:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:n].astype(bool)
+        s = "".join(nib2chr[int(x)].lower() if low else nib2chr[int(x)] for x, low in zip(nibbles[r][:n], bits))
+        got_seqs.append(s)
+    assert sorted(got_seqs) == sorted(h.sequence.sequence for h in want)
+    by_seq = {h.sequence.sequence: h for h in want}
+    for s, inf, r in zip(got_seqs, info, kept):
+        h = by_seq[s]
+        assert sorted(inf.samples) == sorted(h.samples.split(",")), s[:40]
+        assert np.array_equal(ds.host_meta[r].seg.full(), h.segments.full())
