@@ -70,6 +70,7 @@ struct hawk_hapset {
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
+  DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
   DevBuf colsA[8];
 };
 
@@ -193,7 +194,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   (void)hipFree(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
-                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull};
+                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   delete hs;
@@ -709,6 +710,43 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
       (rc = hs->partial.reserve((ncnt / 1024 + 2) * 8)) || (rc = hs->misc.reserve(512 * 8 + 64)) ||
       (rc = hs->guides.reserve(std::max<size_t>((size_t)n_guides * 8, 16))))
     return rc;
+  // Pigeonhole seeds when they pay: enough guides to bucket, and blocks of at least two bases.  HAWK_OT_ALLPAIRS=1
+  // keeps the all-pairs kernel (A/B measurements, and the parity test runs both).
+  static const bool force_allpairs = [] { const char* e = getenv("HAWK_OT_ALLPAIRS"); return e && e[0] == '1'; }();
+  const int G = (int)p->guidelen, nb = (int)p->max_mm + 1;
+  const bool seeded = !force_allpairs && n_guides >= 64 && nb <= OT_MAX_BLOCKS && nb * 2 <= G;
+  OtSeeds sd;
+  memset(&sd, 0, sizeof(sd));
+  if (seeded) {
+    sd.nb = nb;
+    std::vector<uint32_t> goff;
+    std::vector<uint64_t> gcode((size_t)nb * n_guides);
+    std::vector<uint32_t> gid((size_t)nb * n_guides);
+    int startb = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int len = G / nb + (b < G % nb ? 1 : 0), kl = std::min(len, 6);
+      sd.start[b] = startb; sd.klen[b] = kl; sd.off_base[b] = (uint32_t)goff.size();
+      for (int t = 0; t < kl; ++t) sd.pmask2[b] |= 1ull << (2 * (startb + t));
+      const uint32_t nkeys = 1u << (2 * kl), kmask = nkeys - 1u;
+      std::vector<uint32_t> cnt(nkeys + 1, 0);
+      for (uint32_t g = 0; g < n_guides; ++g) ++cnt[((uint32_t)(guides2[g] >> (2 * startb)) & kmask) + 1];
+      for (uint32_t v = 0; v < nkeys; ++v) cnt[v + 1] += cnt[v];
+      goff.insert(goff.end(), cnt.begin(), cnt.end());
+      std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+      for (uint32_t g = 0; g < n_guides; ++g) {  // counting sort: guides of one bucket stay in input order
+        const uint32_t slot = cur[(uint32_t)(guides2[g] >> (2 * startb)) & kmask]++;
+        gcode[(size_t)b * n_guides + slot] = guides2[g];
+        gid[(size_t)b * n_guides + slot] = g;
+      }
+      startb += len;
+    }
+    if ((rc = hs->otoff.reserve(goff.size() * 4)) || (rc = hs->otcode.reserve(gcode.size() * 8)) || (rc = hs->otid.reserve(gid.size() * 4)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(hs->otoff.p, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs->otcode.p, gcode.data(), gcode.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs->otid.p, gid.data(), gid.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+  }
   hipEvent_t* ev = ctx->ev;
   if (n_guides) HIPCHK(hipMemcpyAsync(hs->guides.p, guides2, (size_t)n_guides * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(hs->misc.p, 0, 64, ctx->stream));
@@ -730,8 +768,14 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
   if (nsites) hawk_launch_ot_sites(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
                                    hs->offsets.as<uint64_t>(), hs->sites.as<OtSite>());
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
-  hawk_launch_ot_match(ctx->stream, hs->sites.as<OtSite>(), nsites, hs->guides.as<uint64_t>(), n_guides, (int)p->guidelen,
-                       p->right ? (int)p->pamlen : 0, (int)p->max_mm, hs->hits.as<OtHit>(), cap, d_nhits);
+  if (seeded) {
+    hawk_launch_ot_match_seeded(ctx->stream, hs->sites.as<OtSite>(), nsites, sd, hs->otoff.as<uint32_t>(), hs->otcode.as<uint64_t>(),
+                                hs->otid.as<uint32_t>(), n_guides, G, p->right ? (int)p->pamlen : 0, (int)p->max_mm,
+                                hs->hits.as<OtHit>(), cap, d_nhits);
+  } else {
+    hawk_launch_ot_match(ctx->stream, hs->sites.as<OtSite>(), nsites, hs->guides.as<uint64_t>(), n_guides, (int)p->guidelen,
+                         p->right ? (int)p->pamlen : 0, (int)p->max_mm, hs->hits.as<OtHit>(), cap, d_nhits);
+  }
   HIPCHK(hipEventRecord(ev[4], ctx->stream));
   HIPCHK(hipGetLastError());
   unsigned long long nh = 0;
@@ -753,17 +797,13 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
   if (!nh) return HAWK_OK;
   std::vector<OtHit> hh(nh);
   HIPCHK(hipMemcpy(hh.data(), hs->hits.p, nh * sizeof(OtHit), hipMemcpyDeviceToHost));
-  // the hit sites are few: download the site table only when it is small, else fetch hit by hit
+  // the sites of the hits: gathered into a compact array on the device, one download
   std::vector<OtSite> ss(nh);
-  if (nsites * sizeof(OtSite) <= (256ull << 20)) {
-    std::vector<OtSite> all(nsites);
-    HIPCHK(hipMemcpy(all.data(), hs->sites.p, nsites * sizeof(OtSite), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < nh; ++i) ss[i] = all[hh[i].site];
-  } else {
-    for (uint64_t i = 0; i < nh; ++i)
-      HIPCHK(hipMemcpyAsync(&ss[i], hs->sites.as<OtSite>() + hh[i].site, sizeof(OtSite), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
+  if ((rc = hs->othit.reserve(nh * sizeof(OtSite)))) return rc;
+  hawk_launch_ot_gather(ctx->stream, hs->sites.as<OtSite>(), hs->hits.as<OtHit>(), nh, hs->othit.as<OtSite>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ss.data(), hs->othit.p, nh * sizeof(OtSite), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   for (uint64_t i = 0; i < nh; ++i) {
     if (out_guide) out_guide[i] = hh[i].guide;
     if (out_row) out_row[i] = ss[i].row;

@@ -90,6 +90,16 @@ struct OtSite {   // one PAM-bearing genome window in guide orientation
   uint32_t pad;
 };
 struct OtHit { uint64_t site; uint32_t guide; uint32_t mm; };
+// Seeds of the pigeonhole filter: the spacer is cut into max_mm + 1 blocks, so a pair within max_mm mismatches agrees
+// exactly in at least one block.  Per block: its first base, the bases used as the bucket key (<= 6), where its
+// bucket offsets start in `goff`, and the folded-XOR bits (even positions) of the key bases.
+#define OT_MAX_BLOCKS 8
+struct OtSeeds {
+  int32_t nb;
+  int32_t start[OT_MAX_BLOCKS], klen[OT_MAX_BLOCKS];
+  uint32_t off_base[OT_MAX_BLOCKS];
+  uint64_t pmask2[OT_MAX_BLOCKS];
+};
 
 // launch wrappers
 void hawk_launch_ot_onehot(hipStream_t st, uint32_t* const* plane, uint64_t nwords);
@@ -97,6 +107,10 @@ void hawk_launch_ot_sites(hipStream_t st, const HapSetDev& hs, const ScanParams&
                           const uint64_t* offsets, OtSite* sites);
 void hawk_launch_ot_match(hipStream_t st, const OtSite* sites, uint64_t n_sites, const uint64_t* guides, uint32_t n_guides,
                           int guidelen, int sp0, int max_mm, OtHit* hits, uint64_t cap, unsigned long long* n_hits);
+void hawk_launch_ot_match_seeded(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtSeeds& sd, const uint32_t* goff,
+                                 const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, int guidelen, int sp0, int max_mm,
+                                 OtHit* hits, uint64_t cap, unsigned long long* n_hits);
+void hawk_launch_ot_gather(hipStream_t st, const OtSite* sites, const OtHit* hits, uint64_t n_hits, OtSite* out);
 void hawk_launch_pack(hipStream_t st, const uint8_t* ascii, const uint64_t* seq_off, uint32_t hap0, uint32_t n_hap_batch,
                       uint64_t batch_base, const uint32_t* hap_len, uint32_t S, uint32_t* const* plane,
                       unsigned long long* bad_index);

@@ -14,7 +14,12 @@
 //   k_ot_sites    hit bits -> site records: the guidelen+pamlen window in guide orientation
 //                 (strand 1 reverse-complemented) as a 2-bit code + ambiguity mask
 //   k_ot_match    all pairs site x guide: XOR, fold to one bit per base, popcount, <= max_mm
-//                 survivors appended through a wave-aggregated atomic
+//                 survivors appended through a wave-aggregated atomic (small guide sets)
+//   k_ot_match_seeded  pigeonhole filter: with the spacer cut into max_mm + 1 blocks, a pair within max_mm
+//                 mismatches agrees exactly in one block; the guides are bucketed per block by the block's
+//                 bases (host, counting sort), a site compares only against the buckets its own blocks name:
+//                 ~ (max_mm + 1) / 4^blocklen of the all-pairs work
+//   k_ot_gather   hit sites -> compact array for one download
 #include "hawk_bits.h"
 
 // reverse the low L (<= 32) bits
@@ -142,4 +147,57 @@ void hawk_launch_ot_match(hipStream_t st, const OtSite* sites, uint64_t n_sites,
   if (!n_sites || !n_guides) return;
   hipLaunchKernelGGL(k_ot_match, dim3((uint32_t)((n_sites + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, sites, n_sites,
                      guides, n_guides, guidelen, sp0, max_mm, hits, cap, n_hits);
+}
+
+// Seeded match.  Each thread owns one site and visits, per block, the bucket of guides whose key bases equal the
+// site's (a gather from the L2-resident bucketed guide table).  A pair that agrees in the key bases of several
+// blocks is met several times; it is reported at the first of them.
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ot_match_seeded(const OtSite* __restrict__ sites, uint64_t n_sites, OtSeeds sd,
+                                                                 const uint32_t* __restrict__ goff, const uint64_t* __restrict__ gcode,
+                                                                 const uint32_t* __restrict__ gid, uint32_t n_guides, int guidelen,
+                                                                 int sp0, int max_mm, OtHit* __restrict__ hits, uint64_t cap,
+                                                                 unsigned long long* __restrict__ n_hits) {
+  const uint64_t i = (uint64_t)blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  if (i >= n_sites) return;
+  const OtSite st = sites[i];
+  const uint64_t smask = guidelen >= 32 ? ~0ull : ((1ull << (2 * guidelen)) - 1ull);
+  const uint64_t code = (st.code >> (2 * sp0)) & smask;
+  const uint32_t nmsp = (st.nmask >> sp0) & (guidelen >= 32 ? 0xffffffffu : ((1u << guidelen) - 1u));
+  if (__popc(nmsp) > max_mm) return;  // more ambiguous bases than allowed mismatches: no guide can match
+  const uint64_t nm2 = spread(nmsp);
+  for (int b = 0; b < sd.nb; ++b) {  // wave-uniform
+    const int ks = sd.start[b], kl = sd.klen[b];
+    if ((nmsp >> ks) & ((1u << kl) - 1u)) continue;  // an ambiguous base among the key bases: this block cannot agree
+    const uint32_t key = (uint32_t)(code >> (2 * ks)) & ((1u << (2 * kl)) - 1u);
+    const uint32_t lo = goff[sd.off_base[b] + key], hi = goff[sd.off_base[b] + key + 1];
+    const uint64_t* gc = gcode + (size_t)b * n_guides;
+    const uint32_t* gi = gid + (size_t)b * n_guides;
+    for (uint32_t t = lo; t < hi; ++t) {
+      const uint64_t x = code ^ gc[t];
+      const uint64_t m = ((x | (x >> 1)) & 0x5555555555555555ull) | nm2;
+      const int mm = __popcll(m);
+      if (mm > max_mm) continue;
+      bool earlier = false;
+      for (int j = 0; j < b; ++j) earlier = earlier || (m & sd.pmask2[j]) == 0;
+      if (earlier) continue;
+      const unsigned long long o = atomicAdd(n_hits, 1ull);
+      if (o < cap) { OtHit hh; hh.site = i; hh.guide = gi[t]; hh.mm = (uint32_t)mm; hits[o] = hh; }
+    }
+  }
+}
+void hawk_launch_ot_match_seeded(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtSeeds& sd, const uint32_t* goff,
+                                 const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, int guidelen, int sp0, int max_mm,
+                                 OtHit* hits, uint64_t cap, unsigned long long* n_hits) {
+  if (!n_sites || !n_guides) return;
+  hipLaunchKernelGGL(k_ot_match_seeded, dim3((uint32_t)((n_sites + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, sites,
+                     n_sites, sd, goff, gcode, gid, n_guides, guidelen, sp0, max_mm, hits, cap, n_hits);
+}
+
+__global__ __launch_bounds__(256) void k_ot_gather(const OtSite* __restrict__ sites, const OtHit* __restrict__ hits, uint64_t n_hits,
+                                                   OtSite* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_hits) out[i] = sites[hits[i].site];
+}
+void hawk_launch_ot_gather(hipStream_t st, const OtSite* sites, const OtHit* hits, uint64_t n_hits, OtSite* out) {
+  if (n_hits) hipLaunchKernelGGL(k_ot_gather, dim3((uint32_t)((n_hits + 255) / 256)), dim3(256), 0, st, sites, hits, n_hits, out);
 }
