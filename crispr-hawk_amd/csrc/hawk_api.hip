@@ -717,28 +717,43 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
   const bool seeded = !force_allpairs && n_guides >= 64 && nb <= OT_MAX_BLOCKS && nb * 2 <= G;
   OtSeeds sd;
   memset(&sd, 0, sizeof(sd));
+  // LDS variant: guides in chunks of OT_LDS_CHUNK, 4 key bases per block (nb * 8.5 KB of LDS must leave room for a few
+  // workgroups per CU); HAWK_OT_SEED_GLOBAL=1 keeps the single-table global-gather kernel
+  static const bool seed_global = [] { const char* e = getenv("HAWK_OT_SEED_GLOBAL"); return e && e[0] == '1'; }();
+  const bool seed_lds = seeded && !seed_global && nb <= 6;
+  const uint32_t chunk = seed_lds ? OT_LDS_CHUNK : n_guides;
+  const uint32_t n_chunks = seeded ? (n_guides + chunk - 1) / chunk : 0;
   if (seeded) {
     sd.nb = nb;
-    std::vector<uint32_t> goff;
-    std::vector<uint64_t> gcode((size_t)nb * n_guides);
-    std::vector<uint32_t> gid((size_t)nb * n_guides);
+    const int kmax = seed_lds ? 4 : 6;
     int startb = 0;
     for (int b = 0; b < nb; ++b) {
-      const int len = G / nb + (b < G % nb ? 1 : 0), kl = std::min(len, 6);
-      sd.start[b] = startb; sd.klen[b] = kl; sd.off_base[b] = (uint32_t)goff.size();
+      const int len = G / nb + (b < G % nb ? 1 : 0), kl = std::min(len, kmax);
+      sd.start[b] = startb; sd.klen[b] = kl;
       for (int t = 0; t < kl; ++t) sd.pmask2[b] |= 1ull << (2 * (startb + t));
-      const uint32_t nkeys = 1u << (2 * kl), kmask = nkeys - 1u;
-      std::vector<uint32_t> cnt(nkeys + 1, 0);
-      for (uint32_t g = 0; g < n_guides; ++g) ++cnt[((uint32_t)(guides2[g] >> (2 * startb)) & kmask) + 1];
-      for (uint32_t v = 0; v < nkeys; ++v) cnt[v + 1] += cnt[v];
-      goff.insert(goff.end(), cnt.begin(), cnt.end());
-      std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-      for (uint32_t g = 0; g < n_guides; ++g) {  // counting sort: guides of one bucket stay in input order
-        const uint32_t slot = cur[(uint32_t)(guides2[g] >> (2 * startb)) & kmask]++;
-        gcode[(size_t)b * n_guides + slot] = guides2[g];
-        gid[(size_t)b * n_guides + slot] = g;
-      }
       startb += len;
+    }
+    // tables per (chunk, block): bucket offsets (inside the chunk), codes and guide ids in bucket order
+    std::vector<uint32_t> goff;
+    std::vector<uint64_t> gcode((size_t)n_chunks * nb * chunk, 0);
+    std::vector<uint32_t> gid((size_t)n_chunks * nb * chunk, 0);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const uint32_t g0 = c * chunk, ng = std::min<uint32_t>(chunk, n_guides - g0);
+      for (int b = 0; b < nb; ++b) {
+        const uint32_t nkeys = seed_lds ? OT_LDS_KEYS : (1u << (2 * sd.klen[b])), kmask = (1u << (2 * sd.klen[b])) - 1u;
+        if (c == 0) sd.off_base[b] = (uint32_t)goff.size();  // global variant: one chunk, per-block table sizes differ
+        std::vector<uint32_t> cnt(nkeys + 1, 0);
+        for (uint32_t g = 0; g < ng; ++g) ++cnt[((uint32_t)(guides2[g0 + g] >> (2 * sd.start[b])) & kmask) + 1];
+        for (uint32_t v = 0; v < nkeys; ++v) cnt[v + 1] += cnt[v];
+        goff.insert(goff.end(), cnt.begin(), cnt.end());
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        const size_t base = ((size_t)c * nb + b) * chunk;
+        for (uint32_t g = 0; g < ng; ++g) {  // counting sort: guides of one bucket stay in input order
+          const uint32_t slot = cur[(uint32_t)(guides2[g0 + g] >> (2 * sd.start[b])) & kmask]++;
+          gcode[base + slot] = guides2[g0 + g];
+          gid[base + slot] = g0 + g;
+        }
+      }
     }
     if ((rc = hs->otoff.reserve(goff.size() * 4)) || (rc = hs->otcode.reserve(gcode.size() * 8)) || (rc = hs->otid.reserve(gid.size() * 4)))
       return rc;
@@ -769,9 +784,14 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
                                    hs->offsets.as<uint64_t>(), hs->sites.as<OtSite>());
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
   if (seeded) {
-    hawk_launch_ot_match_seeded(ctx->stream, hs->sites.as<OtSite>(), nsites, sd, hs->otoff.as<uint32_t>(), hs->otcode.as<uint64_t>(),
-                                hs->otid.as<uint32_t>(), n_guides, G, p->right ? (int)p->pamlen : 0, (int)p->max_mm,
-                                hs->hits.as<OtHit>(), cap, d_nhits);
+    if (seed_lds)
+      hawk_launch_ot_match_seeded_lds(ctx->stream, hs->sites.as<OtSite>(), nsites, sd, hs->otoff.as<uint32_t>(),
+                                      hs->otcode.as<uint64_t>(), hs->otid.as<uint32_t>(), n_guides, n_chunks, G,
+                                      p->right ? (int)p->pamlen : 0, (int)p->max_mm, hs->hits.as<OtHit>(), cap, d_nhits);
+    else
+      hawk_launch_ot_match_seeded(ctx->stream, hs->sites.as<OtSite>(), nsites, sd, hs->otoff.as<uint32_t>(), hs->otcode.as<uint64_t>(),
+                                  hs->otid.as<uint32_t>(), n_guides, G, p->right ? (int)p->pamlen : 0, (int)p->max_mm,
+                                  hs->hits.as<OtHit>(), cap, d_nhits);
   } else {
     hawk_launch_ot_match(ctx->stream, hs->sites.as<OtSite>(), nsites, hs->guides.as<uint64_t>(), n_guides, (int)p->guidelen,
                          p->right ? (int)p->pamlen : 0, (int)p->max_mm, hs->hits.as<OtHit>(), cap, d_nhits);

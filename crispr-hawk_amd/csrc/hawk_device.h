@@ -110,6 +110,11 @@ void hawk_launch_ot_match(hipStream_t st, const OtSite* sites, uint64_t n_sites,
 void hawk_launch_ot_match_seeded(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtSeeds& sd, const uint32_t* goff,
                                  const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, int guidelen, int sp0, int max_mm,
                                  OtHit* hits, uint64_t cap, unsigned long long* n_hits);
+#define OT_LDS_CHUNK 1024  // guides per LDS-resident chunk of the seeded match
+#define OT_LDS_KEYS 256    // buckets per block in the LDS variant (4 key bases)
+void hawk_launch_ot_match_seeded_lds(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtSeeds& sd, const uint32_t* goff,
+                                     const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, uint32_t n_chunks, int guidelen,
+                                     int sp0, int max_mm, OtHit* hits, uint64_t cap, unsigned long long* n_hits);
 void hawk_launch_ot_gather(hipStream_t st, const OtSite* sites, const OtHit* hits, uint64_t n_hits, OtSite* out);
 void hawk_launch_pack(hipStream_t st, const uint8_t* ascii, const uint64_t* seq_off, uint32_t hap0, uint32_t n_hap_batch,
                       uint64_t batch_base, const uint32_t* hap_len, uint32_t S, uint32_t* const* plane,

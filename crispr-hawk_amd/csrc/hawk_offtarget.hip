@@ -193,6 +193,73 @@ void hawk_launch_ot_match_seeded(hipStream_t st, const OtSite* sites, uint64_t n
                      n_sites, sd, goff, gcode, gid, n_guides, guidelen, sp0, max_mm, hits, cap, n_hits);
 }
 
+// The same with the guide buckets in LDS.  The global-gather version above moves a 64-byte sector from L2 for every
+// 8-byte guide code a lane reads and runs into the L2 bandwidth (35 TB/s at the full C5 size); here the guides are
+// taken OT_LDS_CHUNK at a time (blockIdx.y), each chunk bucketed on its own with 4 key bases per block, and a
+// workgroup keeps the chunk's codes and bucket offsets in LDS while it walks OT_SITES_PER_WG sites.
+// Tables per chunk c and block b: goff[(c * nb + b) * (OT_LDS_KEYS + 1) ...] (offsets inside the chunk),
+// gcode / gid[(c * nb + b) * OT_LDS_CHUNK ...].
+#define OT_SITES_PER_WG (HAWK_BLOCK * 16)
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ot_match_seeded_lds(const OtSite* __restrict__ sites, uint64_t n_sites, OtSeeds sd,
+                                                                     const uint32_t* __restrict__ goff, const uint64_t* __restrict__ gcode,
+                                                                     const uint32_t* __restrict__ gid, uint32_t n_guides, int guidelen,
+                                                                     int sp0, int max_mm, OtHit* __restrict__ hits, uint64_t cap,
+                                                                     unsigned long long* __restrict__ n_hits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const int nb = sd.nb;
+  uint64_t* s_code = reinterpret_cast<uint64_t*>(s_raw);                                   // [nb][OT_LDS_CHUNK]
+  uint16_t* s_off = reinterpret_cast<uint16_t*>(s_raw + (size_t)nb * OT_LDS_CHUNK * 8);    // [nb][OT_LDS_KEYS + 1]
+  const uint32_t chunk = blockIdx.y;
+  const uint32_t g0 = chunk * OT_LDS_CHUNK;
+  const uint32_t ng = n_guides - g0 < OT_LDS_CHUNK ? n_guides - g0 : OT_LDS_CHUNK;
+  const size_t tb = (size_t)chunk * nb;
+  for (uint32_t t = threadIdx.x; t < (uint32_t)nb * OT_LDS_CHUNK; t += HAWK_BLOCK) {
+    const uint32_t b = t / OT_LDS_CHUNK, j = t % OT_LDS_CHUNK;
+    s_code[t] = j < ng ? gcode[(tb + b) * OT_LDS_CHUNK + j] : 0ull;
+  }
+  for (uint32_t t = threadIdx.x; t < (uint32_t)nb * (OT_LDS_KEYS + 1); t += HAWK_BLOCK)
+    s_off[t] = (uint16_t)goff[tb * (OT_LDS_KEYS + 1) + t];
+  __syncthreads();
+  const uint64_t smask = guidelen >= 32 ? ~0ull : ((1ull << (2 * guidelen)) - 1ull);
+  const uint64_t first = (uint64_t)blockIdx.x * OT_SITES_PER_WG;
+#pragma unroll 1
+  for (uint32_t r = 0; r < OT_SITES_PER_WG / HAWK_BLOCK; ++r) {
+    const uint64_t i = first + (uint64_t)r * HAWK_BLOCK + threadIdx.x;
+    if (i >= n_sites) break;  // sites are handed out in order: nothing behind it either
+    const OtSite st = sites[i];
+    const uint64_t code = (st.code >> (2 * sp0)) & smask;
+    const uint32_t nmsp = (st.nmask >> sp0) & (guidelen >= 32 ? 0xffffffffu : ((1u << guidelen) - 1u));
+    if (__popc(nmsp) > max_mm) continue;
+    const uint64_t nm2 = spread(nmsp);
+    for (int b = 0; b < nb; ++b) {
+      const int ks = sd.start[b], kl = sd.klen[b];
+      if ((nmsp >> ks) & ((1u << kl) - 1u)) continue;
+      const uint32_t key = (uint32_t)(code >> (2 * ks)) & ((1u << (2 * kl)) - 1u);
+      const uint32_t lo = s_off[b * (OT_LDS_KEYS + 1) + key], hi = s_off[b * (OT_LDS_KEYS + 1) + key + 1];
+      for (uint32_t t = lo; t < hi; ++t) {
+        const uint64_t x = code ^ s_code[b * OT_LDS_CHUNK + t];
+        const uint64_t m = ((x | (x >> 1)) & 0x5555555555555555ull) | nm2;
+        const int mm = __popcll(m);
+        if (mm > max_mm) continue;
+        bool earlier = false;
+        for (int j = 0; j < b; ++j) earlier = earlier || (m & sd.pmask2[j]) == 0;
+        if (earlier) continue;
+        const unsigned long long o = atomicAdd(n_hits, 1ull);
+        if (o < cap) { OtHit hh; hh.site = i; hh.guide = gid[(tb + b) * OT_LDS_CHUNK + t]; hh.mm = (uint32_t)mm; hits[o] = hh; }
+      }
+    }
+  }
+}
+void hawk_launch_ot_match_seeded_lds(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtSeeds& sd, const uint32_t* goff,
+                                     const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, uint32_t n_chunks, int guidelen,
+                                     int sp0, int max_mm, OtHit* hits, uint64_t cap, unsigned long long* n_hits) {
+  if (!n_sites || !n_guides) return;
+  const size_t lds = (size_t)sd.nb * OT_LDS_CHUNK * 8 + (size_t)sd.nb * (OT_LDS_KEYS + 1) * 2;
+  const dim3 grid((uint32_t)((n_sites + OT_SITES_PER_WG - 1) / OT_SITES_PER_WG), n_chunks);
+  hipLaunchKernelGGL(k_ot_match_seeded_lds, grid, dim3(HAWK_BLOCK), lds, st, sites, n_sites, sd, goff, gcode, gid, n_guides, guidelen,
+                     sp0, max_mm, hits, cap, n_hits);
+}
+
 __global__ __launch_bounds__(256) void k_ot_gather(const OtSite* __restrict__ sites, const OtHit* __restrict__ hits, uint64_t n_hits,
                                                    OtSite* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
