@@ -25,7 +25,7 @@ def _plant(rng, genome: list, guide: str, pam_seq: str, right: bool, n: int, max
         genome[pos:pos + L] = list(w)
 
 
-@pytest.mark.parametrize("n_guides", [6, 200])  # 6: the all-pairs kernel; 200: the seeded (pigeonhole) kernel
+@pytest.mark.parametrize("n_guides", [6, 200, 2300])  # 6: all pairs; 200: seeded, one LDS chunk; 2300: three chunks
 @pytest.mark.parametrize("pam_s,guidelen,right,max_mm,piece", [("NGG", 20, False, 4, 1 << 22), ("TTTV", 23, True, 3, 4096),
                                                               ("NNGRRT", 21, False, 2, 10000), ("NGG", 20, False, 0, 1 << 22),
                                                               ("NGG", 17, False, 6, 1 << 22)])
