@@ -43,8 +43,9 @@ def cfd_tables_from_dicts(mmscores: Dict[str, float], pamscores: Dict[str, float
     return mm, pam
 
 
-def load_cfd_tables(modelspath: str, debug: bool) -> None:
-    """cfdscore.load_mismatch_pam_scores (cfdscore.py:22-50): mismatch_score.pkl + pam_scores.pkl."""
+def load_cfd_tables(modelspath: str, debug: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """cfdscore.load_mismatch_pam_scores (cfdscore.py:22-50): mismatch_score.pkl + pam_scores.pkl.  The tables become
+    the module's current ones and are returned as (mm[20,4,4], pam[16])."""
     try:
         with open(os.path.join(modelspath, "mismatch_score.pkl"), "rb") as f:
             mmscores = pickle.load(f)
@@ -53,6 +54,7 @@ def load_cfd_tables(modelspath: str, debug: bool) -> None:
     except OSError as e:
         exception_handler(CrisprHawkCfdScoreError, "An error occurred while loading CFD model files", os.EX_NOINPUT, debug, e)
     set_cfd_tables(*cfd_tables_from_dicts(mmscores, pamscores))
+    return _CFD_TABLES
 
 
 def _tables(debug: bool):
