@@ -345,10 +345,15 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
               } else {
                 const int64_t qr = start - ri.startp;
                 if (qr >= ri.lo[s] && qr < ri.hi[s]) {
-                  W2 rc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+                  W2 rc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, ac[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
                   for (int pl = 0; pl < 4; ++pl)
-                    if ((p.need >> pl) & 1u) { rc[pl] = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr); rc[pl].lo &= mlo; rc[pl].hi &= mhi; }
+                    if ((p.need >> pl) & 1u) {  // REF's and this haplotype's slices, all in flight together
+                      rc[pl] = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
+                      ac[pl] = ext_glb(hs.plane[pl] + rowbase, q);
+                    }
+#pragma unroll
+                  for (int pl = 0; pl < 4; ++pl) { rc[pl].lo &= mlo; rc[pl].hi &= mhi; }
                   const bool pamfirst = (p.right != 0) != (s != 0);
                   const int po = pamfirst ? 0 : p.guidelen;
                   const uint64_t pam = s ? p.pam_rev : p.pam_fwd;
@@ -375,9 +380,9 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
                       for (int pl = 0; pl < 4; ++pl) {
                         const bool hot = ((p.need >> pl) & 1u) != 0;
                         if (same && hot == (round == 0)) {
-                          const W2 a = ext_glb(hs.plane[pl] + rowbase, q);
+                          W2 a = ac[pl];
                           W2 b = rc[pl];
-                          if (!hot) b = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
+                          if (!hot) { a = ext_glb(hs.plane[pl] + rowbase, q); b = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr); }
                           same = ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
                         }
                       }
