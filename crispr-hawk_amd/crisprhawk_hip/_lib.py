@@ -19,6 +19,7 @@ HAWK_E_IUPAC = -4
 HAWK_E_CFD = -5
 HAWK_E_NODEVICE = -6
 HAWK_E_UNSUPPORTED = -7
+HAWK_E_COMM = -8
 
 EXPORTS = [
     "hawk_device_count", "hawk_init", "hawk_destroy", "hawk_strerror", "hawk_last_hip_error", "hawk_stream",
@@ -27,7 +28,9 @@ EXPORTS = [
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
     "hawk_table_collapse", "hawk_table_collapse_download", "hawk_gt_parse", "hawk_gt_destroy", "hawk_gt_codes", "hawk_gt_lists",
-    "hawk_gt_lists_download",
+    "hawk_gt_lists_download", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run",
+    "hawk_xplan_destroy", "hawk_hapset_set_ref_partner_range", "hawk_xplan_set_ref_partner_range", "hawk_table_collapse_ex", "hawk_table_collapse_export", "hawk_comm_unique_id", "hawk_comm_init",
+    "hawk_comm_destroy", "hawk_comm_last_error", "hawk_comm_allgather_u64", "hawk_comm_gatherv", "hawk_table_gather",
 ]
 
 
@@ -38,6 +41,10 @@ class HawkLibraryError(RuntimeError):
 
 class HawkDeviceError(RuntimeError):
     """No MI355X visible / HIP failure.  There is deliberately no CPU path."""
+
+
+class HawkCommError(RuntimeError):
+    """RCCL failure (or librccl.so missing) in the multi-GPU exchange."""
 
 
 class HawkStatusError(RuntimeError):
@@ -99,6 +106,9 @@ def lib() -> C.CDLL:
         L.hawk_hapset_destroy.restype = None
         L.hawk_table_destroy.restype = None
         L.hawk_gt_destroy.restype = None
+        L.hawk_xplan_destroy.restype = None
+        L.hawk_comm_destroy.restype = None
+        L.hawk_comm_last_error.restype = C.c_char_p
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is C.c_int:
@@ -114,6 +124,8 @@ def strerror(status: int) -> str:
 def check(status: int, where: str) -> None:
     if status != HAWK_OK:
         detail = lib().hawk_last_hip_error().decode() if status == HAWK_E_HIP else ""
+        if status == HAWK_E_COMM:
+            raise HawkCommError(f"{where}: {lib().hawk_comm_last_error().decode()}")
         if status in (HAWK_E_HIP, HAWK_E_NODEVICE):
             raise HawkDeviceError(f"{where}: {strerror(status)} {detail}")
         raise HawkStatusError(status, where, detail)

@@ -92,9 +92,17 @@ def expand_haplotype(ref: np.ndarray, startp: int, variants: Sequence[Tuple[int,
     return out, PosSegments(seg_rel[keep], seg_gen[keep], len(out))
 
 
-def scan_bounds(seg: PosSegments, region_start: int, region_stop: int, pamlen: int, padding: int = 100) -> Tuple[int, int]:
-    """compute_scan_start_stop (search_guides.py:49-84); region_start/stop are the padded
-    coordinates.  KeyError where the reference's dict lookup fails."""
+def scan_start(seg: PosSegments, region_start: int, padding: int = 100) -> int:
+    """Start half of compute_scan_start_stop (search_guides.py:68-70): posmap_rev[region.start + 100]."""
+    start_p = region_start + padding
+    r = seg.rev(start_p)
+    if r < 0:
+        raise KeyError(start_p)
+    return r
+
+
+def scan_stop(seg: PosSegments, region_stop: int, pamlen: int, padding: int = 100) -> int:
+    """Stop half (search_guides.py:71-84): a deleted stop position walks forward to the next mapped one."""
     stop_p = region_stop - padding
     if seg.rev(stop_p) < 0:
         upper = seg.max_gen()
@@ -105,9 +113,11 @@ def scan_bounds(seg: PosSegments, region_start: int, region_stop: int, pamlen: i
     r = seg.rev(stop_p)
     if r < 0:
         raise KeyError(stop_p)
-    scan_stop = r - pamlen + 1
-    start_p = region_start + padding
-    r = seg.rev(start_p)
-    if r < 0:
-        raise KeyError(start_p)
-    return r, scan_stop
+    return r - pamlen + 1
+
+
+def scan_bounds(seg: PosSegments, region_start: int, region_stop: int, pamlen: int, padding: int = 100) -> Tuple[int, int]:
+    """compute_scan_start_stop (search_guides.py:49-84); region_start/stop are the padded
+    coordinates.  KeyError where the reference's dict lookup fails."""
+    stop = scan_stop(seg, region_stop, pamlen, padding)
+    return scan_start(seg, region_start, padding), stop

@@ -135,15 +135,7 @@ class DeviceHapSet:
         self.set_meta(haps)
 
     def set_meta(self, haps: Sequence[HostHaplotype]) -> None:
-        is_ref = np.array([1 if h.is_ref else 0 for h in haps], dtype=np.uint8)
-        ss = np.array([h.scan[0] for h in haps], dtype=np.int32)
-        se = np.array([h.scan[1] for h in haps], dtype=np.int32)
-        seg_off = np.zeros(self.n_hap + 1, dtype=np.uint32)
-        seg_off[1:] = np.cumsum([len(h.seg.rel) for h in haps])
-        seg_rel = np.concatenate([h.seg.rel for h in haps]).astype(np.uint32)
-        seg_gen = np.concatenate([h.seg.gen for h in haps]).astype(np.int64)
-        refs = np.flatnonzero(is_ref)
-        self.ref_index = int(refs[0]) if len(refs) else -1
+        is_ref, ss, se, seg_off, seg_rel, seg_gen, self.ref_index = _meta_arrays(haps)
         self.is_ref = is_ref
         _lib.check(self._L.hawk_hapset_set_meta(self._h, _p(is_ref), _p(ss), _p(se), _p(seg_off), _p(seg_rel), _p(seg_gen),
                                                 self.ref_index), "hawk_hapset_set_meta")
@@ -193,9 +185,10 @@ class DeviceHapSet:
 
     def search(self, pam_bits: int, pam_bitsrc: int, pamlen: int, guidelen: int, right: bool,
                cfd_mm: Optional[np.ndarray] = None, cfd_pam: Optional[np.ndarray] = None,
-               download: bool = True, collapse: bool = False) -> "GuideTable":
+               download: bool = True, collapse: bool = False, cfd_na_on_ambiguous: bool = False) -> "GuideTable":
         """One fused search.  `collapse` additionally groups the rows the report merges (GuideTable.collapse)
-        while the table is still in HBM."""
+        while the table is still in HBM.  `cfd_na_on_ambiguous`: a guide with a non-ACGT base under a CFD lookup
+        scores NA instead of raising as the reference does (cfdscore.py:93-94) - for regions with N runs."""
         L = self._L
         sp = _lib.SearchParams()
         sp.pam_fwd, sp.pam_rev, sp.pamlen, sp.guidelen, sp.right = pam_bits, pam_bitsrc, pamlen, guidelen, int(bool(right))
@@ -204,7 +197,7 @@ class DeviceHapSet:
             mm = np.ascontiguousarray(cfd_mm, dtype=np.float64).reshape(20, 4, 4)
             pt = np.ascontiguousarray(cfd_pam, dtype=np.float64).reshape(16)
             keep = [mm, pt]
-            sp.score_cfdon, sp.cfd_mm, sp.cfd_pam = 1, mm.ctypes.data, pt.ctypes.data
+            sp.score_cfdon, sp.cfd_mm, sp.cfd_pam = (2 if cfd_na_on_ambiguous else 1), mm.ctypes.data, pt.ctypes.data
         t = C.c_void_p()
         tm = _lib.Timing()
         _lib.check(L.hawk_search(self._h, C.byref(sp), C.byref(t), C.byref(tm)), "hawk_search")
@@ -218,12 +211,102 @@ class DeviceHapSet:
         return tab
 
 
+class ExpansionPlan:
+    """hawk_xplan: the inputs of a device haplotype expansion kept in HBM; `run()` writes a fresh DeviceHapSet from them
+    with device work only (the per-tile step of a whole-contig search)."""
+
+    def __init__(self, handle, hap_len: np.ndarray, device: Optional[int] = None):
+        self._L = _lib.lib()
+        self._x = handle
+        self.hap_len = np.asarray(hap_len, dtype=np.uint32)
+        self.n_hap = len(self.hap_len)
+        self.device = device
+        self.ref_index = -1
+        self.is_ref = None
+
+    def set_meta(self, haps: Sequence["HostHaplotype"]) -> None:
+        is_ref, ss, se, seg_off, seg_rel, seg_gen, ref_index = _meta_arrays(haps)
+        _lib.check(self._L.hawk_xplan_set_meta(self._x, _p(is_ref), _p(ss), _p(se), _p(seg_off), _p(seg_rel), _p(seg_gen), ref_index),
+                   "hawk_xplan_set_meta")
+        self.ref_index, self.is_ref = ref_index, is_ref
+
+    def run(self, want_hash: bool = False, timed: bool = False):
+        """-> (DeviceHapSet, hashes[n_hap, 2] or None, kernel ms or None)"""
+        handle = C.c_void_p()
+        hashes = np.zeros((self.n_hap, 2), dtype=np.uint64) if want_hash else None
+        ms = C.c_float(0)
+        _lib.check(self._L.hawk_xplan_run(self._x, C.byref(handle), _p(hashes), C.byref(ms) if (timed or want_hash) else None),
+                   "hawk_xplan_run")
+        ds = DeviceHapSet.from_handle(handle, self.hap_len, self.device)
+        ds.ref_index, ds.is_ref = self.ref_index, self.is_ref
+        return ds, hashes, (ms.value if (timed or want_hash) else None)
+
+    def close(self) -> None:
+        if getattr(self, "_x", None):
+            self._L.hawk_xplan_destroy(self._x)
+            self._x = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _meta_arrays(haps: Sequence["HostHaplotype"]):
+    n = len(haps)
+    is_ref = np.array([1 if h.is_ref else 0 for h in haps], dtype=np.uint8)
+    ss = np.array([h.scan[0] for h in haps], dtype=np.int32)
+    se = np.array([h.scan[1] for h in haps], dtype=np.int32)
+    seg_off = np.zeros(n + 1, dtype=np.uint32)
+    seg_off[1:] = np.cumsum([len(h.seg.rel) for h in haps])
+    seg_rel = np.concatenate([h.seg.rel for h in haps]).astype(np.uint32)
+    seg_gen = np.concatenate([h.seg.gen for h in haps]).astype(np.int64)
+    refs = np.flatnonzero(is_ref)
+    return is_ref, ss, se, seg_off, seg_rel, seg_gen, (int(refs[0]) if len(refs) else -1)
+
+
+class GroupTable:
+    """Report groups of one collapsed guide table: representative rows as columns + CSR member haplotypes."""
+
+    def __init__(self, guidelen: int, pamlen: int, right: bool, n_groups: int, n_rows: int):
+        self.guidelen, self.pamlen, self.right, self.n_groups, self.n_rows = guidelen, pamlen, right, n_groups, n_rows
+        ng = n_groups
+        self.rep_row = np.empty(ng, np.uint32); self.pos = np.empty(ng, np.uint32); self.strand = np.empty(ng, np.uint8)
+        self.start = np.empty(ng, np.int64); self.stop = np.empty(ng, np.int64); self.flags = np.empty(ng, np.uint8)
+        self.cfdon = np.empty(ng, np.float64); self.win = np.empty((5, ng), np.uint64)
+        self.member_hap = np.empty(n_rows, np.uint32)
+        self.member_off = np.zeros(ng + 1, np.int64)
+        self.gc_num = np.zeros(ng, np.uint8); self.gc_den = np.zeros(ng, np.uint8)
+
+    @property
+    def window_len(self) -> int:
+        return self.guidelen + self.pamlen + 2 * GUIDESEQPAD
+
+    def windows(self, rows: Optional[np.ndarray] = None) -> List[str]:
+        return decode_windows(self.win if rows is None else self.win[:, rows], self.window_len)
+
+
+def decode_windows(win: np.ndarray, W: int) -> List[str]:
+    """[5, n] window slices -> cased strings (bit 0 = leftmost base)."""
+    n = win.shape[1]
+    if n == 0:
+        return []
+    sh = np.arange(W, dtype=np.uint64)
+    code = np.zeros((n, W), dtype=np.uint8)
+    for p in range(5):
+        code |= (((win[p][:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
+    raw = _CODE2CHAR[code].tobytes()
+    return [raw[i * W:(i + 1) * W].decode("ascii") for i in range(n)]
+
+
 class GuideTable:
     """Columnar guide table of one fused search (rows in (haplotype, tile, strand, position) order)."""
 
     def __init__(self, hs: DeviceHapSet, handle, guidelen: int, pamlen: int, right: bool, timing):
         self._hs, self._t = hs, handle
         self.guidelen, self.pamlen, self.right = guidelen, pamlen, right
+        self._timing_struct = timing
         self.timing = {k: getattr(timing, k) for k, _ in timing._fields_}
         n, c, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _lib.check(hs._L.hawk_table_counts(handle, C.byref(n), C.byref(c), C.byref(h)), "hawk_table_counts")
@@ -242,22 +325,42 @@ class GuideTable:
         _lib.check(self._hs._L.hawk_table_download(self._t, ptr(hap), ptr(pos), ptr(strand), ptr(start), ptr(stop),
                                                    ptr(flags), ptr(cfdon), ptr(win)), "hawk_table_download")
 
-    def collapse(self) -> "GuideTable":
+    def collapse(self, flank: Tuple[int, int] = (0, 0), download_perm: bool = True) -> "GuideTable":
         """Group the rows the guide report merges (reports.py:958-1008) on the device, before download():
         `group_perm` (row indices ordered by (start, strand, group)), `group_off` (CSR into it),
-        `gc_num / gc_den` per group (gc_content of the spacer, annotation.py:513-541), `collapse_ms`."""
+        `gc_num / gc_den` per group (gc_content of the spacer, annotation.py:513-541), `collapse_ms`.
+        `flank` = (4, 3) widens the compared sequence to the model scorers' k-mer (scoring.py:50-67): needed when
+        Azimuth / DeepCpf1 columns are on, because the reference groups by the score columns too."""
         if self._t is None:
             raise RuntimeError("collapse() needs the device-resident table: call it before download()")
         ng, ms = C.c_uint64(), C.c_float()
-        _lib.check(self._hs._L.hawk_table_collapse(self._t, C.byref(ng), C.byref(ms)), "hawk_table_collapse")
-        self.n_groups, self.collapse_ms = ng.value, ms.value
-        self.group_perm = np.empty(self.n_rows, np.uint32)
+        _lib.check(self._hs._L.hawk_table_collapse_ex(self._t, int(flank[0]), int(flank[1]), C.byref(ng), C.byref(ms)),
+                   "hawk_table_collapse_ex")
+        self.n_groups, self.collapse_ms, self.collapse_flank = ng.value, ms.value, (int(flank[0]), int(flank[1]))
+        self.group_perm = np.empty(self.n_rows, np.uint32) if download_perm else None
         self.group_off = np.zeros(self.n_groups + 1, np.uint64)
         self.gc_num = np.empty(self.n_groups, np.uint8)
         self.gc_den = np.empty(self.n_groups, np.uint8)
         _lib.check(self._hs._L.hawk_table_collapse_download(self._t, _p(self.group_perm), _p(self.group_off), _p(self.gc_num),
                                                             _p(self.gc_den)), "hawk_table_collapse_download")
         return self
+
+    def export_groups(self) -> "GroupTable":
+        """After collapse(): the group-level view the report is assembled from - one representative row per group (its
+        first member in table order) and every row's haplotype in group order - without downloading the table."""
+        if self._t is None or not hasattr(self, "n_groups"):
+            raise RuntimeError("export_groups() needs collapse() on the device-resident table")
+        ng, n = self.n_groups, self.n_rows
+        g = GroupTable(self.guidelen, self.pamlen, self.right, ng, n)
+        ms = C.c_float()
+        _lib.check(self._hs._L.hawk_table_collapse_export(self._t, _p(g.rep_row), _p(g.pos), _p(g.strand), _p(g.start), _p(g.stop),
+                                                          _p(g.flags), _p(g.cfdon), _p(g.win), _p(g.member_hap), C.byref(ms)),
+                   "hawk_table_collapse_export")
+        g.member_off = self.group_off.astype(np.int64)
+        g.gc_num, g.gc_den = self.gc_num, self.gc_den
+        g.export_ms = ms.value
+        g.n_candidates, g.n_hits = self.n_candidates, self.n_hits
+        return g
 
     def download(self) -> "GuideTable":
         if self._downloaded:
@@ -285,16 +388,7 @@ class GuideTable:
     def windows(self, rows: Optional[np.ndarray] = None) -> List[str]:
         """Guide.sequence of each row: the guidelen+pamlen+20-nt window on the + strand, case
         preserved (search_guides.py:134-160)."""
-        win = self.win if rows is None else self.win[:, rows]
-        n, W = win.shape[1], self.window_len
-        if n == 0:
-            return []
-        sh = np.arange(W, dtype=np.uint64)
-        code = np.zeros((n, W), dtype=np.uint8)
-        for p in range(5):
-            code |= (((win[p][:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
-        raw = _CODE2CHAR[code].tobytes()
-        return [raw[i * W:(i + 1) * W].decode("ascii") for i in range(n)]
+        return decode_windows(self.win if rows is None else self.win[:, rows], self.window_len)
 
     def emission_order(self) -> np.ndarray:
         """Row permutation giving the reference's pre-dedup emission order: haplotype, then strand

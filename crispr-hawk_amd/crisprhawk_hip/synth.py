@@ -217,3 +217,97 @@ def deepcpf1_weights(seed: int = 2002) -> dict:
         w1=n(80, 1200), b1=n(80), w2=n(40, 80), b2=n(40),
         w3=n(40, 40), b3=n(40), w4=n(1, 40), b4=n(1),
     )
+
+
+# --- C4: a whole contig with a phased panel too large to hold as a dense matrix ------------------
+class BlockGenotypes:
+    """The SURVEY §8(d) genotype recipe (every chromosome copy carries the alt independently with probability AF) as a
+    function of (variant, column) that is generated on demand: the matrix is cut into fixed blocks of `vblock` variants
+    x `cblock` columns, each block drawn from its own `default_rng([seed, variant block, column block])`, so any
+    rectangle - a tile's variants x a rank's columns - is reproducible whatever the tiling or the number of ranks.
+    Interface of tiling.DenseGenotypes: carried(var_lo, var_hi, col_lo, col_hi)."""
+
+    def __init__(self, seed: int, af: np.ndarray, n_cols: int, vblock: int = 4096, cblock: int = 626):
+        self.seed, self.af, self.n_cols, self.vblock, self.cblock = seed, np.asarray(af, dtype=np.float32), n_cols, vblock, cblock
+
+    def block(self, vb: int, cb: int) -> np.ndarray:
+        v0, v1 = vb * self.vblock, min(len(self.af), (vb + 1) * self.vblock)
+        c0, c1 = cb * self.cblock, min(self.n_cols, (cb + 1) * self.cblock)
+        rng = np.random.default_rng([self.seed, vb, cb])
+        return rng.random((v1 - v0, c1 - c0), dtype=np.float32) < self.af[v0:v1, None]
+
+    def dense(self, var_lo: int, var_hi: int, col_lo: int, col_hi: int) -> np.ndarray:
+        out = np.zeros((var_hi - var_lo, col_hi - col_lo), dtype=bool)
+        for vb in range(var_lo // self.vblock, (max(var_hi, var_lo + 1) - 1) // self.vblock + 1):
+            v0 = vb * self.vblock
+            a, b = max(var_lo, v0), min(var_hi, v0 + self.vblock)
+            if b <= a:
+                continue
+            for cb in range(col_lo // self.cblock, (max(col_hi, col_lo + 1) - 1) // self.cblock + 1):
+                c0 = cb * self.cblock
+                c, d = max(col_lo, c0), min(col_hi, c0 + self.cblock)
+                if d <= c:
+                    continue
+                out[a - var_lo:b - var_lo, c - col_lo:d - col_lo] = self.block(vb, cb)[a - v0:b - v0, c - c0:d - c0]
+        return out
+
+    def carried(self, var_lo: int, var_hi: int, col_lo: int, col_hi: int):
+        counts = np.zeros(col_hi - col_lo, dtype=np.int64)
+        parts = []
+        step = self.cblock
+        for c in range(col_lo, col_hi, step):  # column slabs: the transpose scan stays cache-sized
+            d = min(col_hi, c + step)
+            sub = self.dense(var_lo, var_hi, c, d)
+            sites, cols = np.nonzero(sub)  # variant-major scan, then a stable (radix) sort by column: (column, variant) order
+            order = np.argsort(cols.astype(np.uint16), kind="stable")
+            counts[c - col_lo:d - col_lo] = np.bincount(cols, minlength=d - c)
+            parts.append(sites[order].astype(np.uint32))
+        return counts, (np.concatenate(parts) if parts else np.zeros(0, np.uint32))
+
+
+def contig_panel(seed: int, contig: str, contig_len: int, n_block: int, n_samples: int, sites_per_mb: float = 31_000.0,
+                 frac_snv: float = 0.90, frac_del: float = 0.05, max_indel: int = 8):
+    """C4: an iid ACGT contig with one leading N block and a phased panel at 1000G density over the
+    non-N part, fully vectorised (1.25 M sites for chr22).  Returns (contig bases as a uint8 array, tiling.VariantPanel
+    with BlockGenotypes).  Sites are non-overlapping (one per slot of max_indel + 2 bases) and never touch N."""
+    from .tiling import VariantPanel
+    rng = np.random.default_rng(seed)
+    seq = np.empty(contig_len, dtype=np.uint8)
+    seq[:n_block] = ord("N")
+    seq[n_block:] = _ACGT[rng.integers(0, 4, size=contig_len - n_block)]
+    span = max_indel + 2
+    lo = n_block + 201            # 1-based first allowed position: clear of the N block and of the region pad
+    hi = contig_len - 200 - span  # keep the tail free: inserted bases push later variants towards the region end
+    n_slots = max(0, (hi - lo) // span)
+    n_sites = min(n_slots, int(round(sites_per_mb * (contig_len - n_block) / 1e6)))
+    slots = np.sort(rng.choice(n_slots, size=n_sites, replace=False))
+    pos = lo + slots * span + rng.integers(0, 2, size=n_sites)
+    kinds = rng.random(n_sites)
+    lens = np.minimum(rng.geometric(0.5, size=n_sites), max_indel)
+    n_cols = 2 * n_samples
+    af = np.exp(rng.uniform(np.log(1.0 / n_cols), np.log(0.5), size=n_sites))
+    alt_pick = rng.integers(1, 4, size=n_sites)
+    ins = rng.integers(0, 4, size=(n_sites, max_indel))
+    code = np.zeros(256, dtype=np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    refb = seq[pos - 1]
+    is_snv = kinds < frac_snv
+    is_del = ~is_snv & (kinds < frac_snv + frac_del)
+    ref: List[str] = [None] * n_sites
+    alt: List[str] = [None] * n_sites
+    refc = [chr(c) for c in refb.tolist()]
+    snv_alt = _ACGT[(code[refb] + alt_pick) % 4]
+    sa = [chr(c) for c in snv_alt.tolist()]
+    blob = seq.tobytes()
+    for k in np.flatnonzero(is_snv).tolist():
+        ref[k], alt[k] = refc[k], sa[k]
+    for k in np.flatnonzero(is_del).tolist():
+        p = int(pos[k])
+        ref[k], alt[k] = blob[p - 1:p + int(lens[k])].decode(), refc[k]
+    for k in np.flatnonzero(~is_snv & ~is_del).tolist():
+        ref[k], alt[k] = refc[k], refc[k] + "".join("ACGT"[b] for b in ins[k, :int(lens[k])])
+    vid = [f"{contig}-{p}-{r}/{a}" for p, r, a in zip(pos.tolist(), ref, alt)]
+    samples = [f"S{i:04d}" for i in range(n_samples)]
+    return seq, VariantPanel(pos.astype(np.int64), ref, alt, vid, af.astype(np.float64), samples,
+                             BlockGenotypes(seed + 1, af, n_cols))

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .expand import expand_haplotype, scan_bounds
+from .expand import expand_haplotype, scan_bounds, scan_start, scan_stop
 from .hapset import HostHaplotype, PosSegments
 from .synth import SynthRegion
 
@@ -114,15 +114,61 @@ def _variant_table(pos: np.ndarray, refs: List[str], alts: List[str], seq: str, 
     return r0, span, chain, altlen, alt_off, alt_codes
 
 
+class ScanOwnership:
+    """Which PAM positions of a haplotype row this set scans, for a row string that is one tile of a larger region
+    (tiling.py).  `own_lo` / `own_hi`: genomic positions of the seams (None = the region's own rule at that end,
+    compute_scan_start_stop, search_guides.py:49-84); a seam maps to the LAST relative position with that genomic
+    position (the reference's posmap_rev rule), walking forward when the position is deleted - the same rule in both
+    neighbouring tiles, so every haplotype position is scanned by exactly one of them.  `partner` = the region's scan
+    range in the REF row's relative positions (hawk_hapset_set_ref_partner_range).  `guard`: haplotype bases that must
+    exist on either side of an interior seam so that is_pamhit_in_range (search_guides.py:395-420) cannot fire there."""
+
+    def __init__(self, own_lo: Optional[int], own_hi: Optional[int], partner: Optional[Tuple[int, int]], guard: int):
+        self.own_lo, self.own_hi, self.partner, self.guard = own_lo, own_hi, partner, guard
+
+
+def _seam_rel(seg: PosSegments, g: int) -> int:
+    r = seg.rev(g)
+    if r >= 0:
+        return r
+    upper = seg.max_gen()
+    for p in range(g + 1, upper + 1):
+        r = seg.rev(p)
+        if r >= 0:
+            return r
+    return seg.length
+
+
+def _scan_for(seg: PosSegments, startp: int, stopp: int, pamlen: int, own: Optional[ScanOwnership]) -> Tuple[int, int]:
+    if own is None:
+        return scan_bounds(seg, startp, stopp, pamlen)
+    if own.own_lo is None:
+        lo = scan_start(seg, startp)
+    if own.own_hi is None:
+        hi = scan_stop(seg, stopp, pamlen)
+    if own.own_lo is not None:
+        lo = _seam_rel(seg, own.own_lo)
+        if lo < own.guard:
+            raise ValueError("tile flank too small: a guide window at the seam would leave the tile (left)")
+    if own.own_hi is not None:
+        hi = _seam_rel(seg, own.own_hi)
+        if hi + own.guard > seg.length:
+            raise ValueError("tile flank too small: a guide window at the seam would leave the tile (right)")
+    return lo, max(lo, hi)
+
+
 def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, samples: List[str], tab, live: np.ndarray,
-                 counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device):
+                 counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device,
+                 own: Optional[ScanOwnership] = None, keep_plan: bool = False):
     """Common tail of the device expansions: rows = REF + every chromosome copy (column) with a non-empty carried
-    list, in column order.  Calls hawk_hapset_expand, then labels / homozygous merge / collapse on the 16-byte
-    content hashes (haplotypes.py:232-368) and the position-map segments + scan bounds of every kept row."""
+    list, in column order.  Builds the expansion plan (hawk_xplan_create), runs it, then labels / homozygous merge /
+    collapse on the 16-byte content hashes (haplotypes.py:232-368) and the position-map segments + scan bounds of every
+    kept row.  With `keep_plan` the plan (inputs + metadata resident in HBM) stays attached as `ds.plan`, so the set can
+    be re-expanded with device work only."""
     import ctypes as C
     from . import _lib
     from .expand import HaplotypeBuildError
-    from .hapset import DeviceHapSet, _p
+    from .hapset import DeviceHapSet, ExpansionPlan, _p
     r0, span, chain, altlen, alt_off, alt_codes = tab
     n_ref, nv = len(seq), len(r0)
     n_hap = 1 + len(live)
@@ -133,21 +179,23 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     row_of = np.repeat(np.arange(len(live)), counts_live)
     hap_len = np.concatenate(([n_ref], n_ref + np.asarray(tot_live, dtype=np.int64))).astype(np.uint32)
     if len(hv_idx):
-        if np.any(hv_o.astype(np.int64) + span[hv_idx] > n_ref):  # the reference's clamp (haplotype.py:199-201) would fire
+        # the reference's clamp (haplotype.py:199-201) would fire.  It compares with the REGION's original length, which a
+        # tile of a larger region cannot know (the shift accumulated before the tile): tiled searches do not reproduce
+        # that end-of-region error (divergences).
+        if own is None and np.any(hv_o.astype(np.int64) + span[hv_idx] > n_ref):
             raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
         same_row = row_of[1:] == row_of[:-1]
         if np.any(same_row & (r0[hv_idx[1:]] < r0[hv_idx[:-1]] + span[hv_idx[:-1]])):
             raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
     L = _lib.lib()
-    handle = C.c_void_p()
-    hashes = np.zeros((n_hap, 2), dtype=np.uint64)
-    ms = C.c_float(0)
+    xh = C.c_void_p()
     u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
     arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(alt_codes)]
-    _lib.check(L.hawk_hapset_expand(ref_set._h, nv, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), len(alt_codes),
-                                    n_hap, _p(hv_off), _p(hv_idx), _p(hv_o), _p(hap_len), C.byref(handle), _p(hashes), C.byref(ms)),
-               "hawk_hapset_expand")
-    ds = DeviceHapSet.from_handle(handle, hap_len, device)
+    _lib.check(L.hawk_xplan_create(ref_set._h, nv, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), len(alt_codes),
+                                   n_hap, _p(hv_off), _p(hv_idx), _p(hv_o), _p(hap_len), C.byref(xh)), "hawk_xplan_create")
+    plan = ExpansionPlan(xh, hap_len, device)
+    ds, hashes, ms_val = plan.run(want_hash=True)
+    ms = C.c_float(ms_val)
     # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes) ----------------
     key = [bytes(hashes[i]) for i in range(n_hap)]
     first: Dict[bytes, int] = {key[0]: 0}
@@ -213,25 +261,40 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
         else:
             seg = PosSegments(np.concatenate((zero_rel, seg_rel_all[a:b].astype(np.uint32))),
                               np.concatenate((first_gen, seg_gen_all[a:b])), int(hap_len[r]))
-        haps.append(HostHaplotype(b"", seg, r == 0, scan_bounds(seg, startp, stopp, pamlen)))
+        haps.append(HostHaplotype(b"", seg, r == 0, _scan_for(seg, startp, stopp, pamlen, own)))
     ds.set_meta(haps)
+    if own is not None and own.partner is not None:
+        _lib.check(L.hawk_hapset_set_ref_partner_range(ds._h, int(own.partner[0]), int(own.partner[1])), "hawk_hapset_set_ref_partner_range")
     ds.alias = alias
     ds.host_meta = haps
+    if keep_plan:
+        plan.set_meta(haps)
+        if own is not None and own.partner is not None:
+            _lib.check(L.hawk_xplan_set_ref_partner_range(plan._x, int(own.partner[0]), int(own.partner[1])), "hawk_xplan_set_ref_partner_range")
+        plan.alias, plan.host_meta = alias, haps
+        ds.plan = plan
+    else:
+        plan.close()
     kept = [i for i in range(n_hap) if alias[i] == i]
     return ds, [info[i] for i in kept], float(ms.value), kept
 
 
-def _ref_only_set(seq: str, startp: int, stopp: int, pamlen: int, device):
+def _ref_only_set(seq, startp: int, stopp: int, pamlen: int, device, own: Optional[ScanOwnership] = None):
+    from . import _lib
     from .hapset import DeviceHapSet
-    ref_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
-    ref_seg = PosSegments.identity(startp, len(seq))
-    meta = HostHaplotype(ref_u8, ref_seg, True, scan_bounds(ref_seg, startp, stopp, pamlen))
+    ref_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8) if isinstance(seq, str) else np.asarray(seq, dtype=np.uint8)
+    ref_seg = PosSegments.identity(startp, len(ref_u8))
+    meta = HostHaplotype(ref_u8, ref_seg, True, _scan_for(ref_seg, startp, stopp, pamlen, own))
     ds = DeviceHapSet([meta], device)
+    if own is not None and own.partner is not None:
+        _lib.check(_lib.lib().hawk_hapset_set_ref_partner_range(ds._h, int(own.partner[0]), int(own.partner[1])),
+                   "hawk_hapset_set_ref_partner_range")
     ds.host_meta = [meta]
     return ds
 
 
-def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None):
+def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None, sample_range: Optional[Tuple[int, int]] = None,
+                     keep_plan: bool = False):
     """build_phased_haplotypes() with the sequence work done by hawk_hapset_expand: the host only
     prepares index arrays (which variants each chromosome copy carries, prefix sums of their length
     changes), labels and position-map segments; no haplotype string is ever formed.
@@ -239,13 +302,15 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     (haplotypes.py:274-294; homozygous copies, 326-333) stay in HBM with an empty scan range."""
     seq, startp, stopp = reg.sequence, reg.startp, reg.stopp
     ref_set = _ref_only_set(seq, startp, stopp, pamlen, device)
-    if not reg.variants:
+    slo, shi = sample_range if sample_range is not None else (0, len(reg.samples))
+    if not reg.variants or shi <= slo:
         ref_set.alias = np.zeros(1, dtype=np.int64)
         return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
     tab = _variant_table(np.array([v.pos for v in reg.variants]), [v.ref for v in reg.variants], [v.alt for v in reg.variants], seq, startp)
     r0, span, chain = tab[0], tab[1], tab[2]
-    # which variants each chromosome copy carries, from the in-memory genotype matrix
-    G = np.stack([v.gt.reshape(-1) for v in reg.variants])  # [site, 2*sample]
+    # which variants each chromosome copy carries, from the in-memory genotype matrix (`sample_range`: this rank's block
+    # of the panel - haplotypes shard across GPUs, REF is on every rank)
+    G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
     cols, sites = np.nonzero(G.T)                             # sorted by column, then site
     counts = np.bincount(cols, minlength=G.shape[1])
     live = np.flatnonzero(counts)
@@ -258,7 +323,11 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     hv_o = (r0[hv_idx] + excl).astype(np.int32)
     tot = np.zeros(len(live), dtype=np.int64)
     np.add.at(tot, row_of, c)
-    return _expand_rows(ref_set, seq, startp, stopp, pamlen, reg.samples, tab, live, counts[live], hv_idx, hv_o, tot, device)
+    if len(live) == 0:
+        ref_set.alias = np.zeros(1, dtype=np.int64)
+        return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
+    return _expand_rows(ref_set, seq, startp, stopp, pamlen, reg.samples[slo:shi], tab, live, counts[live], hv_idx, hv_o, tot, device,
+                        keep_plan=keep_plan)
 
 
 class VcfVariants:

@@ -8,80 +8,93 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
-#include "../../include/hawk.h"
-#include "hawk_device.h"
+#include "hawk_host.h"
 
 static thread_local char g_hip_err[256] = "";
+char* hawk_hip_err_buf() { return g_hip_err; }
 
-#define HIPCHK(expr)                                                                         \
-  do {                                                                                       \
-    hipError_t e_ = (expr);                                                                  \
-    if (e_ != hipSuccess) {                                                                  \
-      snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-      return HAWK_E_HIP;                                                                     \
-    }                                                                                        \
-  } while (0)
-
-struct hawk_ctx {
-  int device;
-  hipStream_t stream;
-  hipEvent_t ev[8];
+// ---------------------------------------------------------------------------- caching device allocator
+namespace {
+struct DevPool {
+  std::multimap<size_t, void*> free_;         // cached blocks by size
+  std::unordered_map<void*, size_t> live_;    // blocks handed out
+  size_t cached = 0;
 };
+DevPool g_pool[HAWK_MAX_DEVICES];
+std::mutex g_pool_mu;
+size_t pool_cap() {  // bytes the cache may hold per device (HAWK_POOL_MAX_GB, default 96): beyond it frees go to hipFree
+  static const size_t cap = [] { const char* e = getenv("HAWK_POOL_MAX_GB"); return (size_t)((e ? atof(e) : 96.0) * (double)(1ull << 30)); }();
+  return cap;
+}
+size_t pool_round(size_t b) { return b < (1u << 20) ? (b + 255) / 256 * 256 : (b + (1u << 20) - 1) >> 20 << 20; }
+DevPool* cur_pool() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= HAWK_MAX_DEVICES) return nullptr;
+  return &g_pool[d];
+}
+void pool_trim_locked(DevPool* P) {
+  for (auto& kv : P->free_) (void)hipFree(kv.second);
+  P->free_.clear();
+  P->cached = 0;
+}
+}  // namespace
 
-// grow-only device buffer
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  int reserve(size_t need) {
-    if (need <= bytes) return HAWK_OK;
-    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-    size_t want = need + need / 8 + 256;
-    HIPCHK(hipMalloc(&p, want));
-    bytes = want;
+int hawk_pool_alloc(void** p, size_t bytes) {
+  *p = nullptr;
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  DevPool* P = cur_pool();
+  if (!P) { snprintf(g_hip_err, sizeof(g_hip_err), "hawk_pool_alloc: no current device"); return HAWK_E_HIP; }
+  const size_t want = pool_round(std::max<size_t>(bytes, 1));
+  auto it = P->free_.lower_bound(want);
+  if (it != P->free_.end() && it->first <= want + want / 4 + (1u << 20)) {
+    *p = it->second;
+    P->live_[*p] = it->first;
+    P->cached -= it->first;
+    P->free_.erase(it);
     return HAWK_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) {  // out of memory: give the cache back and try once more
+    (void)hipGetLastError();
+    pool_trim_locked(P);
+    e = hipMalloc(p, want);
+  }
+  if (e != hipSuccess) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e));
+    *p = nullptr;
+    return HAWK_E_HIP;
+  }
+  P->live_[*p] = want;
+  return HAWK_OK;
+}
 
-struct hawk_hapset {
-  hawk_ctx* ctx;
-  uint32_t n_hap, S;
-  uint64_t total_len;
-  std::vector<uint32_t> hap_len;
-  std::vector<int32_t> scan_start, scan_stop;
-  uint32_t* plane[HAWK_PLANES];
-  uint32_t* d_hap_len;
-  uint8_t* d_is_ref;
-  int32_t *d_scan_start, *d_scan_stop;
-  uint32_t *d_seg_off, *d_seg_rel;
-  int64_t* d_seg_gen;
-  int32_t ref_index;
-  bool has_meta;
-  uint32_t bph;            // workgroups (tiles of 1024 words) per haplotype row
-  TileMeta* d_tile_meta;   // [n_hap * bph] per-tile record (haplotype scalars + first position-map segment)
-  int64_t ref_startp;
-  int64_t min_gen, max_gen;  // range of genomic positions the position maps reach (collapse sort key)
-  uint64_t cols_cap = 0;      // rows the guide-table columns currently hold (0: never reserved)
-  std::vector<double> cfd_host;  // the CFD tables resident in `cfd`
-  // workspace reused across searches
-  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
-  DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
-  DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
-  DevBuf colsA[8];
-};
+void hawk_pool_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  for (int d = 0; d < HAWK_MAX_DEVICES; ++d) {  // the block's own pool (the current device may differ at teardown)
+    DevPool* P = &g_pool[d];
+    auto it = P->live_.find(p);
+    if (it == P->live_.end()) continue;
+    const size_t sz = it->second;
+    P->live_.erase(it);
+    if (P->cached + sz > pool_cap()) { (void)hipFree(p); return; }
+    P->free_.emplace(sz, p);
+    P->cached += sz;
+    return;
+  }
+  (void)hipFree(p);  // not ours
+}
 
-struct hawk_table {
-  hawk_hapset* hs;
-  uint64_t n_rows, n_cand, n_hits, cap;
-  GuideCols cols;  // points into hs->colsA or colsB
-  uint32_t guidelen, pamlen, right;
-  uint64_t n_groups;  // valid after hawk_table_collapse
-  bool collapsed;
-};
+void hawk_pool_trim() {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  if (DevPool* P = cur_pool()) pool_trim_locked(P);
+}
 
 extern "C" {
 
@@ -95,6 +108,7 @@ const char* hawk_strerror(int s) {
     case HAWK_E_CFD: return "non-ACGT base under a CFD table lookup";
     case HAWK_E_NODEVICE: return "no GPU device visible";
     case HAWK_E_UNSUPPORTED: return "parameter outside supported range";
+    case HAWK_E_COMM: return "RCCL failure";
     default: return "unknown status";
   }
 }
@@ -141,7 +155,7 @@ int hawk_sync(hawk_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------- hapset
-int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, hawk_hapset** out) {
+static int hapset_create_impl(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, bool zero_planes, hawk_hapset** out) {
   if (!ctx || !n_hap || !hap_len || !out) return HAWK_E_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   hawk_hapset* hs = new (std::nothrow) hawk_hapset();
@@ -158,27 +172,39 @@ int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, h
   }
   hs->S = (maxw + 2 + 3) / 4 * 4;
   const size_t words = (size_t)n_hap * hs->S;
-  for (int p = 0; p < HAWK_PLANES; ++p) {
-    hs->plane[p] = nullptr;
-    HIPCHK(hipMalloc(&hs->plane[p], words * 4));
-    HIPCHK(hipMemsetAsync(hs->plane[p], 0, words * 4, ctx->stream));
-  }
-  HIPCHK(hipMalloc(&hs->d_hap_len, n_hap * 4));
-  HIPCHK(hipMemcpyAsync(hs->d_hap_len, hap_len, n_hap * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMalloc(&hs->d_is_ref, n_hap));
-  HIPCHK(hipMalloc(&hs->d_scan_start, n_hap * 4));
-  HIPCHK(hipMalloc(&hs->d_scan_stop, n_hap * 4));
-  HIPCHK(hipMalloc(&hs->d_seg_off, (n_hap + 1) * 4));
-  hs->d_seg_rel = nullptr;
-  hs->d_seg_gen = nullptr;
+  for (int p = 0; p < HAWK_PLANES; ++p) hs->plane[p] = nullptr;
+  hs->d_hap_len = nullptr; hs->d_is_ref = nullptr; hs->d_scan_start = nullptr; hs->d_scan_stop = nullptr;
+  hs->d_seg_off = nullptr; hs->d_seg_rel = nullptr; hs->d_seg_gen = nullptr; hs->d_tile_meta = nullptr;
   hs->bph = (hs->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
-  hs->d_tile_meta = nullptr;
-  HIPCHK(hipMalloc(&hs->d_tile_meta, (size_t)n_hap * hs->bph * sizeof(TileMeta)));
   hs->ref_startp = 0;
   hs->ref_index = -1;
   hs->has_meta = false;
+  int rc = HAWK_OK;
+  for (int p = 0; p < HAWK_PLANES && !rc; ++p) rc = hawk_pool_alloc((void**)&hs->plane[p], words * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_hap_len, (size_t)n_hap * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_is_ref, n_hap);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_scan_start, (size_t)n_hap * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_scan_stop, (size_t)n_hap * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_off, (size_t)(n_hap + 1) * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_tile_meta, (size_t)n_hap * hs->bph * sizeof(TileMeta));
+  if (rc) { hawk_hapset_destroy(hs); return rc; }
+  if (zero_planes)
+    for (int p = 0; p < HAWK_PLANES; ++p) HIPCHK(hipMemsetAsync(hs->plane[p], 0, words * 4, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_hap_len, hap_len, (size_t)n_hap * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *out = hs;
+  return HAWK_OK;
+}
+
+int hawk_hapset_create(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, hawk_hapset** out) {
+  return hapset_create_impl(ctx, n_hap, hap_len, true, out);
+}
+
+int hawk_release_cached_memory(hawk_ctx* ctx) {
+  if (!ctx) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hawk_pool_trim();
   return HAWK_OK;
 }
 
@@ -186,17 +212,16 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   if (!hs) return;
   (void)hipSetDevice(hs->ctx->device);
   (void)hipStreamSynchronize(hs->ctx->stream);
-  for (int p = 0; p < HAWK_PLANES; ++p) (void)hipFree(hs->plane[p]);
-  (void)hipFree(hs->d_hap_len); (void)hipFree(hs->d_is_ref); (void)hipFree(hs->d_scan_start);
-  (void)hipFree(hs->d_scan_stop); (void)hipFree(hs->d_seg_off);
-  if (hs->d_seg_rel) (void)hipFree(hs->d_seg_rel);
-  if (hs->d_seg_gen) (void)hipFree(hs->d_seg_gen);
-  (void)hipFree(hs->d_tile_meta);
+  for (int p = 0; p < HAWK_PLANES; ++p) hawk_pool_free(hs->plane[p]);
+  hawk_pool_free(hs->d_hap_len); hawk_pool_free(hs->d_is_ref); hawk_pool_free(hs->d_scan_start);
+  hawk_pool_free(hs->d_scan_stop); hawk_pool_free(hs->d_seg_off);
+  hawk_pool_free(hs->d_seg_rel); hawk_pool_free(hs->d_seg_gen); hawk_pool_free(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
                     &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
+  for (auto& b : hs->crep) b.release();
   delete hs;
 }
 
@@ -214,8 +239,8 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
     if (seq_off[h + 1] - seq_off[h] != hs->hap_len[h]) return HAWK_E_INVALID;
   uint64_t* d_off = nullptr;
   unsigned long long* d_bad = nullptr;
-  HIPCHK(hipMalloc(&d_off, (hs->n_hap + 1) * 8));
-  HIPCHK(hipMalloc(&d_bad, 8));
+  POOLCHK(&d_off, (hs->n_hap + 1) * 8);
+  POOLCHK(&d_bad, 8);
   HIPCHK(hipMemcpyAsync(d_off, seq_off, (hs->n_hap + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
   // stage the ASCII in batches of whole haplotypes (<= 256 MiB of HBM staging)
@@ -224,7 +249,7 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
   for (auto l : hs->hap_len) maxlen = std::max<uint64_t>(maxlen, l);
   const uint64_t stage_bytes = std::max(kStage, maxlen);
   uint8_t* d_stage = nullptr;
-  HIPCHK(hipMalloc(&d_stage, std::min<uint64_t>(stage_bytes, std::max<uint64_t>(hs->total_len, 1))));
+  POOLCHK(&d_stage, std::min<uint64_t>(stage_bytes, std::max<uint64_t>(hs->total_len, 1)));
   uint32_t h0 = 0;
   while (h0 < hs->n_hap) {
     uint32_t h1 = h0;
@@ -238,7 +263,7 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
   }
   unsigned long long bad = ~0ull;
   HIPCHK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
-  (void)hipFree(d_stage); (void)hipFree(d_off); (void)hipFree(d_bad);
+  hawk_pool_free(d_stage); hawk_pool_free(d_off); hawk_pool_free(d_bad);
   if (bad != ~0ull) {
     if (bad_index) *bad_index = bad;
     return HAWK_E_IUPAC;
@@ -246,63 +271,82 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
   return HAWK_OK;
 }
 
-int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
-                         const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index) {
-  if (!hs || !is_ref || !scan_start || !scan_stop || !seg_off || !seg_rel || !seg_gen) return HAWK_E_INVALID;
-  if (ref_index >= (int32_t)hs->n_hap) return HAWK_E_INVALID;
-  hawk_ctx* ctx = hs->ctx;
-  HIPCHK(hipSetDevice(ctx->device));
-  const uint32_t n = hs->n_hap;
+// Host half of set_meta: validate what the kernels will trust and build the per-tile records.
+static int meta_build(uint32_t n, const std::vector<uint32_t>& hap_len, uint32_t bph, const uint8_t* is_ref, const int32_t* scan_start,
+                      const int32_t* scan_stop, const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen,
+                      int32_t ref_index, std::vector<TileMeta>* t0, int64_t* min_gen, int64_t* max_gen) {
+  if (!is_ref || !scan_start || !scan_stop || !seg_off || !seg_rel || !seg_gen) return HAWK_E_INVALID;
+  if (ref_index >= (int32_t)n) return HAWK_E_INVALID;
   for (uint32_t h = 0; h < n; ++h) {
-    // the kernels trust these: validate on the host before anything is launched
     if (seg_off[h + 1] <= seg_off[h] || seg_rel[seg_off[h]] != 0) return HAWK_E_INVALID;
-    if (scan_start[h] < 0 || scan_stop[h] > (int32_t)hs->hap_len[h]) return HAWK_E_INVALID;
+    if (scan_start[h] < 0 || scan_stop[h] > (int32_t)hap_len[h]) return HAWK_E_INVALID;
     for (uint32_t k = seg_off[h] + 1; k < seg_off[h + 1]; ++k)
       if (seg_rel[k] <= seg_rel[k - 1]) return HAWK_E_INVALID;
   }
   if (ref_index >= 0 && seg_off[ref_index + 1] - seg_off[ref_index] != 1) return HAWK_E_INVALID;
-  const uint32_t nseg = seg_off[n];
-  if (hs->d_seg_rel) { (void)hipFree(hs->d_seg_rel); hs->d_seg_rel = nullptr; }
-  if (hs->d_seg_gen) { (void)hipFree(hs->d_seg_gen); hs->d_seg_gen = nullptr; }
-  HIPCHK(hipMalloc(&hs->d_seg_rel, (size_t)nseg * 4));
-  HIPCHK(hipMalloc(&hs->d_seg_gen, (size_t)nseg * 8));
-  HIPCHK(hipMemcpyAsync(hs->d_is_ref, is_ref, n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hs->d_scan_start, scan_start, n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hs->d_scan_stop, scan_stop, n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hs->d_seg_off, seg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hs->d_seg_rel, seg_rel, (size_t)nseg * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hs->d_seg_gen, seg_gen, (size_t)nseg * 8, hipMemcpyHostToDevice, ctx->stream));
-  {
-    // first segment each tile needs: the last one starting at or before the tile's first base
-    std::vector<TileMeta> t0((size_t)n * hs->bph);
-    for (uint32_t h = 0; h < n; ++h) {
-      const uint32_t* b = seg_rel + seg_off[h];
-      const uint32_t* e = seg_rel + seg_off[h + 1];
-      for (uint32_t blk = 0; blk < hs->bph; ++blk) {
-        const uint32_t q0 = blk * HAWK_BLOCK * 128u;
-        const uint32_t* it = std::upper_bound(b, e, q0);  // first seg_rel > q0
-        TileMeta& t = t0[(size_t)h * hs->bph + blk];
-        t.h = h; t.blk = blk; t.hap_len = hs->hap_len[h];
-        t.scan_start = scan_start[h]; t.scan_stop = scan_stop[h]; t.is_ref = is_ref[h] ? 1u : 0u;
-        t.seg0 = (uint32_t)((it - seg_rel) - 1); t.seg_end = seg_off[h + 1];
-      }
+  // first segment each tile needs: the last one starting at or before the tile's first base
+  t0->resize((size_t)n * bph);
+  for (uint32_t h = 0; h < n; ++h) {
+    const uint32_t* sb = seg_rel + seg_off[h];
+    const uint32_t* se = seg_rel + seg_off[h + 1];
+    const uint32_t* it = sb;
+    for (uint32_t blk = 0; blk < bph; ++blk) {
+      const uint32_t q0 = blk * HAWK_BLOCK * 128u;
+      while (it != se && *it <= q0) ++it;  // first seg_rel > q0 (tiles ascend: one walk per row)
+      TileMeta& t = (*t0)[(size_t)h * bph + blk];
+      t.h = h; t.blk = blk; t.hap_len = hap_len[h];
+      t.scan_start = scan_start[h]; t.scan_stop = scan_stop[h]; t.is_ref = is_ref[h] ? 1u : 0u;
+      t.seg0 = (uint32_t)((it - seg_rel) - 1); t.seg_end = seg_off[h + 1];
     }
-    HIPCHK(hipMemcpyAsync(hs->d_tile_meta, t0.data(), t0.size() * sizeof(TileMeta), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  hs->ref_startp = ref_index >= 0 ? seg_gen[seg_off[ref_index]] : 0;
-  hs->min_gen = INT64_MAX; hs->max_gen = INT64_MIN;
+  *min_gen = INT64_MAX; *max_gen = INT64_MIN;
   for (uint32_t h = 0; h < n; ++h)
     for (uint32_t k = seg_off[h]; k < seg_off[h + 1]; ++k) {
-      const uint32_t end = k + 1 < seg_off[h + 1] ? seg_rel[k + 1] : hs->hap_len[h];
-      hs->min_gen = std::min(hs->min_gen, seg_gen[k]);
-      hs->max_gen = std::max(hs->max_gen, seg_gen[k] + (int64_t)(end - seg_rel[k]));
+      const uint32_t end = k + 1 < seg_off[h + 1] ? seg_rel[k + 1] : hap_len[h];
+      *min_gen = std::min(*min_gen, seg_gen[k]);
+      *max_gen = std::max(*max_gen, seg_gen[k] + (int64_t)(end - seg_rel[k]));
     }
+  return HAWK_OK;
+}
+
+int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
+                         const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index) {
+  if (!hs) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t n = hs->n_hap;
+  std::vector<TileMeta> t0;
+  int64_t mn, mx;
+  int rc = meta_build(n, hs->hap_len, hs->bph, is_ref, scan_start, scan_stop, seg_off, seg_rel, seg_gen, ref_index, &t0, &mn, &mx);
+  if (rc) return rc;
+  const uint32_t nseg = seg_off[n];
+  hawk_pool_free(hs->d_seg_rel); hs->d_seg_rel = nullptr;
+  hawk_pool_free(hs->d_seg_gen); hs->d_seg_gen = nullptr;
+  POOLCHK(&hs->d_seg_rel, (size_t)nseg * 4);
+  POOLCHK(&hs->d_seg_gen, (size_t)nseg * 8);
+  HIPCHK(hipMemcpyAsync(hs->d_is_ref, is_ref, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_scan_start, scan_start, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_scan_stop, scan_stop, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_off, seg_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_rel, seg_rel, (size_t)nseg * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_gen, seg_gen, (size_t)nseg * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hs->d_tile_meta, t0.data(), t0.size() * sizeof(TileMeta), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  hs->ref_startp = ref_index >= 0 ? seg_gen[seg_off[ref_index]] : 0;
+  hs->min_gen = mn; hs->max_gen = mx;
   hs->scan_start.assign(scan_start, scan_start + n);
   hs->scan_stop.assign(scan_stop, scan_stop + n);
   hs->ref_index = ref_index;
   hs->has_meta = true;
+  ++hs->cols_gen;  // tables written under the old metadata are stale
+  return HAWK_OK;
+}
+
+int hawk_hapset_set_ref_partner_range(hawk_hapset* hs, int32_t start, int32_t stop) {
+  if (!hs || !hs->has_meta || hs->ref_index < 0) return HAWK_E_INVALID;
+  if (start < 0 || stop > (int32_t)hs->hap_len[hs->ref_index] || stop < start) return HAWK_E_INVALID;
+  hs->has_partner = true; hs->partner_start = start; hs->partner_stop = stop;
+  ++hs->cols_gen;
   return HAWK_OK;
 }
 
@@ -394,15 +438,15 @@ int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t 
   }
   if (nf > cap_fwd || nr > cap_rev || !hits_fwd || !hits_rev) return (nf || nr) ? HAWK_E_CAPACITY : HAWK_OK;
   uint32_t *d_f = nullptr, *d_r = nullptr;
-  HIPCHK(hipMalloc(&d_f, std::max<uint64_t>(nf, 1) * 4));
-  HIPCHK(hipMalloc(&d_r, std::max<uint64_t>(nr, 1) * 4));
+  POOLCHK(&d_f, std::max<uint64_t>(nf, 1) * 4);
+  POOLCHK(&d_r, std::max<uint64_t>(nr, 1) * 4);
   hawk_launch_emit_hits(ctx->stream, d, sp.bph, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
                         hs->offsets.as<uint64_t>(), nf, d_f, d_r);
   HIPCHK(hipGetLastError());
   if (nf) HIPCHK(hipMemcpyAsync(hits_fwd, d_f, nf * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (nr) HIPCHK(hipMemcpyAsync(hits_rev, d_r, nr * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_f); (void)hipFree(d_r);
+  hawk_pool_free(d_f); hawk_pool_free(d_r);
   return HAWK_OK;
 }
 
@@ -437,7 +481,8 @@ int hawk_pam_scan_time(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint
 }
 
 // ---------------------------------------------------------------------------- fused search
-static int reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
+}  // extern "C"
+int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   int rc;
   const size_t sz[8] = {cap * 4, cap * 4, cap, cap * 8, cap * 8, cap, cap * 8, cap * 8 * HAWK_PLANES};
   for (int i = 0; i < 8; ++i) if ((rc = b[i].reserve(std::max<size_t>(sz[i], 16)))) return rc;
@@ -446,9 +491,11 @@ static int reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   c->cfdon = b[6].as<double>(); c->win = b[7].as<uint64_t>(); c->cap = cap;
   return HAWK_OK;
 }
+extern "C" {
 
 int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, hawk_timing* timing) {
   if (!hs || !p || !out || !hs->has_meta) return HAWK_E_INVALID;
+  if (p->score_cfdon > 2) return HAWK_E_INVALID;
   if (p->score_cfdon && (p->right || !p->cfd_mm || !p->cfd_pam || p->pamlen < 2)) return HAWK_E_INVALID;
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -456,6 +503,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   int rc = make_scan_params(hs, p->pam_fwd, p->pam_rev, p->pamlen, p->guidelen, p->right, true, &sp);
   if (rc) return rc;
   const HapSetDev d = make_dev(hs);
+  ++hs->cols_gen;  // the columns are about to be rewritten: earlier tables of this set become stale
   const uint64_t ntile = (uint64_t)hs->n_hap * sp.bph;
   if ((rc = hs->counts.reserve(ntile * 4)) || (rc = hs->offsets.reserve((ntile + 1) * 8)) ||
       (rc = hs->totals.reserve(sizeof(ScanTotals))) || (rc = hs->misc.reserve(512 * 8 + 64)) ||
@@ -484,7 +532,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 512 * 8);
   GuideParams gp;
   gp.pamlen = sp.pamlen; gp.guidelen = sp.guidelen; gp.right = sp.right; gp.L = sp.L;
-  gp.score_cfdon = p->score_cfdon ? 1 : 0;
+  gp.score_cfdon = (int32_t)p->score_cfdon;  // 1: a non-ACGT base under a lookup is HAWK_E_CFD; 2: it scores NaN ("NA")
   gp.cfd_mm = hs->cfd.as<double>(); gp.cfd_pam = hs->cfd.as<double>() + 320; gp.bph = sp.bph;
   RefInfo ri;
   ri.index = hs->ref_index; ri.startp = hs->ref_startp;
@@ -494,8 +542,12 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
       const bool pamfirst = (sp.right != 0) != (s != 0);
       const int po = pamfirst ? 0 : sp.guidelen;
       const int haplen = (int)hs->hap_len[hs->ref_index];
-      ri.lo[s] = std::max(hs->scan_start[hs->ref_index] - po, HAWK_PAD);
-      ri.hi[s] = std::min(hs->scan_stop[hs->ref_index] - po, haplen - sp.L - HAWK_PAD + 1);
+      // where REF has guides a haplotype row can be grouped with: REF's own scan range, or - for a tile of a larger
+      // region - the region's scan range as far as this tile's REF string reaches (hawk_hapset_set_ref_partner_range)
+      const int rs = hs->has_partner ? hs->partner_start : hs->scan_start[hs->ref_index];
+      const int re = hs->has_partner ? hs->partner_stop : hs->scan_stop[hs->ref_index];
+      ri.lo[s] = std::max(rs - po, HAWK_PAD);
+      ri.hi[s] = std::min(re - po, haplen - sp.L - HAWK_PAD + 1);
     }
   }
   GuideCols none = {};
@@ -508,7 +560,11 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   HIPCHK(hipEventRecord(ev[2], ctx->stream));
   HIPCHK(hipGetLastError());
   ScanTotals tot;
+#ifdef HAWK_ABLATION  // measurement hook of the ablation builds only (tools/ab.sh): never compiled into the product library
   static const bool count_only = [] { const char* e = getenv("HAWK_COUNT_ONLY"); return e && e[0] == '1'; }();
+#else
+  const bool count_only = false;
+#endif
   GuideCols ca;
   int status = 0;
   uint64_t nrows = 0;
@@ -517,7 +573,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     // Columns from an earlier search on this set are still reserved: launch the emit pass straight behind the offset
     // scan instead of waiting for the row count to cross PCIe (the kernels take their offsets from HBM and refuse to
     // write past the capacity).  If the table turns out larger, the normal path below runs after a reserve.
-    if ((rc = reserve_cols(hs->colsA, hs->cols_cap, &ca))) return rc;
+    if ((rc = hawk_reserve_cols(hs->colsA, hs->cols_cap, &ca))) return rc;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
                        hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
@@ -540,7 +596,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   }
   if (!emitted) {
     const uint64_t want = std::max<uint64_t>(nrows, 1);
-    if ((rc = reserve_cols(hs->colsA, std::max<uint64_t>(want, hs->cols_cap), &ca))) return rc;
+    if ((rc = hawk_reserve_cols(hs->colsA, std::max<uint64_t>(want, hs->cols_cap), &ca))) return rc;
     hs->cols_cap = ca.cap;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
@@ -564,13 +620,22 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   if (status) return status;
   hawk_table* t = new (std::nothrow) hawk_table();
   if (!t) return HAWK_E_INVALID;
-  t->hs = hs; t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = ca; t->cap = ca.cap;
+  t->hs = hs; t->ctx = ctx; t->gen = hs->cols_gen;
+  t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = ca; t->cap = ca.cap;
   t->guidelen = p->guidelen; t->pamlen = p->pamlen; t->right = p->right ? 1 : 0; t->n_groups = 0; t->collapsed = false;
   *out = t;
   return HAWK_OK;
 }
 
-void hawk_table_destroy(hawk_table* t) { delete t; }  // columns live in the hapset's workspace
+void hawk_table_destroy(hawk_table* t) {  // columns live in the hapset's workspace, or in own[] for a merged table
+  if (!t) return;
+  if (!t->hs) {
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    for (auto& b : t->own) b.release();
+  }
+  delete t;
+}
 
 int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candidates, uint64_t* n_hits) {
   if (!t) return HAWK_E_INVALID;
@@ -582,8 +647,8 @@ int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candida
 
 int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
                         uint8_t* flags, double* cfdon, uint64_t* win) {
-  if (!t) return HAWK_E_INVALID;
-  hawk_ctx* ctx = t->hs->ctx;
+  if (!t || hawk_table_stale(t)) return HAWK_E_INVALID;
+  hawk_ctx* ctx = t->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   const uint64_t n = t->n_rows;
   if (!n) return HAWK_OK;
@@ -604,7 +669,7 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
 
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
                               void** flags, void** cfdon, void** win, uint64_t* win_plane_stride) {
-  if (!t) return HAWK_E_INVALID;
+  if (!t || hawk_table_stale(t)) return HAWK_E_INVALID;
   const GuideCols& c = t->cols;
   if (hap) *hap = c.hap;
   if (pos) *pos = c.pos;
@@ -618,8 +683,9 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
   return HAWK_OK;
 }
 
-int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
-  if (!t || !n_groups) return HAWK_E_INVALID;
+int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms) {
+  if (!t || !n_groups || !t->hs || hawk_table_stale(t)) return HAWK_E_INVALID;
+  if (flank_up > HAWK_PAD || flank_down > HAWK_PAD) return HAWK_E_UNSUPPORTED;
   hawk_hapset* hs = t->hs;
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -627,6 +693,7 @@ int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
   t->collapsed = false;
   *n_groups = 0;
   if (kernel_ms) *kernel_ms = 0.f;
+  hs->collapse_gen = t->gen;
   if (n == 0) { t->n_groups = 0; t->collapsed = true; return HAWK_OK; }
   if (n > 0xffffffffull || hs->max_gen - hs->min_gen > 0xffffffffll) return HAWK_E_UNSUPPORTED;
   unsigned end_bit = 32;
@@ -641,10 +708,10 @@ int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
   for (int attempt = 0; attempt < 4; ++attempt) {  // a new seed whenever two different rows collide in the hash bits
     HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 16, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (hawk_launch_collapse(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)t->right, hs->min_gen,
-                             end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p, temp_bytes, hs->ckeys.as<uint64_t>(),
-                             hs->cvals.as<uint32_t>(), hs->cflags.as<uint32_t>(), hs->cgidx.as<uint32_t>(),
-                             hs->ccnt.as<unsigned long long>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(),
+    if (hawk_launch_collapse(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)t->right, (int)flank_up,
+                             (int)flank_down, hs->min_gen, end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p,
+                             temp_bytes, hs->ckeys.as<uint64_t>(), hs->cvals.as<uint32_t>(), hs->cflags.as<uint32_t>(),
+                             hs->cgidx.as<uint32_t>(), hs->ccnt.as<unsigned long long>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(),
                              hs->cgc.as<uint8_t>() + n, hs->cfull.p))
       return HAWK_E_HIP;
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -663,8 +730,17 @@ int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
   return HAWK_OK;
 }
 
+int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {
+  return hawk_table_collapse_ex(t, 0, 0, n_groups, kernel_ms);
+}
+
+// the collapse results live in the set's workspace: valid for the table that was collapsed last, until the next search
+static bool collapse_valid(const hawk_table* t) {
+  return t && t->collapsed && t->hs && !hawk_table_stale(t) && t->hs->collapse_gen == t->gen;
+}
+
 int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den) {
-  if (!t || !t->collapsed) return HAWK_E_INVALID;
+  if (!collapse_valid(t)) return HAWK_E_INVALID;
   hawk_hapset* hs = t->hs;
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -675,6 +751,42 @@ int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_
   if (gc_num) HIPCHK(hipMemcpyAsync(gc_num, hs->cgc.p, ng, hipMemcpyDefault, ctx->stream));
   if (gc_den) HIPCHK(hipMemcpyAsync(gc_den, hs->cgc.as<uint8_t>() + n, ng, hipMemcpyDefault, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return HAWK_OK;
+}
+
+int hawk_table_collapse_export(hawk_table* t, uint32_t* rep_row, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
+                               uint8_t* flags, double* cfdon, uint64_t* win, uint32_t* member_hap, float* kernel_ms) {
+  if (!collapse_valid(t)) return HAWK_E_INVALID;
+  hawk_hapset* hs = t->hs;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t n = t->n_rows, ng = t->n_groups;
+  if (kernel_ms) *kernel_ms = 0.f;
+  if (n == 0) return HAWK_OK;
+  // the representatives' columns and the member list reuse collapse workspace that is dead by now:
+  // ckeys (2n u64: the sort's key ping-pong) holds the rep columns when they fit, cflags (n u32) the members
+  GuideCols rep;
+  int rc = hawk_reserve_cols(hs->crep, ng, &rep);
+  if (rc) return rc;
+  uint32_t* d_mem = hs->cflags.as<uint32_t>();
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+  hawk_launch_collapse_export(ctx->stream, t->cols, n, ng, hs->cvals.as<uint32_t>() + n, hs->cgoff.as<uint64_t>(), rep, d_mem);
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIPCHK(hipGetLastError());
+  hipStream_t st = ctx->stream;
+  if (rep_row) HIPCHK(hipMemcpyAsync(rep_row, rep.hap, ng * 4, hipMemcpyDefault, st));
+  if (pos) HIPCHK(hipMemcpyAsync(pos, rep.pos, ng * 4, hipMemcpyDefault, st));
+  if (strand) HIPCHK(hipMemcpyAsync(strand, rep.strand, ng, hipMemcpyDefault, st));
+  if (start) HIPCHK(hipMemcpyAsync(start, rep.start, ng * 8, hipMemcpyDefault, st));
+  if (stop) HIPCHK(hipMemcpyAsync(stop, rep.stop, ng * 8, hipMemcpyDefault, st));
+  if (flags) HIPCHK(hipMemcpyAsync(flags, rep.flags, ng, hipMemcpyDefault, st));
+  if (cfdon) HIPCHK(hipMemcpyAsync(cfdon, rep.cfdon, ng * 8, hipMemcpyDefault, st));
+  if (win)
+    for (int p = 0; p < HAWK_PLANES; ++p)
+      HIPCHK(hipMemcpyAsync(win + (size_t)p * ng, rep.win + (size_t)p * rep.cap, ng * 8, hipMemcpyDefault, st));
+  if (member_hap) HIPCHK(hipMemcpyAsync(member_hap, d_mem, n * 4, hipMemcpyDefault, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
   return HAWK_OK;
 }
 
@@ -844,8 +956,8 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
   char *d_wt = nullptr, *d_sg = nullptr, *d_p = nullptr;
   double *d_tab = nullptr, *d_out = nullptr;
   int* d_status = nullptr;
-  HIPCHK(hipMalloc(&d_wt, n * len)); HIPCHK(hipMalloc(&d_sg, n * len)); HIPCHK(hipMalloc(&d_p, n * 2));
-  HIPCHK(hipMalloc(&d_tab, 336 * 8)); HIPCHK(hipMalloc(&d_out, n * 8)); HIPCHK(hipMalloc(&d_status, 4));
+  POOLCHK(&d_wt, n * len); POOLCHK(&d_sg, n * len); POOLCHK(&d_p, n * 2);
+  POOLCHK(&d_tab, 336 * 8); POOLCHK(&d_out, n * 8); POOLCHK(&d_status, 4);
   HIPCHK(hipMemcpyAsync(d_wt, wt, n * len, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_sg, sg, n * len, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_p, pam2, n * 2, hipMemcpyHostToDevice, ctx->stream));
@@ -858,15 +970,48 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
   HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_wt); (void)hipFree(d_sg); (void)hipFree(d_p); (void)hipFree(d_tab); (void)hipFree(d_out); (void)hipFree(d_status);
+  hawk_pool_free(d_wt); hawk_pool_free(d_sg); hawk_pool_free(d_p); hawk_pool_free(d_tab); hawk_pool_free(d_out); hawk_pool_free(d_status);
   return status;
 }
 
 // ---------------------------------------------------------------------------- f1 haplotype expansion
-int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
-                       const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
-                       uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
-                       const uint32_t* hap_len, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms) {
+// An expansion plan keeps everything hawk_hapset_expand needs in HBM - the variant table, the carried-variant lists, the
+// per-workgroup variant ranges and (after hawk_xplan_set_meta) the metadata of the rows it produces - so that running
+// it is device work only: the per-tile loop of a whole-contig search re-expands its tiles without touching the host.
+struct hawk_xplan {
+  hawk_ctx* ctx;
+  uint32_t n_var, n_hap, ref_len;
+  uint64_t ncar;
+  std::vector<uint32_t> hap_len;
+  uint32_t* ref_plane[4];  // the REF region's code planes, copied: the plan does not depend on the life of ref_set
+  uint32_t ref_S;
+  DevBuf r0, span, ao, al, codes, off, idx, o, wk0, wn, hash;
+  // metadata of the produced rows (hawk_xplan_set_meta)
+  bool has_meta;
+  std::vector<int32_t> scan_start, scan_stop;
+  DevBuf m_is_ref, m_ss, m_se, m_seg_off, m_seg_rel, m_seg_gen, m_tile;
+  uint32_t nseg, bph, S;
+  int32_t ref_index;
+  int64_t ref_startp, min_gen, max_gen;
+  bool has_partner = false;
+  int32_t partner_start = 0, partner_stop = 0;
+};
+
+void hawk_xplan_destroy(hawk_xplan* x) {
+  if (!x) return;
+  (void)hipSetDevice(x->ctx->device);
+  (void)hipStreamSynchronize(x->ctx->stream);
+  for (auto& p : x->ref_plane) hawk_pool_free(p);
+  DevBuf* bufs[] = {&x->r0, &x->span, &x->ao, &x->al, &x->codes, &x->off, &x->idx, &x->o, &x->wk0, &x->wn, &x->hash,
+                    &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile};
+  for (auto* b : bufs) b->release();
+  delete x;
+}
+
+int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                      const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
+                      uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
+                      const uint32_t* hap_len, hawk_xplan** out) {
   if (!ref_set || !out || !n_hap || !hv_off || !hap_len || (n_var && (!v_r0 || !v_span || !v_alt_off || !v_alt_len || !alt_codes)))
     return HAWK_E_INVALID;
   hawk_ctx* ctx = ref_set->ctx;
@@ -879,6 +1024,7 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
     if ((uint64_t)v_alt_off[i] + v_alt_len[i] > alt_codes_len) return HAWK_E_INVALID;
     if (i && v_r0[i] < v_r0[i - 1]) return HAWK_E_INVALID;  // sorted by position (alleles of one site may share it)
   }
+  uint32_t maxlen = 0;
   for (uint32_t h = 0; h < n_hap; ++h) {
     if (hv_off[h + 1] < hv_off[h]) return HAWK_E_INVALID;
     int64_t off = 0;
@@ -891,45 +1037,164 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
       prev = vi;
     }
     if ((int64_t)hap_len[h] != (int64_t)ref_len + off) return HAWK_E_INVALID;
+    if (hap_len[h] >= (1u << 31) - 256) return HAWK_E_UNSUPPORTED;
+    maxlen = std::max(maxlen, hap_len[h]);
   }
-  hawk_hapset* hs = nullptr;
-  int rc = hawk_hapset_create(ctx, n_hap, hap_len, &hs);
-  if (rc) return rc;
-  uint32_t *d_r0 = nullptr, *d_span = nullptr, *d_ao = nullptr, *d_al = nullptr, *d_idx = nullptr;
-  uint8_t* d_codes = nullptr; uint64_t* d_off = nullptr; int32_t* d_o = nullptr; unsigned long long* d_hash = nullptr;
-  int32_t* d_wk0 = nullptr; uint32_t* d_wn = nullptr;
-  const size_t nwg = (size_t)n_hap * ((hs->S + HAWK_BLOCK - 1) / HAWK_BLOCK);
+  HIPCHK(hipSetDevice(ctx->device));
+  hawk_xplan* x = new (std::nothrow) hawk_xplan();
+  if (!x) return HAWK_E_INVALID;
+  x->ctx = ctx; x->n_var = n_var; x->n_hap = n_hap; x->ref_len = ref_len; x->ncar = ncar;
+  x->hap_len.assign(hap_len, hap_len + n_hap);
+  x->has_meta = false; x->nseg = 0; x->ref_index = -1; x->ref_startp = 0; x->min_gen = 0; x->max_gen = 0;
+  for (auto& p : x->ref_plane) p = nullptr;
+  x->ref_S = ref_set->S;
+  x->S = ((maxlen + 31) / 32 + 2 + 3) / 4 * 4;  // the stride hapset_create_impl will choose
+  x->bph = (x->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  const size_t nwg = (size_t)n_hap * ((x->S + HAWK_BLOCK - 1) / HAWK_BLOCK);
   const size_t nv = std::max<size_t>(n_var, 1), nc = std::max<size_t>(ncar, 1);
-  HIPCHK(hipMalloc(&d_r0, nv * 4)); HIPCHK(hipMalloc(&d_span, nv * 4)); HIPCHK(hipMalloc(&d_ao, nv * 4)); HIPCHK(hipMalloc(&d_al, nv * 4));
-  HIPCHK(hipMalloc(&d_codes, std::max<size_t>(alt_codes_len, 1))); HIPCHK(hipMalloc(&d_off, (size_t)(n_hap + 1) * 8));
-  HIPCHK(hipMalloc(&d_idx, nc * 4)); HIPCHK(hipMalloc(&d_o, nc * 4)); HIPCHK(hipMalloc(&d_hash, (size_t)n_hap * 16));
-  HIPCHK(hipMalloc(&d_wk0, nwg * 4)); HIPCHK(hipMalloc(&d_wn, nwg * 4));
+  int rc = HAWK_OK;
+  for (int p = 0; p < 4 && !rc; ++p) rc = hawk_pool_alloc((void**)&x->ref_plane[p], (size_t)x->ref_S * 4);
+  if (!rc) rc = x->r0.reserve(nv * 4);
+  if (!rc) rc = x->span.reserve(nv * 4);
+  if (!rc) rc = x->ao.reserve(nv * 4);
+  if (!rc) rc = x->al.reserve(nv * 4);
+  if (!rc) rc = x->codes.reserve(std::max<size_t>(alt_codes_len, 1));
+  if (!rc) rc = x->off.reserve((size_t)(n_hap + 1) * 8);
+  if (!rc) rc = x->idx.reserve(nc * 4);
+  if (!rc) rc = x->o.reserve(nc * 4);
+  if (!rc) rc = x->wk0.reserve(nwg * 4);
+  if (!rc) rc = x->wn.reserve(nwg * 4);
+  if (!rc) rc = x->hash.reserve((size_t)n_hap * 16);
+  if (rc) { hawk_xplan_destroy(x); return rc; }
   hipStream_t st = ctx->stream;
-  if (n_var) {
-    HIPCHK(hipMemcpyAsync(d_r0, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_span, v_span, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_ao, v_alt_off, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_al, v_alt_len, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_codes, alt_codes, alt_codes_len, hipMemcpyHostToDevice, st));
+  hipError_t e = hipSuccess;
+  for (int p = 0; p < 4 && e == hipSuccess; ++p)
+    e = hipMemcpyAsync(x->ref_plane[p], ref_set->plane[p], (size_t)x->ref_S * 4, hipMemcpyDeviceToDevice, st);
+  if (n_var && e == hipSuccess) {
+    e = hipMemcpyAsync(x->r0.p, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(x->span.p, v_span, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(x->ao.p, v_alt_off, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(x->al.p, v_alt_len, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(x->codes.p, alt_codes, alt_codes_len, hipMemcpyHostToDevice, st);
   }
-  HIPCHK(hipMemcpyAsync(d_off, hv_off, (size_t)(n_hap + 1) * 8, hipMemcpyHostToDevice, st));
-  if (ncar) {
-    HIPCHK(hipMemcpyAsync(d_idx, hv_idx, ncar * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_o, hv_o, ncar * 4, hipMemcpyHostToDevice, st));
+  if (e == hipSuccess) e = hipMemcpyAsync(x->off.p, hv_off, (size_t)(n_hap + 1) * 8, hipMemcpyHostToDevice, st);
+  if (ncar && e == hipSuccess) {
+    e = hipMemcpyAsync(x->idx.p, hv_idx, ncar * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(x->o.p, hv_o, ncar * 4, hipMemcpyHostToDevice, st);
   }
-  HIPCHK(hipMemsetAsync(d_hash, 0, (size_t)n_hap * 16, st));
-  HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hawk_launch_hx_build(st, ref_set->plane, d_r0, d_span, d_ao, d_al, d_codes, d_off, d_idx, d_o, hs->d_hap_len, n_hap, hs->S, hs->plane, d_wk0, d_wn);
-  hawk_launch_hx_hash(st, hs->plane, n_hap, hs->S, d_hash);
-  HIPCHK(hipEventRecord(ctx->ev[1], st));
-  HIPCHK(hipGetLastError());
-  if (hash_out) HIPCHK(hipMemcpyAsync(hash_out, d_hash, (size_t)n_hap * 16, hipMemcpyDeviceToHost, st));
+  if (e == hipSuccess) {
+    hawk_launch_hx_index(st, x->off.as<uint64_t>(), x->o.as<int32_t>(), n_hap, x->S, x->wk0.as<int32_t>(), x->wn.as<uint32_t>());
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "hawk_xplan_create: %s", hipGetErrorString(e));
+    hawk_xplan_destroy(x);
+    return HAWK_E_HIP;
+  }
+  *out = x;
+  return HAWK_OK;
+}
+
+int hawk_xplan_set_meta(hawk_xplan* x, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
+                        const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index) {
+  if (!x) return HAWK_E_INVALID;
+  hawk_ctx* ctx = x->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t n = x->n_hap;
+  std::vector<TileMeta> t0;
+  int64_t mn, mx;
+  int rc = meta_build(n, x->hap_len, x->bph, is_ref, scan_start, scan_stop, seg_off, seg_rel, seg_gen, ref_index, &t0, &mn, &mx);
+  if (rc) return rc;
+  const uint32_t nseg = seg_off[n];
+  if ((rc = x->m_is_ref.reserve(n)) || (rc = x->m_ss.reserve((size_t)n * 4)) || (rc = x->m_se.reserve((size_t)n * 4)) ||
+      (rc = x->m_seg_off.reserve((size_t)(n + 1) * 4)) || (rc = x->m_seg_rel.reserve((size_t)nseg * 4)) ||
+      (rc = x->m_seg_gen.reserve((size_t)nseg * 8)) || (rc = x->m_tile.reserve(t0.size() * sizeof(TileMeta))))
+    return rc;
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(x->m_is_ref.p, is_ref, n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_ss.p, scan_start, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_se.p, scan_stop, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_seg_off.p, seg_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_seg_rel.p, seg_rel, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_seg_gen.p, seg_gen, (size_t)nseg * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_tile.p, t0.data(), t0.size() * sizeof(TileMeta), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
+  x->nseg = nseg; x->ref_index = ref_index; x->ref_startp = ref_index >= 0 ? seg_gen[seg_off[ref_index]] : 0;
+  x->min_gen = mn; x->max_gen = mx;
+  x->scan_start.assign(scan_start, scan_start + n);
+  x->scan_stop.assign(scan_stop, scan_stop + n);
+  x->has_meta = true;
+  return HAWK_OK;
+}
+
+int hawk_xplan_set_ref_partner_range(hawk_xplan* x, int32_t start, int32_t stop) {
+  if (!x || !x->has_meta || x->ref_index < 0) return HAWK_E_INVALID;
+  if (start < 0 || stop > (int32_t)x->hap_len[x->ref_index] || stop < start) return HAWK_E_INVALID;
+  x->has_partner = true; x->partner_start = start; x->partner_stop = stop;
+  return HAWK_OK;
+}
+
+int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms) {
+  if (!x || !out) return HAWK_E_INVALID;
+  hawk_ctx* ctx = x->ctx;
+  hawk_hapset* hs = nullptr;
+  int rc = hapset_create_impl(ctx, x->n_hap, x->hap_len.data(), false, &hs);  // the build kernel writes every word of every row
+  if (rc) return rc;
+  if (hs->S != x->S) { hawk_hapset_destroy(hs); return HAWK_E_INVALID; }
+  hipStream_t st = ctx->stream;
+  hipError_t e = hipMemsetAsync(x->hash.p, 0, (size_t)x->n_hap * 16, st);
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev[0], st);
+  if (e == hipSuccess) {
+    hawk_launch_hx_build(st, x->ref_plane, x->r0.as<uint32_t>(), x->span.as<uint32_t>(), x->ao.as<uint32_t>(), x->al.as<uint32_t>(),
+                         x->codes.as<uint8_t>(), x->off.as<uint64_t>(), x->idx.as<uint32_t>(), x->o.as<int32_t>(), hs->d_hap_len,
+                         x->n_hap, hs->S, hs->plane, x->wk0.as<int32_t>(), x->wn.as<uint32_t>());
+    if (hash_out) hawk_launch_hx_hash(st, hs->plane, x->n_hap, hs->S, x->hash.as<unsigned long long>());
+    e = hipEventRecord(ctx->ev[1], st);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess && hash_out) e = hipMemcpyAsync(hash_out, x->hash.p, (size_t)x->n_hap * 16, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && x->has_meta) {  // install the rows' metadata, device to device
+    const uint32_t n = x->n_hap;
+    rc = hawk_pool_alloc((void**)&hs->d_seg_rel, (size_t)x->nseg * 4);
+    if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_gen, (size_t)x->nseg * 8);
+    if (rc) { hawk_hapset_destroy(hs); return rc; }
+    e = hipMemcpyAsync(hs->d_is_ref, x->m_is_ref.p, n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_start, x->m_ss.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_stop, x->m_se.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_off, x->m_seg_off.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_rel, x->m_seg_rel.p, (size_t)x->nseg * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_gen, x->m_seg_gen.p, (size_t)x->nseg * 8, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_tile_meta, x->m_tile.p, (size_t)n * x->bph * sizeof(TileMeta), hipMemcpyDeviceToDevice, st);
+    hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
+    hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
+    hs->ref_index = x->ref_index; hs->has_meta = true;
+    hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
+  }
+  if (e == hipSuccess && (hash_out || kernel_ms)) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "hawk_xplan_run: %s", hipGetErrorString(e));
+    hawk_hapset_destroy(hs);
+    return HAWK_E_HIP;
+  }
   if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
-  (void)hipFree(d_r0); (void)hipFree(d_span); (void)hipFree(d_ao); (void)hipFree(d_al); (void)hipFree(d_codes); (void)hipFree(d_off);
-  (void)hipFree(d_idx); (void)hipFree(d_o); (void)hipFree(d_hash); (void)hipFree(d_wk0); (void)hipFree(d_wn);
   *out = hs;
   return HAWK_OK;
+}
+
+int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                       const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
+                       uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
+                       const uint32_t* hap_len, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms) {
+  hawk_xplan* x = nullptr;
+  int rc = hawk_xplan_create(ref_set, n_var, v_r0, v_span, v_alt_off, v_alt_len, alt_codes, alt_codes_len, n_hap, hv_off, hv_idx, hv_o,
+                             hap_len, &x);
+  if (rc) return rc;
+  std::vector<uint64_t> tmp;
+  if (!hash_out) { tmp.resize((size_t)n_hap * 2); hash_out = tmp.data(); }  // run synchronously either way
+  rc = hawk_xplan_run(x, out, hash_out, kernel_ms);
+  hawk_xplan_destroy(x);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------- f3: VCF genotypes
@@ -957,10 +1222,10 @@ int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const u
   g->d_codes = nullptr; g->d_flags = nullptr; g->d_col_off = nullptr; g->d_idx = nullptr; g->d_o = nullptr; g->d_delta = nullptr;
   if (kernel_ms) *kernel_ms = 0.f;
   const size_t ncode = std::max<size_t>((size_t)n_lines * 2 * n_samples, 1);
-  HIPCHK(hipMalloc(&g->d_codes, ncode)); HIPCHK(hipMalloc(&g->d_flags, std::max<size_t>(n_lines, 1)));
+  POOLCHK(&g->d_codes, ncode); POOLCHK(&g->d_flags, std::max<size_t>(n_lines, 1));
   if (n_lines) {
     uint8_t* d_text = nullptr; uint64_t *d_lo = nullptr, *d_go = nullptr;
-    HIPCHK(hipMalloc(&d_text, text_len)); HIPCHK(hipMalloc(&d_lo, (n_lines + 1) * 8)); HIPCHK(hipMalloc(&d_go, n_lines * 8));
+    POOLCHK(&d_text, text_len); POOLCHK(&d_lo, (n_lines + 1) * 8); POOLCHK(&d_go, n_lines * 8);
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemcpyAsync(d_text, text, text_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_lo, line_off, (n_lines + 1) * 8, hipMemcpyHostToDevice, st));
@@ -972,7 +1237,7 @@ int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const u
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
-    (void)hipFree(d_text); (void)hipFree(d_lo); (void)hipFree(d_go);
+    hawk_pool_free(d_text); hawk_pool_free(d_lo); hawk_pool_free(d_go);
   }
   *out = g;
   return HAWK_OK;
@@ -981,11 +1246,11 @@ int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const u
 void hawk_gt_destroy(hawk_gt* g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->device);
-  (void)hipFree(g->d_codes); (void)hipFree(g->d_flags);
-  if (g->d_col_off) (void)hipFree(g->d_col_off);
-  if (g->d_idx) (void)hipFree(g->d_idx);
-  if (g->d_o) (void)hipFree(g->d_o);
-  if (g->d_delta) (void)hipFree(g->d_delta);
+  hawk_pool_free(g->d_codes); hawk_pool_free(g->d_flags);
+  if (g->d_col_off) hawk_pool_free(g->d_col_off);
+  if (g->d_idx) hawk_pool_free(g->d_idx);
+  if (g->d_o) hawk_pool_free(g->d_o);
+  if (g->d_delta) hawk_pool_free(g->d_delta);
   delete g;
 }
 
@@ -1007,10 +1272,10 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t n_cols = 2 * g->n_samples, n_chunk = (n_var + 63u) / 64u;
   hipStream_t st = ctx->stream;
-  if (g->d_col_off) { (void)hipFree(g->d_col_off); g->d_col_off = nullptr; }
-  if (g->d_idx) { (void)hipFree(g->d_idx); g->d_idx = nullptr; }
-  if (g->d_o) { (void)hipFree(g->d_o); g->d_o = nullptr; }
-  if (g->d_delta) { (void)hipFree(g->d_delta); g->d_delta = nullptr; }
+  if (g->d_col_off) { hawk_pool_free(g->d_col_off); g->d_col_off = nullptr; }
+  if (g->d_idx) { hawk_pool_free(g->d_idx); g->d_idx = nullptr; }
+  if (g->d_o) { hawk_pool_free(g->d_o); g->d_o = nullptr; }
+  if (g->d_delta) { hawk_pool_free(g->d_delta); g->d_delta = nullptr; }
   g->n_var = n_var; g->n_entries = 0;
   if (kernel_ms) *kernel_ms = 0.f;
   std::vector<uint64_t> off(n_cols + 1, 0);
@@ -1021,10 +1286,10 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   }
   uint32_t *d_vl = nullptr, *d_cnt = nullptr; uint8_t* d_va = nullptr; int32_t *d_r0 = nullptr, *d_ch = nullptr;
   unsigned long long* d_bal = nullptr;
-  HIPCHK(hipMalloc(&d_vl, (size_t)n_var * 4)); HIPCHK(hipMalloc(&d_va, n_var)); HIPCHK(hipMalloc(&d_r0, (size_t)n_var * 4));
-  HIPCHK(hipMalloc(&d_ch, (size_t)n_var * 4)); HIPCHK(hipMalloc(&d_cnt, (size_t)n_cols * 4));
-  HIPCHK(hipMalloc(&d_bal, (size_t)n_cols * n_chunk * 8));
-  HIPCHK(hipMalloc(&g->d_col_off, (size_t)(n_cols + 1) * 8)); HIPCHK(hipMalloc(&g->d_delta, (size_t)n_cols * 8));
+  POOLCHK(&d_vl, (size_t)n_var * 4); POOLCHK(&d_va, n_var); POOLCHK(&d_r0, (size_t)n_var * 4);
+  POOLCHK(&d_ch, (size_t)n_var * 4); POOLCHK(&d_cnt, (size_t)n_cols * 4);
+  POOLCHK(&d_bal, (size_t)n_cols * n_chunk * 8);
+  POOLCHK(&g->d_col_off, (size_t)(n_cols + 1) * 8); POOLCHK(&g->d_delta, (size_t)n_cols * 8);
   HIPCHK(hipMemcpyAsync(d_vl, var_line, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_va, var_allele, n_var, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_r0, var_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
@@ -1037,7 +1302,7 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   HIPCHK(hipStreamSynchronize(st));
   for (uint32_t c = 0; c < n_cols; ++c) off[c + 1] = off[c] + cnt[c];  // 2 * n_samples values: a host prefix sum
   const uint64_t ne = off[n_cols];
-  HIPCHK(hipMalloc(&g->d_idx, std::max<size_t>(ne, 1) * 4)); HIPCHK(hipMalloc(&g->d_o, std::max<size_t>(ne, 1) * 4));
+  POOLCHK(&g->d_idx, std::max<size_t>(ne, 1) * 4); POOLCHK(&g->d_o, std::max<size_t>(ne, 1) * 4);
   HIPCHK(hipMemcpyAsync(g->d_col_off, off.data(), (size_t)(n_cols + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(ctx->ev[2], st));
   hawk_launch_gt_fill(st, n_cols, d_r0, d_ch, n_var, d_bal, g->d_col_off, g->d_idx, g->d_o, g->d_delta);
@@ -1052,7 +1317,7 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   }
   memcpy(col_off, off.data(), (size_t)(n_cols + 1) * 8);
   g->n_entries = ne;
-  (void)hipFree(d_vl); (void)hipFree(d_va); (void)hipFree(d_r0); (void)hipFree(d_ch); (void)hipFree(d_cnt); (void)hipFree(d_bal);
+  hawk_pool_free(d_vl); hawk_pool_free(d_va); hawk_pool_free(d_r0); hawk_pool_free(d_ch); hawk_pool_free(d_cnt); hawk_pool_free(d_bal);
   return HAWK_OK;
 }
 
@@ -1074,7 +1339,7 @@ int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* we
   HIPCHK(hipSetDevice(ctx->device));
   const size_t nw = HAWK_DEEPCPF1_NPARAMS;
   char* d_s = nullptr; float *d_w = nullptr, *d_o = nullptr; int* d_status = nullptr;
-  HIPCHK(hipMalloc(&d_s, n * 34)); HIPCHK(hipMalloc(&d_w, nw * 4)); HIPCHK(hipMalloc(&d_o, n * 4)); HIPCHK(hipMalloc(&d_status, 4));
+  POOLCHK(&d_s, n * 34); POOLCHK(&d_w, nw * 4); POOLCHK(&d_o, n * 4); POOLCHK(&d_status, 4);
   HIPCHK(hipMemcpyAsync(d_s, seqs34, n * 34, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_w, weights, nw * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream));
@@ -1084,7 +1349,7 @@ int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* we
   HIPCHK(hipMemcpyAsync(out, d_o, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_s); (void)hipFree(d_w); (void)hipFree(d_o); (void)hipFree(d_status);
+  hawk_pool_free(d_s); hawk_pool_free(d_w); hawk_pool_free(d_o); hawk_pool_free(d_status);
   return status;
 }
 
@@ -1108,10 +1373,10 @@ int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_m
   const size_t nn = m->n_nodes, nt = m->n_trees;
   char* d_s = nullptr; int32_t *d_off = nullptr, *d_f = nullptr, *d_l = nullptr, *d_r = nullptr;
   double *d_th = nullptr, *d_v = nullptr, *d_o = nullptr, *d_fo = nullptr; int* d_status = nullptr;
-  HIPCHK(hipMalloc(&d_s, n * 30)); HIPCHK(hipMalloc(&d_off, (nt + 1) * 4)); HIPCHK(hipMalloc(&d_f, nn * 4));
-  HIPCHK(hipMalloc(&d_l, nn * 4)); HIPCHK(hipMalloc(&d_r, nn * 4)); HIPCHK(hipMalloc(&d_th, nn * 8)); HIPCHK(hipMalloc(&d_v, nn * 8));
-  HIPCHK(hipMalloc(&d_o, n * 8)); HIPCHK(hipMalloc(&d_status, 4));
-  if (feats_out) HIPCHK(hipMalloc(&d_fo, n * 627 * 8));
+  POOLCHK(&d_s, n * 30); POOLCHK(&d_off, (nt + 1) * 4); POOLCHK(&d_f, nn * 4);
+  POOLCHK(&d_l, nn * 4); POOLCHK(&d_r, nn * 4); POOLCHK(&d_th, nn * 8); POOLCHK(&d_v, nn * 8);
+  POOLCHK(&d_o, n * 8); POOLCHK(&d_status, 4);
+  if (feats_out) POOLCHK(&d_fo, n * 627 * 8);
   hipStream_t st = ctx->stream;
   HIPCHK(hipMemcpyAsync(d_s, seqs30, n * 30, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_off, m->tree_off, (nt + 1) * 4, hipMemcpyHostToDevice, st));
@@ -1128,8 +1393,8 @@ int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_m
   if (feats_out) HIPCHK(hipMemcpyAsync(feats_out, d_fo, n * 627 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  (void)hipFree(d_s); (void)hipFree(d_off); (void)hipFree(d_f); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_th);
-  (void)hipFree(d_v); (void)hipFree(d_o); (void)hipFree(d_status); if (d_fo) (void)hipFree(d_fo);
+  hawk_pool_free(d_s); hawk_pool_free(d_off); hawk_pool_free(d_f); hawk_pool_free(d_l); hawk_pool_free(d_r); hawk_pool_free(d_th);
+  hawk_pool_free(d_v); hawk_pool_free(d_o); hawk_pool_free(d_status); if (d_fo) hawk_pool_free(d_fo);
   return status;
 }
 

@@ -33,13 +33,21 @@ struct RowKey {
   uint64_t core[HAWK_PLANES];
   uint32_t sr;  // strand | origin << 1
 };
-__device__ __forceinline__ RowKey row_key(const GuideCols& c, const uint8_t* __restrict__ is_ref, uint64_t i, uint64_t mask) {
+// The compared slice is the spacer+PAM core widened by `up` bases on the guide's 5' side and `down` on its 3' side
+// (0/0: the report without model scores; 4/3: the k-mer the model scorers read, scoring.py:50-67, so that rows whose
+// flanks differ - and whose Azimuth / DeepCpf1 scores may therefore differ - stay separate, reports.py:978-1003).
+// Rows are stored on the + strand: a strand-1 guide's 5' side is the window's right side.
+__device__ __forceinline__ RowKey row_key(const GuideCols& c, const uint8_t* __restrict__ is_ref, uint64_t i, int L, int up, int down) {
   RowKey k;
   k.start = c.start[i];
   k.stop = c.stop[i];
-  k.sr = (uint32_t)c.strand[i] | ((uint32_t)(is_ref[c.hap[i]] != 0) << 1);
+  const uint32_t strand = c.strand[i];
+  k.sr = strand | ((uint32_t)(is_ref[c.hap[i]] != 0) << 1);
+  const int fl = strand ? down : up, fr = strand ? up : down;
+  const int width = L + fl + fr;
+  const uint64_t mask = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
 #pragma unroll
-  for (int pl = 0; pl < HAWK_PLANES; ++pl) k.core[pl] = (c.win[(size_t)pl * c.cap + i] >> HAWK_PAD) & mask;
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) k.core[pl] = (c.win[(size_t)pl * c.cap + i] >> (HAWK_PAD - fl)) & mask;
   return k;
 }
 __device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
@@ -49,12 +57,12 @@ __device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, uint64_t mask,
+__global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
                                                        int64_t base, uint64_t seed, uint64_t* __restrict__ keys,
                                                        uint32_t* __restrict__ vals, ulonglong4* __restrict__ full) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const RowKey k = row_key(c, is_ref, i, mask);
+  const RowKey k = row_key(c, is_ref, i, L, up, down);
   // the full key as one 64-byte record: the head pass compares neighbours of the SORTED order, i.e. rows scattered
   // over the table - one line per row here instead of nine (one per column) there
   full[2 * i] = make_ulonglong4((unsigned long long)k.start, (unsigned long long)k.stop, (unsigned long long)k.sr, k.core[0]);
@@ -134,13 +142,12 @@ size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit) {
 // keys/vals: [2][n] ping-pong; flags, gidx: [n]; counters: [2], zeroed by the caller; group_off must hold
 // n + 1 entries (the number of groups is only known afterwards)
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
-                         int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
+                         int flank_up, int flank_down, int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
                          uint8_t* gc_den, void* full) {
   const int L = guidelen + pamlen;
-  const uint64_t mask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, mask, base, seed, keys, vals, (ulonglong4*)full);
+  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, L, flank_up, flank_down, base, seed, keys, vals, (ulonglong4*)full);
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, keys, keys + n, vals, vals + n, n, 0, end_bit, st) != hipSuccess) return -2;
   hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, (const ulonglong4*)full, n, keys + n, vals + n, flags, counters);
@@ -149,4 +156,30 @@ int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_r
   hipLaunchKernelGGL(k_collapse_groups, grid, block, 0, st, c, n, vals + n, flags, gidx, guidelen, pamlen, right, group_off, gc_num,
                      gc_den);
   return 0;
+}
+
+// ---- group export: one representative row per group + every row's haplotype in group order, so that the host
+// downloads group-level columns (74 B per report row) and 4 B per guide row instead of the whole table
+__global__ __launch_bounds__(256) void k_collapse_export(GuideCols c, uint64_t n, uint64_t ng, const uint32_t* __restrict__ perm,
+                                                         const uint64_t* __restrict__ group_off, GuideCols rep,
+                                                         uint32_t* __restrict__ member_hap) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) member_hap[j] = c.hap[perm[j]];
+  if (j < ng) {
+    const uint64_t r = perm[group_off[j]];  // the group's first member in table order
+    rep.hap[j] = (uint32_t)r;               // the representative's row index in the full table
+    rep.pos[j] = c.pos[r];
+    rep.strand[j] = c.strand[r];
+    rep.start[j] = c.start[r];
+    rep.stop[j] = c.stop[r];
+    rep.flags[j] = c.flags[r];
+    rep.cfdon[j] = c.cfdon[r];
+#pragma unroll
+    for (int pl = 0; pl < HAWK_PLANES; ++pl) rep.win[(size_t)pl * rep.cap + j] = c.win[(size_t)pl * c.cap + r];
+  }
+}
+void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n, uint64_t ng, const uint32_t* perm,
+                                 const uint64_t* group_off, const GuideCols& rep, uint32_t* member_hap) {
+  const uint64_t m = n > ng ? n : ng;
+  hipLaunchKernelGGL(k_collapse_export, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, c, n, ng, perm, group_off, rep, member_hap);
 }

@@ -128,10 +128,12 @@ void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const Sca
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, hipEvent_t mid = nullptr);
 size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit);
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
-                         int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
+                         int flank_up, int flank_down, int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
                          uint8_t* gc_den, void* full);
 size_t hawk_collapse_full_bytes(uint64_t n);
+void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n, uint64_t ng, const uint32_t* perm,
+                                 const uint64_t* group_off, const GuideCols& rep, uint32_t* member_hap);
 void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* line_off, const uint64_t* gt_off, uint64_t n_lines,
                           uint32_t n_samples, uint8_t* codes, uint8_t* flags);
 void hawk_launch_gt_count(hipStream_t st, const uint8_t* codes, uint32_t n_cols, const uint32_t* var_line, const uint8_t* var_allele,
@@ -147,6 +149,8 @@ void hawk_launch_deepcpf1(hipStream_t st, const char* seqs, uint64_t n, const fl
 void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t n_trees, const int32_t* tree_off,
                          const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold,
                          const double* value, double init, double lr, double* out, double* feats_out, int* status);
+void hawk_launch_hx_index(hipStream_t st, const uint64_t* hv_off, const int32_t* hv_o, uint32_t n_hap, uint32_t S, int32_t* wg_k0,
+                          uint32_t* wg_n);
 void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
                           const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
                           const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,

@@ -59,37 +59,40 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restr
   const int32_t p_lo = (int32_t)(wb * HAWK_BLOCK * 32u), p_hi = p_lo + HAWK_BLOCK * 32;
   const int32_t len = (int32_t)hap_len[h];
   const int s_k0 = wg_k0[blockIdx.x];  // k_hx_index
-  const int s_n = (int)wg_n[blockIdx.x];
-  const int k0 = s_k0 < 0 ? 0 : s_k0, n = s_n;
+  const int n = (int)wg_n[blockIdx.x];
+  const int k0 = s_k0 < 0 ? 0 : s_k0;  // row-local index of the first staged variant
   for (int i = threadIdx.x; i < n; i += HAWK_BLOCK) {
     const uint32_t vi = hv_idx[lo + k0 + i];
     s_v[i] = HxVar{hv_o[lo + k0 + i], v_r0[vi], v_span[vi], v_alt_len[vi], v_alt_off[vi]};
   }
   __syncthreads();
   if (w >= S) return;
+  // more carried variants start inside this workgroup's 8192 positions than LDS holds (> HX_MAXV, i.e. one every
+  // ~40 nt): the ones beyond the staged range are read from global memory (workgroup-uniform flag, rare)
+  const bool overflow = k0 + n < K && hv_o[lo + k0 + n] < p_hi;
+  // variant kk of the row (0 <= kk < K): staged copy when there is one
+  auto getv = [&](int kk) -> HxVar {
+    if (kk >= k0 && kk < k0 + n) return s_v[kk - k0];
+    const uint32_t vi = hv_idx[lo + kk];
+    return HxVar{hv_o[lo + kk], v_r0[vi], v_span[vi], v_alt_len[vi], v_alt_off[vi]};
+  };
+  auto geto = [&](int kk) -> int32_t { return kk >= k0 && kk < k0 + n ? s_v[kk - k0].o : hv_o[lo + kk]; };
   uint32_t oA = 0, oC = 0, oG = 0, oT = 0, oV = 0;
   const int32_t p0 = (int32_t)(w * 32u);
   if (p0 < len) {
     const int32_t pend = p0 + 32 < len ? p0 + 32 : len;
-    // local index of the last staged variant with o <= p0 (-1: none; then s_k0 < 0 and we copy REF 1:1)
-    int a = 0, b = n;
-    while (a < b) { const int m = (a + b) >> 1; if (s_v[m].o <= p0) a = m + 1; else b = m; }
+    // k: row-local index of the last carried variant with o <= p0 (-1: none, the word starts in unmodified REF).
+    // Variants before k0 start before the workgroup's first position and before variant k0 (or there is none <= p_lo),
+    // so the search range is [k0, k0 + n), extended to the rest of the row in overflow mode.
+    int a = k0, b = overflow ? K : k0 + n;
+    while (a < b) { const int m = (a + b) >> 1; if (geto(m) <= p0) a = m + 1; else b = m; }
     int k = a - 1;
-    const bool overflow = k0 + n < K && hv_o[lo + k0 + n] < p_hi;  // more variants than fit in LDS: handled below
     int32_t cur = p0;
-    int guard = 0;
-    while (cur < pend && guard++ < 80) {
-      HxVar v;
-      bool havev = k >= 0 && k < n;
-      if (havev) v = s_v[k];
-      else if (k >= n && overflow) {  // rare: read the variant from global memory
-        const uint32_t vi = hv_idx[lo + k0 + k];
-        v = HxVar{hv_o[lo + k0 + k], v_r0[vi], v_span[vi], v_alt_len[vi], v_alt_off[vi]};
-        havev = true;
-      }
-      int32_t next_o = 0x7fffffff;  // output start of the following variant
-      if (k + 1 < n) next_o = s_v[k + 1].o;
-      else if (k0 + k + 1 < K) next_o = hv_o[lo + k0 + k + 1];
+    while (cur < pend) {  // every iteration advances cur or k; k only while variants start inside the word
+      const bool havev = k >= 0;
+      HxVar v = HxVar{0, 0, 0, 0, 0};
+      if (havev) v = getv(k);
+      const int32_t next_o = k + 1 < K ? geto(k + 1) : 0x7fffffff;  // output start of the following variant
       if (havev && cur < v.o + (int32_t)v.alt_len) {
         // alt allele bases [cur - o, ...)
         const int32_t e = v.o + (int32_t)v.alt_len < pend ? v.o + (int32_t)v.alt_len : pend;
@@ -102,15 +105,15 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restr
       } else {
         // copy REF: r = position in REF of output position cur
         const uint32_t r = havev ? v.r0 + v.span + (uint32_t)(cur - (v.o + (int32_t)v.alt_len)) : (uint32_t)cur;
-        int32_t e = pend < next_o ? pend : next_o;
+        const int32_t e = pend < next_o ? pend : next_o;
         const int nb = e - cur;
         if (nb > 0) {
           const uint32_t m = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
           const int sh = cur - p0;
           oA |= (ext_glb(refA, r).lo & m) << sh; oC |= (ext_glb(refC, r).lo & m) << sh;
           oG |= (ext_glb(refG, r).lo & m) << sh; oT |= (ext_glb(refT, r).lo & m) << sh;
+          cur = e;
         }
-        cur = e;
       }
       if (cur >= next_o) ++k;  // the next variant starts here
     }
@@ -119,13 +122,18 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restr
   pA[o] = oA; pC[o] = oC; pG[o] = oG; pT[o] = oT; pV[o] = oV;
 }
 
+void hawk_launch_hx_index(hipStream_t st, const uint64_t* hv_off, const int32_t* hv_o, uint32_t n_hap, uint32_t S, int32_t* wg_k0,
+                          uint32_t* wg_n) {
+  const uint32_t wpr = (S + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  const uint64_t nwg = (uint64_t)n_hap * wpr;
+  hipLaunchKernelGGL(k_hx_index, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, hv_off, hv_o, n_hap, wpr, wg_k0, wg_n);
+}
+
 void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
                           const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
                           const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,
                           uint32_t* const* plane, int32_t* wg_k0, uint32_t* wg_n) {
   const uint32_t wpr = (S + HAWK_BLOCK - 1) / HAWK_BLOCK;
-  const uint64_t nwg = (uint64_t)n_hap * wpr;
-  hipLaunchKernelGGL(k_hx_index, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, hv_off, hv_o, n_hap, wpr, wg_k0, wg_n);
   hipLaunchKernelGGL(k_hx_build, dim3(n_hap * wpr), dim3(HAWK_BLOCK), 0, st, ref[0], ref[1], ref[2], ref[3], v_r0, v_span, v_alt_off,
                      v_alt_len, alt_codes, hv_off, hv_idx, hv_o, hap_len, S, wpr, wg_k0, wg_n, plane[0], plane[1], plane[2], plane[3],
                      plane[4]);

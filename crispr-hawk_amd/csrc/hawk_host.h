@@ -1,0 +1,106 @@
+// hawk_host.h — host-side objects behind the opaque handles of include/hawk.h, shared by the C-ABI
+// translation units (hawk_api.hip, hawk_comm.hip).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "../../include/hawk.h"
+#include "hawk_device.h"
+
+#define HAWK_MAX_DEVICES 16
+char* hawk_hip_err_buf();  // thread-local text of the last HIP failure (hawk_last_hip_error)
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      snprintf(hawk_hip_err_buf(), 256, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return HAWK_E_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+struct hawk_ctx {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[8];
+};
+
+// Caching device allocator, one per device: a freed block goes to a free list and is handed to the next request of a
+// similar size, so a per-tile loop (expand -> search -> collapse, tile after tile) allocates its planes, columns and
+// workspaces once.  Everything in this library runs on one stream per context, so stream order makes the reuse safe.
+int hawk_pool_alloc(void** p, size_t bytes);   // HAWK_OK / HAWK_E_HIP (after releasing the cache and retrying once)
+void hawk_pool_free(void* p);
+void hawk_pool_trim();                          // hipFree every cached block of the current device
+#define POOLCHK(ptr, bytes)                                                      \
+  do {                                                                           \
+    int rc_ = hawk_pool_alloc(reinterpret_cast<void**>(ptr), (bytes));           \
+    if (rc_) return rc_;                                                         \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return HAWK_OK;
+    if (p) { hawk_pool_free(p); p = nullptr; bytes = 0; }
+    size_t want = need + need / 8 + 256;
+    int rc = hawk_pool_alloc(&p, want);
+    if (rc) return rc;
+    bytes = want;
+    return HAWK_OK;
+  }
+  void release() { if (p) hawk_pool_free(p); p = nullptr; bytes = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct hawk_hapset {
+  hawk_ctx* ctx;
+  uint32_t n_hap, S;
+  uint64_t total_len;
+  std::vector<uint32_t> hap_len;
+  std::vector<int32_t> scan_start, scan_stop;
+  uint32_t* plane[HAWK_PLANES];
+  uint32_t* d_hap_len;
+  uint8_t* d_is_ref;
+  int32_t *d_scan_start, *d_scan_stop;
+  uint32_t *d_seg_off, *d_seg_rel;
+  int64_t* d_seg_gen;
+  int32_t ref_index;
+  bool has_meta;
+  bool has_partner = false;          // hawk_hapset_set_ref_partner_range
+  int32_t partner_start = 0, partner_stop = 0;
+  uint32_t bph;            // workgroups (tiles of 1024 words) per haplotype row
+  TileMeta* d_tile_meta;   // [n_hap * bph] per-tile record (haplotype scalars + first position-map segment)
+  int64_t ref_startp;
+  int64_t min_gen, max_gen;  // range of genomic positions the position maps reach (collapse sort key)
+  uint64_t cols_cap = 0;      // rows the guide-table columns currently hold (0: never reserved)
+  uint64_t cols_gen = 0;      // bumped by every hawk_search: a hawk_table of an older generation is stale
+  uint64_t collapse_gen = 0;  // generation of the table whose collapse results sit in the c* buffers
+  std::vector<double> cfd_host;  // the CFD tables resident in `cfd`
+  // workspace reused across searches
+  DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
+  DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
+  DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
+  DevBuf colsA[8];
+  DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
+};
+
+struct hawk_table {
+  hawk_hapset* hs;  // nullptr for a merged table (hawk_table_gather): it owns its columns
+  hawk_ctx* ctx;
+  uint64_t n_rows, n_cand, n_hits, cap;
+  GuideCols cols;  // points into hs->colsA, or into own[] for a merged table
+  uint32_t guidelen, pamlen, right;
+  uint64_t n_groups;  // valid after hawk_table_collapse
+  bool collapsed;
+  uint64_t gen;     // hs->cols_gen when the table was written
+  DevBuf own[8];
+};
+// HAWK_E_INVALID when a later hawk_search on the same set has overwritten the table's columns
+inline bool hawk_table_stale(const hawk_table* t) { return t->hs && t->gen != t->hs->cols_gen; }
+
+int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c);
+

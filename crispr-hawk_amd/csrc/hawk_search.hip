@@ -481,7 +481,7 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
             if (gp.score_cfdon && has_ref) {
               bool err;
               score = cfdon_from_slices(core, rcore, s, L, cfdmask, s_cfd, err);
-              if (err) atomicExch(status, -5 /* HAWK_E_CFD */);
+              if (err && gp.score_cfdon == 1) atomicExch(status, -5 /* HAWK_E_CFD; score_cfdon == 2 leaves NaN = "NA" */);
             }
             out.cfdon[o] = score;
           }
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
       }
       bool err;
       score = cfdon_from_slices(core, rcore, s, L, cfdmask, s_cfd, err);
-      if (err) atomicExch(status, -5 /* HAWK_E_CFD */);
+      if (err && gp.score_cfdon == 1) atomicExch(status, -5 /* HAWK_E_CFD; score_cfdon == 2 leaves NaN = "NA" */);
     }
     out.cfdon[o] = score;
   }

@@ -35,7 +35,8 @@ typedef enum {
   HAWK_E_IUPAC = -4,      /* non-IUPAC character: CrisprHawkIupacTableError (encoder.py:37-45) */
   HAWK_E_CFD = -5,        /* non-ACGT base under a CFD lookup: CrisprHawkCfdScoreError (cfdscore.py:93-94) */
   HAWK_E_NODEVICE = -6,   /* no gfx950 device visible */
-  HAWK_E_UNSUPPORTED = -7 /* parameter outside the kernel's range (e.g. guidelen+pamlen > 44) */
+  HAWK_E_UNSUPPORTED = -7, /* parameter outside the kernel's range (e.g. guidelen+pamlen > 44) */
+  HAWK_E_COMM = -8         /* RCCL failure or librccl.so missing (hawk_comm_last_error() has the text) */
 } hawk_status;
 
 typedef struct hawk_ctx hawk_ctx;
@@ -54,6 +55,9 @@ const char* hawk_last_hip_error(void);
 /* the hipStream_t all of this context's work is enqueued on (for external event timing) */
 void* hawk_stream(hawk_ctx* ctx);
 int hawk_sync(hawk_ctx* ctx);
+/* Device memory is served by a caching allocator (freed planes / columns / workspaces are reused by the next
+ * haplotype set of the same shape, e.g. the next tile of a whole-contig search); this returns the cache to HIP. */
+int hawk_release_cached_memory(hawk_ctx* ctx);
 
 /* ---- haplotype set: replaces encode() per haplotype (crisprhawk.py:64-81, encoder.py:48-57)
  * plus the Haplotype fields the search reads (haplotype.py:395-491) ---------------------- */
@@ -77,6 +81,13 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
 int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
                          const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index);
 
+/* Tiles of a larger region (region-tiled whole-contig search): a haplotype row is grouped with the REF guide at its
+ * (start, strand) (remove_redundant_guides, search_guides.py:340-369; CFDon's wild type, scoring.py:368-381) wherever in
+ * the REGION that guide's PAM lies, while this set's REF row only scans the tile it owns.  [start, stop) is the
+ * region's scan range (compute_scan_start_stop) in the REF row's relative positions, clipped to the row; default =
+ * REF's own scan range.  Call after hawk_hapset_set_meta. */
+int hawk_hapset_set_ref_partner_range(hawk_hapset* hs, int32_t start, int32_t stop);
+
 /* Row stride in 32-bit words, and a copy of one plane (0..4 = A,C,G,T,V) to host
  * (n_hap * stride words) — for tests and for decoding windows on the host. */
 int hawk_hapset_stride(const hawk_hapset* hs, uint32_t* stride_words);
@@ -99,6 +110,23 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
                        uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
                        const uint32_t* hap_len, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms);
 
+/* The same expansion as a reusable plan: hawk_xplan_create validates the inputs once and keeps them in HBM (it copies
+ * the REF planes, so ref_set may be destroyed), hawk_xplan_run writes a fresh haplotype set from them with device work
+ * only, hawk_xplan_set_meta stores the metadata (arguments as hawk_hapset_set_meta) every later run installs into the
+ * set it returns.  This is what the region-tiling loop of a whole-contig search (search_guides.py:510-548 over one
+ * 50 Mb region; here one tile at a time inside a fixed HBM budget) runs per tile.  hash_out / kernel_ms may be NULL
+ * (then the run is asynchronous on the context's stream). */
+typedef struct hawk_xplan hawk_xplan;
+int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                      const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
+                      uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
+                      const uint32_t* hap_len, hawk_xplan** out);
+int hawk_xplan_set_meta(hawk_xplan* x, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
+                        const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index);
+int hawk_xplan_set_ref_partner_range(hawk_xplan* x, int32_t start, int32_t stop);
+int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms);
+void hawk_xplan_destroy(hawk_xplan* x);
+
 /* ---- K2: pam_search() (search_guides.py:102-131) ---------------------------------------
  * Raw PAM hits of every haplotype inside its [scan_start, scan_stop): ascending relative
  * positions per haplotype, forward-PAM hits in hits_fwd and reverse-complement-PAM hits in
@@ -119,7 +147,9 @@ typedef struct {
   uint64_t pam_fwd, pam_rev; /* PAM.bits, PAM.bitsrc */
   uint32_t pamlen, guidelen;
   uint32_t right;            /* --right: guide downstream of the PAM (Cpf1-like) */
-  uint32_t score_cfdon;      /* 1: compute CFDon for every kept guide (needs right == 0) */
+  uint32_t score_cfdon;      /* 1: compute CFDon for every kept guide (needs right == 0); a non-ACGT base under a
+                                table lookup is HAWK_E_CFD, as the reference's KeyError (cfdscore.py:93-94).
+                                2: the same, but such a guide scores NaN ("NA") - the opt-in for regions with N runs */
   const double* cfd_mm;      /* [20][4][4]: position, wildtype RNA base A,C,G,U, sgRNA base A,C,G,T */
   const double* cfd_pam;     /* [16]: PAM[-2:] dinucleotide, 4*b0+b1 over A,C,G,T */
 } hawk_search_params;
@@ -142,8 +172,11 @@ void hawk_table_destroy(hawk_table* t);
 int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candidates, uint64_t* n_hits);
 /* Column download (each array n_rows long; any pointer may be NULL; destinations may be host or
  * device memory - the copy kind is inferred, so a table can be exported into buffers a
- * collective library owns without a host bounce).  Rows are ordered by
- * (haplotype, strand, position) — the reference's pre-dedup emission order.
+ * collective library owns without a host bounce).  Rows are ordered by (haplotype, 32 768-position tile,
+ * strand, position): the kernels emit tile by tile, so the two strands of a haplotype interleave per tile;
+ * sorting by (haplotype, strand, position) gives the reference's pre-dedup emission order.
+ * Lifetime: the columns live in the haplotype set's workspace.  The next hawk_search (or hawk_hapset_set_meta) on
+ * the same set overwrites them; from then on every call below on the older table returns HAWK_E_INVALID.
  *   pos: relative PAM position (what retrieve_guides iterates), start/stop: genomic
  *   (search_guides.py:260-280), strand 0/1, flags bit0 = a REF guide shares (start,strand),
  *   cfdon: NaN when no REF guide shares the key, win[5][n_rows]: bits [pos_window) of planes
@@ -169,6 +202,35 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
  *                        gc_num / gc_den (annotation.py:513-541 -> Biopython gc_fraction, ambiguous bases dropped) */
 int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms);
 int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den);
+/* The same grouping with the compared sequence widened by flank_up bases 5' and flank_down bases 3' of the guide (as it
+ * reads after annotation.reverse_guides): 4 / 3 is the k-mer the model scorers see (scoring.py:50-67), so with Azimuth
+ * or DeepCpf1 switched on rows that differ only in those flanks - and may score differently - stay separate, as the
+ * reference's groupby over the score columns keeps them (reports.py:978-1003). */
+int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms);
+/* Group-level export after a collapse: per group its first member in table order (rep_row = that row's index, and the
+ * row's columns: pos, strand, start, stop, flags, cfdon, win[5][n_groups]) and, for every row in group order (CSR by
+ * group_off), the haplotype it came from (member_hap[n_rows]) - what the report needs (74 B per report row + 4 B per
+ * guide row) without downloading the table. */
+int hawk_table_collapse_export(hawk_table* t, uint32_t* rep_row, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
+                               uint8_t* flags, double* cfdon, uint64_t* win, uint32_t* member_hap, float* kernel_ms);
+
+/* ---- the one exchange of a multi-GPU job.  One process per GPU, haplotypes block-partitioned with REF
+ * on every rank (search_guides.py:111-131, 530-547 loop over independent haplotypes), no collective on the search
+ * path; afterwards every rank's guide table goes to one rank over RCCL / xGMI.  The caller moves the 128-byte id from
+ * rank 0 to the others (crisprhawk_hip/parallel.py does it over TCP).  hawk_table_gather: all-gather of the row
+ * counts, then grouped ncclSend / ncclRecv of the columns straight from the tables' device memory; on `dst` *merged
+ * is a table that owns its columns (download / device_columns / destroy), haplotype indices moved by each rank's
+ * hap_offset (local row 0 = REF stays 0).  hawk_comm_gatherv: variable-length byte gather of host or device buffers
+ * (recv_off[world + 1] byte offsets, needed on dst only). */
+typedef struct hawk_comm hawk_comm;
+int hawk_comm_unique_id(uint8_t* id128);
+int hawk_comm_init(hawk_ctx* ctx, int world, int rank, const uint8_t* id128, hawk_comm** out);
+void hawk_comm_destroy(hawk_comm* c);
+const char* hawk_comm_last_error(void);
+int hawk_comm_allgather_u64(hawk_comm* c, const uint64_t* mine, uint32_t k, uint64_t* all);
+int hawk_comm_gatherv(hawk_comm* c, const void* send, uint64_t send_bytes, int send_on_device, void* recv,
+                      const uint64_t* recv_off, int recv_on_device, int dst);
+int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst, hawk_table** merged, float* ms);
 
 /* ---- f3: VCF sample columns -> allele codes -> carried-variant lists.  Replaces the per-sample Python work of
  * VariantRecord.read_vcf_line -> _genotypes_to_samples (variant.py:286-311, 558-619) and the inversion into

@@ -1,7 +1,9 @@
-"""N > 1 path on CPU: world_size-2 gloo process group, block partition of the samples and the
-single variable-length gather of guide tables (crisprhawk_hip.parallel).  No GPU, no HIP."""
+"""N > 1 path on CPU: world_size 2, block partition of the samples and the single variable-length gather of guide
+tables (crisprhawk_hip.parallel) - over a gloo process group (tests/util.GlooComm adapts it to the communicator
+interface) and over the package's own TcpComm, the stand-ins for RcclComm.  No GPU, no HIP."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -33,8 +35,10 @@ def _worker(rank, world, port, sizes, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+    from util import GlooComm
     lo, _ = shard_range(1000, rank, world)
-    merged = gather_tables(_fake_table(rank, sizes[rank]), hap_offset=lo)
+    merged = gather_tables(_fake_table(rank, sizes[rank]), hap_offset=lo, comm=GlooComm())
     if rank == 0:
         np.savez(os.path.join(out_dir, "merged.npz"), **merged)
     dist.barrier()
@@ -104,8 +108,9 @@ def _worker_collapsed(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import GlooComm
     cols, perm, off, isref_row, labels, _ = _rank_rows(rank, world)
-    res = gather_collapsed(cols, perm, off, isref_row, hap_offset=1000 * rank, guidelen=20, pamlen=3)
+    res = gather_collapsed(cols, perm, off, isref_row, hap_offset=1000 * rank, guidelen=20, pamlen=3, comm=GlooComm())
     if rank == 0:
         rep, moff, members = res
         np.savez(os.path.join(out_dir, "collapsed.npz"), moff=moff, members=members, **rep)
@@ -147,3 +152,40 @@ def test_gather_collapsed_world2_gloo(tmp_path):
         assert key in want and want[key] == mem and key not in seen, key
         assert sorted(mem) == [int(x) for x in members[moff[g]:moff[g + 1]]]
         seen.add(key)
+
+
+def _worker_tcp(rank, world, rdzv, sizes, out_dir):
+    from crisprhawk_hip.parallel import TcpComm
+    comm = TcpComm(rank, world, rdzv=rdzv, timeout=60)
+    assert comm.bcast_obj(b"id" * 64 if rank == 0 else None) == b"id" * 64  # how the RCCL unique id travels
+    got = comm.allgather_i64([rank, 10 * rank + 1])
+    assert got.tolist() == [[r, 10 * r + 1] for r in range(world)]
+    lo, _ = shard_range(1000, rank, world)
+    merged = gather_tables(_fake_table(rank, sizes[rank]), hap_offset=lo, comm=comm)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "merged_tcp.npz"), **merged)
+    comm.barrier()
+    comm.close()
+
+
+def test_gather_tables_world3_tcp(tmp_path):
+    """The package's own socket communicator (bench.py's control plane): rendezvous through a port file, id
+    broadcast, count all-gather, variable-length gather with an empty rank."""
+    import multiprocessing as mp
+    sizes = [11, 0, 23]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_tcp, args=(r, 3, str(tmp_path / "rdzv"), sizes, str(tmp_path))) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = np.load(tmp_path / "merged_tcp.npz")
+    parts = [_fake_table(r, sizes[r]) for r in range(3)]
+    off = [shard_range(1000, r, 3)[0] for r in range(3)]
+    for k in got.files:
+        want = np.concatenate([p[k] for p in parts])
+        if k == "hap":
+            want = np.concatenate([np.where(p["hap"] == 0, 0, p["hap"].astype(np.int64) + o).astype(np.uint32)
+                                   for p, o in zip(parts, off)])
+        assert np.array_equal(got[k], want), k

@@ -84,3 +84,39 @@ def synth_region_from_fixture(fx):
     reg.variants = [synth.VariantSite(p, r, a, af, np.array([[int(c) for c in row] for row in gt], dtype=np.uint8))
                     for p, r, a, af, gt in fx["variants"]]
     return reg
+
+
+class GlooComm:
+    """The communicator interface of crisprhawk_hip.parallel (rank, world, barrier, allgather_i64, gatherv_bytes) over a
+    torch.distributed gloo process group: the CPU stand-in the world_size-2 tests run the exchange logic on."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def allgather_i64(self, vec):
+        import torch
+        mine = torch.tensor([int(v) for v in vec], dtype=torch.int64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(out, mine)
+        return torch.stack(out).numpy()
+
+    def gatherv_bytes(self, arr, dst=0):
+        import numpy as np
+        import torch
+        a = np.ascontiguousarray(arr)
+        n = len(a)
+        counts = self.allgather_i64([n])[:, 0]
+        width = int(np.prod(a.shape[1:], dtype=np.int64)) * a.dtype.itemsize if a.ndim > 1 else a.dtype.itemsize
+        buf = torch.zeros((int(counts.max()), max(width, 1)), dtype=torch.uint8)
+        if n:
+            buf[:n, :width] = torch.from_numpy(a.reshape(n, -1).view(np.uint8).reshape(n, -1).copy())
+        recv = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == dst else None
+        self._dist.gather(buf, recv, dst=dst)
+        if self.rank != dst:
+            return None
+        return [recv[r][: int(counts[r]), :width].numpy().copy().view(a.dtype).reshape((-1,) + a.shape[1:]) for r in range(self.world)]
