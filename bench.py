@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — candidate guides scored per second on the BASELINE.json workload.
+"""bench.py — candidate guides scored per second on the BASELINE.json workloads.
 
-A "step" is one pass of the device hot path (hawk_search: PAM scan fused with the in-range and
-REF-identical filters -> compaction -> coordinates / redundancy removal / window gather ->
-CFDon) over one haplotype set that is already resident in HBM as bit-sliced planes.  Default
-workload = BASELINE.json configs[2] ("C3": 1 Mb region x 2504 phased samples, NGG, 20 nt), the
-configuration the metric is quoted on.
+    python bench.py [--gpus N --steps K --warmup W] [--config c3|c1|c4|c5] [--weak]
 
-    python bench.py [--gpus N --steps K --warmup W]        # N > 1 via torch.distributed.run
+A "step" is one pass of the device hot path over inputs that are already resident in HBM:
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the longer of k_search_count
-and k_emit_list) with its algorithmic bytes against the 8 TB/s HBM peak, using its HIP-event duration
-measured on the stream it runs on:
-  k_emit_list     0.625 B read per scanned haplotype position (five bit planes) + 74 B written and 4 B
-                  of hand-over list read per guide row;
-  k_search_count  one bit per position for each plane the PAM names plus the variant plane
-                  (NGG/CCN: 0.375 B) + 4 B of hand-over list written per guide row.
-`cpu_baseline` times the
-C oracle (a port of the reference's algorithm, oracle/hawk_oracle.c) on a bounded sample of the
-same workload on the host cores (rank 0, N == 1 only).
+  c3 (default, the configuration the metric is quoted on: 1 Mb region x 2504 phased samples, NGG, 20 nt)
+      hawk_search (PAM scan fused with the in-range / REF-identical filters -> redundancy verdict -> coordinates ->
+      window gather -> CFDon) over the haplotype planes.
+  c1  the same on the 10 kb variant-free region (latency case; one haplotype: ranks are replicas).
+  c4  whole chr22-sized contig x 2504 samples, region-tiled: per tile hawk_xplan_run (expansion) -> hawk_search ->
+      hawk_table_collapse; resident inputs are the REF planes, the variant table and the carried-variant lists.
+  c5  off-target enumeration: TTTV / 23 nt / <= 4 mismatches against a packed synthetic genome (hawk_offtarget_scan).
+
+N > 1: one process per GPU.  Launched by the driver under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment) or, when `--gpus N` is given and WORLD_SIZE is not set, by this script itself (N child
+processes started before anything touches the GPU).  The ONE haplotype set is block-partitioned over the ranks
+(strong scaling, REF on every rank; `--weak` gives every rank its own 2504-sample panel instead); c5 shards the genome.
+There is no data-path collective: barriers and the timing / count reductions run over the package's TCP control plane,
+and the single exchange of the job - the RCCL gather of the guide tables over xGMI (hawk_table_gather) - is measured
+once after the timed loop and reported as `gather` next to `value`.
+
+One JSON line on stdout (rank 0): the driver's contract fields plus `roofline` (dominant kernel, algorithmic bytes over
+its HIP-event duration, against the 8 TB/s HBM peak), `cpu_baseline` (the C oracle on one host thread, bounded sample),
+`cpu_baseline_all_cores`, `end_to_end` (in-memory records -> expand -> search+CFDon -> collapse -> D2H of the report
+groups, wall clock) and per-kernel times.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,21 +42,362 @@ for _p in (ROOT, os.path.join(ROOT, "crispr-hawk_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 78.6e12  # 256 CUs x 4 SIMDs x 32 lanes/cycle x 2.4 GHz (MI355X_MICROARCH.md: F32 vector peak 157.3 TF = 2 flop x this)
 # Algorithmic bytes of one fused launch: every scanned haplotype position is read once as
 # 0.5 B of IUPAC code + 0.125 B of the variant plane (K3's REF-identical filter);
 # the emit pass additionally writes each guide row once (74 B: K3 record + packed window + K4 score).
 READ_BYTES_PER_POS = 0.625
 ROW_BYTES = 74
 LIST_BYTES = 4  # one u32 hand-over entry per guide row (count pass writes it, k_emit_list reads it)
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def log(msg):
     print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def usable_cores() -> int:
+    """Host threads this process may really use: the affinity mask, cut by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: `--gpus N` without a torch.distributed.run environment
+# ---------------------------------------------------------------------------------------------------
+def launch(n: int, argv) -> int:
+    """Start N rank processes (before this process has touched the GPU) and relay rank 0's stdout."""
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="hawk_rdzv_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HAWK_RDZV_DIR=rdzv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # a failed rank leaves the others waiting at a barrier: stop exactly the processes started here
+                    q.terminate()
+    try:
+        os.rmdir(rdzv)
+    except OSError:
+        pass
+    return rc
+
+
+class Ranks:
+    """rank / world / device of this process + the control-plane communicator (TCP; no torch, no RCCL)."""
+
+    def __init__(self, args):
+        from crisprhawk_hip import _lib, parallel
+        self.rank, self.world, self.local = parallel.env_rank_world()
+        self.backend = os.environ.get("HAWK_BENCH_BACKEND", "rccl")
+        if self.backend == "gloo":  # older name of the rehearsal backend
+            self.backend = "tcp"
+        ndev = _lib.device_count()
+        if ndev == 0:
+            raise _lib.HawkDeviceError("bench.py needs an MI355X: there is no CPU fallback on the product path")
+        # rehearsal on a box with fewer GPUs than ranks (HAWK_BENCH_ONE_GPU=1 or the tcp backend): wrap around
+        self.device = self.local % ndev if (os.environ.get("HAWK_BENCH_ONE_GPU") == "1" or self.backend == "tcp") else self.local
+        self.ctl = parallel.TcpComm(self.rank, self.world)
+        self._lib = _lib
+        self.ctx = _lib.context(self.device)
+
+    def barrier(self):
+        self._lib.check(self._lib.lib().hawk_sync(self.ctx), "hawk_sync")
+        self.ctl.barrier()
+
+    def max_float(self, x: float) -> float:
+        return max(self.ctl.allgather_obj(float(x)))
+
+    def sum_ints(self, vec):
+        return self.ctl.allgather_i64(vec).sum(axis=0).tolist()
+
+
+def timed_steps(R: Ranks, step, steps: int, warmup: int):
+    """W warm-up steps, then exactly K steps bracketed by device sync + barrier on both sides; the MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    R.barrier()
+    t0 = time.perf_counter()
+    outs = [step() for _ in range(steps)]
+    R.barrier()
+    return R.max_float(time.perf_counter() - t0), outs
+
+
+def pam_need_planes(pam) -> int:
+    from crisprhawk_hip.pam import IUPAC_BITS
+    need = 0
+    for nib in pam.bits_list + [IUPAC_BITS[c] for c in pam.pamrc.upper()]:
+        if nib != 15:
+            need |= nib
+    return need
+
+
+def search_roofline(pam, positions, rows, count_ms, emit_list_ms, emit_ms, traffic_key=None):
+    """The dominant kernel of the fused search (the longer of the count pass and the list-driven emit pass), priced with
+    the bytes it has to move."""
+    need = pam_need_planes(pam)
+    count_bpp = 0.125 * (bin(need).count("1") + 1)
+    if emit_list_ms == 0.0:  # HAWK_LIST_EMIT=0: the recompute-everything emit pass
+        emit_name, e_ms, emit_bytes = "k_search_emit", emit_ms, READ_BYTES_PER_POS * positions + ROW_BYTES * rows
+        count_bytes = count_bpp * positions
+    else:
+        emit_name, e_ms, emit_bytes = "k_emit_list", emit_list_ms, READ_BYTES_PER_POS * positions + (ROW_BYTES + LIST_BYTES) * rows
+        count_bytes = count_bpp * positions + LIST_BYTES * rows
+    cands = [(emit_name, e_ms, emit_bytes, READ_BYTES_PER_POS), ("k_search_count", count_ms, count_bytes, count_bpp)]
+    cands.sort(key=lambda c: -c[1])
+    (dom, dom_ms, dom_bytes, bpp), (oth, oth_ms, oth_bytes, _) = cands
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+    traffic = None
+    if traffic_key and os.path.exists(PROFILE_TRAFFIC):
+        tk = json.load(open(PROFILE_TRAFFIC)).get(traffic_key, {}).get(dom)
+        traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]  # PMC bytes per launch of the committed profile
+    step_bytes = READ_BYTES_PER_POS * positions + ROW_BYTES * rows  # every plane bit read once + every row written once
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes, "read_bytes_per_position": bpp,
+            "row_bytes": ROW_BYTES, "list_bytes_per_row": LIST_BYTES,
+            "other_kernel": {"kernel": oth, "launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_bytes,
+                             "frac": (oth_bytes / (oth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if oth_ms else None},
+            "step_level": {"algorithmic_bytes": step_bytes, "what": "planes read once (0.625 B/position) + rows written once (74 B)"}}
+
+
+def pam_scan_kernel(ds, pam):
+    """The K2 PAM-scan kernel on its own (what `pam_search` runs): north_star's >= 40 % of HBM peak target."""
+    import ctypes as C
+    from crisprhawk_hip import _lib
+    ps_ms, ps_pos = C.c_float(0), C.c_uint64(0)
+    _lib.check(_lib.lib().hawk_pam_scan_time(ds._h, C.c_uint64(pam.bits), C.c_uint64(pam.bitsrc), len(pam), 20, C.byref(ps_ms),
+                                             C.byref(ps_pos)), "hawk_pam_scan_time")
+    # bytes the scan really moves: one bit per position for each plane the PAM names (NGG/CCN: G and C only) plus the
+    # forward and reverse hit bits; SURVEY.md §8(d) prices the nibble formulation at 0.75 B/position
+    ps_bpp = 0.125 * bin(pam_need_planes(pam)).count("1") + 0.25
+    ps_bytes = ps_bpp * ps_pos.value
+    ach = ps_bytes / (ps_ms.value * 1e-3) / 1e9
+    return {"kernel": "k_scan_raw", "launch_ms": ps_ms.value, "bytes_per_position": ps_bpp, "bytes_per_launch": ps_bytes, "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "survey_algorithmic_bytes_per_position": 0.75,
+            "positions_per_s": ps_pos.value / (ps_ms.value * 1e-3)}
+
+
+def base_line(args, R: Ranks, value, elapsed, scaling, dtype, config):
+    return {"metric": "candidate guides scored/sec", "value": value, "unit": "candidates/s", "n_gpus": R.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": config}
+
+
+# ---------------------------------------------------------------------------------------------------
+# c3 / c1: one region, haplotype planes resident
+# ---------------------------------------------------------------------------------------------------
+def run_region(args, R: Ranks):
+    from crisprhawk_hip import synth
+    from crisprhawk_hip.pam import PAM
+    from crisprhawk_hip.parallel import shard_range
+    from crisprhawk_hip.workload import _ref_only_set, expand_on_device
+
+    c1 = args.config == "c1"
+    t0 = time.time()
+    if c1:
+        reg = synth.config_c1()
+    else:
+        reg = synth.make_region(1003, "chr22", args.region_len + 200_000, 100_000, 100_000 + args.region_len)
+        # strong scaling: ONE panel, block-partitioned; --weak: every rank its own panel (round 1's measurement)
+        synth.add_phased_variants(reg, 1003_1 + (7919 * R.rank if args.weak else 0), args.sites, args.samples)
+    pam = PAM(args.pam, args.right, True)
+    pam.encode(0)
+    n_samples = len(reg.samples)
+    slo, shi = (0, n_samples) if (args.weak or c1) else shard_range(n_samples, R.rank, R.world)
+    t1 = time.time()
+    ds, info, expand_ms, kept = expand_on_device(reg, len(pam), device=R.device, sample_range=(slo, shi))
+    region_nt = int(ds.hap_len[0])
+    log(f"workload: {ds.n_hap} haplotype rows x {region_nt} nt (samples {slo}..{shi} of {n_samples}), {len(reg.variants)} sites; "
+        f"synthesised in {t1 - t0:.1f}s, expanded on the device in {time.time() - t1:.1f}s (kernels {expand_ms:.2f} ms, "
+        f"{5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes)")
+    score = (not args.right) and pam.cas_system in (3, 4)  # scoring.py:749-792: CFDon for SpCas9/xCas9 PAMs
+    mm, pt = synth.cfd_tables() if score else (None, None)
+
+    def step(keep=False):
+        tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+        if not keep:
+            tab.close()
+        return tab
+
+    elapsed, tabs = timed_steps(R, step, args.steps, args.warmup)
+    tab = tabs[-1]
+    tm = [t.timing for t in tabs]
+    avg = lambda k: float(np.mean([t[k] for t in tm]))
+    cand, rows, positions = tab.n_candidates, tab.n_rows, tab.timing["scanned_positions"]
+    # REF is scanned by every rank: count it once in the whole-job totals
+    ref_c = ref_r = ref_p = 0
+    if R.world > 1 and not args.weak and not c1:
+        ref_ds = _ref_only_set(reg.sequence, reg.startp, reg.stopp, len(pam), R.device)
+        rt = ref_ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+        ref_c, ref_r, ref_p = rt.n_candidates, rt.n_rows, rt.timing["scanned_positions"]
+        rt.close()
+        ref_ds.close()
+    tot = R.sum_ints([cand, rows, positions, ds.n_hap])
+    dup = R.world - 1
+    cand_all, rows_all, pos_all = tot[0] - dup * ref_c, tot[1] - dup * ref_r, tot[2] - dup * ref_p
+    if c1:  # replicas: every rank searched the same haplotype
+        cand_all, rows_all, pos_all = cand * R.world, rows * R.world, positions * R.world
+
+    workload = ("C1: 10 kb region, no VCF (BASELINE.json configs[1])" if c1 else
+                "C3: 1 Mb region x 2504 phased samples (BASELINE.json configs[2])" if (args.samples, args.region_len) == (2504, 1_000_000)
+                else "custom")
+    out = None
+    if R.rank == 0:
+        out = base_line(args, R, cand_all * args.steps / elapsed, elapsed, "weak" if (args.weak or c1) else "strong", "u32",
+                        {"workload": workload, "pam": args.pam, "guidelen": args.guidelen, "right": args.right, "region_nt": region_nt,
+                         "haplotypes_rank0": ds.n_hap, "haplotype_rows_all_ranks": tot[3] - dup, "samples": n_samples,
+                         "partition": "replicas" if c1 else ("own panel per rank" if args.weak else "sample blocks of one panel, REF on every rank"),
+                         "variant_sites": len(reg.variants), "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
+                         "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all})
+        tkey = "c3" if workload.startswith("C3") and R.world == 1 else None
+        out["roofline"] = search_roofline(pam, positions, rows, avg("count_ms"), avg("emit_list_ms"), avg("emit_ms"), tkey)
+        sl = out["roofline"]["step_level"]
+        sl["ms"] = avg("total_ms")
+        sl["frac"] = sl["algorithmic_bytes"] / (sl["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sl["ms"] else None
+        out["kernels_ms"] = {"count": avg("count_ms"), "offsets": avg("offsets_ms"), "emit": avg("emit_ms"), "emit_list": avg("emit_list_ms"),
+                             "device_total": avg("total_ms")}
+        out["pam_scan_kernel"] = pam_scan_kernel(ds, pam)
+        out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap, "where": "device (hawk_xplan_run), outside the timed steps"}
+    for t in tabs:
+        t.close()
+
+    # ---- the one exchange of the job (N > 1): guide tables to rank 0 over RCCL ----------------------
+    if R.world > 1 and not args.no_gather:
+        g = gather_once(R, ds, step, tot[3])
+        if R.rank == 0:
+            out["gather"] = g
+    if R.rank == 0 and R.world == 1:
+        if not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(args, R, reg, pam, mm, pt, info, kept, c1)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(reg, pam, args, mm, pt)
+            if not c1 and not args.no_cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
+    ds.close()
+    return out
+
+
+def gather_once(R: Ranks, ds, step, n_hap_total):
+    """Measured once after the timed loop and reported next to `value`, not inside it: the per-step path has no
+    data-path collective.  Full table (74 B/row) device to device, then the collapsed form (one
+    representative row per report group + 4 B per member)."""
+    from crisprhawk_hip import parallel
+    if R.backend != "rccl":
+        return {"skipped": f"backend {R.backend}: the RCCL exchange needs one GPU per rank"}
+    res = {}
+    try:
+        comm = parallel.RcclComm(R.ctl, R.device)
+        n_all = R.ctl.allgather_i64([ds.n_hap])[:, 0]
+        hap_off = int(n_all[:R.rank].sum() - R.rank)  # rows of the earlier ranks, their REF rows not counted
+        tab = step(keep=True)
+        comm.barrier()
+        t0 = time.perf_counter()
+        merged, ms = comm.gather_table(tab, hap_off, 0)
+        comm.barrier()
+        wall = time.perf_counter() - t0
+        rows = R.sum_ints([tab.n_rows])[0]
+        if R.rank == 0:
+            res["full_table"] = {"ms_on_stream": ms, "wall_ms": wall * 1e3, "rows": rows, "bytes_to_rank0": rows * ROW_BYTES,
+                                 "GBps": rows * ROW_BYTES / wall / 1e9, "merged_rows": merged.n_rows}
+            merged.close()
+        # collapsed: per-rank device collapse + group export, then representatives + member lists
+        t0 = time.perf_counter()
+        tab.collapse(download_perm=False)
+        g = tab.export_groups()
+        tab.close()
+        t1 = time.perf_counter()
+        rep = {k: getattr(g, k) for k in ("pos", "strand", "start", "stop", "flags", "cfdon")}
+        rep["win"] = np.ascontiguousarray(g.win.T)
+        mem = g.member_hap.astype(np.int64)
+        mem = np.where(mem == 0, 0, mem + hap_off).astype(np.uint32)
+        first = g.member_hap[g.member_off[:-1]] if g.n_groups else np.zeros(0, np.uint32)
+        origin = np.asarray(ds.is_ref, dtype=np.uint8)[first]
+        parts = {k: comm.gatherv_bytes(v, 0) for k, v in rep.items()}
+        o_p, s_p, m_p = comm.gatherv_bytes(origin, 0), comm.gatherv_bytes(np.diff(g.member_off), 0), comm.gatherv_bytes(mem, 0)
+        t2 = time.perf_counter()
+        if R.rank == 0:
+            repc = {k: np.concatenate(v) for k, v in parts.items()}
+            mg, moff, members = parallel.merge_groups(repc, np.concatenate(o_p), np.concatenate(s_p), np.concatenate(m_p),
+                                                      g.guidelen, g.pamlen)
+            t3 = time.perf_counter()
+            nbytes = sum(sum(a.nbytes for a in v) for v in parts.values()) + sum(a.nbytes for a in m_p) + sum(a.nbytes for a in s_p)
+            res["collapsed"] = {"collapse_export_s": t1 - t0, "exchange_s": t2 - t1, "merge_on_rank0_s": t3 - t2, "bytes_to_rank0": nbytes,
+                                "groups": len(moff) - 1, "members": len(members)}
+        comm.barrier()
+        comm.close()
+    except Exception as e:  # the value line must survive a failed exchange
+        res["error"] = f"{type(e).__name__}: {e}"
+        log(f"gather failed: {res['error']}")
+    return res
+
+
+def end_to_end(args, R: Ranks, reg, pam, mm, pt, info, kept, c1):
+    """in-memory records -> device expansion -> search + CFDon -> collapse -> D2H of the report groups,
+    wall clock (rank 0, N = 1).  With --report the guide report (f2) is assembled from the groups as well."""
+    from crisprhawk_hip.workload import expand_on_device
+    t0 = time.perf_counter()
+    ds, info2, ems, kept2 = expand_on_device(reg, len(pam), device=R.device)
+    t1 = time.perf_counter()
+    tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+    R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+    t2 = time.perf_counter()
+    tab.collapse(download_perm=False)
+    g = tab.export_groups()
+    t3 = time.perf_counter()
+    d2h = sum(getattr(g, k).nbytes for k in ("rep_row", "pos", "strand", "start", "stop", "flags", "cfdon", "win", "member_hap")) + \
+        g.member_off.nbytes + g.gc_num.nbytes + g.gc_den.nbytes
+    res = {"wall_s": t3 - t0, "candidates_per_s": tab.n_candidates / (t3 - t0),
+           "stages_s": {"expand (host index preparation + kernels)": t1 - t0, "search + CFDon": t2 - t1,
+                        "collapse + D2H of the report groups": t3 - t2},
+           "kernels_ms": {"expand": ems, "search": tab.timing["total_ms"], "collapse": tab.collapse_ms, "export": g.export_ms},
+           "rows": tab.n_rows, "groups": g.n_groups, "d2h_bytes": int(d2h),
+           "what": "in-memory variant records + genotype matrix -> hawk_xplan_create/run -> hawk_search -> hawk_table_collapse -> "
+                   "hawk_table_collapse_export; FASTA/VCF text ingest (f3) is timed by --vcf"}
+    if args.report and not c1:
+        from crisprhawk_hip import reports
+        from crisprhawk_hip.workload import hap_labels
+        t4 = time.perf_counter()
+        df = reports.report_from_groups(g, hap_labels(reg.contig, reg.variants, ds, info2, kept2), pam, reg.contig,
+                                        f"{reg.contig}:{reg.bed_start}-{reg.bed_stop}", is_ref_hap=np.asarray(ds.is_ref, dtype=bool))
+        t5 = time.perf_counter()
+        txt = reports.to_tsv(df)
+        t6 = time.perf_counter()
+        res["report"] = {"assemble_s": t5 - t4, "report_rows": int(len(df)), "tsv_text_s": t6 - t5, "tsv_bytes": len(txt),
+                         "what": "reports.report_from_groups (columnar; samples / haplotype ids joined by the library's host helpers) "
+                                 "+ reports.to_tsv"}
+        res["wall_with_report_s"] = t6 - t0
+        del txt
+    if args.vcf and not c1:
+        res["vcf_ingest"] = time_vcf_ingest(reg, ds, len(pam), R.device)
+    tab.close()
+    ds.close()
+    return res
+
+
 def time_vcf_ingest(reg, ds_ref, pamlen, device):
     """f3 at workload scale: the VCF text of the region's records (what readers.VCF.fetch_block returns) ->
-    hawk_gt_parse -> hawk_gt_lists -> hawk_hapset_expand, compared with the planes of the in-memory path."""
+    hawk_gt_parse -> hawk_gt_lists -> expansion, compared with the planes of the in-memory path."""
     from crisprhawk_hip.readers import VcfBlock
     from crisprhawk_hip.workload import expand_from_vcf
     t0 = time.perf_counter()
@@ -73,6 +422,7 @@ def time_vcf_ingest(reg, ds_ref, pamlen, device):
     ds2, info2, ms, kept2, vt = expand_from_vcf(reg.sequence, reg.startp, reg.stopp, blk, reg.samples, pamlen, True, device)
     t2 = time.perf_counter()
     same = bool(ds2.n_hap == ds_ref.n_hap and np.array_equal(ds2.planes(), ds_ref.planes()))
+    ds2.close()
     log(f"vcf ingest: {len(text) / 1e6:.0f} MB of records -> {ds2.n_hap} haplotype rows in {t2 - t1:.2f}s "
         f"(parse {ms['parse']:.2f} ms, lists {ms['lists']:.2f} ms, expand {ms['expand']:.2f} ms); planes identical: {same}")
     return {"text_bytes": int(len(text)), "records": len(blk), "samples": ns, "make_text_s": t1 - t0, "ingest_wall_s": t2 - t1,
@@ -80,297 +430,332 @@ def time_vcf_ingest(reg, ds_ref, pamlen, device):
             "planes_identical_to_in_memory_path": same}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=2504)
-    ap.add_argument("--sites", type=int, default=31000)
-    ap.add_argument("--region-len", type=int, default=1_000_000)
-    ap.add_argument("--pam", default="NGG")
-    ap.add_argument("--guidelen", type=int, default=20)
-    ap.add_argument("--right", action="store_true")
-    ap.add_argument("--cpu-haps", type=int, default=1280, help="haplotypes in the cpu_baseline sample (about 12 s of single-thread oracle work on C3)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-expand", action="store_true", help="build the haplotype strings on the host and pack them (K1) instead of expanding on the device")
-    ap.add_argument("--vcf", action="store_true", help="also time the VCF-text ingest of the workload (f3: device genotype parser + carried lists)")
-    ap.add_argument("--report", action="store_true", help="also assemble the guide report (f2) of the whole workload once and time it")
-    ap.add_argument("--no-collapse", action="store_true", help="skip the one-off report-row collapse after the timed loop")
-    ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("HAWK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 control flow without RCCL
-    cdev = "cuda" if backend == "nccl" else "cpu"           # where the small collective tensors live
-    if world > 1:
-        import torch
-        import torch.distributed as dist  # RCCL ("nccl") process group: barrier, timing reduce, table gather
-
-        if os.environ.get("HAWK_BENCH_ONE_GPU") == "1":  # rehearsal: every rank on GPU 0 of a one-GPU box
-            local = 0
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-
-    from crisprhawk_hip import _lib, synth
-    from crisprhawk_hip.hapset import DeviceHapSet
-    from crisprhawk_hip.pam import PAM
-    from crisprhawk_hip.workload import build_phased_haplotypes, expand_on_device
-
-    if _lib.device_count() == 0:
-        raise _lib.HawkDeviceError("bench.py needs an MI355X: there is no CPU fallback on the product path")
-
-    # ---- workload: haplotypes are independent units -> each rank owns its own 2504 samples
-    # (weak scaling: per-GPU work fixed); REF is on every rank (needed by the alt==REF filter)
-    t0 = time.time()
-    reg = synth.make_region(1003, "chr22", args.region_len + 200_000, 100_000, 100_000 + args.region_len)
-    synth.add_phased_variants(reg, 1003_1 + 7919 * rank, args.sites, args.samples)
-    pam = PAM(args.pam, args.right, True)
-    pam.encode(0)
-    expand_ms = None
-    if args.host_expand:
-        haps, _info = build_phased_haplotypes(reg, len(pam))
-        log(f"workload: {len(haps)} haplotypes x {len(haps[0].seq)} nt, {len(reg.variants)} sites, built on the host in {time.time() - t0:.1f}s")
-        t0 = time.time()
-        ds = DeviceHapSet(haps, device=local)
-        region_nt = len(haps[0].seq)
-        log(f"resident in HBM ({5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes) in {time.time() - t0:.1f}s")
-    else:  # the haplotypes are expanded on the device from REF + variant table + genotypes
-        t1 = time.time()
-        ds, _info, expand_ms, _kept = expand_on_device(reg, len(pam), device=local)
-        region_nt = int(ds.hap_len[0])
-        log(f"workload: {ds.n_hap} haplotype rows x {region_nt} nt, {len(reg.variants)} sites; synthesised in {t1 - t0:.1f}s, "
-            f"expanded on the device in {time.time() - t1:.1f}s (kernels {expand_ms:.2f} ms, {5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes)")
-    score = (not args.right) and pam.cas_system in (3, 4)  # scoring.py:749-792: CFDon for SpCas9/xCas9 PAMs
-    mm, pt = synth.cfd_tables() if score else (None, None)
-
-    counts_all = None
-    if dist is not None:
-        import torch
-        counts_all = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
-
-    def step(keep=False):
-        tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
-        if dist is not None:  # the table directory every rank needs before any exchange: rows + candidates per rank
-            mine = torch.tensor([tab.n_rows, tab.n_candidates], dtype=torch.int64, device=cdev)
-            dist.all_gather_into_tensor(counts_all, mine)
-        if not keep:
-            tab.close()
-        return tab
-
-    def barrier():
-        _lib.check(_lib.lib().hawk_sync(ds._ctx), "hawk_sync")
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t_start = time.perf_counter()
-    scan_ms, tot_ms, kern = [], [], {"offsets_ms": [], "emit_ms": [], "emit_list_ms": []}
-    tab = None
-    for _ in range(args.steps):
-        tab = step()
-        scan_ms.append(tab.timing["count_ms"])
-        tot_ms.append(tab.timing["total_ms"])
-        for k in kern:
-            kern[k].append(tab.timing[k])
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    cand, rows, positions = tab.n_candidates, tab.n_rows, tab.timing["scanned_positions"]
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([cand, rows, positions], dtype=torch.int64, device=cdev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        cand_all, rows_all, pos_all = (int(x) for x in c.tolist())
-    else:
-        cand_all, rows_all, pos_all = cand, rows, positions
-
-    # the PAM-scan kernel on its own (K2, what `pam_search` runs): north_star's >= 40 % of HBM peak target
-    import ctypes as C
-    ps_ms, ps_pos = C.c_float(0), C.c_uint64(0)
-    _lib.check(_lib.lib().hawk_pam_scan_time(ds._h, C.c_uint64(pam.bits), C.c_uint64(pam.bitsrc), len(pam), 20, C.byref(ps_ms),
-                                             C.byref(ps_pos)), "hawk_pam_scan_time")
-    # f2 (outside the timed steps): which rows the report merges, sorted and grouped in HBM
-    collapse = None
-    if rank == 0 and not args.no_collapse:
-        tc = step(keep=True) if dist is None else ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
-        ng, cms = C.c_uint64(), C.c_float()
-        _lib.check(_lib.lib().hawk_table_collapse(tc._t, C.byref(ng), C.byref(cms)), "hawk_table_collapse")
-        collapse = {"kernels_ms": cms.value, "rows": tc.n_rows, "groups": ng.value,
-                    "what": "k_collapse_keys + rocprim radix sort (key, row) + k_collapse_heads + scan + k_collapse_groups"}
-        if args.report and not args.host_expand:
-            from crisprhawk_hip import reports as hip_reports
-            from crisprhawk_hip.workload import row_labels
-            t0 = time.perf_counter()
-            tc.collapse()
-            t1 = time.perf_counter()
-            inp = hip_reports.ReportInput.from_table(tc)
-            t2 = time.perf_counter()
-            df = hip_reports.report_frame(inp, row_labels(reg, ds, _info, _kept), pam, reg.contig, f"{reg.contig}:{reg.bed_start}-{reg.bed_stop}")
-            t3 = time.perf_counter()
-            collapse["report"] = {"report_rows": int(len(df)), "collapse_and_download_group_arrays_s": t1 - t0,
-                                  "table_download_and_decode_s": t2 - t1, "assemble_s": t3 - t2,
-                                  "what": "crisprhawk_hip.reports.report_frame: one pass per report row (variants, AFs, samples, order)"}
-            log(f"report: {len(df)} rows from {tc.n_rows} guide rows in {t3 - t0:.1f}s")
-        tc.close()
-    vcf_ingest = None
-    if rank == 0 and args.vcf and not args.host_expand:
-        vcf_ingest = time_vcf_ingest(reg, ds, len(pam), local)
-    gather = None
-    if dist is not None and not args.no_gather and backend == "nccl":
-        gather = gather_once(ds, step, dist, rank, world)
-
-    out = None
-    if rank == 0:
-        scan_avg_ms = float(np.mean(scan_ms))
-        emit_avg_ms = float(np.mean(kern["emit_ms"]))
-        # dominant kernel = the longer of the count pass and the list-driven emit pass, each priced with the
-        # bytes it has to move
-        need = 0
-        for nib in pam.bits_list + [{"A": 1, "C": 2, "G": 4, "T": 8}.get(c, 0) or synth_iupac(c) for c in pam.pamrc.upper()]:
-            if nib != 15:
-                need |= nib
-        count_bpp = 0.125 * (bin(need).count("1") + 1)
-        emit_list_avg_ms = float(np.mean(kern["emit_list_ms"]))
-        if emit_list_avg_ms == 0.0:  # HAWK_LIST_EMIT=0: the recompute-everything emit pass
-            emit_name, emit_ms_, emit_bytes = "k_search_emit", emit_avg_ms, READ_BYTES_PER_POS * positions + ROW_BYTES * rows
-            count_bytes = count_bpp * positions
-        else:
-            emit_name, emit_ms_, emit_bytes = "k_emit_list", emit_list_avg_ms, READ_BYTES_PER_POS * positions + (ROW_BYTES + LIST_BYTES) * rows
-            count_bytes = count_bpp * positions + LIST_BYTES * rows
-        if emit_ms_ >= scan_avg_ms:
-            dom, dom_ms, algo_bytes, bpp = emit_name, emit_ms_, emit_bytes, READ_BYTES_PER_POS
-        else:
-            dom, dom_ms, algo_bytes, bpp = "k_search_count", scan_avg_ms, count_bytes, count_bpp
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and (args.samples, args.sites, args.region_len, args.pam, args.guidelen) == (2504, 31000, 1_000_000, "NGG", 20):
-            tk = json.load(open(tpath))["kernels"].get(dom)
-            traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]  # PMC bytes per launch of the committed profile
-        out = {
-            "metric": "candidate guides scored/sec", "value": cand_all * args.steps / elapsed, "unit": "candidates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "C3: 1 Mb region x 2504 phased samples (BASELINE.json configs[2])" if (args.samples, args.region_len) == (2504, 1_000_000) else "custom",
-                       "pam": args.pam, "guidelen": args.guidelen, "right": args.right, "region_nt": region_nt,
-                       "haplotypes_per_gpu": ds.n_hap, "samples_per_gpu": args.samples, "variant_sites": len(reg.variants),
-                       "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
-                       "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": dom_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes, "read_bytes_per_position": bpp,
-                         "row_bytes": ROW_BYTES, "list_bytes_per_row": LIST_BYTES,
-                         "other_kernel": {"kernel": "k_search_count" if dom != "k_search_count" else emit_name,
-                                          "launch_ms": scan_avg_ms if dom != "k_search_count" else emit_ms_,
-                                          "algorithmic_bytes_per_launch": count_bytes if dom != "k_search_count" else emit_bytes,
-                                          "frac": (count_bytes / (scan_avg_ms * 1e-3) if dom != "k_search_count" else emit_bytes / (emit_ms_ * 1e-3)) / 1e9 / HBM_PEAK_GBS}},
-            "kernels_ms": {"count": scan_avg_ms, **{k[:-3]: float(np.mean(v)) for k, v in kern.items()},
-                           "device_total": float(np.mean(tot_ms))},
-        }
-        # bytes the scan really moves: one bit per position for each plane the PAM names (NGG/CCN: G and C only)
-        # plus the forward and reverse hit bits; SURVEY.md §8(d) prices the nibble formulation at 0.75 B/position.
-        need = 0
-        for nib in pam.bits_list + [{"A": 1, "C": 2, "G": 4, "T": 8}.get(c, 0) or synth_iupac(c) for c in pam.pamrc.upper()]:
-            if nib != 15:
-                need |= nib
-        ps_bpp = 0.125 * bin(need).count("1") + 0.25
-        ps_bytes = ps_bpp * ps_pos.value
-        out["pam_scan_kernel"] = {"kernel": "k_scan_raw", "launch_ms": ps_ms.value, "bytes_per_position": ps_bpp,
-                                  "bytes_per_launch": ps_bytes, "achieved": ps_bytes / (ps_ms.value * 1e-3) / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ps_bytes / (ps_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "survey_algorithmic_bytes_per_position": 0.75,
-                                  "positions_per_s": ps_pos.value / (ps_ms.value * 1e-3)}
-        if expand_ms is not None:
-            out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap, "where": "device (hawk_hapset_expand), outside the timed steps"}
-        if collapse is not None:
-            out["collapse"] = collapse
-        if vcf_ingest is not None:
-            out["vcf_ingest"] = vcf_ingest
-        if gather is not None:
-            out["gather"] = gather
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(reg, pam, args, mm, pt)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-
-
-def synth_iupac(c):
-    from crisprhawk_hip.pam import IUPAC_BITS
-    return IUPAC_BITS[c]
-
-
-def gather_once(ds, step, dist, rank, world):
-    """The single exchange of the job: every rank's guide table to rank 0 over RCCL (xGMI), device to
-    device.  Measured once after the timed loop and reported next to `value`, not inside it: the
-    per-step path has no data-path collective."""
-    import torch
-    tab = step(keep=True)
-    n = tab.n_rows
-    cnt = torch.zeros(world, dtype=torch.int64, device="cuda")
-    dist.all_gather_into_tensor(cnt, torch.tensor([n], dtype=torch.int64, device="cuda"))
-    nmax = int(cnt.max().item())
-    widths = (4, 4, 1, 8, 8, 1, 8, 40)  # hap pos strand start stop flags cfdon win[5]
-    send = [torch.zeros(nmax * w, dtype=torch.uint8, device="cuda") for w in widths]
-    tab.export_to(*[t.data_ptr() for t in send])
-    tab.close()
-    recv = [[torch.empty_like(t) for _ in range(world)] for t in send] if rank == 0 else [None] * len(send)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for t, r in zip(send, recv):
-        dist.gather(t, r, dst=0)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    total = int(cnt.sum().item()) * sum(widths)
-    return {"ms": dt * 1e3, "bytes_to_rank0": total, "GBps": total / dt / 1e9, "rows": int(cnt.sum().item())}
+# ---------------------------------------------------------------------------------------------------
+# cpu baselines (the oracle = a C port of the reference's algorithm; bounded samples of the same workload)
+# ---------------------------------------------------------------------------------------------------
+def _oracle_batch(reg, pamlen, b, per):
+    from crisprhawk_hip.workload import build_phased_haplotypes
+    from oracle import oracle as ora
+    n = max(1, len(reg.samples))
+    lo = (b * per) % n
+    sub, _ = build_phased_haplotypes(reg, pamlen, sample_slice=slice(lo, lo + per))
+    hs = ora.HapSet([bytes(h.seq).decode("ascii") for h in sub], [h.seg.full() for h in sub], [h.is_ref for h in sub], [h.scan for h in sub])
+    blob_args = hs.packed()
+    hs.packed = lambda blob_args=blob_args: blob_args
+    return hs, len(sub)
 
 
 def cpu_baseline(reg, pam, args, mm, pt):
-    """The oracle (C port of the reference algorithm) on the first --cpu-haps haplotypes of the same workload, one
-    host thread: search + reverse_guides + CFDon.  The sample is walked in batches of 80 samples (REF + <= 160
-    haplotypes each, so host memory stays bounded); building the batch's strings and marshalling them are not
-    timed (the GPU side starts from resident planes too)."""
-    from crisprhawk_hip.workload import build_phased_haplotypes
+    """The oracle on the first --cpu-haps haplotypes of the same workload, one host thread: search + reverse_guides +
+    CFDon.  The sample is walked in batches of 80 samples (REF + <= 160 haplotypes each, so host memory stays bounded);
+    building the batch's strings and marshalling them are not timed (the GPU side starts from resident planes too)."""
     from oracle import oracle as ora
-
-    cand, dt, nh, per = 0, 0.0, 0, 80
-    n_samples = len(reg.samples)
-    b = 0
-    while nh < max(2, args.cpu_haps) and b * per < max(1, n_samples):
-        sub, _ = build_phased_haplotypes(reg, len(pam), sample_slice=slice(b * per, (b + 1) * per))
-        hs = ora.HapSet([bytes(h.seq).decode("ascii") for h in sub], [h.seg.full() for h in sub], [h.is_ref for h in sub],
-                        [h.scan for h in sub])
-        blob_args = hs.packed()
-        hs.packed = lambda blob_args=blob_args: blob_args
+    cand, dt, nh, per, b = 0, 0.0, 0, 80, 0
+    reps = 0
+    while True:
+        hs, n_sub = _oracle_batch(reg, len(pam), b, per)
         t0 = time.perf_counter()
         res = ora.search(hs, pam.pam, args.guidelen, args.right)
         ora.reverse_and_cfdon(res, hs.is_ref, args.guidelen, len(pam), mm, pt, decode=False)
         dt += time.perf_counter() - t0
         cand += res.n_candidates
-        nh += len(sub)
+        nh += n_sub
         b += 1
-        if not reg.variants:
+        reps += 1
+        if reg.variants:
+            if nh >= max(2, args.cpu_haps) or b * per >= len(reg.samples):
+                break
+        elif dt > 2.0 or reps >= 2000:  # variant-free region: repeat the one haplotype for a measurable time
             break
     return {"value": cand / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
             "sample": f"{nh} haplotype scans of the same workload in {b} batches of REF + <= {2 * per} haplotypes "
-                      f"({cand} candidates, {dt:.1f} s, 1 thread of {os.cpu_count()})"}
+                      f"({cand} candidates, {dt:.1f} s, 1 thread of {usable_cores()} usable)"}
+
+
+def _cpu_worker(wid, n_workers, batches, argv, barrier, q):
+    """One oracle worker (own process, spawn context - the parent has initialised HIP): prepare its batches untimed,
+    meet the others at the barrier, then search + CFDon back to back; report start / end stamps and candidates."""
+    sys.argv = ["bench.py"] + argv
+    args = build_parser().parse_args(argv)
+    from crisprhawk_hip import synth
+    from crisprhawk_hip.pam import PAM
+    from oracle import oracle as ora
+    reg = synth.make_region(1003, "chr22", args.region_len + 200_000, 100_000, 100_000 + args.region_len)
+    synth.add_phased_variants(reg, 1003_1, args.sites, args.samples)
+    pam = PAM(args.pam, args.right, True)
+    pam.encode(0)
+    score = (not args.right) and pam.cas_system in (3, 4)
+    mm, pt = synth.cfd_tables() if score else (None, None)
+    sets = [_oracle_batch(reg, len(pam), wid * batches + k, 40)[0] for k in range(batches)]
+    barrier.wait()
+    t0 = time.time()
+    cand = 0
+    for hs in sets:
+        res = ora.search(hs, pam.pam, args.guidelen, args.right)
+        ora.reverse_and_cfdon(res, hs.is_ref, args.guidelen, len(pam), mm, pt, decode=False)
+        cand += res.n_candidates
+    q.put((wid, t0, time.time(), cand, sum(len(h.seqs) for h in sets)))
+
+
+def cpu_baseline_all_cores(args):
+    """the same oracle on every usable host core at once (one process per core, each with its own
+    bounded sample of the workload); rate = all candidates / (last end - first start)."""
+    import multiprocessing as mp
+    n = min(usable_cores(), int(os.environ.get("HAWK_CPU_WORKERS", "64")))
+    ctx = mp.get_context("spawn")
+    barrier, q = ctx.Barrier(n), ctx.Queue()
+    argv = [a for a in sys.argv[1:]]
+    procs = [ctx.Process(target=_cpu_worker, args=(w, n, 8, argv, barrier, q)) for w in range(n)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(n):
+            res.append(q.get(timeout=600))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.terminate()
+    start, end = min(r[1] for r in res), max(r[2] for r in res)
+    cand, nh = sum(r[3] for r in res), sum(r[4] for r in res)
+    return {"value": cand / (end - start), "unit": "candidates/s", "cores": n, "kind": "port",
+            "sample": f"{n} processes x 8 batches of REF + <= 80 haplotypes ({nh} haplotype scans, {cand} candidates) in "
+                      f"{end - start:.1f} s between the common start and the last finish; set-up {start - t0:.0f} s not timed"}
+
+
+# ---------------------------------------------------------------------------------------------------
+# c4: whole contig, region-tiled
+# ---------------------------------------------------------------------------------------------------
+def run_c4(args, R: Ranks):
+    from crisprhawk_hip import synth
+    from crisprhawk_hip.pam import PAM
+    from crisprhawk_hip.parallel import shard_range
+    from crisprhawk_hip.tiling import TiledRegionSearch
+
+    pam = PAM(args.pam, args.right, True)
+    pam.encode(0)
+    t0 = time.time()
+    n_block = int(args.contig_len * args.n_block_frac)
+    seq, panel = synth.contig_panel(1004, "chr22", args.contig_len, n_block, args.samples, sites_per_mb=args.sites / (args.region_len / 1e6))
+    slo, shi = (0, args.samples) if args.weak else shard_range(args.samples, R.rank, R.world)
+    startp, stopp = 1, args.contig_len  # BED 100 .. contig_len - 100: the whole contig, padding inside it
+    trs = TiledRegionSearch(lambda lo, hi: seq[lo - 1:hi], "chr22", startp, stopp, panel, pam, args.guidelen, args.right,
+                            tile_nt=args.tile_nt, device=R.device, sample_range=(slo, shi))
+    log(f"c4 workload: contig {args.contig_len} nt ({n_block} nt leading N), {len(panel.pos)} sites, samples {slo}..{shi} of {args.samples}, "
+        f"{len(trs.tiles)} tiles of {args.tile_nt} nt; synthesised in {time.time() - t0:.1f}s")
+    t1 = time.time()
+    hbm = 0
+    for t in range(len(trs.tiles)):
+        pt_ = trs.prepare_tile(t, keep_plan=True)
+        if pt_._first is not None and pt_.plan is not None:  # the preparation run's planes are not needed again
+            pt_._first.close()
+            pt_._first = None
+        log(f"  tile {t}: {pt_.n_hap} rows prepared ({time.time() - t1:.0f}s)")
+    log(f"prepared {len(trs.tiles)} tiles (plans resident in HBM) in {time.time() - t1:.1f}s")
+    score = (not args.right) and pam.cas_system in (3, 4)
+    cfd = synth.cfd_tables() if score else None
+
+    def step():
+        stats = []
+        for t in range(len(trs.tiles)):
+            _g, st = trs.run_tile(t, cfd, (0, 0), True, export=False)
+            stats.append(st)
+        return stats
+
+    elapsed, outs = timed_steps(R, step, args.steps, args.warmup)
+    st = outs[-1]
+    cand = sum(s["candidates"] for s in st)
+    rows = sum(s["rows"] for s in st)
+    positions = sum(s["scanned_positions"] for s in st)
+    groups = sum(s["groups"] for s in st)
+    # REF rows are scanned by every rank: count them once
+    ref_c = ref_p = 0
+    if R.world > 1 and not args.weak:
+        sub = TiledRegionSearch(lambda lo, hi: seq[lo - 1:hi], "chr22", startp, stopp, None, pam, args.guidelen, args.right,
+                                tile_nt=args.tile_nt, device=R.device)
+        for t in range(len(sub.tiles)):
+            _g, s_ = sub.run_tile(t, cfd, (0, 0), True, export=False)
+            ref_c += s_["candidates"]; ref_p += s_["scanned_positions"]
+        sub.close()
+    tot = R.sum_ints([cand, rows, positions, groups])
+    dup = R.world - 1
+    cand_all, pos_all = tot[0] - dup * ref_c, tot[2] - dup * ref_p
+    out = None
+    if R.rank == 0:
+        search_ms = sum(s["search_ms"] for s in st)
+        collapse_ms = sum(s["collapse_ms"] for s in st)
+        out = base_line(args, R, cand_all * args.steps / elapsed, elapsed, "weak" if args.weak else "strong", "u32",
+                        {"workload": f"C4: whole contig ({args.contig_len} nt, {n_block} nt leading N block) x {args.samples} phased samples, "
+                                     f"region-tiled (BASELINE.json configs[3])", "pam": args.pam, "guidelen": args.guidelen,
+                         "right": args.right, "tiles": len(trs.tiles), "tile_nt": args.tile_nt, "variant_sites": len(panel.pos),
+                         "partition": "sample blocks of one panel, REF on every rank" if not args.weak else "own columns per rank",
+                         "step": "per tile: hawk_xplan_run -> hawk_search (+CFDon, NA on N) -> hawk_table_collapse",
+                         "candidates_per_step": cand_all, "guide_rows_rank0": rows, "report_groups_rank0": groups,
+                         "scanned_positions_per_step": pos_all})
+        step_bytes = READ_BYTES_PER_POS * positions + ROW_BYTES * rows
+        out["roofline"] = {"bound": "hbm", "kernel": "hawk_search (k_search_count + k_emit_list, summed over tiles)",
+                           "achieved": step_bytes / (search_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": step_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "launch_ms": search_ms,
+                           "algorithmic_bytes_per_launch": step_bytes}
+        out["kernels_ms"] = {"search_all_tiles": search_ms, "collapse_all_tiles": collapse_ms,
+                             "wall_per_step": elapsed / args.steps * 1e3}
+        out["per_tile"] = [{k: s[k] for k in ("tile", "n_hap", "rows", "groups", "search_ms", "collapse_ms")} for s in st]
+    trs.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# c5: off-target enumeration against a packed genome
+# ---------------------------------------------------------------------------------------------------
+def run_c5(args, R: Ranks):
+    from crisprhawk_hip.genome import GenomeIndex
+    from crisprhawk_hip.pam import PAM
+    pam_s, guidelen, right = ("TTTV", 23, True) if args.pam == "NGG" and not args.right else (args.pam, args.guidelen, args.right)
+    pam = PAM(pam_s, right, True)
+    pam.encode(0)
+    t0 = time.time()
+    rng = np.random.default_rng(1006)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    per = args.genome_nt // args.genome_contigs
+    contigs = {}
+    for i in range(args.genome_contigs):
+        contigs[f"chr{i + 1}"] = acgt[rng.integers(0, 4, size=per, dtype=np.uint8)]
+    names = list(contigs)
+    guides = []
+    grng = np.random.default_rng(1005)
+    while len(guides) < args.guides:  # spacers cut out of the genome: every guide has its on-target
+        c = contigs[names[int(grng.integers(0, len(names)))]]
+        p = int(grng.integers(0, per - 64))
+        guides.append(c[p:p + guidelen].tobytes().decode())
+    t_syn = time.time() - t0
+    t0 = time.time()
+    idx = GenomeIndex(contigs, guidelen, len(pam), device=R.device, shard=(R.rank, R.world))
+    t_idx = time.time() - t0
+    del contigs
+    log(f"c5 workload: {args.genome_nt} nt genome in {args.genome_contigs} contigs, rows {idx.row_lo}..{idx.row_hi} of {idx.n_rows_total} on this rank; "
+        f"synthesised in {t_syn:.1f}s, packed + one-hot in {t_idx:.1f}s; {len(guides)} guides {pam_s}/{guidelen} mm<={args.mm}")
+
+    def step():
+        return idx.scan_arrays(guides, pam, right, args.mm)
+
+    elapsed, outs = timed_steps(R, step, args.steps, args.warmup)
+    hits, tm = outs[-1]
+    tms = [o[1] for o in outs]
+    avg = lambda k: float(np.mean([t[k] for t in tms]))
+    tot = R.sum_ints([tm["n_sites"], tm["scanned_positions"], len(hits["guide"])])
+    pairs_all = tot[0] * len(guides)
+    out = None
+    if R.rank == 0:
+        out = base_line(args, R, pairs_all * args.steps / elapsed, elapsed, "strong", "u64 (2-bit codes, XOR + popcount)",
+                        {"workload": f"C5: off-target enumeration, {pam_s} / {guidelen} nt / right={right} / <= {args.mm} mismatches vs a "
+                                     f"{args.genome_nt}-nt packed synthetic genome (BASELINE.json configs[4])",
+                         "guides": len(guides), "genome_nt": args.genome_nt, "contigs": args.genome_contigs,
+                         "partition": "genome rows (4 Mb pieces) block-partitioned over ranks, guides replicated",
+                         "pam_sites_all_ranks": tot[0], "hits_all_ranks": tot[2], "scanned_positions": tot[1]})
+        out["metric"] = "PAM-site x guide comparisons/sec (off-target enumeration)"
+        out["unit"] = "site-guide pairs/s"
+        pairs = tm["n_sites"] * len(guides)
+        ach = pairs * 10 / (avg("match_ms") * 1e-3) if avg("match_ms") else 0.0  # ~10 integer lane-ops per all-pairs compare
+        out["roofline"] = {"bound": "valu", "kernel": "k_ot_match_seeded_lds (pigeonhole-seeded match)", "achieved": ach / 1e12,
+                           "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-ops/s (all-pairs equivalent: 10 integer ops per site-guide pair)",
+                           "frac": ach / VALU_PEAK_LANE_OPS, "traffic": None, "launch_ms": avg("match_ms"),
+                           "note": "the seeded kernel visits ~ (mm+1)/4^4 of the pairs; 'achieved' prices the pairs it RESOLVES at the "
+                                   "all-pairs cost, so frac > 1 is possible and means the filter beats brute force at the VALU peak",
+                           "scan_kernel": {"kernel": "k_scan_raw", "launch_ms": avg("scan_ms"),
+                                           "achieved_GBps": 0.75 * tm["scanned_positions"] / (avg("scan_ms") * 1e-3) / 1e9 if avg("scan_ms") else None,
+                                           "frac_of_hbm": 0.75 * tm["scanned_positions"] / (avg("scan_ms") * 1e-3) / 1e9 / HBM_PEAK_GBS if avg("scan_ms") else None}}
+        out["kernels_ms"] = {k: avg(k) for k in ("scan_ms", "sites_ms", "match_ms", "total_ms")}
+        out["index_build_s"] = t_idx
+    if R.world > 1:
+        from crisprhawk_hip import parallel
+        t0 = time.perf_counter()
+        comm = R.ctl
+        if R.backend == "rccl":
+            try:
+                comm = parallel.RcclComm(R.ctl, R.device)
+            except Exception as e:
+                log(f"RCCL unavailable for the hit gather ({e}); using the TCP control plane")
+        parts = {k: comm.gatherv_bytes(v, 0) for k, v in hits.items()}
+        if R.rank == 0:
+            out["gather"] = {"hits": int(sum(len(p) for p in parts["guide"])), "wall_ms": (time.perf_counter() - t0) * 1e3,
+                             "via": type(comm).__name__}
+    if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_offtargets(args, pam_s, guidelen, right, guides)
+    return out
+
+
+def cpu_baseline_offtargets(args, pam_s, guidelen, right, guides):
+    """The oracle's brute force (every window x every guide, both strands) on a genome sample sized for ~10 s."""
+    from oracle import oracle as ora
+    rng = np.random.default_rng(1006)
+    n = 200_000
+    g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes().decode()
+    sub = guides[:200]
+    t0 = time.perf_counter()
+    hits = ora.offtargets(g, sub, pam_s, right, args.mm)
+    dt = time.perf_counter() - t0
+    # PAM density of the sample stands in for "sites": pairs the brute force resolves = PAM-bearing windows x guides
+    bits, bitsrc, _, _ = ora.pam_encode(pam_s)
+    f, r = ora.scan(ora.encode(g), 0, n - len(pam_s) + 1, bits, bitsrc, len(pam_s))
+    pairs = (len(f) + len(r)) * len(sub)
+    return {"value": pairs / dt, "unit": "site-guide pairs/s", "cores": 1, "kind": "port",
+            "sample": f"oracle brute force on a {n}-nt sample of the genome x {len(sub)} guides ({len(hits)} hits, {dt:.1f} s, 1 thread)"}
+
+
+# ---------------------------------------------------------------------------------------------------
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c1", "c3", "c4", "c5"], default="c3")
+    ap.add_argument("--weak", action="store_true", help="every rank its own panel (weak scaling) instead of one block-partitioned panel")
+    ap.add_argument("--samples", type=int, default=2504)
+    ap.add_argument("--sites", type=int, default=31000, help="variant sites per --region-len bases")
+    ap.add_argument("--region-len", type=int, default=1_000_000)
+    ap.add_argument("--pam", default="NGG")
+    ap.add_argument("--guidelen", type=int, default=20)
+    ap.add_argument("--right", action="store_true")
+    ap.add_argument("--contig-len", type=int, default=50_818_468, help="c4: contig length (chr22)")
+    ap.add_argument("--n-block-frac", type=float, default=10.5 / 50.818468, help="c4: leading N block as a fraction of the contig")
+    ap.add_argument("--tile-nt", type=int, default=4_000_000, help="c4: bases a tile owns")
+    ap.add_argument("--genome-nt", type=int, default=3_100_000_000, help="c5: genome size")
+    ap.add_argument("--genome-contigs", type=int, default=24)
+    ap.add_argument("--guides", type=int, default=10_000, help="c5: unique spacers")
+    ap.add_argument("--mm", type=int, default=4)
+    ap.add_argument("--cpu-haps", type=int, default=1280, help="haplotypes in the cpu_baseline sample (about 12 s of single-thread oracle work on C3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--vcf", action="store_true", help="end_to_end: also time the VCF-text ingest of the workload (f3)")
+    ap.add_argument("--report", action="store_true", help="end_to_end: also assemble the guide report (f2) of the whole workload")
+    ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # our own launcher: N fresh processes, started before this one has made any GPU call
+        sys.exit(launch(args.gpus, sys.argv[1:]))
+    defaults = {"c3": (20, 3), "c1": (200, 20), "c4": (2, 1), "c5": (3, 1)}[args.config]
+    if args.steps is None:
+        args.steps = defaults[0]
+    if args.warmup is None:
+        args.warmup = defaults[1]
+    R = Ranks(args)
+    if args.config in ("c3", "c1"):
+        out = run_region(args, R)
+    elif args.config == "c4":
+        out = run_c4(args, R)
+    else:
+        out = run_c5(args, R)
+    R.ctl.barrier()
+    R.ctl.close()
+    if R.rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

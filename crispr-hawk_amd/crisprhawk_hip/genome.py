@@ -62,34 +62,53 @@ class OffTargetHit:
 
 
 class GenomeIndex:
-    def __init__(self, contigs: Dict[str, str], guidelen: int, pamlen: int, piece: int = 1 << 22, device: Optional[int] = None):
+    """`shard = (rank, world)`: the genome's rows (pieces) are block-partitioned over the ranks of a multi-GPU job
+    ("shard the genome by contig/offset across ranks, guides replicated, rows gathered"); every rank keeps the
+    descriptors of ALL rows, so a hit's global row index names its contig and offset anywhere."""
+
+    def __init__(self, contigs: Dict[str, object], guidelen: int, pamlen: int, piece: int = 1 << 22, device: Optional[int] = None,
+                 shard: Optional[Tuple[int, int]] = None):
         self.L = guidelen + pamlen
         self.guidelen, self.pamlen = guidelen, pamlen
         overlap = self.L - 1
-        self.rows: List[Tuple[str, int, int]] = []  # (contig, offset, owned window starts)
-        haps: List[HostHaplotype] = []
+        self.rows: List[Tuple[str, int, int]] = []  # (contig, offset, owned window starts), all ranks' rows
+        spans = []
         self.total = 0
         for name, seq in contigs.items():
             n = len(seq)
             self.total += n
-            arr = np.frombuffer(seq.encode("ascii") if isinstance(seq, str) else seq, dtype=np.uint8)
             for off in range(0, max(n, 1), piece):
                 end = min(n, off + piece + overlap)
                 if end - off < self.L:
                     continue
                 own = min(piece, n - off)  # window starts [0, own) belong to this row ...
                 own = min(own, end - off - self.L + 1)  # ... as far as the window fits
-                haps.append(HostHaplotype(arr[off:end], PosSegments.identity(off, end - off), True, (0, own)))
+                spans.append((name, off, end))
                 self.rows.append((name, off, own))
-        if not haps:
+        if not self.rows:
             raise ValueError("genome shorter than one guide+PAM window")
-        self.ds = DeviceHapSet(haps, device)
-        _lib.check(self.ds._L.hawk_genome_finalize(self.ds._h), "hawk_genome_finalize")
+        self.n_rows_total = len(self.rows)
+        self.row_lo, self.row_hi = 0, self.n_rows_total
+        if shard is not None and shard[1] > 1:
+            from .parallel import shard_range
+            self.row_lo, self.row_hi = shard_range(self.n_rows_total, shard[0], shard[1])
+        haps: List[HostHaplotype] = []
+        for (name, off, end), (_n, _o, own) in zip(spans[self.row_lo:self.row_hi], self.rows[self.row_lo:self.row_hi]):
+            seq = contigs[name]
+            arr = np.frombuffer(seq.encode("ascii"), dtype=np.uint8) if isinstance(seq, str) else np.frombuffer(seq, dtype=np.uint8)
+            haps.append(HostHaplotype(arr[off:end], PosSegments.identity(off, end - off), True, (0, own)))
+        self.ds = None
+        if haps:  # a rank may own no row of a tiny genome
+            self.ds = DeviceHapSet(haps, device)
+            _lib.check(self.ds._L.hawk_genome_finalize(self.ds._h), "hawk_genome_finalize")
         self.last_timing = None
 
-    def scan(self, guides: Sequence[str], pam, right: bool, max_mm: int, cap: int = 1 << 20) -> List[OffTargetHit]:
-        """All windows within ``max_mm`` mismatches of any guide, both strands, sorted by
-        (guide, contig order, position, strand)."""
+    def scan_arrays(self, guides: Sequence[str], pam, right: bool, max_mm: int, cap: int = 1 << 20):
+        """One hawk_offtarget_scan over this rank's rows: ({guide, row (global), q, strand, mm, code, nmask} arrays, timing)."""
+        empty = dict(guide=np.zeros(0, np.uint32), row=np.zeros(0, np.uint32), q=np.zeros(0, np.uint32), strand=np.zeros(0, np.uint8),
+                     mm=np.zeros(0, np.uint8), code=np.zeros(0, np.uint64), nmask=np.zeros(0, np.uint32))
+        if self.ds is None:
+            return empty, dict(scan_ms=0.0, sites_ms=0.0, match_ms=0.0, total_ms=0.0, n_sites=0, scanned_positions=0)
         L = self.ds._L
         g2 = encode_guides(guides)
         par = _lib.OtParams(pam.bits, pam.bitsrc, len(pam), self.guidelen, int(bool(right)), max_mm)
@@ -107,10 +126,28 @@ class GenomeIndex:
             break
         self.last_timing = {k: getattr(tm, k) for k, _ in tm._fields_}
         k = int(n.value)
-        order = np.lexsort((ost[:k], oq[:k], orow[:k], og[:k]))
-        hits = []
+        hits = dict(guide=og[:k].copy(), row=(orow[:k] + np.uint32(self.row_lo)), q=oq[:k].copy(), strand=ost[:k].copy(), mm=omm[:k].copy(),
+                    code=oc[:k].copy(), nmask=onm[:k].copy())
+        return hits, self.last_timing
+
+    def hits_from_arrays(self, h) -> List["OffTargetHit"]:
+        """Arrays of scan_arrays (of this rank, or gathered from every rank) -> sorted OffTargetHit list."""
+        order = np.lexsort((h["strand"], h["q"], h["row"], h["guide"]))
+        out = []
         for i in order:
-            name, off, _ = self.rows[int(orow[i])]
-            hits.append(OffTargetHit(int(og[i]), name, off + int(oq[i]), "-" if ost[i] else "+", int(omm[i]),
-                                     decode_window(int(oc[i]), int(onm[i]), self.L)))
-        return hits
+            name, off, _ = self.rows[int(h["row"][i])]
+            out.append(OffTargetHit(int(h["guide"][i]), name, off + int(h["q"][i]), "-" if h["strand"][i] else "+", int(h["mm"][i]),
+                                    decode_window(int(h["code"][i]), int(h["nmask"][i]), self.L)))
+        return out
+
+    def scan(self, guides: Sequence[str], pam, right: bool, max_mm: int, cap: int = 1 << 20, comm=None) -> List[OffTargetHit]:
+        """All windows within ``max_mm`` mismatches of any guide, both strands, sorted by
+        (guide, contig order, position, strand).  With a communicator (parallel.RcclComm / TcpComm) the hits of every
+        rank's genome shard are gathered to rank 0, which returns the whole list (other ranks return [])."""
+        hits, _tm = self.scan_arrays(guides, pam, right, max_mm, cap)
+        if comm is not None and comm.world > 1:
+            parts = {k: comm.gatherv_bytes(v, 0) for k, v in hits.items()}
+            if comm.rank != 0:
+                return []
+            hits = {k: np.concatenate(v) for k, v in parts.items()}
+        return self.hits_from_arrays(hits)

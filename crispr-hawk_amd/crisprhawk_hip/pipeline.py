@@ -20,7 +20,7 @@ from . import reports
 from . import scoring
 from .pam import CPF1, PAM, SPCAS9, XCAS9
 from .readers import VCF, Bed, Fasta
-from .workload import HapInfo, RowLabel, expand_from_vcf
+from .workload import HapInfo, RowLabel, expand_from_vcf, hap_labels
 
 PADDING = 100  # region_constructor.py:21
 
@@ -71,25 +71,30 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         samples = v.samples if v is not None else []
         ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device)
-        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt, download=False, collapse=True)
-        labels = _labels(ds, info, kept, vt)
+        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt, download=False)
+        labels = hap_labels(coord.contig, vt, ds, info, kept)
         bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041
-        inp = reports.ReportInput.from_table(tab)
+        # With a model scorer on, the reference's groupby includes its score column (reports.py:978-1003): rows that
+        # differ only in the 4 + 3 flanking bases the scorer reads stay separate, so the device groups on the k-mer.
+        azimuth_on = pam.cas_system in (SPCAS9, XCAS9) and azimuth_model is not None
+        deepcpf1_on = pam.cas_system == CPF1 and deepcpf1_weights is not None
+        tab.collapse((4, 3) if (azimuth_on or deepcpf1_on) else (0, 0), download_perm=False)
+        groups = tab.export_groups()
+        tab.close()
         # model-based scorers run once per report row, on the group representatives (scoring.py:749-813), when the
         # caller has supplied their parameters
         scores = {}
-        if tab.n_rows:
-            rows, kmers = reports.scorer_kmers(inp)
-            def _col(vals):
-                a = np.full(tab.n_rows, np.nan)
-                a[rows] = vals
-                return a
-            if pam.cas_system in (SPCAS9, XCAS9) and azimuth_model is not None:
-                scores["score_azimuth"] = _col(scoring.azimuth(kmers, debug))
-            if pam.cas_system == CPF1 and deepcpf1_weights is not None:
-                scores["score_deepcpf1"] = _col(scoring.deepcpf1(kmers, debug))
-        df = reports.report_frame(inp, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score)
+        if groups.n_groups and (azimuth_on or deepcpf1_on):
+            kmers = reports.group_kmers(groups)
+            if azimuth_on:
+                scores["score_azimuth"] = np.asarray(scoring.azimuth(kmers, debug), dtype=np.float64)
+            if deepcpf1_on:
+                scores["score_deepcpf1"] = np.asarray(scoring.deepcpf1(kmers, debug), dtype=np.float64)
+        df = reports.report_from_groups(groups, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score,
+                                        is_ref_hap=np.asarray(ds.is_ref, dtype=bool))
+        ds.close()
         path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
-        df.to_csv(path, sep="\t", index=False)
+        with open(path, "w") as f:
+            f.write(reports.to_tsv(df))
         paths[str(coord)] = path
     return paths

@@ -292,8 +292,17 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
 
 
 def to_tsv(df) -> str:
-    """What _store_report writes (reports.py:739)."""
-    return df.to_csv(sep="\t", index=False)
+    """What _store_report writes (reports.py:739: DataFrame.to_csv(sep="\\t", index=False)).  The text is joined column-wise
+    here (a C3 report is ~0.7 GB, which pandas' writer takes many seconds over); fields that csv's minimal quoting would
+    touch - a quote, a tab, a line break - send the frame through pandas itself."""
+    cols = list(df.columns)
+    if len(df) == 0:
+        return df.to_csv(sep="\t", index=False)
+    lists = [df[c].tolist() if df[c].dtype == object else df[c].astype(str).tolist() for c in cols]
+    body = "\n".join(["\t".join(r) for r in zip(*lists)])
+    if '"' in body or "\r" in body or body.count("\n") != len(df) - 1 or body.count("\t") != (len(cols) - 1) * len(df):
+        return df.to_csv(sep="\t", index=False)
+    return "\t".join(cols) + "\n" + body + "\n"
 
 
 def report_filename(contig: str, bed_start: int, bed_stop: int, pam: PAM, guidelen: int) -> str:
@@ -309,3 +318,397 @@ def report_table(tab, haplotypes, pam: PAM, contig: str, bed_start: int, bed_sto
     path = os.path.join(outdir, report_filename(contig, bed_start, bed_stop, pam, tab.guidelen))
     df.to_csv(path, sep="\t", index=False)
     return path
+
+
+# ---------------------------------------------------------------------------------------------------
+# Columnar assembly from report groups (the fast path: nothing is computed per group in Python
+# except for rows whose variants include indels)
+# ---------------------------------------------------------------------------------------------------
+_RC_LUT = np.arange(256, dtype=np.uint8)
+for _a, _b in _RC_TRANS.items():
+    _RC_LUT[_a] = _b
+_CODE2CHAR = np.frombuffer(b"?ACMGRSVTWYHKDBN?acmgrsvtwyhkdbn", dtype=np.uint8)
+
+
+class ReportGroups:
+    """What report_from_groups needs: one representative row per group as columns + CSR member haplotypes.
+    hapset.GroupTable (device export) and tiling.MergedGroups provide it; `from_report_input` builds it from
+    row-level inputs (tests: oracle rows)."""
+
+    def __init__(self, guidelen, pamlen, right, pos, strand, start, stop, cfdon, win, gc_num, gc_den, member_off, member_hap):
+        self.guidelen, self.pamlen, self.right = guidelen, pamlen, bool(right)
+        self.pos, self.strand, self.start, self.stop, self.cfdon = pos, strand, start, stop, cfdon
+        self.win, self.gc_num, self.gc_den = win, gc_num, gc_den  # win: [5, n_groups] uint64 window slices
+        self.member_off = np.asarray(member_off, dtype=np.int64)
+        self.member_hap = np.asarray(member_hap, dtype=np.int64)
+        self.n_groups = len(self.member_off) - 1
+
+    @classmethod
+    def from_report_input(cls, inp: "ReportInput") -> "ReportGroups":
+        perm = np.asarray(inp.group_perm, dtype=np.int64)
+        off = np.asarray(inp.group_off, dtype=np.int64)
+        reps = perm[off[:-1]]
+        W = inp.guidelen + inp.pamlen + 2 * GUIDESEQPAD
+        win = np.zeros((5, len(reps)), dtype=np.uint64)
+        lut = np.zeros(256, dtype=np.uint8)
+        for code, ch in enumerate(_CODE2CHAR.tobytes()):
+            if ch != ord("?"):
+                lut[ch] = code
+        if len(reps):
+            mat = np.frombuffer("".join(inp.windows[int(r)] for r in reps).encode("ascii"), dtype=np.uint8).reshape(len(reps), W)
+            codes = lut[mat].astype(np.uint64)
+            sh = np.arange(W, dtype=np.uint64)
+            for p in range(5):
+                win[p] = (((codes >> np.uint64(p)) & np.uint64(1)) << sh).sum(axis=1, dtype=np.uint64)
+        cfd = None if inp.cfdon is None else np.asarray(inp.cfdon)[reps]
+        return cls(inp.guidelen, inp.pamlen, inp.right, np.asarray(inp.pos)[reps], np.asarray(inp.strand)[reps], np.asarray(inp.start)[reps],
+                   np.asarray(inp.stop)[reps], cfd, win, np.asarray(inp.gc_num), np.asarray(inp.gc_den), off, np.asarray(inp.hap)[perm])
+
+
+def _ragged_join(item_label: np.ndarray, group_off: np.ndarray, strings: Sequence[str]) -> List[str]:
+    """Per group: ",".join(strings[l] for its items) through the library's host helper (hawk_host_ragged_join)."""
+    import ctypes as C
+    from . import _lib
+    ng = len(group_off) - 1
+    if ng == 0:
+        return []
+    enc = [s.encode("ascii") for s in strings]
+    pool = np.frombuffer(b"".join(enc), dtype=np.uint8) if enc else np.zeros(0, np.uint8)
+    pool_off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    pool_off[1:] = np.cumsum([len(e) for e in enc])
+    item = np.ascontiguousarray(item_label, dtype=np.uint32)
+    goff = np.ascontiguousarray(group_off, dtype=np.uint64)
+    out_off = np.zeros(ng + 1, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L = _lib.lib()
+    _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), C.c_uint64(len(enc)), C.c_uint8(44), None,
+                                       C.c_uint64(0), p(out_off)), "hawk_host_ragged_join")
+    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), C.c_uint64(len(enc)), C.c_uint8(44), p(out),
+                                       C.c_uint64(len(out)), p(out_off)), "hawk_host_ragged_join")
+    buf = memoryview(out)
+    o = out_off.tolist()
+    return [str(buf[o[g]:o[g + 1]], "ascii") for g in range(ng)]
+
+
+def _pool(strings: Sequence[str]):
+    enc = [x.encode("ascii") for x in strings]
+    pool = np.frombuffer(b"".join(enc), dtype=np.uint8) if enc else np.zeros(0, np.uint8)
+    off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        off[1:] = np.cumsum([len(e) for e in enc])
+    return np.ascontiguousarray(pool), off
+
+
+def _decode_groups(out: np.ndarray, out_off: np.ndarray) -> List[str]:
+    buf = memoryview(out)
+    o = out_off.tolist()
+    return [str(buf[o[g]:o[g + 1]], "ascii") for g in range(len(o) - 1)]
+
+
+def _hap_items(per_hap: List[List[str]]):
+    """Per-haplotype item lists -> (vocabulary in sorted order, CSR offsets, item ranks ascending per haplotype)."""
+    vocab = sorted({x for items in per_hap for x in items})
+    rank = {x: i for i, x in enumerate(vocab)}
+    off = np.zeros(len(per_hap) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in per_hap])
+    flat = np.array([r for items in per_hap for r in sorted(rank[x] for x in items)], dtype=np.uint32)
+    return vocab, off, flat
+
+
+def _group_join(member_off, member_hap, per_hap: List[List[str]]) -> List[str]:
+    """Per group ",".join(sorted(set(items of its member haplotypes))) - hawk_host_group_join."""
+    import ctypes as C
+    from . import _lib
+    ng = len(member_off) - 1
+    if ng == 0:
+        return []
+    vocab, hoff, flat = _hap_items(per_hap)
+    pool, poff = _pool(vocab)
+    moff = np.ascontiguousarray(member_off, dtype=np.uint64)
+    mh = np.ascontiguousarray(member_hap, dtype=np.uint32)
+    out_off = np.zeros(ng + 1, dtype=np.uint64)
+    p = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    L = _lib.lib()
+    args = (p(moff), p(mh), C.c_uint64(ng), p(hoff), p(flat), C.c_uint64(len(per_hap)), p(pool), p(poff), C.c_uint64(len(vocab)), C.c_uint8(44))
+    _lib.check(L.hawk_host_group_join(*args, None, C.c_uint64(0), p(out_off)), "hawk_host_group_join")
+    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    _lib.check(L.hawk_host_group_join(*args, p(out), C.c_uint64(len(out)), p(out_off)), "hawk_host_group_join")
+    return _decode_groups(out, out_off)
+
+
+def _samples_column(member_off, member_hap, hap_samples: List[str]) -> List[str]:
+    """reports.py:767-810 for every group: sorted unique `sample:genotype` entries, phased genotypes OR-ed per sample
+    (hawk_host_group_samples).  `hap_samples[h]`: the samples label of haplotype row h ("" for rows that hold none)."""
+    import ctypes as C
+    from . import _lib
+    per_hap = [x.split(",") if x else [] for x in hap_samples]
+    ng = len(member_off) - 1
+    if ng == 0:
+        return []
+    vocab, hoff, flat = _hap_items(per_hap)
+    if not any("|" in e for e in vocab):
+        return _group_join(member_off, member_hap, per_hap)
+    n_e = len(vocab)
+    ok = np.zeros(n_e, dtype=np.uint8)
+    a1, a2 = np.zeros(n_e, np.uint16), np.zeros(n_e, np.uint16)
+    names = []
+    for i, e in enumerate(vocab):
+        nm = e
+        if e.count(":") == 1 and "|" in e:
+            sname, gt = e.split(":")
+            xy = gt.split("|")
+            if len(xy) == 2 and xy[0].isdigit() and xy[1].isdigit() and int(xy[0]) < 65536 and int(xy[1]) < 65536:
+                nm, a1[i], a2[i], ok[i] = sname, int(xy[0]), int(xy[1]), 1
+        names.append(nm)
+    uniq: Dict[str, int] = {}  # samples in the order of their first entry in the sorted entry list
+    sid = np.array([uniq.setdefault(n, len(uniq)) for n in names], dtype=np.uint32)
+    npool, noff = _pool(list(uniq))
+    epool, eoff = _pool(vocab)
+    moff = np.ascontiguousarray(member_off, dtype=np.uint64)
+    mh = np.ascontiguousarray(member_hap, dtype=np.uint32)
+    out_off = np.zeros(ng + 1, dtype=np.uint64)
+    flags = np.zeros(ng, dtype=np.uint8)
+    p = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    L = _lib.lib()
+    args = (p(moff), p(mh), C.c_uint64(ng), p(hoff), p(flat), C.c_uint64(len(per_hap)), p(sid), p(a1), p(a2), p(ok), C.c_uint64(n_e),
+            p(npool), p(noff), C.c_uint64(len(uniq)), p(epool), p(eoff))
+    _lib.check(L.hawk_host_group_samples(*args, None, C.c_uint64(0), p(out_off), p(flags)), "hawk_host_group_samples")
+    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    _lib.check(L.hawk_host_group_samples(*args, p(out), C.c_uint64(len(out)), p(out_off), p(flags)), "hawk_host_group_samples")
+    res = _decode_groups(out, out_off)
+    odd = np.flatnonzero(flags == 3)  # a group mixing phased entries with others: the reference's own per-group walk
+    for g in odd.tolist():
+        res[g] = collapse_samples([hap_samples[int(x)] for x in member_hap[member_off[g]:member_off[g + 1]]])
+    return res
+
+
+def _hapids_column(member_off, member_hap, hap_ids: List[str]) -> List[str]:
+    return _group_join(member_off, member_hap, [x.split(",") if x else [] for x in hap_ids])
+
+
+class HapLabels:
+    """What the report needs to know about the haplotype rows, as columns: per row its `samples` label, its id, whether
+    it is REF, its position map, and the variants it carries as indices into ONE variant table (ids + allele
+    frequencies) - instead of one object per row holding a 1000-id string and a 1000-entry AF dict."""
+
+    def __init__(self, samples: List[str], ids: List[str], is_ref: np.ndarray, var_off: np.ndarray, var_idx: np.ndarray,
+                 vid: List[str], af: np.ndarray, segments: list):
+        self.samples, self.ids, self.is_ref = samples, ids, np.asarray(is_ref, dtype=bool)
+        self.var_off, self.var_idx = np.asarray(var_off, dtype=np.int64), np.asarray(var_idx, dtype=np.int64)
+        self.vid, self.af, self.segments = vid, np.asarray(af, dtype=np.float64), segments
+        self._vt = None
+
+    def __len__(self):
+        return len(self.samples)
+
+    @classmethod
+    def from_objects(cls, haplotypes) -> "HapLabels":
+        """From per-row label objects (.samples .variants .afs .id .segments; None for rows collapsed onto another)."""
+        vocab: Dict[str, int] = {}
+        vid: List[str] = []
+        af: List[float] = []
+        off, idx, samples, ids, is_ref, segs = [0], [], [], [], [], []
+        for h in haplotypes:
+            if h is None:
+                samples.append(""); ids.append(""); is_ref.append(False); segs.append(None)
+                off.append(len(idx))
+                continue
+            samples.append(h.samples); ids.append(h.id); is_ref.append(h.samples == "REF"); segs.append(h.segments)
+            if h.samples != "REF" and h.variants not in ("NA", ""):
+                for v in set(h.variants.split(",")):
+                    k = vocab.get(v)
+                    if k is None:
+                        k = vocab[v] = len(vid)
+                        vid.append(v)
+                        af.append(float(h.afs[v]))
+                    idx.append(k)
+            off.append(len(idx))
+        return cls(samples, ids, np.array(is_ref, dtype=bool), np.array(off), np.array(idx, dtype=np.int64), vid, np.array(af), segs)
+
+    def variant_table(self):
+        """(adjusted position, is SNV, SNV alt base, ref, alt, formatted AF) per variant of `vid` (annotation.py:53-62)."""
+        if self._vt is None:
+            parsed = [_parse_variant(v) for v in self.vid]
+            pos = np.array([p[0] for p in parsed], dtype=np.int64) if parsed else np.zeros(0, np.int64)
+            snv = np.array([len(p[1]) == len(p[2]) for p in parsed], dtype=bool) if parsed else np.zeros(0, bool)
+            alt0 = np.array([ord(p[2][0]) if (len(p[1]) == len(p[2]) == 1) else 0 for p in parsed], dtype=np.uint8) if parsed else np.zeros(0, np.uint8)
+            afs = [format_af(x) if str(x) != "nan" else "NA" for x in self.af.tolist()]
+            self._vt = (pos, snv, alt0, [p[1] for p in parsed], [p[2] for p in parsed], afs)
+        return self._vt
+
+
+def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
+    """variant_id / af of every group from its representative (annotation.py:246-370).  Rows whose haplotype carries only
+    SNVs around the guide are resolved in bulk; rows with an indel among the candidates go through
+    polish_guide_variants exactly as report_frame does."""
+    ng, L = G.n_groups, G.guidelen + G.pamlen
+    vid_col, af_col = ["NA"] * ng, ["NA"] * ng
+    if len(lab.var_idx) == 0:
+        return vid_col, af_col
+    t_pos, t_snv, t_alt0, t_ref, t_alt, t_af = lab.variant_table()
+    H = len(lab)
+    cnt_h = np.diff(lab.var_off)
+    v_hap = np.repeat(np.arange(H, dtype=np.int64), cnt_h)
+    v_var = lab.var_idx
+    BIG = np.int64(1) << np.int64(40)
+    vkey = v_hap * BIG + t_pos[v_var]
+    if len(vkey) > 1 and not (vkey[1:] >= vkey[:-1]).all():  # rows list their variants in position order as a rule
+        o = np.argsort(vkey, kind="stable")
+        vkey, v_var = vkey[o], v_var[o]
+    alt_rows = np.flatnonzero(~lab.is_ref[rep_hap] & (cnt_h[rep_hap] > 0))
+    if len(alt_rows) == 0:
+        return vid_col, af_col
+    hh = rep_hap[alt_rows]
+    start, stop = np.asarray(G.start, np.int64)[alt_rows], np.asarray(G.stop, np.int64)[alt_rows]
+    a = np.searchsorted(vkey, hh * BIG + start, side="left")
+    b = np.searchsorted(vkey, hh * BIG + np.maximum(stop, start + L), side="right")
+    cnt = b - a
+    pair_row = np.repeat(np.arange(len(alt_rows)), cnt)
+    pair_var = v_var[np.repeat(a, cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))]
+    has_indel = np.zeros(len(alt_rows), dtype=bool)
+    np.logical_or.at(has_indel, pair_row, ~t_snv[pair_var])
+    fast = ~has_indel & ((stop - start) == L)
+    # ---- SNV-only rows: base i = pos - start of the + strand core must be the alt allele in lower case
+    fp = fast[pair_row]
+    pr, pv = pair_row[fp], pair_var[fp]
+    i = t_pos[pv] - start[pr]
+    inside = (i >= 0) & (i < L)
+    pr, pv, i = pr[inside], pv[inside], i[inside]
+    ch = cores[alt_rows[pr], i]
+    ok = (ch == (t_alt0[pv] | 0x20)) & (t_alt0[pv] != 0)
+    pr, pv = pr[ok], pv[ok]
+    # ids of one row in string order (annotation.py:284: sorted), duplicates dropped
+    name_rank = np.argsort(np.argsort(np.array(lab.vid))) if lab.vid else np.zeros(0, np.int64)
+    order = np.lexsort((name_rank[pv], pr))
+    pr, pv = pr[order], pv[order]
+    keep = np.ones(len(pr), dtype=bool)
+    keep[1:] = (pr[1:] != pr[:-1]) | (pv[1:] != pv[:-1])
+    pr, pv = pr[keep], pv[keep]
+    roff = np.concatenate(([0], np.cumsum(np.bincount(pr, minlength=len(alt_rows)))))
+    ids = _ragged_join(pv, roff, lab.vid)
+    af_names = sorted(set(t_af))
+    af_rank = {s_: k for k, s_ in enumerate(af_names)}
+    af_of_var = np.array([af_rank[x] for x in t_af], dtype=np.int64)
+    afs = _ragged_join(af_of_var[pv], roff, af_names)  # allele frequencies follow the ids' order (guide.py:311-328)
+    na_id = af_rank.get("NA", -1)
+    some_af = np.zeros(len(alt_rows), dtype=bool)
+    np.logical_or.at(some_af, pr, af_of_var[pv] != na_id)
+    for k in np.flatnonzero(fast).tolist():
+        g = int(alt_rows[k])
+        vid_col[g] = ids[k]
+        af_col[g] = afs[k] if (some_af[k] and ids[k]) else "NA"
+    # ---- rows with an indel among the candidates (or a non-linear position map): the reference's own walk over the
+    # candidates (variants elsewhere on the haplotype cannot match a position of this guide)
+    slow = np.flatnonzero(~fast)
+    if len(slow):
+        s_off = np.concatenate(([0], np.cumsum(cnt)))
+        pvl = pair_var.tolist()
+        for k in slow.tolist():
+            g = int(alt_rows[k])
+            parsed = defaultdict(list)
+            for v in set(pvl[s_off[k]:s_off[k + 1]]):
+                parsed[int(t_pos[v])].append((lab.vid[v], t_ref[v], t_alt[v]))
+            s = int(G.strand[g])
+            stored_right = G.right != bool(s)
+            pivot = int(G.pos[g]) if stored_right else int(G.pos[g]) - G.guidelen
+            gen = lab.segments[int(hh[k])].lookup(np.arange(pivot, pivot + L))
+            core = cores[g].tobytes().decode("ascii")
+            variant_id = polish_guide_variants(core, gen, int(G.stop[g]), parsed)
+            vids = variant_id.split(",")
+            afl = [t_af[_vid_index(lab, v)] for v in vids] if variant_id else []
+            vid_col[g] = ",".join(sorted(set(vids))) if variant_id else ""
+            af_col[g] = "NA" if not afl or (len(set(afl)) == 1 and afl[0] == "NA") else ",".join(afl)
+    return vid_col, af_col
+
+
+def _vid_index(lab: HapLabels, v: str) -> int:
+    m = getattr(lab, "_vid_map", None)
+    if m is None:
+        m = lab._vid_map = {x: i for i, x in enumerate(lab.vid)}
+    return m[v]
+
+
+def group_kmers(G) -> List[str]:
+    """Scorer inputs of the group representatives: `guide.sequence[6:-7].upper()` after reverse_guides
+    (scoring.py:50-67) - 30-mers for 20+3 Cas9 guides, 34-mers for 23+4 Cpf1 guides."""
+    from .hapset import decode_windows
+    W = G.guidelen + G.pamlen + 2 * GUIDESEQPAD
+    out = []
+    for w, s in zip(decode_windows(np.asarray(G.win), W), np.asarray(G.strand).tolist()):
+        if s == 1:
+            w = w[::-1].translate(_RC_TRANS)
+        out.append(w[6:-7].upper())
+    return out
+
+
+def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
+                       with_cfdon: bool = True, is_ref_hap: Optional[np.ndarray] = None):
+    """report_frame's result from group-level inputs (hapset.GroupTable, tiling.MergedGroups.groups(), ReportGroups),
+    assembled column by column: same DataFrame, same order, same strings.  `scores[c]` is per GROUP here."""
+    import pandas as pd
+    cols = select_reportcols(pam, G.right)
+    ng = G.n_groups
+    if ng == 0:
+        return pd.DataFrame({c: [] for c in cols})
+    L, W = G.guidelen + G.pamlen, G.guidelen + G.pamlen + 2 * GUIDESEQPAD
+    member_off = np.asarray(G.member_off, dtype=np.int64)
+    member_hap = np.asarray(G.member_hap, dtype=np.int64)
+    rep_hap = member_hap[member_off[:-1]]
+    lab = haplotypes if isinstance(haplotypes, HapLabels) else HapLabels.from_objects(haplotypes)
+    if is_ref_hap is None:
+        is_ref_hap = lab.is_ref
+    # cased + strand cores of the representatives, from the window slices
+    sh = np.arange(GUIDESEQPAD, GUIDESEQPAD + L, dtype=np.uint64)
+    code = np.zeros((ng, L), dtype=np.uint8)
+    for p in range(5):
+        code |= (((np.asarray(G.win[p])[:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
+    cores = _CODE2CHAR[code]
+    vid_col, af_col = _variant_columns(G, rep_hap, cores, lab)
+    # reverse_guides (annotation.py:27-51): strand-1 rows read as their reverse complement, case preserved
+    strand = np.asarray(G.strand).astype(np.int64)
+    guide = cores.copy()
+    rev = strand == 1
+    guide[rev] = _RC_LUT[cores[rev][:, ::-1]]
+    if G.right:
+        pam_b, sg_b = guide[:, :G.pamlen], guide[:, G.pamlen:]
+    else:
+        sg_b, pam_b = guide[:, :G.guidelen], guide[:, G.guidelen:]
+    to_str = lambda m: np.ascontiguousarray(m).view(f"S{m.shape[1]}").ravel().astype(f"U{m.shape[1]}")
+    data = {"chr": np.full(ng, contig, dtype=object), "start": np.asarray(G.start, dtype=np.int64), "stop": np.asarray(G.stop, dtype=np.int64),
+            "sgRNA_sequence": to_str(sg_b), "pam": to_str(pam_b), "pam_class": np.full(ng, compute_pam_class(pam), dtype=object),
+            "strand": np.where(rev, "-", "+")}
+    score_cols = [c for c in cols if c.startswith("score_")]
+    for c in score_cols:
+        vals = None
+        if c == "score_cfdon" and with_cfdon and G.cfdon is not None:
+            vals = np.asarray(G.cfdon, dtype=np.float64)
+        elif scores and c in scores:
+            vals = np.asarray(scores[c], dtype=np.float64)
+        data[c] = np.array(["NA"] * ng if vals is None else ["NA" if v != v else str(round_score(v)) for v in vals.tolist()], dtype=object)
+    num, den = np.asarray(G.gc_num).tolist(), np.asarray(G.gc_den).tolist()
+    data["gc_content"] = np.array([str(n / d if d else 0.0) for n, d in zip(num, den)], dtype=object)
+    data["origin"] = np.where(is_ref_hap[rep_hap], "ref", "alt")
+    data["samples"] = np.array(_samples_column(member_off, member_hap, lab.samples), dtype=object)
+    data["variant_id"] = np.array(vid_col, dtype=object)
+    data["af"] = np.array(af_col, dtype=object)
+    data["target"] = np.full(ng, target, dtype=object)
+    data["haplotype_id"] = np.array(_hapids_column(member_off, member_hap, lab.ids), dtype=object)
+    # pandas groupby(sort=True) order over the group columns (reports.py:978-1003), then _format_report's stable sort on
+    # (start, stop): one lexsort with (start, stop) as the leading keys
+    gcols = REPORTCOLS[:5]
+    if pam.cas_system in (SPCAS9, XCAS9):
+        gcols = gcols + REPORTCOLS[6:12] + REPORTCOLS[13:14] + REPORTCOLS[15:17]
+    elif pam.cas_system == CPF1:
+        gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[12:13] + REPORTCOLS[15:17]
+    else:
+        gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[15:17]
+    keys = []
+    for c in reversed(gcols):
+        if c in ("chr",):
+            continue
+        k = data[c]
+        keys.append(k if k.dtype.kind in "iuU" else k.astype("U"))
+    keys += [data["stop"], data["start"]]
+    order = np.lexsort(keys)
+    return pd.DataFrame({c: data[c][order] for c in cols})

@@ -329,6 +329,13 @@ class MergedGroups:
         self.members = parts["members"]
         self.n_groups = len(parts["sizes"])
 
+    def groups(self):
+        """reports.ReportGroups view (the input of reports.report_from_groups)."""
+        from .reports import ReportGroups
+        c = self.cols
+        return ReportGroups(self.guidelen, self.pamlen, self.right, c["pos"], c["strand"], c["start"], c["stop"], c["cfdon"],
+                            np.ascontiguousarray(c["win"].T), c["gc_num"], c["gc_den"], self.member_off, self.members)
+
     def report_input(self):
         """A reports.ReportInput over pseudo-rows (one per member; the representative's fields at a group's first row)."""
         from .hapset import decode_windows

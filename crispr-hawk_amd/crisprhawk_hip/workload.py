@@ -437,3 +437,31 @@ def row_labels(reg: SynthRegion, ds, info: List[HapInfo], kept: List[int]) -> Li
         out[r] = RowLabel(",".join(inf.samples), ",".join(ids) if ids else "NA", {k: af[k] for k in ids}, f"hap_{r:08d}",
                           ds.host_meta[r].seg)
     return out
+
+
+def hap_labels(contig: str, variants, ds, info: List[HapInfo], kept: List[int]):
+    """reports.HapLabels of an expanded set, straight from the carried-variant index lists (no per-row id strings):
+    `variants` = the variant records in table order with .pos .ref .alt .af (synth.VariantSite) or a VcfVariants."""
+    from .reports import HapLabels
+    if hasattr(variants, "id"):
+        vid, af = list(variants.id), np.asarray(variants.af, dtype=np.float64)
+    else:
+        vid = [f"{contig}-{v.pos}-{v.ref}/{v.alt}" for v in variants]
+        af = np.array([float(v.af) for v in variants], dtype=np.float64)
+    n = ds.n_hap
+    samples, ids, segs = [""] * n, [""] * n, [None] * n
+    is_ref = np.zeros(n, dtype=bool)
+    cnt = np.zeros(n, dtype=np.int64)
+    parts = []
+    for k, (r, inf) in enumerate(zip(kept, info)):
+        samples[r] = ",".join(inf.samples)
+        ids[r] = f"hap_{k:08d}"
+        segs[r] = ds.host_meta[r].seg
+        is_ref[r] = r == 0 or samples[r] == "REF"
+        idx = np.asarray(inf.variant_idx, dtype=np.int64)
+        cnt[r] = len(idx)
+    order = np.argsort(np.asarray(kept))
+    for j in order.tolist():
+        parts.append(np.asarray(info[j].variant_idx, dtype=np.int64))
+    var_idx = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+    return HapLabels(samples, ids, is_ref, np.concatenate(([0], np.cumsum(cnt))), var_idx, vid, af, segs)

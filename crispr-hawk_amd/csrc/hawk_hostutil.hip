@@ -1,0 +1,237 @@
+// hawk_hostutil.hip — host-side helpers of the report assembly.  No device code: the guide report's
+// `samples` and `haplotype_id` columns list every carrier of every report row (C3: 28 M entries, ~330 MB of text);
+// joining them is a ragged byte gather that Python cannot do at memory speed, so it lives here, multi-threaded.
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/hawk.h"
+
+namespace {
+template <class F> void par_groups(uint64_t n_groups, F f) {
+  unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  if (n_groups < 4096) nt = 1;
+  const uint64_t per = (n_groups + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t)
+    th.emplace_back([=] { f(std::min<uint64_t>(n_groups, t * per), std::min<uint64_t>(n_groups, (t + 1) * per)); });
+  f(0, std::min<uint64_t>(n_groups, per));
+  for (auto& x : th) x.join();
+}
+inline unsigned dec_len(uint32_t v) { unsigned n = 1; while (v >= 10) { v /= 10; ++n; } return n; }
+inline uint8_t* put_dec(uint8_t* w, uint32_t v) {
+  char tmp[12]; int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *w++ = (uint8_t)tmp[--n];
+  return w;
+}
+}  // namespace
+
+extern "C" {
+
+// For every group g the items item_label[group_off[g] .. group_off[g+1]) name byte strings pool[pool_off[l] .. pool_off[l+1]);
+// the group's output is those strings joined by `sep`.  out_off[n_groups + 1] receives the byte offsets of the groups in
+// `out` (always written); the bytes are written when `out` is non-NULL and out_cap suffices, else HAWK_E_CAPACITY with
+// the required size in out_off[n_groups].
+int hawk_host_ragged_join(const uint32_t* item_label, const uint64_t* group_off, uint64_t n_groups, const uint8_t* pool,
+                          const uint64_t* pool_off, uint64_t n_labels, uint8_t sep, uint8_t* out, uint64_t out_cap,
+                          uint64_t* out_off) {
+  if (!group_off || !out_off || (group_off[n_groups] && (!item_label || !pool || !pool_off))) return HAWK_E_INVALID;
+  const uint64_t n_items = group_off[n_groups];
+  for (uint64_t g = 0; g < n_groups; ++g)
+    if (group_off[g + 1] < group_off[g]) return HAWK_E_INVALID;
+  unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  if (n_groups < 4096) nt = 1;
+  const uint64_t per = (n_groups + nt - 1) / nt;
+  // pass 1: sizes
+  std::vector<int> bad(nt, 0);
+  auto size_pass = [&](unsigned t) {
+    const uint64_t g0 = std::min<uint64_t>(n_groups, t * per), g1 = std::min<uint64_t>(n_groups, g0 + per);
+    for (uint64_t g = g0; g < g1; ++g) {
+      uint64_t sz = 0;
+      for (uint64_t i = group_off[g]; i < group_off[g + 1]; ++i) {
+        const uint32_t l = item_label[i];
+        if (l >= n_labels) { bad[t] = 1; return; }
+        sz += pool_off[l + 1] - pool_off[l] + 1;
+      }
+      out_off[g + 1] = sz ? sz - 1 : 0;  // separators between items only
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(size_pass, t);
+    size_pass(0);
+    for (auto& x : th) x.join();
+  }
+  for (int b : bad) if (b) return HAWK_E_INVALID;
+  out_off[0] = 0;
+  for (uint64_t g = 0; g < n_groups; ++g) out_off[g + 1] += out_off[g];
+  (void)n_items;
+  if (!out) return HAWK_OK;
+  if (out_off[n_groups] > out_cap) return HAWK_E_CAPACITY;
+  auto write_pass = [&](unsigned t) {
+    const uint64_t g0 = std::min<uint64_t>(n_groups, t * per), g1 = std::min<uint64_t>(n_groups, g0 + per);
+    for (uint64_t g = g0; g < g1; ++g) {
+      uint8_t* w = out + out_off[g];
+      for (uint64_t i = group_off[g]; i < group_off[g + 1]; ++i) {
+        const uint32_t l = item_label[i];
+        const uint64_t n = pool_off[l + 1] - pool_off[l];
+        if (i != group_off[g]) *w++ = sep;
+        memcpy(w, pool + pool_off[l], n);
+        w += n;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(write_pass, t);
+  write_pass(0);
+  for (auto& x : th) x.join();
+  return HAWK_OK;
+}
+
+
+// Per group: the sorted set of the items its member haplotypes carry, joined by `sep` (collapse_haplotype_ids,
+// reports.py:845-857, and the unphased form of collapse_samples).  Haplotype h carries items hap_item[hap_item_off[h] ..
+// hap_item_off[h+1]), each an index into the label pool whose order IS the sort order.
+int hawk_host_group_join(const uint64_t* member_off, const uint32_t* member_hap, uint64_t n_groups, const uint64_t* hap_item_off,
+                         const uint32_t* hap_item, uint64_t n_haps, const uint8_t* pool, const uint64_t* pool_off, uint64_t n_labels,
+                         uint8_t sep, uint8_t* out, uint64_t out_cap, uint64_t* out_off) {
+  if (!member_off || !out_off || !hap_item_off || (member_off[n_groups] && (!member_hap || !pool_off))) return HAWK_E_INVALID;
+  for (uint64_t i = 0; i < member_off[n_groups]; ++i) if (member_hap[i] >= n_haps) return HAWK_E_INVALID;
+  for (uint64_t i = 0; i < hap_item_off[n_haps]; ++i) if (hap_item[i] >= n_labels) return HAWK_E_INVALID;
+  auto run = [&](bool write) {
+    par_groups(n_groups, [&, write](uint64_t g0, uint64_t g1) {
+      std::vector<uint32_t> items;
+      for (uint64_t g = g0; g < g1; ++g) {
+        items.clear();
+        bool sorted = true;
+        for (uint64_t i = member_off[g]; i < member_off[g + 1]; ++i) {
+          const uint32_t h = member_hap[i];
+          for (uint64_t k = hap_item_off[h]; k < hap_item_off[h + 1]; ++k) {
+            if (!items.empty() && hap_item[k] < items.back()) sorted = false;
+            items.push_back(hap_item[k]);
+          }
+        }
+        if (!sorted) std::sort(items.begin(), items.end());
+        items.erase(std::unique(items.begin(), items.end()), items.end());
+        if (!write) {
+          uint64_t sz = 0;
+          for (uint32_t l : items) sz += pool_off[l + 1] - pool_off[l] + 1;
+          out_off[g + 1] = sz ? sz - 1 : 0;
+        } else {
+          uint8_t* w = out + out_off[g];
+          bool first = true;
+          for (uint32_t l : items) {
+            if (!first) *w++ = sep;
+            first = false;
+            const uint64_t n = pool_off[l + 1] - pool_off[l];
+            memcpy(w, pool + pool_off[l], n);
+            w += n;
+          }
+        }
+      }
+    });
+  };
+  run(false);
+  out_off[0] = 0;
+  for (uint64_t g = 0; g < n_groups; ++g) out_off[g + 1] += out_off[g];
+  if (!out) return HAWK_OK;
+  if (out_off[n_groups] > out_cap) return HAWK_E_CAPACITY;
+  run(true);
+  return HAWK_OK;
+}
+
+// The `samples` column of a phased panel (reports.py:767-810: sorted unique `sample:a|b` entries, then one entry per sample
+// with the per-copy maxima, samples in the order of their first entry).  Haplotype h carries entries hap_ent[...]; entry e
+// belongs to sample ent_sample[e] (samples numbered in that first-entry order) with alleles ent_a1[e] | ent_a2[e];
+// ent_ok[e] = 0 marks an entry that is not `name:int|int`.  group_flags[g]: bit 0 = the group holds an ok (phased) entry,
+// bit 1 = it holds one that is not.  A group with only such entries gets them joined as they are (entry strings in ent_pool);
+// a group mixing both kinds gets an empty string (the caller resolves it).
+int hawk_host_group_samples(const uint64_t* member_off, const uint32_t* member_hap, uint64_t n_groups, const uint64_t* hap_ent_off,
+                            const uint32_t* hap_ent, uint64_t n_haps, const uint32_t* ent_sample, const uint16_t* ent_a1,
+                            const uint16_t* ent_a2, const uint8_t* ent_ok, uint64_t n_entries, const uint8_t* name_pool,
+                            const uint64_t* name_off, uint64_t n_samples, const uint8_t* ent_pool, const uint64_t* ent_pool_off,
+                            uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint8_t* group_flags) {
+  if (!member_off || !out_off || !hap_ent_off || !group_flags || (member_off[n_groups] && (!member_hap || !name_off))) return HAWK_E_INVALID;
+  for (uint64_t i = 0; i < member_off[n_groups]; ++i) if (member_hap[i] >= n_haps) return HAWK_E_INVALID;
+  for (uint64_t i = 0; i < hap_ent_off[n_haps]; ++i) if (hap_ent[i] >= n_entries) return HAWK_E_INVALID;
+  for (uint64_t e = 0; e < n_entries; ++e) if (ent_sample[e] >= n_samples) return HAWK_E_INVALID;
+  struct Ent { uint32_t s; uint16_t a, b; };
+  auto run = [&](bool write) {
+    par_groups(n_groups, [&, write](uint64_t g0, uint64_t g1) {
+      std::vector<Ent> v;
+      std::vector<uint32_t> raw;
+      for (uint64_t g = g0; g < g1; ++g) {
+        v.clear();
+        raw.clear();
+        bool sorted = true;
+        uint8_t fl = 0;
+        for (uint64_t i = member_off[g]; i < member_off[g + 1]; ++i) {
+          const uint32_t h = member_hap[i];
+          for (uint64_t k = hap_ent_off[h]; k < hap_ent_off[h + 1]; ++k) {
+            const uint32_t e = hap_ent[k];
+            fl |= ent_ok[e] ? 1 : 2;
+            if (!v.empty() && ent_sample[e] < v.back().s) sorted = false;
+            v.push_back(Ent{ent_sample[e], ent_a1[e], ent_a2[e]});
+            raw.push_back(e);
+          }
+        }
+        group_flags[g] = fl;
+        if (fl == 2) {  // no phased entry at all (e.g. the REF group): the sorted unique entries as they are
+          std::sort(raw.begin(), raw.end());
+          raw.erase(std::unique(raw.begin(), raw.end()), raw.end());
+          if (!write) {
+            uint64_t sz = 0;
+            for (uint32_t e : raw) sz += ent_pool_off[e + 1] - ent_pool_off[e] + 1;
+            out_off[g + 1] = sz ? sz - 1 : 0;
+          } else {
+            uint8_t* w = out + out_off[g];
+            bool first = true;
+            for (uint32_t e : raw) {
+              if (!first) *w++ = ',';
+              first = false;
+              const uint64_t len = ent_pool_off[e + 1] - ent_pool_off[e];
+              memcpy(w, ent_pool + ent_pool_off[e], len);
+              w += len;
+            }
+          }
+          continue;
+        }
+        if (fl & 2) { if (!write) out_off[g + 1] = 0; continue; }
+        if (!sorted) std::stable_sort(v.begin(), v.end(), [](const Ent& x, const Ent& y) { return x.s < y.s; });
+        size_t n = 0;  // merge neighbours of one sample: per-copy maxima
+        for (size_t i = 0; i < v.size(); ++i) {
+          if (n && v[n - 1].s == v[i].s) { v[n - 1].a = std::max(v[n - 1].a, v[i].a); v[n - 1].b = std::max(v[n - 1].b, v[i].b); }
+          else v[n++] = v[i];
+        }
+        if (!write) {
+          uint64_t sz = 0;
+          for (size_t i = 0; i < n; ++i) sz += name_off[v[i].s + 1] - name_off[v[i].s] + 1 + dec_len(v[i].a) + 1 + dec_len(v[i].b) + 1;
+          out_off[g + 1] = sz ? sz - 1 : 0;
+        } else {
+          uint8_t* w = out + out_off[g];
+          for (size_t i = 0; i < n; ++i) {
+            if (i) *w++ = ',';
+            const uint64_t len = name_off[v[i].s + 1] - name_off[v[i].s];
+            memcpy(w, name_pool + name_off[v[i].s], len);
+            w += len;
+            *w++ = ':';
+            w = put_dec(w, v[i].a);
+            *w++ = '|';
+            w = put_dec(w, v[i].b);
+          }
+        }
+      }
+    });
+  };
+  run(false);
+  out_off[0] = 0;
+  for (uint64_t g = 0; g < n_groups; ++g) out_off[g + 1] += out_off[g];
+  if (!out) return HAWK_OK;
+  if (out_off[n_groups] > out_cap) return HAWK_E_CAPACITY;
+  run(true);
+  return HAWK_OK;
+}
+
+}  // extern "C"

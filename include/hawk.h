@@ -214,6 +214,32 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
 int hawk_table_collapse_export(hawk_table* t, uint32_t* rep_row, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
                                uint8_t* flags, double* cfdon, uint64_t* win, uint32_t* member_hap, float* kernel_ms);
 
+/* Host-side helper of the report assembly (no device work): the report's `samples` / `haplotype_id` columns list every
+ * carrier of every report row (reports.py:767-857) - a ragged join of label strings.  Items item_label[group_off[g] ..
+ * group_off[g+1]) of group g name byte strings pool[pool_off[l] .. pool_off[l+1]); the group's text is those strings
+ * joined by `sep`.  out_off[n_groups+1] always receives the groups' byte offsets; with out == NULL only sizes are
+ * computed; HAWK_E_CAPACITY when out_cap is too small (required size in out_off[n_groups]). */
+int hawk_host_ragged_join(const uint32_t* item_label, const uint64_t* group_off, uint64_t n_groups, const uint8_t* pool,
+                          const uint64_t* pool_off, uint64_t n_labels, uint8_t sep, uint8_t* out, uint64_t out_cap,
+                          uint64_t* out_off);
+
+/* The same for a group's SET of items: haplotype h carries the items hap_item[hap_item_off[h] .. hap_item_off[h+1]) (indices
+ * into a label pool held in sort order); per group the sorted unique items of its members member_hap[member_off[g] ..
+ * member_off[g+1]) are joined - collapse_haplotype_ids (reports.py:845-857) and the unphased collapse_samples. */
+int hawk_host_group_join(const uint64_t* member_off, const uint32_t* member_hap, uint64_t n_groups, const uint64_t* hap_item_off,
+                         const uint32_t* hap_item, uint64_t n_haps, const uint8_t* pool, const uint64_t* pool_off, uint64_t n_labels,
+                         uint8_t sep, uint8_t* out, uint64_t out_cap, uint64_t* out_off);
+/* The phased `samples` column (reports.py:767-810): per group one `name:a|b` per sample (samples numbered in the order of
+ * their first entry in the sorted entry list) with the per-copy maxima over the members' entries.  ent_ok[e] = 0 marks an
+ * entry that is not `name:int|int`; group_flags[g] bit 0: the group holds a well-formed entry, bit 1: it holds one that is
+ * not; a group with none well-formed gets its sorted unique entries joined as they are (strings in ent_pool), one mixing
+ * both kinds is left empty for the caller to resolve. */
+int hawk_host_group_samples(const uint64_t* member_off, const uint32_t* member_hap, uint64_t n_groups, const uint64_t* hap_ent_off,
+                            const uint32_t* hap_ent, uint64_t n_haps, const uint32_t* ent_sample, const uint16_t* ent_a1,
+                            const uint16_t* ent_a2, const uint8_t* ent_ok, uint64_t n_entries, const uint8_t* name_pool,
+                            const uint64_t* name_off, uint64_t n_samples, const uint8_t* ent_pool, const uint64_t* ent_pool_off,
+                            uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint8_t* group_flags);
+
 /* ---- the one exchange of a multi-GPU job.  One process per GPU, haplotypes block-partitioned with REF
  * on every rank (search_guides.py:111-131, 530-547 loop over independent haplotypes), no collective on the search
  * path; afterwards every rank's guide table goes to one rank over RCCL / xGMI.  The caller moves the 128-byte id from

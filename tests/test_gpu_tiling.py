@@ -105,9 +105,11 @@ def test_tiled_report_equals_untiled_device_report():
                             pam, 20, False, tile_nt=2600, flank=300)
     mg = trs.run(cfd=(mm, pt))
     df2 = reports.report_frame(mg.report_input(), mg.labels, pam, reg.contig, target)
+    df3 = reports.report_from_groups(mg.groups(), mg.labels, pam, reg.contig, target)
     cols = [c for c in df1.columns if c != "haplotype_id"]
     assert len(df1) == len(df2) and len(df1) > 1000
     assert df1[cols].to_csv(sep="\t", index=False) == df2[cols].to_csv(sep="\t", index=False)
+    assert df2.to_csv(sep="\t", index=False) == df3.to_csv(sep="\t", index=False)
 
 
 def test_tiles_with_n_run_and_no_variants():

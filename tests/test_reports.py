@@ -63,6 +63,42 @@ def test_report_from_oracle_rows_matches_reference_tsv(case):
                               np.array(num), np.array(den), guidelen, len(pam_s), right)
     df = reports.report_frame(inp, labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     assert reports.to_tsv(df) == fx["report_tsv"]
+    # the columnar assembler (group-level inputs, ragged joins in the library's host helper) writes the same text
+    df2 = reports.report_from_groups(reports.ReportGroups.from_report_input(inp), labels, _pam(fx), fx["contig"], fx["target"],
+                                     with_cfdon=fx["cfd"])
+    assert reports.to_tsv(df2) == fx["report_tsv"]
+
+
+def test_samples_column_general_cases():
+    """The vectorised `samples` column against the per-group reference logic (reports.py:767-810) on member sets the
+    fixtures do not hold: collapsed haplotypes with several labels, both copies of a sample in one group, members in
+    arbitrary order, sample names of different widths, multi-allelic genotypes, an unphased panel, a REF group."""
+    rng = np.random.default_rng(5)
+    names = ["S1", "S10", "NA12878", "HG00096", "x"]
+
+    class H:
+        def __init__(self, samples, hid):
+            self.samples, self.id = samples, hid
+    haps = [H("REF", "hap_ref")]
+    for n in names:
+        haps += [H(f"{n}:1|0", f"h{len(haps)}"), H(f"{n}:0|1", f"h{len(haps) + 1}"), H(f"{n}:2|0", f"h{len(haps) + 2}")]
+    haps += [H("S1:1|1,x:0|1", "hA,hB"), H("HG00096:1|1", "hC")]
+    member_off, member_hap = [0], []
+    want_s, want_h = [], []
+    for g in range(300):
+        k = int(rng.integers(1, 8))
+        mem = rng.choice(np.arange(1, len(haps)), size=k, replace=False) if g % 17 else np.array([0])
+        member_hap += mem.tolist()
+        member_off.append(len(member_hap))
+        want_s.append(reports.collapse_samples([haps[int(x)].samples for x in mem]))
+        want_h.append(reports.collapse_haplotype_ids([haps[int(x)].id for x in mem]))
+    off, mh = np.array(member_off), np.array(member_hap)
+    assert reports._samples_column(off, mh, [h.samples for h in haps]) == want_s
+    assert reports._hapids_column(off, mh, [h.id for h in haps]) == want_h
+    unph = [H("REF", "r")] + [H(f"{n}:0/1", f"u{i}") for i, n in enumerate(names)]
+    off2, mh2 = np.array([0, 2, 3, 5]), np.array([1, 3, 0, 2, 5])
+    want = [reports.collapse_samples([unph[int(x)].samples for x in mh2[a:b]]) for a, b in zip(off2[:-1], off2[1:])]
+    assert reports._samples_column(off2, mh2, [h.samples for h in unph]) == want
 
 
 @pytest.mark.gpu
@@ -75,8 +111,12 @@ def test_report_from_device_table_matches_reference_tsv(case):
     ds = DeviceHapSet([HostHaplotype(seq, lb.segments, r, sc) for seq, lb, r, sc in zip(hs.seqs, labels, hs.is_ref, hs.scan)])
     bits, bitsrc, _, _ = ora.pam_encode(pam_s)
     mm, pt = synth.cfd_tables() if fx["cfd"] else (None, None)
-    tab = ds.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, collapse=True)
+    tab = ds.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, download=False, collapse=True)
     assert tab.n_rows == fx["rows_before_collapse"]
+    groups = tab.export_groups()  # device group export -> columnar assembler (what pipeline.search_files runs)
+    df2 = reports.report_from_groups(groups, labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"],
+                                     is_ref_hap=np.asarray(ds.is_ref, dtype=bool))
+    assert reports.to_tsv(df2) == fx["report_tsv"]
     df = reports.report_frame(reports.ReportInput.from_table(tab), labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     assert reports.to_tsv(df) == fx["report_tsv"]
 
