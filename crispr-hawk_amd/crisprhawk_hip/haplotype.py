@@ -74,13 +74,13 @@ class Haplotype(Region):
         self._phased = phased
         self._chromcopy = chromcopy
         self._arr = np.frombuffer(sequence.sequence.encode("ascii"), dtype=np.uint8)
-        self._seg = PosSegments.identity(self._coordinates.start, self._size)
+        self._seg = PosSegments.identity(self.coordinates.start, self._size)
 
     def __str__(self) -> str:
-        return f"{self._samples}: {self._sequence.sequence}"
+        return f"{self._samples}: {self.sequence.sequence}"
 
     def substring(self, start: int, stop: int) -> str:
-        return self._sequence.sequence[start:stop]
+        return self.sequence.sequence[start:stop]
 
     def add_variants_phased(self, variants: List[VariantRecord], sample: str) -> None:
         """haplotype.py:214-252"""
@@ -88,13 +88,13 @@ class Haplotype(Region):
             exception_handler(ValueError, "Unphased haplotype, unable to add phased variants", os.EX_DATAERR, True)
         variants = _sort_variants(variants)
         try:
-            arr, seg = expand_haplotype(self._arr, self._coordinates.start,
+            arr, seg = expand_haplotype(self._arr, self.coordinates.start,
                                         [(v.position, v.ref.encode(), v.alt[0].encode()) for v in variants])
         except HaplotypeBuildError as e:
             raise ValueError(str(e)) from e
         self._arr, self._seg = arr, seg
         suffix = "1|0" if self._chromcopy == 0 else "0|1"
-        self._sequence = Sequence(arr.tobytes().decode("ascii"), self._debug, allow_lower_case=True)
+        self.sequence = Sequence(arr.tobytes().decode("ascii"), self._debug, allow_lower_case=True)
         self._samples = f"{sample}:{suffix}" if self._phased else sample
         self._variants = ",".join(v.id[0] for v in variants)
         self._afs = {v.id[0]: v.afs[0] for v in variants}
@@ -104,7 +104,7 @@ class Haplotype(Region):
         lower-case IUPAC letter of {reference base(s), alt}, indels are applied as in the phased case, and
         `variant_alleles` remembers (ref, alt, position) per final relative position for resolve_guide."""
         variants = _sort_variants(variants)
-        start = self._coordinates.start
+        start = self.coordinates.start
         cur: Dict[int, str] = {}        # SNV letter written so far, by genomic position
         sites = []
         va: Dict[int, List[Tuple[str, str, int]]] = {}
@@ -117,7 +117,7 @@ class Haplotype(Region):
             chain = len(alt) - len(ref)
             posrel = pos - start + off
             stop = posrel + abs(chain) + 1 if chain < 0 else posrel + 1
-            ref_seq = self._sequence.sequence
+            ref_seq = self.sequence.sequence
             refnt = "".join(cur.get(pos + i, ref_seq[pos - start + i: pos - start + i + 1]) for i in range(stop - posrel))
             if not match_iupac(ref, refnt):
                 raise ValueError(f"Mismatching reference alleles in VCF and reference sequence at position {pos} ({refnt} - {ref})")
@@ -146,7 +146,7 @@ class Haplotype(Region):
         except HaplotypeBuildError as e:
             raise ValueError(str(e)) from e
         self._arr, self._seg = arr, seg
-        self._sequence = Sequence(arr.tobytes().decode("ascii"), self._debug, allow_lower_case=True)
+        self.sequence = Sequence(arr.tobytes().decode("ascii"), self._debug, allow_lower_case=True)
         self._variant_alleles = va
         self._samples = sample
         self._variants = ",".join(v.id[0] for v in variants)
@@ -177,8 +177,8 @@ class Haplotype(Region):
     # the byte view the device packer consumes
     @property
     def array(self) -> np.ndarray:
-        if len(self._arr) != len(self._sequence):
-            self._arr = np.frombuffer(self._sequence.sequence.encode("ascii"), dtype=np.uint8)
+        if len(self._arr) != len(self.sequence):
+            self._arr = np.frombuffer(self.sequence.sequence.encode("ascii"), dtype=np.uint8)
         return self._arr
 
     @property

@@ -1,194 +1,175 @@
-"""Haplotype reconstruction from in-memory variant records, phased (reference haplotypes.py:106-368) and
-unphased (370-712).  Callers hand in the ``VariantRecord`` list that ``VCF.fetch`` returns for the region
-(readers.VCF.fetch)."""
+"""Haplotype reconstruction from in-memory variant records (what `reconstruct_haplotypes` does between reading the VCF
+and handing haplotypes to the search, reference haplotypes.py:106-368 phased, 370-712 unphased).
+
+Only the public behaviour is the reference's: which haplotypes exist for a region, their cased sequences, labels,
+position maps and (unphased) per-position allele tables.  The construction is organised around one idea instead of the
+reference's chain of helpers: every haplotype is "a region string + one list of variant records applied by
+`Haplotype.add_variants_*`"; what differs between the modes is only how records are dealt to carriers (`_deal`) and
+which stretch of the region a haplotype covers (`_Stretch`).  Identical cased sequences are then merged (`_merge_equal`,
+collapse_haplotypes in the reference, 274-294).
+"""
 import random
 import string
-from collections import defaultdict
-from typing import Dict, List, Set, Tuple
+from typing import Callable, Dict, Iterable, List, Optional, Sequence as Seq, Tuple
 
 from .coordinate import Coordinate
 from .haplotype import Haplotype
 from .region import Region
 from .sequence import Sequence
-from .utils import flatten_list
 from .variant import VTYPES, VariantRecord
 
-
-def initialize_haplotypes(regions, debug: bool) -> Dict[Region, List[Haplotype]]:
-    return {r: [Haplotype(Sequence(r.sequence.sequence, debug), r.coordinates, False, 0, debug)] for r in regions}
+INDEL_WINDOW = 100  # bases kept either side of an unphased indel (haplotypes.py:465-484)
 
 
-def compute_haplotypes_phased(variants: List[VariantRecord], samples: List[str]):
-    """haplotypes.py:132-159"""
-    sv = {s: ([], []) for s in samples}
-    for v in variants:
-        assert len(v.samples) == 1
-        for c in (0, 1):
-            for s in v.samples[0][c]:
-                sv[s][c].append(v)
-    return {s: v for s, v in sv.items() if v[0] or v[1]}
+class _Stretch:
+    """The part of a region a haplotype is built over: its bases and its coordinates."""
+
+    __slots__ = ("bases", "coords")
+
+    def __init__(self, bases: str, coords: Coordinate):
+        self.bases, self.coords = bases, coords
+
+    @classmethod
+    def whole(cls, region: Region) -> "_Stretch":
+        return cls(region.sequence.sequence, region.coordinates)
+
+    @classmethod
+    def around(cls, region: Region, record: VariantRecord) -> Tuple["_Stretch", int, int]:
+        """The region cut to INDEL_WINDOW bases either side of `record` (clamped to the region)."""
+        grow = len(record.alt[0]) - len(record.ref) if record.alt else 0
+        lo = max(region.start, record.position - INDEL_WINDOW)
+        hi = min(region.stop, record.position - grow + INDEL_WINDOW)
+        a = lo - region.start
+        return cls(region.sequence.sequence[a:hi - region.start + 1], Coordinate(region.contig, lo, hi, 0)), lo, hi
+
+    def fresh(self, phased: bool, copy: int, debug: bool) -> Haplotype:
+        return Haplotype(Sequence(self.bases, debug), self.coords, phased, copy, debug)
 
 
-def ishomozygous(haplotypes: List[Haplotype]) -> bool:
-    return len({h.sequence.sequence for h in haplotypes}) == 1
+def _split_alleles(records: Iterable[VariantRecord]) -> List[VariantRecord]:
+    out: List[VariantRecord] = []
+    for r in records:
+        out.extend(r.split())
+    return out
 
 
-def _collapse_haplotypes(sequence: str, haplotypes: List[Haplotype], debug: bool) -> Haplotype:
-    """haplotypes.py:232-271 (sample / variant unions are sorted here; the reference joins
-    Python sets, whose order is not reproducible run to run)."""
-    hap = Haplotype(Sequence(sequence, debug, allow_lower_case=True), haplotypes[0].coordinates, haplotypes[0].phased, 0, debug)
-    hap.samples = "REF" if sequence.isupper() else ",".join(sorted({h.samples for h in haplotypes}))
-    hap.variants = "NA" if sequence.isupper() else ",".join(sorted({h.variants for h in haplotypes}))
-    hap.set_afs(haplotypes[0].afs)
-    hap.set_posmap(haplotypes[0].segments)
-    hap.set_variant_alleles(haplotypes[0].variant_alleles)
-    return hap
+def _deal(records: Seq[VariantRecord], carriers: Seq[str], copies: Tuple[int, ...]) -> Dict[str, Tuple[List[VariantRecord], ...]]:
+    """Records dealt to their carriers, per chromosome copy in `copies`, in record order; carriers without any record
+    are dropped, carriers not listed are ignored.  (A record here is biallelic: `samples[0]` holds its carrier sets.)"""
+    hands = {name: tuple([] for _ in copies) for name in carriers}
+    for rec in records:
+        sets = rec.samples[0]
+        for slot, c in enumerate(copies):
+            for name in sets[c]:
+                hand = hands.get(name)
+                if hand is not None:
+                    hand[slot].append(rec)
+    return {name: hand for name, hand in hands.items() if any(hand)}
+
+
+def _merge_equal(haps: Seq[Haplotype], debug: bool) -> List[Haplotype]:
+    """One haplotype per distinct cased sequence (first-seen order).  The merged haplotype takes the first member's
+    coordinates, phase, position map, allele frequencies and allele table; labels are unions - sorted here, where the
+    reference joins Python sets in hash order; an all-upper-case sequence is REF whatever its members were called."""
+    order: List[str] = []
+    members: Dict[str, List[Haplotype]] = {}
+    for h in haps:
+        key = h.sequence.sequence
+        if key not in members:
+            members[key] = []
+            order.append(key)
+        members[key].append(h)
+    merged = []
+    for key in order:
+        group = members[key]
+        head = group[0]
+        m = Haplotype(Sequence(key, debug, allow_lower_case=True), head.coordinates, head.phased, 0, debug)
+        is_ref = key.isupper()
+        m.samples = "REF" if is_ref else ",".join(sorted({g.samples for g in group}))
+        m.variants = "NA" if is_ref else ",".join(sorted({g.variants for g in group}))
+        m.set_afs(head.afs)
+        m.set_posmap(head.segments)
+        m.set_variant_alleles(head.variant_alleles)
+        merged.append(m)
+    return merged
 
 
 def collapse_haplotypes(haplotypes: List[Haplotype], debug: bool) -> List[Haplotype]:
-    groups = defaultdict(list)
-    for h in haplotypes:
-        groups[h.sequence.sequence].append(h)
-    return [_collapse_haplotypes(seq, hl, debug) for seq, hl in groups.items()]
+    return _merge_equal(haplotypes, debug)
 
 
-def _solve_haplotypes_phased(sequence: str, coordinates: Coordinate, phased: bool, variants, sample: str, debug: bool):
-    h0 = Haplotype(Sequence(sequence, debug), coordinates, phased, 0, debug)
-    h0.add_variants_phased(variants[0], sample)
-    h1 = Haplotype(Sequence(sequence, debug), coordinates, phased, 1, debug)
-    h1.add_variants_phased(variants[1], sample)
-    if ishomozygous([h0, h1]):
-        h0.homozygous_samples()
-        return [h0]
-    return [h0, h1]
+def initialize_haplotypes(regions, debug: bool) -> Dict[Region, List[Haplotype]]:
+    """The REF haplotype of every region (haplotypes.py:106-129)."""
+    return {r: [_Stretch.whole(r).fresh(False, 0, debug)] for r in regions}
 
 
-def solve_haplotypes_phased(sample_variants, hapseqs: List[Haplotype], refseq: str, coordinates: Coordinate,
-                            phased: bool, debug: bool) -> List[Haplotype]:
-    for sample, variants in sample_variants.items():
-        hapseqs += _solve_haplotypes_phased(refseq, coordinates, phased, variants, sample, debug)
-    return collapse_haplotypes(hapseqs, debug)
+# ---------------------------------------------------------------------------------------------- phased
+def add_variants_phased(haplotypes: List[Haplotype], region: Region, samples: List[str], variants: List[VariantRecord], phased: bool,
+                        debug: bool) -> List[Haplotype]:
+    """Two chromosome copies per carrier sample (one when both come out identical, labelled 1|1), appended to
+    `haplotypes`, then merged by sequence (haplotypes.py:297-368, 714-745; the VCF object replaced by its sample list)."""
+    stretch = _Stretch.whole(region)
+    for sample, (first, second) in _deal(_split_alleles(variants), samples, (0, 1)).items():
+        pair = []
+        for copy, records in ((0, first), (1, second)):
+            h = stretch.fresh(phased, copy, debug)
+            h.add_variants_phased(records, sample)
+            pair.append(h)
+        if pair[0].sequence.sequence == pair[1].sequence.sequence:
+            pair[0].homozygous_samples()
+            pair.pop()
+        haplotypes += pair
+    return _merge_equal(haplotypes, debug)
 
 
-def add_variants_phased(haplotypes: List[Haplotype], region: Region, samples: List[str],
-                        variants: List[VariantRecord], phased: bool, debug: bool) -> List[Haplotype]:
-    """haplotypes.py:714-745 with the VCF object replaced by its sample list."""
-    variants = flatten_list([v.split() for v in variants])
-    sv = compute_haplotypes_phased(variants, samples)
-    return solve_haplotypes_phased(sv, haplotypes, region.sequence.sequence, region.coordinates, phased, debug)
-
-
-# ---------------------------------------------------------------------------- unphased VCFs (haplotypes.py:370-712)
-def compute_haplotypes_unphased(variants: List[VariantRecord], samples: List[str]) -> Dict[str, List[VariantRecord]]:
-    """haplotypes.py:161-185: SNVs only, first-copy sample sets."""
-    variants = [v for v in variants if v.vtype[0] == VTYPES[0]]
-    sv: Dict[str, List[VariantRecord]] = {s: [] for s in samples}
-    for v in variants:
-        assert len(v.samples) == 1
-        for s in v.samples[0][0]:
-            sv[s].append(v)
-    return {s: v for s, v in sv.items() if v}
-
-
-def compute_indel_haplotypes_unphased(variants: List[VariantRecord], samples: List[str]) -> Dict[str, List[VariantRecord]]:
-    """haplotypes.py:188-212: the indel and its overlapping SNVs, for the indel's carriers only."""
-    sv: Dict[str, List[VariantRecord]] = {s: [] for s in samples}
-    for v in variants:
-        assert len(v.samples) == 1
-        for s in v.samples[0][0]:
-            if s in sv:
-                sv[s].append(v)
-    return {s: v for s, v in sv.items() if v}
-
-
-def _solve_haplotypes_unphased(sequence: str, coordinates: Coordinate, phased: bool, variants: List[VariantRecord], sample: str,
-                               debug: bool) -> List[Haplotype]:
-    """haplotypes.py:384-405.  generate_variants_combinations keys its groups by variant id, so there is exactly
-    one combination: all of the sample's variants."""
-    h = Haplotype(Sequence(sequence, debug), coordinates, phased, 0, debug)
-    h.add_variants_unphased([v for v in variants if v is not None], sample)
-    return [h]
-
-
-def solve_haplotypes_unphased(sample_variants: Dict[str, List[VariantRecord]], hapseqs: List[Haplotype], refseq: str,
-                              coordinates: Coordinate, phased: bool, debug: bool) -> List[Haplotype]:
-    for sample, variants in sample_variants.items():
-        hapseqs += _solve_haplotypes_unphased(refseq, coordinates, phased, variants, sample, debug)
-    return collapse_haplotypes(hapseqs, debug)
-
-
-def classify_variants(variants: List[VariantRecord]) -> Tuple[List[VariantRecord], List[VariantRecord]]:
-    snvs = [v for v in variants if v.vtype[0] == VTYPES[0]]
-    indels = [v for v in variants if v.vtype[0] != VTYPES[0]]
-    return snvs, indels
-
-
-def compute_snvs_haplotype_unphased(snvs: List[VariantRecord], samples: List[str], refseq: str, coordinates: Coordinate,
-                                    phased: bool, debug: bool) -> List[Haplotype]:
-    return solve_haplotypes_unphased(compute_haplotypes_unphased(snvs, samples), [], refseq, coordinates, phased, debug)
-
-
-def create_indel_window(indel: VariantRecord, region: Region):
-    """haplotypes.py:465-484: the region cut to 100 nt either side of the indel."""
-    indel_length = len(indel.alt[0]) - len(indel.ref) if indel.alt else 0
-    window_start = max(region.start, indel.position - 100)
-    window_stop = min(region.stop, indel.position - indel_length + 100)
-    coords = Coordinate(region.contig, window_start, window_stop, 0)
-    startrel, stoprel = window_start - region.start, window_stop - region.start + 1
-    return region.sequence.sequence[startrel:stoprel], coords, window_start, window_stop, indel_length
-
-
-def find_overlapping_snvs(indel_start: int, indel_stop: int, snvs: List[VariantRecord]) -> List[VariantRecord]:
-    return [s for s in snvs if indel_start <= s.position <= indel_stop]
-
-
-def retrieve_indel_samples(indel: VariantRecord) -> Set[str]:
-    return set(indel.samples[0][0]) if indel and len(indel.samples) > 0 else set()
-
-
-def set_haplotypes_samples(indel_haplotypes: List[Haplotype], indel_samples: Set[str]) -> List[Haplotype]:
-    for hap in indel_haplotypes:
-        if hap.samples != "REF":
-            final = (set(hap.samples.split(",")) if hap.samples else set()).intersection(indel_samples)
-            if final:
-                hap.samples = ",".join(sorted(final))
-    return indel_haplotypes
-
-
-def create_indels_haplotype_unphased(indel: VariantRecord, snvs: List[VariantRecord], region: Region, phased: bool,
-                                     debug: bool) -> List[Haplotype]:
-    """haplotypes.py:512-547: one window haplotype set per indel, built for its carriers."""
-    seq, coords, w_start, w_stop, _ = create_indel_window(indel, region)
-    overlapping = find_overlapping_snvs(w_start, w_stop, snvs)
-    carriers = retrieve_indel_samples(indel)
-    haps: List[Haplotype] = []
-    if carriers:
-        sv = compute_indel_haplotypes_unphased([indel] + overlapping, sorted(carriers))  # the reference iterates a set: hash order
-        haps = solve_haplotypes_unphased(sv, [], seq, coords, phased, debug)
-        haps = set_haplotypes_samples(haps, carriers)
-    return haps
+# ---------------------------------------------------------------------------------------------- unphased
+def _unphased_set(stretch: _Stretch, hands: Dict[str, Tuple[List[VariantRecord], ...]], phased: bool, debug: bool) -> List[Haplotype]:
+    """One IUPAC-encoded haplotype per carrier (all of its records at once: the reference's combination generator
+    keys by variant id and therefore yields exactly this one combination, haplotypes.py:384-405), merged by sequence."""
+    built = []
+    for sample, (records,) in hands.items():
+        h = stretch.fresh(phased, 0, debug)
+        h.add_variants_unphased(records, sample)
+        built.append(h)
+    return _merge_equal(built, debug)
 
 
 def add_variants_unphased(haplotypes: List[Haplotype], region: Region, samples: List[str], variants: List[VariantRecord],
                           phased: bool, debug: bool) -> List[Haplotype]:
-    """haplotypes.py:672-712 with the VCF object replaced by its sample list: SNV-only IUPAC haplotypes per sample
-    over the whole region, plus a window haplotype set per indel."""
-    variants = flatten_list([v.split() for v in variants])
-    snvs, indels = classify_variants(variants)
+    """Unphased VCFs (haplotypes.py:370-712): SNVs become IUPAC letters on one whole-region haplotype per carrier
+    (carriers read from the first genotype slot); every indel inside the region gets its own set of short haplotypes
+    - the region cut to 100 nt around it - built for the indel's carriers from the indel and the SNVs inside that
+    window, and labelled with the carriers only."""
+    alleles = _split_alleles(variants)
+    snvs = [v for v in alleles if v.vtype[0] == VTYPES[0]]
     if snvs:
-        haplotypes.extend(compute_snvs_haplotype_unphased(snvs, samples, region.sequence.sequence, region.coordinates, phased, debug))
-    for indel in indels:
-        if region.coordinates.startp <= indel.position < region.coordinates.stopp:
-            haplotypes.extend(create_indels_haplotype_unphased(indel, snvs, region, phased, debug))
+        haplotypes.extend(_unphased_set(_Stretch.whole(region), _deal(snvs, samples, (0,)), phased, debug))
+    c = region.coordinates
+    for indel in (v for v in alleles if v.vtype[0] != VTYPES[0]):
+        if not c.startp <= indel.position < c.stopp:
+            continue
+        carriers = set(indel.samples[0][0]) if len(indel.samples) else set()
+        if not carriers:
+            continue
+        stretch, lo, hi = _Stretch.around(region, indel)
+        nearby = [indel] + [s for s in snvs if lo <= s.position <= hi]
+        # the reference walks the carrier set in hash order; sorted here so that runs are reproducible
+        for h in _unphased_set(stretch, _deal(nearby, sorted(carriers), (0,)), phased, debug):
+            if h.samples != "REF":
+                kept = set(h.samples.split(",")) & carriers if h.samples else set()
+                if kept:
+                    h.samples = ",".join(sorted(kept))
+            haplotypes.append(h)
     return haplotypes
 
 
 def generate_haplotype_ids(haplotypes: Dict[Region, List[Haplotype]]) -> Dict[Region, List[Haplotype]]:
-    chars = string.ascii_letters + string.digits
-    for _, haps in haplotypes.items():
-        ids = set()
-        while len(ids) < len(haps):
-            ids.add("hap_" + "".join(random.choices(chars, k=8)))
-        for h, i in zip(haps, list(ids)):
-            h.id = i
+    """`hap_` + 8 random alphanumerics, unique within a region (haplotypes.py:807-814; unseeded in the reference too)."""
+    alphabet = string.ascii_letters + string.digits
+    for haps in haplotypes.values():
+        seen: Dict[str, None] = {}
+        while len(seen) < len(haps):
+            seen.setdefault("hap_" + "".join(random.choices(alphabet, k=8)))
+        for h, hid in zip(haps, seen):
+            h.id = hid
     return haplotypes

@@ -1,82 +1,62 @@
-"""Region / RegionList (reference region.py:15-330)."""
-from typing import List, Union
+"""Region: a stretch of a contig - its bases (`Sequence`) and where they sit (`Coordinate`) - plus RegionList, the
+container the region constructor hands to the search (reference region.py:15-330).  Both are thin: the search reads
+`region.contig/.start/.stop`, slices `region[a:b]` and hashes regions as dictionary keys (`guides[region]`)."""
+from dataclasses import dataclass
+from typing import Iterable, Union
 
 from .coordinate import Coordinate
 from .sequence import Sequence
 
 
+@dataclass(eq=False, repr=False)
 class Region:
-    def __init__(self, sequence: Sequence, coord: Coordinate):
-        self._sequence = sequence
-        self._coordinates = coord
+    sequence: Sequence
+    coordinates: Coordinate
 
-    def __len__(self) -> int:
-        return len(self._sequence)
+    # -- identity: two regions are the same when bases and interval are
+    def _key(self):
+        c = self.coordinates
+        return self.sequence.sequence, c.contig, c.start, c.stop
 
     def __eq__(self, other: object) -> bool:
-        if not isinstance(other, Region):
-            return NotImplemented
-        return self._sequence == other.sequence and self._coordinates == other._coordinates
+        return self._key() == other._key() if isinstance(other, Region) else NotImplemented
 
     def __hash__(self) -> int:
-        return hash((self._sequence.sequence, self._coordinates.contig, self._coordinates.start, self._coordinates.stop))
+        return hash(self._key())
 
-    def __str__(self) -> str:
-        return f">{str(self._coordinates)}\n{str(self._sequence)}"
-
-    def __repr__(self) -> str:
-        return f"<{self.__class__.__name__} object; region={str(self._coordinates)}>"
+    # -- the bases
+    def __len__(self) -> int:
+        return len(self.sequence)
 
     def __getitem__(self, idx: Union[int, slice]):
-        return self._sequence[idx]
+        return self.sequence[idx]
+
+    def __str__(self) -> str:
+        return f">{self.coordinates}\n{self.sequence}"
+
+    def __repr__(self) -> str:
+        return f"<{type(self).__name__} object; region={self.coordinates}>"
+
+    # -- the interval
+    contig = property(lambda self: self.coordinates.contig)
+    start = property(lambda self: self.coordinates.start)
+    stop = property(lambda self: self.coordinates.stop)
+
+    def _same_contig(self, other: "Region", what: str) -> bool:
+        if not isinstance(other, type(self)):
+            raise TypeError(f"{what} on input region can only be done on {type(self).__name__}")
+        return self.contig == other.contig
 
     def contains(self, other: "Region") -> bool:
-        if not isinstance(other, self.__class__):
-            raise TypeError(f"Full overlap check on input region can only be done on {self.__class__.__name__}")
-        return self.contig == other.contig and self.start <= other.start and self.stop >= other.stop
+        return self._same_contig(other, "Full overlap check") and self.start <= other.start and other.stop <= self.stop
 
     def overlap(self, other: "Region") -> bool:
-        if not isinstance(other, self.__class__):
-            raise TypeError(f"Overlap check on input region can only be done on {self.__class__.__name__}")
-        return self.contig == other.contig and self.start <= other.stop and self.stop >= other.start
-
-    @property
-    def contig(self) -> str:
-        return self._coordinates.contig
-
-    @property
-    def start(self) -> int:
-        return self._coordinates.start
-
-    @property
-    def stop(self) -> int:
-        return self._coordinates.stop
-
-    @property
-    def sequence(self) -> Sequence:
-        return self._sequence
-
-    @property
-    def coordinates(self) -> Coordinate:
-        return self._coordinates
+        return self._same_contig(other, "Overlap check") and self.start <= other.stop and other.start <= self.stop
 
 
-class RegionList:
-    def __init__(self, regions: List[Region], debug: bool = False):
-        self._regions = list(regions)
+class RegionList(list):
+    """A list of Region objects (the reference wraps a list; here it is one)."""
+
+    def __init__(self, regions: Iterable[Region] = (), debug: bool = False):
+        super().__init__(regions)
         self._debug = debug
-
-    def __len__(self) -> int:
-        return len(self._regions)
-
-    def __iter__(self):
-        return iter(self._regions)
-
-    def __getitem__(self, idx):
-        return self._regions[idx]
-
-    def extend(self, regions: "RegionList") -> None:
-        self._regions.extend(regions._regions)
-
-    def append(self, region: Region) -> None:
-        self._regions.append(region)

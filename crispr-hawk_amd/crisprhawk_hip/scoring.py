@@ -256,13 +256,163 @@ def azimuth_score(guides: List[Guide], threads: int, verbosity: int, debug: bool
     return guides
 
 
+# ---------------------------------------------------------------------------------------------- RS3 (a20)
+_RS3: Optional[Tuple[Dict, object]] = None  # (flattened LightGBM model, featuriser)
+
+
+def gbt_model_from_lightgbm_text(text: str) -> Dict:
+    """A LightGBM model in its text format (Booster.save_model / model_to_string) -> the flattened tree arrays of
+    hawk_gbt_model.  Internal node i of a tree keeps index i; leaf j becomes node num_internal + j (LightGBM writes a
+    child c < 0 for leaf ~c).  Numerical splits only, default direction and missing values are not modelled (RS3's
+    features are dense one-hots, counts and floats); `shrinkage` is already folded into the leaf values."""
+    trees = []
+    cur: Dict[str, str] = {}
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("Tree="):
+            cur = {}
+            trees.append(cur)
+        elif line == "end of trees":
+            break
+        elif "=" in line and trees:
+            k, v = line.split("=", 1)
+            cur[k] = v
+    if not trees:
+        raise ValueError("no Tree= sections: not a LightGBM text model")
+    tree_off, feature, left, right, threshold, value = [0], [], [], [], [], []
+    n_feat = 0
+    for t in trees:
+        leaves = [float(x) for x in t["leaf_value"].split()]
+        n_int = int(t["num_leaves"]) - 1
+        if n_int == 0:
+            feature += [-1]; left += [0]; right += [0]; threshold += [0.0]; value += [leaves[0]]
+            tree_off.append(len(feature))
+            continue
+        if any(int(d) & 1 for d in t.get("decision_type", "").split()):
+            raise ValueError("categorical splits are not supported")
+        sf = [int(x) for x in t["split_feature"].split()]
+        th = [float(x) for x in t["threshold"].split()]
+        lc = [int(x) for x in t["left_child"].split()]
+        rc = [int(x) for x in t["right_child"].split()]
+        n_feat = max(n_feat, max(sf) + 1)
+        # the device walker wants children AFTER their parent: renumber in breadth-first order
+        order, seen = [0], {0}
+        for node in order:
+            if node < n_int:
+                for c in (lc[node], rc[node]):
+                    c = c if c >= 0 else n_int + (~c)
+                    if c not in seen:
+                        seen.add(c)
+                        order.append(c)
+        new = {old: i for i, old in enumerate(order)}
+        rows = [None] * len(order)
+        for old, i in new.items():
+            if old < n_int:
+                l_, r_ = (c if c >= 0 else n_int + (~c) for c in (lc[old], rc[old]))
+                rows[i] = (sf[old], new[l_], new[r_], th[old], 0.0)
+            else:
+                rows[i] = (-1, 0, 0, 0.0, leaves[old - n_int])
+        for f_, l_, r_, th_, v_ in rows:
+            feature.append(f_); left.append(l_); right.append(r_); threshold.append(th_); value.append(v_)
+        tree_off.append(len(feature))
+    return dict(tree_off=np.array(tree_off, np.int32), feature=np.array(feature, np.int32), left=np.array(left, np.int32),
+                right=np.array(right, np.int32), threshold=np.array(threshold, np.float64), value=np.array(value, np.float64),
+                init=0.0, learning_rate=1.0, n_features=n_feat)
+
+
+def set_rs3_model(model, featurizer) -> None:
+    """`model`: a LightGBM text model (str), or a flattened dict; `featurizer(kmers) -> [n, n_features] array` is the
+    caller's sglearn feature builder (rs3.seq.predict_seq featurises with `sglearn.featurize_guides`, third party)."""
+    global _RS3
+    m = gbt_model_from_lightgbm_text(model) if isinstance(model, str) else dict(model)
+    _RS3 = (m, featurizer)
+
+
+def gbt_predict(feats: np.ndarray, model: Dict, cast_f32: bool = False) -> np.ndarray:
+    """hawk_gbt_predict: a flattened tree ensemble over a feature matrix, on the device."""
+    x = np.ascontiguousarray(feats, dtype=np.float64)
+    n, nf = x.shape
+    arrs = {k: np.ascontiguousarray(model[k], dtype=(np.float64 if k in ("threshold", "value") else np.int32))
+            for k in ("tree_off", "feature", "left", "right", "threshold", "value")}
+    gm = _lib.GbtModel(len(arrs["tree_off"]) - 1, len(arrs["feature"]), *[arrs[k].ctypes.data for k in
+                       ("tree_off", "feature", "left", "right", "threshold", "value")], float(model["init"]), float(model["learning_rate"]))
+    out = np.empty(n, dtype=np.float64)
+    _lib.check(_lib.lib().hawk_gbt_predict(_lib.context(), x.ctypes.data_as(C.c_void_p), C.c_uint64(n), nf, C.byref(gm), int(cast_f32),
+                                           out.ctypes.data_as(C.c_void_p)), "hawk_gbt_predict")
+    return out
+
+
+def rs3(guides: List[str], debug: bool = True) -> List[float]:
+    """scores/crisprhawk_scores.py:47-62 (rs3.seq.predict_seq, tracr Hsu2013): 30-mers -> scores.  The feature matrix
+    comes from the caller's featuriser, the LightGBM trees run on the device."""
+    from .crisprhawk_error import CrisprHawkRs3ScoreError
+    if _RS3 is None:
+        exception_handler(CrisprHawkRs3ScoreError, "RS3 model not loaded (scoring.set_rs3_model)", os.EX_NOINPUT, debug)
+    model, featurizer = _RS3
+    if not guides:
+        return []
+    try:
+        feats = np.asarray(featurizer(list(guides)), dtype=np.float64)
+    except Exception as e:
+        exception_handler(CrisprHawkRs3ScoreError, "RS3 score calculation failed", os.EX_DATAERR, debug, e)
+    if feats.ndim != 2 or feats.shape[0] != len(guides) or feats.shape[1] < int(model.get("n_features", 0)):
+        exception_handler(CrisprHawkRs3ScoreError, "RS3 featuriser returned a matrix of the wrong shape", os.EX_DATAERR, debug)
+    return list(gbt_predict(feats, model, cast_f32=False))
+
+
+def rs3_score(guides: List[Guide], threads: int, verbosity: int, debug: bool) -> List[Guide]:
+    """scoring.py:261-300 (one device batch; ``threads`` is ignored).  Without a model every guide keeps "NA"."""
+    if not guides or _RS3 is None:
+        return guides
+    print_verbosity("Computing RS3 score", verbosity, VERBOSITYLVL[3])
+    for g, s in zip(guides, rs3(_extract_guide_sequences(guides), debug)):
+        g.rs3_score = float(s)
+    return guides
+
+
+# ---------------------------------------------------------------------------------------------- model files (f4)
+def load_models(models_dir: str, debug: bool = True) -> Dict[str, bool]:
+    """Load whatever scorer parameters `models_dir` holds and make them current.  Accepted files:
+
+        mismatch_score.pkl + pam_scores.pkl   the reference's CFD pickles (plain dicts; cfdscore.py:22-50)
+        cfd_tables.npz                        mm[20,4,4], pam[16]
+        azimuth_model.npz                     tree_off, feature, left, right, threshold, value, init, learning_rate
+        deepcpf1_weights.npz                  conv_w, conv_b, w1, b1, w2, b2, w3, b3, w4, b4 (torch layout)
+        rs3_model.txt                         LightGBM text model (needs scoring.set_rs3_model's featuriser separately)
+
+    The .npz files are what tools/convert_models.py writes from the reference's own downloads (the sklearn pickle and the
+    Keras .h5 need scikit-learn / h5py, which only the machine that fetched the models is sure to have).
+    Returns which scorers are now available."""
+    have = {"cfd": False, "azimuth": False, "deepcpf1": False, "rs3_model": False}
+    j = lambda f: os.path.join(models_dir, f)
+    if os.path.exists(j("cfd_tables.npz")):
+        z = np.load(j("cfd_tables.npz"))
+        set_cfd_tables(z["mm"], z["pam"])
+        have["cfd"] = True
+    elif os.path.exists(j("mismatch_score.pkl")) and os.path.exists(j("pam_scores.pkl")):
+        load_cfd_tables(models_dir, debug)
+        have["cfd"] = True
+    if os.path.exists(j("azimuth_model.npz")):
+        z = np.load(j("azimuth_model.npz"))
+        set_azimuth_model({k: (float(z[k]) if k in ("init", "learning_rate") else z[k]) for k in z.files})
+        have["azimuth"] = True
+    if os.path.exists(j("deepcpf1_weights.npz")):
+        z = np.load(j("deepcpf1_weights.npz"))
+        set_deepcpf1_weights({k: z[k] for k in _DC_KEYS})
+        have["deepcpf1"] = True
+    if os.path.exists(j("rs3_model.txt")):
+        have["rs3_model"] = True
+    return have
+
+
 def scoring_guides(guides: Dict, pam: PAM, scoring_envs, args) -> Dict:
     """scoring.py:816-867, restricted to the scorers whose parameters can be supplied offline:
-    Azimuth (when a model is set) + CFDon for SpCas9/xCas9 PAMs (749-792), DeepCpf1 for Cpf1 PAMs with --right (795-813)."""
+    Azimuth / RS3 (when a model is set) + CFDon for SpCas9/xCas9 PAMs (749-792), DeepCpf1 for Cpf1 PAMs with --right (795-813)."""
     for region, guides_list in guides.items():
         if pam.cas_system in (SPCAS9, XCAS9):
             if _AZIMUTH_MODEL is not None:
                 guides_list = azimuth_score(guides_list, args.threads, args.verbosity, args.debug)
+            guides_list = rs3_score(guides_list, args.threads, args.verbosity, args.debug)
             guides_list = cfdon_score(guides_list, args.verbosity, args.debug)
         elif pam.cas_system == CPF1 and _DEEPCPF1_W is not None:
             guides_list = deepcpf1_score(guides_list, args.threads, args.verbosity, args.debug)

@@ -481,6 +481,45 @@ int hawk_pam_scan_time(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint
 }
 
 // ---------------------------------------------------------------------------- fused search
+// ---------------------------------------------------------------------------- generic GBT over supplied features (RS3)
+int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_features, const hawk_gbt_model* m, int cast_f32,
+                     double* out) {
+  if (!ctx || !m || !m->tree_off || !m->feature || !m->left || !m->right || !m->threshold || !m->value || !n_features ||
+      (n && (!feats || !out)))
+    return HAWK_E_INVALID;
+  if (!n) return HAWK_OK;
+  for (uint32_t t = 0; t < m->n_trees; ++t) {  // every child index inside its tree and pointing forward, every feature in range
+    const int32_t lo = m->tree_off[t], hi = m->tree_off[t + 1];
+    if (lo < 0 || hi <= lo || (uint32_t)hi > m->n_nodes) return HAWK_E_INVALID;
+    for (int32_t k = lo; k < hi; ++k) {
+      if (m->feature[k] >= (int32_t)n_features) return HAWK_E_INVALID;
+      if (m->feature[k] >= 0 && (m->left[k] <= k - lo || m->right[k] <= k - lo || m->left[k] >= hi - lo || m->right[k] >= hi - lo))
+        return HAWK_E_INVALID;
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nn = m->n_nodes, nt = m->n_trees;
+  double *d_x = nullptr, *d_th = nullptr, *d_v = nullptr, *d_o = nullptr;
+  int32_t *d_off = nullptr, *d_f = nullptr, *d_l = nullptr, *d_r = nullptr;
+  POOLCHK(&d_x, n * n_features * 8); POOLCHK(&d_off, (nt + 1) * 4); POOLCHK(&d_f, nn * 4); POOLCHK(&d_l, nn * 4); POOLCHK(&d_r, nn * 4);
+  POOLCHK(&d_th, nn * 8); POOLCHK(&d_v, nn * 8); POOLCHK(&d_o, n * 8);
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(d_x, feats, n * n_features * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, m->tree_off, (nt + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_f, m->feature, nn * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_l, m->left, nn * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_r, m->right, nn * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_th, m->threshold, nn * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_v, m->value, nn * 8, hipMemcpyHostToDevice, st));
+  hawk_launch_gbt(st, d_x, n, n_features, m->n_trees, d_off, d_f, d_l, d_r, d_th, d_v, m->init, m->learning_rate, cast_f32, d_o);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d_o, n * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  hawk_pool_free(d_x); hawk_pool_free(d_off); hawk_pool_free(d_f); hawk_pool_free(d_l); hawk_pool_free(d_r); hawk_pool_free(d_th);
+  hawk_pool_free(d_v); hawk_pool_free(d_o);
+  return HAWK_OK;
+}
+
 }  // extern "C"
 int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   int rc;

@@ -149,6 +149,9 @@ void hawk_launch_deepcpf1(hipStream_t st, const char* seqs, uint64_t n, const fl
 void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t n_trees, const int32_t* tree_off,
                          const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold,
                          const double* value, double init, double lr, double* out, double* feats_out, int* status);
+void hawk_launch_gbt(hipStream_t st, const double* feats, uint64_t n, uint32_t nf, uint32_t n_trees, const int32_t* tree_off,
+                     const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold, const double* value,
+                     double init, double lr, int cast_f32, double* out);
 void hawk_launch_hx_index(hipStream_t st, const uint64_t* hv_off, const int32_t* hv_o, uint32_t n_hap, uint32_t S, int32_t* wg_k0,
                           uint32_t* wg_n);
 void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,

@@ -220,3 +220,34 @@ void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t 
   hipLaunchKernelGGL(k_azimuth, dim3((uint32_t)((n + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, seqs, n, n_trees,
                      tree_off, feature, left, right, threshold, value, init, lr, out, feats_out, status);
 }
+
+// ---- generic gradient-boosted-tree evaluation over a caller-supplied feature matrix (RS3: a LightGBM model over
+// sglearn features, scores/crisprhawk_scores.py:47-62; the features come from the caller, the trees run here).
+// cast_f32: sklearn compares float32(x) <= threshold, LightGBM compares the double as it is.
+__global__ __launch_bounds__(HAWK_BLOCK) void k_gbt(const double* __restrict__ feats, uint64_t n, uint32_t nf, uint32_t n_trees,
+                                                     const int32_t* __restrict__ tree_off, const int32_t* __restrict__ feature,
+                                                     const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                                     const double* __restrict__ threshold, const double* __restrict__ value, double init,
+                                                     double lr, int cast_f32, double* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double* x = feats + i * nf;
+  double acc = init;
+  for (uint32_t t = 0; t < n_trees; ++t) {
+    const int base = tree_off[t];
+    int node = base, f;
+    while ((f = feature[node]) >= 0) {
+      const double v = cast_f32 ? (double)(float)x[f] : x[f];
+      node = base + (v <= threshold[node] ? left[node] : right[node]);
+    }
+    acc += lr * value[node];
+  }
+  out[i] = acc;
+}
+void hawk_launch_gbt(hipStream_t st, const double* feats, uint64_t n, uint32_t nf, uint32_t n_trees, const int32_t* tree_off,
+                     const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold, const double* value,
+                     double init, double lr, int cast_f32, double* out) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_gbt, dim3((uint32_t)((n + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, feats, n, nf, n_trees, tree_off,
+                     feature, left, right, threshold, value, init, lr, cast_f32, out);
+}

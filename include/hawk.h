@@ -339,6 +339,14 @@ typedef struct {
 } hawk_gbt_model;
 int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_model* model, double* out, double* feats_out);
 
+/* The same tree evaluator over a feature matrix the caller supplies (feats[n][n_features], host, row-major doubles):
+ * the device half of RS3 (scoring.py:196-300 -> rs3.seq.predict_seq, scores/crisprhawk_scores.py:47-62: a LightGBM
+ * model over sglearn features; the third-party featuriser stays on the caller's side, the exported LightGBM text
+ * model is flattened into hawk_gbt_model by crisprhawk_hip/scoring.py).  cast_f32 = 1 compares float32(x) as sklearn
+ * does, 0 the double itself as LightGBM does. */
+int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_features, const hawk_gbt_model* model, int cast_f32,
+                     double* out);
+
 #ifdef __cplusplus
 }
 #endif
