@@ -39,6 +39,44 @@ def _labels(ds, info: List[HapInfo], kept: List[int], vt) -> List[Optional[RowLa
     return out
 
 
+def _search_unphased(coord, seq: str, vcf, pam: PAM, guidelen: int, right: bool, outdir: str, mm, pt, debug: bool) -> str:
+    """One BED interval of an unphased VCF: IUPAC haplotypes + indel windows on the host (haplotypes.add_variants_unphased,
+    reference haplotypes.py:370-712), the device search over them, resolve_guide on the host (search_guides.py:163-257),
+    then the reference's order of business: annotate -> reverse_guides -> CFDon -> report."""
+    from . import haplotypes as hap_mod
+    from .annotation import reverse_guides
+    from .haplotype import Haplotype
+    from .region import Region
+    from .search_guides import search
+    from .sequence import Sequence
+    region = Region(Sequence(seq, debug), coord)
+    haps = [Haplotype(Sequence(seq, debug), region.coordinates, False, 0, debug)]
+    records = vcf.fetch(coord)
+    if records:
+        haps = hap_mod.add_variants_unphased(haps, region, vcf.samples, records, False, debug)
+    for i, h in enumerate(haps):
+        h.id = f"hap_{i:08d}"
+    guides = search(pam, region, haps, None, guidelen, right, bool(records), False, 0, debug)
+    cfd = None
+    if mm is not None:
+        scoring.set_cfd_tables(mm, pt)
+        windows = [g.sequence for g in guides]  # the report wants the + strand windows: keep them across the reversal
+        rights = [g.right for g in guides]
+        scored = scoring.cfdon_score(reverse_guides(list(guides), 0), 0, debug)
+        val = {id(g): g.cfdon_score for g in scored}
+        cfd = [float("nan") if val[id(g)] == "NA" else float(val[id(g)]) for g in guides]
+        for g, w, r in zip(guides, windows, rights):  # undo the in-place reversal
+            if g.strand == 1:
+                g.reverse_complement()
+            assert g.sequence == w and g.right == r
+    bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING
+    df = reports.report_from_guides(guides, haps, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", cfd)
+    path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
+    with open(path, "w") as f:
+        f.write(reports.to_tsv(df))
+    return path
+
+
 def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidelen: int, right: bool, outdir: str,
                  cfd_tables=None, azimuth_model=None, deepcpf1_weights=None, device: Optional[int] = None,
                  debug: bool = True) -> Dict[str, str]:
@@ -66,7 +104,9 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         seq = fastas[coord.contig].fetch(coord).sequence
         v = vcf_by_contig.get(coord.contig)
         if v is not None and not v.phased:
-            raise ValueError("search_files handles phased VCFs; unphased inputs go through search_guides.search")
+            paths[str(coord)] = _search_unphased(coord, seq, v, pam, guidelen, right, outdir, mm if score else None, pt if score else None,
+                                                 debug)
+            continue
         from .readers import VcfBlock
         blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         samples = v.samples if v is not None else []

@@ -17,6 +17,7 @@ Scores other than CFDon need model files the reference downloads at run time: th
 "NA" unless the caller passes arrays.  The result is a pandas DataFrame with the reference's
 column order; `to_tsv` writes what `_store_report` writes.
 """
+import os
 from collections import defaultdict
 from typing import Dict, List, Optional, Sequence
 
@@ -380,7 +381,7 @@ def _ragged_join(item_label: np.ndarray, group_off: np.ndarray, strings: Sequenc
     goff = np.ascontiguousarray(group_off, dtype=np.uint64)
     out_off = np.zeros(ng + 1, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    L = _lib.lib()
+    L = _host_lib()
     _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), C.c_uint64(len(enc)), C.c_uint8(44), None,
                                        C.c_uint64(0), p(out_off)), "hawk_host_ragged_join")
     out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
@@ -389,6 +390,17 @@ def _ragged_join(item_label: np.ndarray, group_off: np.ndarray, strings: Sequenc
     buf = memoryview(out)
     o = out_off.tolist()
     return [str(buf[o[g]:o[g + 1]], "ascii") for g in range(ng)]
+
+
+def _host_lib():
+    """The library holding the host-side join helpers: libhawk_hip.so, or - for the sanitizer run of csrc/Makefile's
+    asan-host target - a host-only build of hawk_hostutil named by HAWK_HOSTUTIL_LIB."""
+    import ctypes as C
+    alt = os.environ.get("HAWK_HOSTUTIL_LIB")
+    if alt:
+        return C.CDLL(alt)
+    from . import _lib
+    return _lib.lib()
 
 
 def _pool(strings: Sequence[str]):
@@ -429,7 +441,7 @@ def _group_join(member_off, member_hap, per_hap: List[List[str]]) -> List[str]:
     mh = np.ascontiguousarray(member_hap, dtype=np.uint32)
     out_off = np.zeros(ng + 1, dtype=np.uint64)
     p = lambda a_: a_.ctypes.data_as(C.c_void_p)
-    L = _lib.lib()
+    L = _host_lib()
     args = (p(moff), p(mh), C.c_uint64(ng), p(hoff), p(flat), C.c_uint64(len(per_hap)), p(pool), p(poff), C.c_uint64(len(vocab)), C.c_uint8(44))
     _lib.check(L.hawk_host_group_join(*args, None, C.c_uint64(0), p(out_off)), "hawk_host_group_join")
     out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
@@ -470,7 +482,7 @@ def _samples_column(member_off, member_hap, hap_samples: List[str]) -> List[str]
     out_off = np.zeros(ng + 1, dtype=np.uint64)
     flags = np.zeros(ng, dtype=np.uint8)
     p = lambda a_: a_.ctypes.data_as(C.c_void_p)
-    L = _lib.lib()
+    L = _host_lib()
     args = (p(moff), p(mh), C.c_uint64(ng), p(hoff), p(flat), C.c_uint64(len(per_hap)), p(sid), p(a1), p(a2), p(ok), C.c_uint64(n_e),
             p(npool), p(noff), C.c_uint64(len(uniq)), p(epool), p(eoff))
     _lib.check(L.hawk_host_group_samples(*args, None, C.c_uint64(0), p(out_off), p(flags)), "hawk_host_group_samples")
@@ -712,3 +724,43 @@ def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores
     keys += [data["stop"], data["start"]]
     order = np.lexsort(keys)
     return pd.DataFrame({c: data[c][order] for c in cols})
+
+
+def report_from_guides(guides, haplotypes, pam: PAM, contig: str, target: str, cfdon: Optional[Sequence[float]] = None):
+    """The report of a Guide list as search() returns it (windows still on the + strand, i.e. BEFORE
+    annotation.reverse_guides) - the route of unphased inputs, whose guides are resolved on the host
+    (search_guides.resolve_guide) and therefore are not rows of the device table.  Rows the report merges are grouped
+    here as _collapse_report_entries groups them; `cfdon[i]` is guide i's CFDon score (NaN = "NA")."""
+    if not guides:
+        return report_frame(ReportInput(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.int64),
+                                        np.zeros(0, np.int64), [], None, np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.uint8),
+                                        np.zeros(0, np.uint8), 0, len(pam), False), haplotypes, pam, contig, target)
+    g0 = guides[0]
+    guidelen, pamlen = g0.guidelen, g0.pamlen
+    right = bool(g0.right) != bool(g0.strand)  # Guide.right is stored flipped for strand 1 (search_guides.py:538)
+    n = len(guides)
+    start = np.array([g.start for g in guides], dtype=np.int64)
+    stop = np.array([g.stop for g in guides], dtype=np.int64)
+    strand = np.array([g.strand for g in guides], dtype=np.uint8)
+    hap = np.array([g._hip_hap for g in guides], dtype=np.int64)
+    pos = np.array([g._hip_pos for g in guides], dtype=np.int64)
+    wins = [g.sequence for g in guides]
+    cfd = None if cfdon is None else np.asarray(cfdon, dtype=np.float64)
+    groups: Dict[tuple, List[int]] = {}
+    for i in range(n):
+        sc = None if cfd is None else (None if cfd[i] != cfd[i] else round_score(float(cfd[i])))
+        key = (int(start[i]), int(stop[i]), int(strand[i]), haplotypes[int(hap[i])].samples == "REF", wins[i][GUIDESEQPAD:-GUIDESEQPAD], sc)
+        groups.setdefault(key, []).append(i)
+    perm, off, num, den = [], [0], [], []
+    for key, rows in groups.items():
+        perm += rows
+        off.append(len(perm))
+        core = key[4]
+        pamfirst = right != bool(key[2])
+        spacer = core[pamlen:] if pamfirst else core[:guidelen]
+        gc = sum(spacer.count(c) for c in "CGScgs")
+        num.append(gc)
+        den.append(gc + sum(spacer.count(c) for c in "ATWUatwu"))
+    inp = ReportInput(start, stop, strand, hap, pos, wins, cfd, np.array(perm, dtype=np.int64), np.array(off, dtype=np.int64),
+                      np.array(num), np.array(den), guidelen, pamlen, right)
+    return report_frame(inp, haplotypes, pam, contig, target, with_cfdon=cfd is not None)

@@ -188,6 +188,7 @@ def guides_from_table(tab: GuideTable, haplotypes: List[Haplotype], debug: bool,
         g = Guide(int(tab.start[i]), int(tab.stop[i]), wins[i], tab.guidelen, tab.pamlen, int(tab.strand[i]), h.samples,
                   h.variants, h.afs, _pm, debug, r, h.id)
         g._hip_cfdon = float(tab.cfdon[i])
+        g._hip_pos, g._hip_hap = int(tab.pos[i]), int(tab.hap[i])
         guides.append(g)
     return guides
 
@@ -224,6 +225,8 @@ def _resolve_unphased(tab: GuideTable, haplotypes: List[Haplotype], pam: PAM, gu
             def _pm(seg=h.segments, pivot=pivot):
                 g = seg.lookup(np.arange(pivot, pivot + L))
                 return {k: int(g[k]) for k in range(L)}
-            guides.append(Guide(int(tab.start[i]), int(tab.stop[i]), seq, guidelen, len(pam), strand, h.samples, h.variants,
-                                h.afs, _pm, debug, r, h.id))
+            g = Guide(int(tab.start[i]), int(tab.stop[i]), seq, guidelen, len(pam), strand, h.samples, h.variants,
+                      h.afs, _pm, debug, r, h.id)
+            g._hip_pos, g._hip_hap = pos, int(tab.hap[i])  # where the row came from (reports.report_from_guides)
+            guides.append(g)
     return remove_redundant_guides(guides, debug)

@@ -36,6 +36,8 @@ class OracleError(RuntimeError):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("HAWK_ORACLE_LIB"):  # e.g. the ASan build (make -C oracle asan-run)
+        return os.environ["HAWK_ORACLE_LIB"]
     so = os.path.join(_HERE, "libhawk_oracle.so")
     src = os.path.join(_HERE, "hawk_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

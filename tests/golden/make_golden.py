@@ -320,12 +320,32 @@ def _gc_fraction_restated(seq: str) -> float:
     return gc / n if n else 0.0
 
 
-def g7_report(name, reg, pam_s, guidelen, right, cfd=True):
+def _ref_haplotypes_unphased(reg: synth.SynthRegion, region: Region):
+    """The reference's add_variants_unphased body (haplotypes.py:672-712) on records whose genotypes read a/b."""
+    haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
+    records = []
+    for v in reg.variants:
+        vr = VariantRecord(True)
+        fields = reg.vcf_fields(v)
+        fields[9:] = [g.replace("|", "/") for g in fields[9:]]
+        vr.read_vcf_line(fields, reg.samples, False)
+        records.append(vr)
+    variants = flatten_list([r.split() for r in records])
+    snvs, indels = R_haps.classify_variants(variants)
+    if snvs:
+        haps.extend(R_haps.compute_snvs_haplotype_unphased(snvs, reg.samples, region.sequence.sequence, region.coordinates, False, True))
+    for indel in indels:
+        if region.coordinates.startp <= indel.position < region.coordinates.stopp:
+            haps.extend(R_haps.create_indels_haplotype_unphased(indel, snvs, region, False, True))
+    return haps, True, False
+
+
+def g7_report(name, reg, pam_s, guidelen, right, cfd=True, unphased=False):
     from crisprhawk import annotation as R_ann
     from crisprhawk import reports as R_rep
     import math
     region = _ref_region(reg)
-    haps, variants_present, phased = _ref_haplotypes(reg, region)
+    haps, variants_present, phased = _ref_haplotypes_unphased(reg, region) if unphased else _ref_haplotypes(reg, region)
     for i, h in enumerate(haps):
         h.id = f"hap_{i:08d}"
     pam = R_pam.PAM(pam_s, right, True)
@@ -360,8 +380,9 @@ def g7_report(name, reg, pam_s, guidelen, right, cfd=True):
         region_seq=reg.sequence, samples=reg.samples,
         variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants],
         pam=pam_s, guidelen=guidelen, right=right, cfd=cfd, target=str(region.coordinates),
-        haplotypes=[dict(id=h.id, samples=h.samples, variants=h.variants,
-                         afs={k: (None if v != v else v) for k, v in h.afs.items()}) for h in haps],
+        haplotypes=[dict(id=h.id, samples=h.samples, variants=h.variants, seq=(h.sequence.sequence if unphased else None),
+                         start=h.coordinates.start, afs={k: (None if v != v else v) for k, v in h.afs.items()}) for h in haps],
+        unphased=unphased,
         rows_before_collapse=n_rows, report_tsv=tsv,
     )
     dump(f"g7_report_{name}.json.gz", obj)
@@ -386,6 +407,10 @@ def g7_all():
     reg = synth.make_region(3071, "chrS", 8000, 1000, 7000)
     synth.add_phased_variants(reg, 3072, 90, 3, af_min=0.2, af_max=0.6)
     g7_report("sacas9", reg, "NNGRRT", 21, False, cfd=False)
+    # unphased VCF: IUPAC haplotypes + indel windows -> resolve_guide -> the same annotation / report chain
+    reg = synth.make_region(3081, "chrV", 5000, 1000, 4000)
+    synth.add_phased_variants(reg, 3082, 45, 3, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.2, af_max=0.6)
+    g7_report("unphased", reg, "NGG", 20, False, unphased=True)
 
 
 # ---------------------------------------------------------------------------- G4 (unphased)

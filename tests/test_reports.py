@@ -146,6 +146,35 @@ def test_files_to_report_matches_reference_tsv(tmp_path, case):
 
 
 @pytest.mark.gpu
+def test_unphased_files_to_report_matches_reference_tsv(tmp_path):
+    """An unphased VCF through pipeline.search_files: host haplotype construction (haplotypes.add_variants_unphased) ->
+    device search -> resolve_guide -> annotate / CFDon / report, against the TSV the reference wrote for the same
+    records (g7_report_unphased).  The reference walks indel carriers in set order, so haplotype ids are matched by
+    content before the text is compared."""
+    import io
+    import pandas as pd
+    from crisprhawk_hip import pipeline, readers
+    fx = load_golden("g7_report_unphased.json.gz")
+    contig_seq = "N" * (fx["startp"] - 1) + fx["region_seq"] + "ACGT" * 10
+    fa, bed, vcf = str(tmp_path / "g.fa"), str(tmp_path / "r.bed"), str(tmp_path / "v.vcf")
+    readers.write_fasta(fa, fx["contig"], contig_seq, 80)
+    with open(bed, "w") as f:
+        f.write(f"{fx['contig']}\t{fx['bed_start']}\t{fx['bed_stop']}\n")
+    rows = [[fx["contig"], str(p), ".", r, a, ".", "PASS", f"AF={af:.6g}", "GT"] + [f"{g[0]}/{g[1]}" for g in gts]
+            for p, r, a, af, gts in fx["variants"]]
+    readers.write_vcf(vcf, fx["contig"], fx["samples"], rows, False)
+    (path,) = pipeline.search_files(fa, bed, [vcf], fx["pam"], fx["guidelen"], fx["right"], str(tmp_path / "out"),
+                                    cfd_tables=synth.cfd_tables()).values()
+    got = pd.read_csv(path, sep="\t", dtype=str, keep_default_na=False)
+    want = pd.read_csv(io.StringIO(fx["report_tsv"]), sep="\t", dtype=str, keep_default_na=False)
+    assert list(got.columns) == list(want.columns) and len(got) == len(want)
+    for c in got.columns:
+        if c != "haplotype_id":
+            assert (got[c] == want[c]).all(), (c, got[c][got[c] != want[c]].head(), want[c][got[c] != want[c]].head())
+    assert (got["haplotype_id"].str.count(",") == want["haplotype_id"].str.count(",")).all()
+
+
+@pytest.mark.gpu
 def test_pipeline_model_scorers_fill_their_columns(tmp_path):
     """With DeepCpf1 weights set, the Cpf1 report's score column holds str(round(score, 4)) of the device scorer
     on each row's 34-mer (guide.py:456-462); every other column stays as in the reference TSV."""
