@@ -27,6 +27,7 @@ def _plant(rng, genome: list, guide: str, pam_seq: str, right: bool, n: int, max
 
 @pytest.mark.parametrize("n_guides", [6, 200, 2300])  # 6: all pairs; 200: seeded, one LDS chunk; 2300: three chunks
 @pytest.mark.parametrize("pam_s,guidelen,right,max_mm,piece", [("NGG", 20, False, 4, 1 << 22), ("TTTV", 23, True, 3, 4096),
+                                                              ("TTTV", 23, True, 4, 1 << 22),  # C5 as BASELINE.json states it
                                                               ("NNGRRT", 21, False, 2, 10000), ("NGG", 20, False, 0, 1 << 22),
                                                               ("NGG", 17, False, 6, 1 << 22)])
 def test_offtarget_scan_matches_bruteforce(pam_s, guidelen, right, max_mm, piece, n_guides):
@@ -105,3 +106,119 @@ def test_offtargets_search_pipeline(tmp_path):
     tsv = (tmp_path / "offtargets_chrG_10000_10400.tsv").read_text().splitlines()
     assert tsv[0].split("\t") == ["chrom", "position", "strand", "grna", "spacer", "pam", "mm", "bulge_size", "bulg_type", "cfd", "elevation"]
     assert len(tsv) - 1 >= len(out)
+
+
+def _verify_hits_on_host(contig_arrays, idx, hits, guides, pam_s, guidelen, right, max_mm):
+    """Every reported hit re-derived from the genome bytes: PAM positions inside the PAM's IUPAC sets, mismatch count
+    as reported and <= max_mm, window code as reported."""
+    from crisprhawk_hip.genome import decode_window
+    from crisprhawk_hip.pam import IUPAC_BITS
+    L = guidelen + len(pam_s)
+    nib = {"A": 1, "C": 2, "G": 4, "T": 8}
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    n = len(hits["guide"])
+    sel = np.arange(n) if n <= 20000 else np.random.default_rng(0).choice(n, 20000, replace=False)
+    for i in sel.tolist():
+        name, off, _own = idx.rows[int(hits["row"][i])]
+        p0 = off + int(hits["q"][i])
+        w = contig_arrays[name][p0:p0 + L]
+        if hits["strand"][i]:
+            w = comp[w[::-1]]
+        w = w.tobytes().decode()
+        assert decode_window(int(hits["code"][i]), int(hits["nmask"][i]), L) == w
+        sp, pm = (w[len(pam_s):], w[:len(pam_s)]) if right else (w[:guidelen], w[guidelen:])
+        assert all(nib[c] & IUPAC_BITS[q] for c, q in zip(pm, pam_s))
+        mm = sum(a != b for a, b in zip(sp, guides[int(hits["guide"][i])]))
+        assert mm == int(hits["mm"][i]) <= max_mm
+
+
+def test_c5_full_size_properties(monkeypatch):
+    """C5 at a size no brute force reaches (3 x 10^8 nt here; bench.py --config c5 runs 3.1 x 10^9): the three match
+    kernels (all pairs, pigeonhole seeds from L2, pigeonhole seeds from LDS) must report the same hit set, every guide
+    must find its planted on-target, and every hit must re-verify against the genome bytes on the host."""
+    import subprocess, sys, os, json
+    code = r"""
+import json, sys, hashlib
+import numpy as np
+sys.path[:0] = [%r, %r]
+from crisprhawk_hip.genome import GenomeIndex
+from crisprhawk_hip.pam import PAM
+rng = np.random.default_rng(1006)
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+contigs = {f"chr{i+1}": acgt[rng.integers(0, 4, size=12_500_000, dtype=np.uint8)] for i in range(24)}
+grng = np.random.default_rng(1005)
+names = list(contigs)
+guides = []
+while len(guides) < 3000:
+    c = contigs[names[int(grng.integers(0, 24))]]
+    p = int(grng.integers(0, len(c) - 64))
+    guides.append(c[p:p + 23].tobytes().decode())
+pam = PAM("TTTV", True, True); pam.encode(0)
+idx = GenomeIndex(contigs, 23, 4)
+hits, tm = idx.scan_arrays(guides, pam, True, 4)
+order = np.lexsort((hits["strand"], hits["q"], hits["row"], hits["guide"]))
+h = hashlib.sha256()
+for k in ("guide", "row", "q", "strand", "mm", "code", "nmask"):
+    h.update(np.ascontiguousarray(hits[k][order]).tobytes())
+print("RESULT", json.dumps({"n": int(len(order)), "digest": h.hexdigest(), "n_sites": int(tm["n_sites"]), "match_ms": tm["match_ms"]}))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "crispr-hawk_amd"), root)
+    res = {}
+    for label, env in (("seeded_lds", {}), ("seeded_global", {"HAWK_OT_SEED_GLOBAL": "1"}), ("all_pairs", {"HAWK_OT_ALLPAIRS": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[label] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][7:])
+    assert res["seeded_lds"]["digest"] == res["seeded_global"]["digest"] == res["all_pairs"]["digest"]
+    assert res["seeded_lds"]["n"] >= 100  # ~1 guide in 85 sits behind a TTTV and is its own on-target; the rest are chance near-matches
+    # in-process: host re-verification of the default kernel's hits
+    rng = np.random.default_rng(1006)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = {f"chr{i+1}": acgt[rng.integers(0, 4, size=12_500_000, dtype=np.uint8)] for i in range(24)}
+    grng = np.random.default_rng(1005)
+    names = list(contigs)
+    guides, origin = [], []
+    while len(guides) < 3000:
+        ci = int(grng.integers(0, 24))
+        c = contigs[names[ci]]
+        p = int(grng.integers(0, len(c) - 64))
+        guides.append(c[p:p + 23].tobytes().decode())
+        origin.append((names[ci], p))
+    pam = PAM("TTTV", True, True)
+    pam.encode(0)
+    idx = GenomeIndex(contigs, 23, 4)
+    hits, _tm = idx.scan_arrays(guides, pam, True, 4)
+    assert len(hits["guide"]) == res["seeded_lds"]["n"]
+    _verify_hits_on_host(contigs, idx, hits, guides, "TTTV", 23, True, 4)
+    # a guide cut out right behind a TTTV is its own 0-mismatch on-target at PAM start = origin - 4
+    found = {(int(g), idx.rows[int(r)][0], idx.rows[int(r)][1] + int(q)) for g, r, q, s, m in
+             zip(hits["guide"], hits["row"], hits["q"], hits["strand"], hits["mm"]) if m == 0 and s == 0}
+    planted = 0
+    for gi, (name, p) in enumerate(origin):
+        if p >= 4:
+            pm = contigs[name][p - 4:p].tobytes().decode()
+            if pm[:3] == "TTT" and pm[3] in "ACG":
+                planted += 1
+                assert (gi, name, p - 4) in found
+    assert planted >= 10
+
+
+def test_sharded_genome_index_partitions_the_hits():
+    """SURVEY §8(e) for C5: the genome's rows block-partitioned over ranks, guides replicated; the union of the
+    shards' hits (global row numbers) is the unsharded scan's hit set."""
+    rng = np.random.default_rng(78)
+    contigs = {f"c{i}": synth.random_sequence(rng, 90_000 + 7000 * i) for i in range(5)}
+    guides = [contigs["c1"][p:p + 20] for p in range(100, 70_000, 700)]
+    pam = PAM("NGG", False, True)
+    pam.encode(0)
+    whole, _ = GenomeIndex(contigs, 20, 3, piece=20_000).scan_arrays(guides, pam, False, 3)
+    parts = []
+    for r in range(3):
+        idx = GenomeIndex(contigs, 20, 3, piece=20_000, shard=(r, 3))
+        assert (idx.row_hi - idx.row_lo) in (idx.n_rows_total // 3, idx.n_rows_total // 3 + 1)
+        parts.append(idx.scan_arrays(guides, pam, False, 3)[0])
+    key = lambda h: sorted(zip(h["guide"].tolist(), h["row"].tolist(), h["q"].tolist(), h["strand"].tolist(), h["mm"].tolist()))
+    merged = {k: np.concatenate([p[k] for p in parts]) for k in whole}
+    assert key(merged) == key(whole) and len(whole["guide"]) > 100
