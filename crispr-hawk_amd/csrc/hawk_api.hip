@@ -218,7 +218,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   hawk_pool_free(hs->d_seg_rel); hawk_pool_free(hs->d_seg_gen); hawk_pool_free(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
-                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit};
+                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   for (auto& b : hs->crep) b.release();
@@ -233,6 +233,7 @@ int hawk_hapset_stride(const hawk_hapset* hs, uint32_t* stride_words) {
 
 int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* seq_off, uint64_t* bad_index) {
   if (!hs || !seqs || !seq_off) return HAWK_E_INVALID;
+  hs->refbits_valid = false;
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   for (uint32_t h = 0; h < hs->n_hap; ++h)
@@ -338,6 +339,7 @@ int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* 
   hs->scan_stop.assign(scan_stop, scan_stop + n);
   hs->ref_index = ref_index;
   hs->has_meta = true;
+  hs->refbits_valid = false;
   ++hs->cols_gen;  // tables written under the old metadata are stale
   return HAWK_OK;
 }
@@ -346,6 +348,7 @@ int hawk_hapset_set_ref_partner_range(hawk_hapset* hs, int32_t start, int32_t st
   if (!hs || !hs->has_meta || hs->ref_index < 0) return HAWK_E_INVALID;
   if (start < 0 || stop > (int32_t)hs->hap_len[hs->ref_index] || stop < start) return HAWK_E_INVALID;
   hs->has_partner = true; hs->partner_start = start; hs->partner_stop = stop;
+  hs->refbits_valid = false;
   ++hs->cols_gen;
   return HAWK_OK;
 }
@@ -360,6 +363,7 @@ int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words) 
 
 int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes) {
   if (!hs || !planes) return HAWK_E_INVALID;
+  hs->refbits_valid = false;
   HIPCHK(hipSetDevice(hs->ctx->device));
   const size_t words = (size_t)hs->n_hap * hs->S;
   for (int p = 0; p < HAWK_PLANES; ++p)
@@ -587,6 +591,23 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
       const int re = hs->has_partner ? hs->partner_stop : hs->scan_stop[hs->ref_index];
       ri.lo[s] = std::max(rs - po, HAWK_PAD);
       ri.hi[s] = std::min(re - po, haplen - sp.L - HAWK_PAD + 1);
+    }
+  }
+  ri.bits[0] = ri.bits[1] = nullptr;
+  ri.n_bits = 0;
+  if (hs->ref_index >= 0) {
+    // REF's candidate windows as bitmaps (k_ref_bits): rebuilt only when the PAM / guide geometry or REF's range changed
+    const uint64_t key[6] = {p->pam_fwd, p->pam_rev, ((uint64_t)p->pamlen << 32) | p->guidelen, (uint64_t)(p->right ? 1 : 0),
+                             ((uint64_t)(uint32_t)ri.lo[0] << 32) | (uint32_t)ri.hi[0], ((uint64_t)(uint32_t)ri.lo[1] << 32) | (uint32_t)ri.hi[1]};
+    if ((rc = hs->refbits.reserve((size_t)hs->S * 4 * 2))) return rc;
+    ri.bits[0] = hs->refbits.as<uint32_t>();
+    ri.bits[1] = hs->refbits.as<uint32_t>() + hs->S;
+    ri.n_bits = hs->S * 32u;
+    if (!hs->refbits_valid || memcmp(hs->refbits_key, key, sizeof(key)) != 0) {
+      hawk_launch_ref_bits(ctx->stream, d, sp, ri, hs->refbits.as<uint32_t>(), hs->refbits.as<uint32_t>() + hs->S);
+      HIPCHK(hipGetLastError());
+      memcpy(hs->refbits_key, key, sizeof(key));
+      hs->refbits_valid = true;
     }
   }
   GuideCols none = {};

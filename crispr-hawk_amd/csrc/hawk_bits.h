@@ -94,7 +94,8 @@ struct Ld6 {
 __device__ __forceinline__ void load6_issue(const uint32_t* __restrict__ row, uint32_t u, uint32_t S, bool active, Ld6& r) {
   r.v = make_uint4(0, 0, 0, 0);
   r.t = make_uint2(0, 0);
-  if (active) r.v = *reinterpret_cast<const uint4*>(row + 4 * (size_t)u);
+  if (__all(active)) r.v = *reinterpret_cast<const uint4*>(row + 4 * (size_t)u);  // every wave but a row's last: no exec-mask detour
+  else if (active) r.v = *reinterpret_cast<const uint4*>(row + 4 * (size_t)u);
   if ((threadIdx.x & (WAVE - 1)) == WAVE - 1 && active && 4 * u + 4 < S)
     r.t = *reinterpret_cast<const uint2*>(row + 4 * (size_t)u + 4);  // 16-byte aligned
 }

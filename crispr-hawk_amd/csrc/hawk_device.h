@@ -79,7 +79,10 @@ struct RefInfo {
   int32_t index;
   int32_t lo[2], hi[2];
   int64_t startp;
+  const uint32_t* bits[2];  // per strand: bit q set <=> REF has a candidate window starting at q (k_ref_bits); n_bits valid bits
+  uint32_t n_bits;
 };
+void hawk_launch_ref_bits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const RefInfo& ri, uint32_t* bitsF, uint32_t* bitsR);
 
 // K7 records
 struct OtSite {   // one PAM-bearing genome window in guide orientation

@@ -84,6 +84,9 @@ struct hawk_hapset {
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
   DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
+  DevBuf refbits;             // REF's candidate-window bitmaps, one per strand (k_ref_bits)
+  bool refbits_valid = false;
+  uint64_t refbits_key[6] = {0, 0, 0, 0, 0, 0};
   DevBuf colsA[8];
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
 };

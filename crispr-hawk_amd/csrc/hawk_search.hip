@@ -100,7 +100,7 @@ __device__ __forceinline__ double cfdon_from_slices(const W2 (&core)[4], const W
 }
 
 template <int PASS>
-__device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParams& p, const GuideParams& gp, const RefInfo& ri,
+__device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParams& p_in, const GuideParams& gp, const RefInfo& ri,
                                             const TileMeta* __restrict__ tmeta, uint32_t* __restrict__ counts,
                                             unsigned long long* __restrict__ shards,
                                             const uint64_t* __restrict__ offsets, const GuideCols& out, int* status,
@@ -116,6 +116,7 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
   __shared__ double s_cfd[PASS == 1 ? 336 : 1];
   __shared__ uint32_t s_w[HAWK_BLOCK / WAVE];
   __shared__ uint32_t s_acc[4];
+  const ScanParams& p = p_in;
   const uint32_t tid = threadIdx.x;
   const uint32_t tile = blockIdx.x;
   // list mode: the count pass hands the valid survivors of small tiles to k_emit_list; this kernel's emit
@@ -189,10 +190,13 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
     }
   }
   if (stage) {
-    if (tid < NSEG) {
+    if (tid < NSEG) {  // NSEG == WAVE: wave 0 holds the whole slice
       s_segrel[tid] = seg_in ? seg_r : 0xffffffffu;
       s_seggen[tid] = seg_g;
-      if (seg_in) atomicAdd(&s_acc[3], 1u);
+      if (PASS == 1) {  // the count pass searches the sentinel-padded slice with a fixed step count and needs no length
+        const unsigned long long bm = __ballot(seg_in);
+        if (tid == 0) s_acc[3] = (uint32_t)__popcll(bm);
+      }
     }
   }
   uint32_t kF[4], kR[4];
@@ -208,7 +212,8 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
     const int loF = sloF > qmin ? sloF : qmin, hiF = shiF < qmax ? shiF : qmax;
     const int loR = sloR > qmin ? sloR : qmin, hiR = shiR < qmax ? shiR : qmax;
     const int base0 = (int)(u * 128u);
-    const bool interior = base0 >= loF && base0 >= loR && base0 + 128 <= hiF && base0 + 128 <= hiR;
+    // the fast path is taken per WAVE (a per-lane branch would cost exec-mask bookkeeping on the scalar unit in every wave)
+    const bool interior = __all(base0 >= loF && base0 >= loR && base0 + 128 <= hiF && base0 + 128 <= hiR);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       uint32_t f = mF[k], r = mR[k];
@@ -294,34 +299,89 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
         int64_t start = 0, stop = 0;
         bool has_ref = false;
         W2 core[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, rcore[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        // ---- count pass: survivor lookup, position map and verdict as straight-line code.  Every lane runs it (lanes past
+        // the last survivor redo survivor `base` and are masked at the end): per-lane branches and data-dependent loops cost
+        // exec-mask bookkeeping on the CU's one scalar unit in every wave, which is what this kernel was bound by.
+        int64_t c_start = 0;
+        bool c_has_ref = false;
+        uint32_t c_valid = 0;
+        if (PASS == 0 && (i & ~(uint32_t)(WAVE - 1)) < n) {  // wave-uniform: a wave whose 64 slots lie past the last survivor skips
+          // survivor number g of the tile (strand 0 in position order, then strand 1): the thread that found it is the
+          // last one whose exclusive offset is <= the survivor's rank within its strand
+          const uint32_t g = base + (i < n ? i : 0u);
+          s = g >= TF ? 1u : 0u;
+          const uint32_t target = s ? g - TF : g;
+          const uint32_t sh16 = s ? 16u : 0u;
+          uint32_t lo = 0;
+#pragma unroll
+          for (uint32_t step = HAWK_BLOCK / 2; step; step >>= 1) lo += (((s_ex[lo + step] >> sh16) & 0xffffu) <= target) ? step : 0u;
+          uint32_t j = target - ((s_ex[lo] >> sh16) & 0xffffu);  // its rank among that thread's bits
+          const uint4 w4 = *reinterpret_cast<const uint4*>(&s_kw[s][4 * lo]);
+          const uint32_t c0 = (uint32_t)__popc(w4.x), c1 = c0 + (uint32_t)__popc(w4.y), c2 = c1 + (uint32_t)__popc(w4.z);
+          const uint32_t kw = (j >= c0 ? 1u : 0u) + (j >= c1 ? 1u : 0u) + (j >= c2 ? 1u : 0u);
+          const uint32_t x = kw == 0 ? w4.x : kw == 1 ? w4.y : kw == 2 ? w4.z : w4.w;
+          j -= kw == 0 ? 0u : kw == 1 ? c0 : kw == 2 ? c1 : c2;
+          uint32_t bpos = 0;  // position of the j-th set bit of x: halving search on popcounts
+#pragma unroll
+          for (uint32_t wdt = 16; wdt; wdt >>= 1) {
+            const uint32_t c = (uint32_t)__popc((x >> bpos) & ((1u << wdt) - 1u));
+            const bool up = j >= c;
+            j -= up ? c : 0u;
+            bpos += up ? wdt : 0u;
+          }
+          ql = (4 * lo + kw) * 32 + bpos;
+          const uint32_t q = tile_q0 + ql;
+          if (ovf) {  // workgroup-uniform, rare: more than NSEG segments in the tile
+            c_start = posmap_global(hs, h, q);
+          } else {    // unused slots of s_segrel hold 0xffffffff: a fixed six-step search needs no bounds
+            uint32_t sj = 0;
+#pragma unroll
+            for (uint32_t step = NSEG / 2; step; step >>= 1) sj += (s_segrel[sj + step] <= q) ? step : 0u;
+            c_start = s_seggen[sj] + (int64_t)(q - s_segrel[sj]);
+          }
+          c_valid = 1;
+          c_has_ref = isref;
+          if (dedup && ABL != 2) {  // workgroup-uniform
+            // A REF guide shares (start, strand) iff REF has a candidate window starting at qr = start - startp: one bit of
+            // the per-strand bitmaps k_ref_bits left in HBM (2 x 125 KB on C3, L2-resident).  The survivor is redundant
+            // iff the four code planes agree as well: the planes the PAM names (just streamed, L2-hot) are compared for
+            // every lane, the others only in the rare wave where those agree.
+            const int64_t qr64 = c_start - ri.startp;
+            const bool inr = qr64 >= 0 && qr64 < (int64_t)ri.n_bits;
+            const uint32_t qr = inr ? (uint32_t)qr64 : 0u;
+            const uint32_t rw = (s ? ri.bits[1] : ri.bits[0])[qr >> 5];
+            c_has_ref = inr && ((rw >> (qr & 31u)) & 1u);
+            bool same = c_has_ref;
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl)
+              if ((p.need >> pl) & 1u) {  // wave-uniform
+                const W2 b = ext_glb(hs.plane[pl] + refbase, qr);
+                const W2 a = ext_glb(hs.plane[pl] + rowbase, q);
+                same = same && ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
+              }
+            if (__any(same)) {
+#pragma unroll
+              for (int pl = 0; pl < 4; ++pl)
+                if (!((p.need >> pl) & 1u)) {
+                  const W2 b = ext_glb(hs.plane[pl] + refbase, qr);
+                  const W2 a = ext_glb(hs.plane[pl] + rowbase, q);
+                  same = same && ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
+                }
+            }
+            c_valid = same ? 0u : 1u;
+          }
+        }
         if (i < n) {
           if (PASS == 0) {
-            // survivor number g of the tile (strand 0 in position order, then strand 1): the thread that found it
-            // is the last one whose exclusive offset is <= the survivor's rank within its strand
-            const uint32_t g = base + i;
-            s = g >= TF ? 1u : 0u;
-            const uint32_t target = s ? g - TF : g;
-            uint32_t lo = 0;
-#pragma unroll
-            for (uint32_t step = HAWK_BLOCK / 2; step; step >>= 1) {
-              const uint32_t v = s ? s_ex[lo + step] >> 16 : s_ex[lo + step] & 0xffffu;
-              if (v <= target) lo += step;
-            }
-            uint32_t j = target - (s ? s_ex[lo] >> 16 : s_ex[lo] & 0xffffu);  // its rank among that thread's bits
-            const uint4 w4 = *reinterpret_cast<const uint4*>(&s_kw[s][4 * lo]);
-            uint32_t x = w4.x, kw = 0;
-            uint32_t c = (uint32_t)__popc(w4.x);
-            if (j >= c) { j -= c; x = w4.y; kw = 1; c = (uint32_t)__popc(w4.y);
-              if (j >= c) { j -= c; x = w4.z; kw = 2; c = (uint32_t)__popc(w4.z);
-                if (j >= c) { j -= c; x = w4.w; kw = 3; } } }
-            for (; j; --j) x &= x - 1;  // clusters are short: a few iterations at most
-            ql = (4 * lo + kw) * 32 + (uint32_t)__builtin_ctz(x);
+            // filled in by the branch-free block in front of `if (i < n)`
           } else {
             const uint32_t e = s_list[i];
             s = e >> 31; ql = e & 0x7fffffffu;
           }
           const uint32_t q = tile_q0 + ql;
-          if (ovf) {
+          if (PASS == 0) {
+            start = c_start;
+          } else if (ovf) {
             start = posmap_global(hs, h, q);
             if (PASS == 1) stop = posmap_global(hs, h, q + (uint32_t)L);
           } else {
@@ -334,64 +394,8 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
           }
           valid = 1;
           if (PASS == 0) {
-            // count pass: the verdict (and, for the hand-over list, whether a REF guide shares the key).
-            // A REF guide exists at (start, strand) iff the window start qr = start - startp lies in REF's
-            // candidate range and REF's PAM matches there (tested on the planes the PAM names, which the scan
-            // just streamed: L2-hot).  The survivor is redundant iff additionally the four code planes agree:
-            // compare the hot planes first, the others are fetched only when those agree (e.g. an A<->T SNV).
-            if (ri.index >= 0 && ABL != 2) {
-              if (isref) {
-                has_ref = true;
-              } else {
-                const int64_t qr = start - ri.startp;
-                if (qr >= ri.lo[s] && qr < ri.hi[s]) {
-                  W2 rc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, ac[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-#pragma unroll
-                  for (int pl = 0; pl < 4; ++pl)
-                    if ((p.need >> pl) & 1u) {  // REF's and this haplotype's slices, all in flight together
-                      rc[pl] = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr);
-                      ac[pl] = ext_glb(hs.plane[pl] + rowbase, q);
-                    }
-#pragma unroll
-                  for (int pl = 0; pl < 4; ++pl) { rc[pl].lo &= mlo; rc[pl].hi &= mhi; }
-                  const bool pamfirst = (p.right != 0) != (s != 0);
-                  const int po = pamfirst ? 0 : p.guidelen;
-                  const uint64_t pam = s ? p.pam_rev : p.pam_fwd;
-                  bool ok = true;
-                  for (int t = 0; t < p.pamlen; ++t) {
-                    const uint32_t nib = (uint32_t)(pam >> (4 * (p.pamlen - 1 - t))) & 15u;
-                    const int off = po + t;
-                    uint32_t sel = 0;
-                    if (off < 32) {
-                      if (nib & 1u) sel |= rc[0].lo; if (nib & 2u) sel |= rc[1].lo;
-                      if (nib & 4u) sel |= rc[2].lo; if (nib & 8u) sel |= rc[3].lo;
-                    } else {
-                      if (nib & 1u) sel |= rc[0].hi; if (nib & 2u) sel |= rc[1].hi;
-                      if (nib & 4u) sel |= rc[2].hi; if (nib & 8u) sel |= rc[3].hi;
-                    }
-                    ok = ok && (nib == 15u || ((sel >> (off & 31)) & 1u));
-                  }
-                  if (ok) {
-                    has_ref = true;
-                    bool same = true;
-#pragma unroll
-                    for (int round = 0; round < 2; ++round) {
-#pragma unroll
-                      for (int pl = 0; pl < 4; ++pl) {
-                        const bool hot = ((p.need >> pl) & 1u) != 0;
-                        if (same && hot == (round == 0)) {
-                          W2 a = ac[pl];
-                          W2 b = rc[pl];
-                          if (!hot) { a = ext_glb(hs.plane[pl] + rowbase, q); b = ext_glb(hs.plane[pl] + refbase, (uint32_t)qr); }
-                          same = ((a.lo ^ b.lo) & mlo) == 0 && ((a.hi ^ b.hi) & mhi) == 0;
-                        }
-                      }
-                    }
-                    if (same) valid = 0;
-                  }
-                }
-              }
-            }
+            has_ref = c_has_ref;
+            valid = c_valid;
           } else {
 #pragma unroll
           for (int pl = 0; pl < 4; ++pl) {
@@ -496,15 +500,17 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
     // in list mode (and whenever phase C did not run) thread 0 alone holds the tile's count
     const bool spread = stage && !list_mode && T != 0 && !(PASS == 0 && !dedup);
     const uint32_t w0s = spread ? wave_sum(nvalid) : nvalid;  // workgroup-uniform choice
-    if ((tid & (WAVE - 1)) == 0) {
-      atomicAdd(&s_acc[0], w0s); atomicAdd(&s_acc[1], w1s & 0xffffu); atomicAdd(&s_acc[2], w1s >> 16);
-    }
+    __syncthreads();  // s_w is free again (the last scan's second barrier lies behind every reader)
+    if ((tid & (WAVE - 1)) == 0) { s_w[tid / WAVE] = w0s; s_kw[0][tid / WAVE] = w1s; }
     __syncthreads();
     if (tid == 0) {
-      counts[tile] = s_acc[0];
-      if (s_acc[1] | s_acc[2]) {
-        atomicAdd(&shards[(tile & 255u) * 2 + 0], (unsigned long long)s_acc[1]);
-        atomicAdd(&shards[(tile & 255u) * 2 + 1], (unsigned long long)s_acc[2]);
+      uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+      for (int wv = 0; wv < HAWK_BLOCK / WAVE; ++wv) { a0 += s_w[wv]; a1 += s_kw[0][wv] & 0xffffu; a2 += s_kw[0][wv] >> 16; }
+      counts[tile] = a0;
+      if (a1 | a2) {
+        atomicAdd(&shards[(tile & 255u) * 2 + 0], (unsigned long long)a1);
+        atomicAdd(&shards[(tile & 255u) * 2 + 1], (unsigned long long)a2);
       }
     }
   }
@@ -667,6 +673,37 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_emit_list(HapSetDev hs, ScanPara
     }
     out.cfdon[o] = score;
   }
+}
+
+// REF's candidate windows as two bitmaps (bit q of strand s: REF has a guide whose window starts at q) - what "a REF
+// guide shares (start, strand)" (search_guides.py:340-369) is tested against, one bit per survivor, in the count pass.
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ref_bits(HapSetDev hs, ScanParams p, RefInfo ri, uint32_t* __restrict__ bitsF,
+                                                          uint32_t* __restrict__ bitsR) {
+  const uint32_t u = blockIdx.x * HAWK_BLOCK + threadIdx.x;
+  const bool active = u < hs.S / 4;
+  const size_t rowbase = (size_t)ri.index * hs.S;
+  uint32_t A[6], C[6], G[6], Tp[6];
+  load6(hs.plane[0] + rowbase, u, hs.S, active, A);
+  load6(hs.plane[1] + rowbase, u, hs.S, active, C);
+  load6(hs.plane[2] + rowbase, u, hs.S, active, G);
+  load6(hs.plane[3] + rowbase, u, hs.S, active, Tp);
+  const int poF = p.right ? 0 : p.guidelen, poR = p.right ? p.guidelen : 0;
+  uint32_t mF[4], mR[4];
+  pam_match(A, C, G, Tp, p.pam_fwd, p.pamlen, poF, mF);
+  pam_match(A, C, G, Tp, p.pam_rev, p.pamlen, poR, mR);
+  if (!active) return;
+  const int base0 = (int)(u * 128u);
+  uint4 f, r;
+  f.x = mF[0] & range_mask(base0, ri.lo[0], ri.hi[0]);       r.x = mR[0] & range_mask(base0, ri.lo[1], ri.hi[1]);
+  f.y = mF[1] & range_mask(base0 + 32, ri.lo[0], ri.hi[0]);  r.y = mR[1] & range_mask(base0 + 32, ri.lo[1], ri.hi[1]);
+  f.z = mF[2] & range_mask(base0 + 64, ri.lo[0], ri.hi[0]);  r.z = mR[2] & range_mask(base0 + 64, ri.lo[1], ri.hi[1]);
+  f.w = mF[3] & range_mask(base0 + 96, ri.lo[0], ri.hi[0]);  r.w = mR[3] & range_mask(base0 + 96, ri.lo[1], ri.hi[1]);
+  *reinterpret_cast<uint4*>(bitsF + 4 * (size_t)u) = f;
+  *reinterpret_cast<uint4*>(bitsR + 4 * (size_t)u) = r;
+}
+void hawk_launch_ref_bits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const RefInfo& ri, uint32_t* bitsF, uint32_t* bitsR) {
+  const uint32_t nb = (hs.S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  hipLaunchKernelGGL(k_ref_bits, dim3(nb), dim3(HAWK_BLOCK), 0, st, hs, p, ri, bitsF, bitsR);
 }
 
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,

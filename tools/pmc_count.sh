@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 export HAWK_COUNT_ONLY=1
 for v in ${PMC_VARIANTS:-full abl1 abl2}; do
   if [ $v != full ]; then export CRISPRHAWK_HIP_LIB=$root/build_abl/libhawk_$v.so; else unset CRISPRHAWK_HIP_LIB; fi
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $out/$v -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gather --no-collapse > /dev/null 2> $out/$v.log
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $out/$v -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> $out/$v.log
 done
 cd $root
 python3 - <<'PY'

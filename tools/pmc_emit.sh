@@ -5,8 +5,8 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/pmc_emit
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out/a -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gather --no-collapse > /dev/null 2> $out/a.log
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/b -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gather --no-collapse > /dev/null 2> $out/b.log || true
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out/a -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> $out/a.log
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/b -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> $out/b.log || true
 cd $root
 python3 - <<'PY'
 import csv, glob, collections, os
