@@ -690,9 +690,9 @@ def cpu_baseline_offtargets(args, pam_s, guidelen, right, guides):
     """The oracle's brute force (every window x every guide, both strands) on a genome sample sized for ~10 s."""
     from oracle import oracle as ora
     rng = np.random.default_rng(1006)
-    n = 200_000
+    n = 5_000_000
     g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes().decode()
-    sub = guides[:200]
+    sub = guides[:2000]
     t0 = time.perf_counter()
     hits = ora.offtargets(g, sub, pam_s, right, args.mm)
     dt = time.perf_counter() - t0
