@@ -284,7 +284,20 @@ def run_region(args, R: Ranks):
 
     # ---- the one exchange of the job (N > 1): guide tables to rank 0 over RCCL ----------------------
     if R.world > 1 and not args.no_gather:
+        # RCCL with peers cannot be rehearsed on the one-GPU boxes this was built on: if the exchange hangs rather than
+        # fails, the measured line must still come out - a watchdog prints it (gather: timeout) and ends the rank
+        import threading
+
+        def _bail():
+            if R.rank == 0:
+                out["gather"] = {"error": f"no completion within {args.gather_timeout} s (watchdog)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(args.gather_timeout, _bail)
+        wd.daemon = True
+        wd.start()
         g = gather_once(R, ds, step, tot[3])
+        wd.cancel()
         if R.rank == 0:
             out["gather"] = g
     if R.rank == 0 and R.world == 1:
@@ -732,6 +745,7 @@ def build_parser():
     ap.add_argument("--vcf", action="store_true", help="end_to_end: also time the VCF-text ingest of the workload (f3)")
     ap.add_argument("--report", action="store_true", help="end_to_end: also assemble the guide report (f2) of the whole workload")
     ap.add_argument("--no-gather", action="store_true", help="skip the one-off RCCL gather of the guide tables after the timed loop")
+    ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds the post-loop exchange may take before the line is printed without it")
     return ap
 
 

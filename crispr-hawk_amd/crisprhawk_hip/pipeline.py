@@ -20,6 +20,7 @@ from . import reports
 from . import scoring
 from .pam import CPF1, PAM, SPCAS9, XCAS9
 from .readers import VCF, Bed, Fasta
+from .expand import HaplotypeBuildError
 from .workload import HapInfo, RowLabel, expand_from_vcf, hap_labels
 
 PADDING = 100  # region_constructor.py:21
@@ -39,10 +40,12 @@ def _labels(ds, info: List[HapInfo], kept: List[int], vt) -> List[Optional[RowLa
     return out
 
 
-def _search_unphased(coord, seq: str, vcf, pam: PAM, guidelen: int, right: bool, outdir: str, mm, pt, debug: bool) -> str:
-    """One BED interval of an unphased VCF: IUPAC haplotypes + indel windows on the host (haplotypes.add_variants_unphased,
-    reference haplotypes.py:370-712), the device search over them, resolve_guide on the host (search_guides.py:163-257),
-    then the reference's order of business: annotate -> reverse_guides -> CFDon -> report."""
+def _search_host_built(coord, seq: str, vcf, phased: bool, pam: PAM, guidelen: int, right: bool, outdir: str, mm, pt, debug: bool) -> str:
+    """One BED interval with the haplotypes built on the host by the mirror of the reference's own construction
+    (haplotypes.py:106-368 phased, 370-712 unphased) - the route of unphased VCFs (IUPAC haplotypes + indel windows,
+    resolve_guide on the host, search_guides.py:163-257) and the fallback for phased records the device expansion
+    declines (a chromosome copy carrying overlapping records, multi-base deletion alts).  The search itself still runs
+    on the device; then the reference's order of business: annotate -> reverse_guides -> CFDon -> report."""
     from . import haplotypes as hap_mod
     from .annotation import reverse_guides
     from .haplotype import Haplotype
@@ -53,10 +56,11 @@ def _search_unphased(coord, seq: str, vcf, pam: PAM, guidelen: int, right: bool,
     haps = [Haplotype(Sequence(seq, debug), region.coordinates, False, 0, debug)]
     records = vcf.fetch(coord)
     if records:
-        haps = hap_mod.add_variants_unphased(haps, region, vcf.samples, records, False, debug)
+        build = hap_mod.add_variants_phased if phased else hap_mod.add_variants_unphased
+        haps = build(haps, region, vcf.samples, records, phased, debug)
     for i, h in enumerate(haps):
         h.id = f"hap_{i:08d}"
-    guides = search(pam, region, haps, None, guidelen, right, bool(records), False, 0, debug)
+    guides = search(pam, region, haps, None, guidelen, right, bool(records), phased, 0, debug)
     cfd = None
     if mm is not None:
         scoring.set_cfd_tables(mm, pt)
@@ -104,13 +108,20 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         seq = fastas[coord.contig].fetch(coord).sequence
         v = vcf_by_contig.get(coord.contig)
         if v is not None and not v.phased:
-            paths[str(coord)] = _search_unphased(coord, seq, v, pam, guidelen, right, outdir, mm if score else None, pt if score else None,
-                                                 debug)
+            paths[str(coord)] = _search_host_built(coord, seq, v, False, pam, guidelen, right, outdir, mm if score else None,
+                                                   pt if score else None, debug)
             continue
         from .readers import VcfBlock
         blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         samples = v.samples if v is not None else []
-        ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device)
+        try:
+            ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device)
+        except HaplotypeBuildError:
+            # records the device expansion does not take (overlapping records on one chromosome copy, deletions with a
+            # multi-base alt): the host builder mirrors the reference's own construction, the search stays on the device
+            paths[str(coord)] = _search_host_built(coord, seq, v, True, pam, guidelen, right, outdir, mm if score else None,
+                                                   pt if score else None, debug)
+            continue
         tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt, download=False)
         labels = hap_labels(coord.contig, vt, ds, info, kept)
         bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041

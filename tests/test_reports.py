@@ -146,6 +146,31 @@ def test_files_to_report_matches_reference_tsv(tmp_path, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["phased4", "indel_dense"])
+def test_host_built_fallback_writes_the_same_report(tmp_path, monkeypatch, case):
+    """Phased records the device expansion declines (overlapping records on one chromosome copy) fall back to
+    the host haplotype builder; forced here on inputs the device does take, the fallback must write the reference's TSV."""
+    from crisprhawk_hip import pipeline, readers
+    from crisprhawk_hip.expand import HaplotypeBuildError
+    fx = load_golden(f"g7_report_{case}.json.gz")
+    contig_seq = "N" * (fx["startp"] - 1) + fx["region_seq"] + "ACGT" * 10
+    fa, bed, vcf = str(tmp_path / "g.fa"), str(tmp_path / "r.bed"), str(tmp_path / "v.vcf")
+    readers.write_fasta(fa, fx["contig"], contig_seq, 80)
+    with open(bed, "w") as f:
+        f.write(f"{fx['contig']}\t{fx['bed_start']}\t{fx['bed_stop']}\n")
+    rows = [[fx["contig"], str(p), ".", r, a, ".", "PASS", f"AF={af:.6g}", "GT"] + [f"{g[0]}|{g[1]}" for g in gts]
+            for p, r, a, af, gts in fx["variants"]]
+    readers.write_vcf(vcf, fx["contig"], fx["samples"], rows, False)
+
+    def refuse(*a, **k):
+        raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
+    monkeypatch.setattr(pipeline, "expand_from_vcf", refuse)
+    (path,) = pipeline.search_files(fa, bed, [vcf], fx["pam"], fx["guidelen"], fx["right"], str(tmp_path / "out"),
+                                    cfd_tables=synth.cfd_tables() if fx["cfd"] else None).values()
+    assert open(path).read() == fx["report_tsv"]
+
+
+@pytest.mark.gpu
 def test_unphased_files_to_report_matches_reference_tsv(tmp_path):
     """An unphased VCF through pipeline.search_files: host haplotype construction (haplotypes.add_variants_unphased) ->
     device search -> resolve_guide -> annotate / CFDon / report, against the TSV the reference wrote for the same
