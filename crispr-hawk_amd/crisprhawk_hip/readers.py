@@ -166,38 +166,142 @@ class VcfBlock:
         return len(self.gt_off)
 
 
+class _TextSource:
+    """Random access to the (decompressed) bytes of a VCF without holding them: a plain text file is read by seek; a
+    BGZF file (bgzip: independent <= 64 KB gzip members with their size in the header's BC field) by inflating only the
+    blocks a byte range touches; a plain gzip stream has no random access and is held decompressed (the one case that
+    costs memory).  `chunks()` streams the whole text once for the index pass."""
+
+    CHUNK = 32 << 20
+
+    def __init__(self, fname: str):
+        self.fname = fname
+        with open(fname, "rb") as f:
+            head = f.read(18)
+        self.kind = "plain"
+        self._whole = None
+        if head[:2] == b"\x1f\x8b":
+            is_bgzf = len(head) >= 18 and head[3] & 4 and head[12:14] == b"BC"
+            self.kind = "bgzf" if is_bgzf else "gzip"
+        if self.kind == "bgzf":
+            self._index_blocks()
+        elif self.kind == "gzip":
+            with gzip.open(fname, "rb") as f:
+                self._whole = np.frombuffer(f.read(), dtype=np.uint8)
+
+    def _index_blocks(self) -> None:
+        c_off, u_off, u = [], [], 0
+        with open(self.fname, "rb") as f:
+            pos = 0
+            while True:
+                hdr = f.read(18)
+                if len(hdr) < 18:
+                    break
+                bsize = int.from_bytes(hdr[16:18], "little") + 1
+                f.seek(pos + bsize - 4)
+                isize = int.from_bytes(f.read(4), "little")
+                c_off.append(pos); u_off.append(u)
+                u += isize
+                pos += bsize
+                f.seek(pos)
+        self._c_off = np.array(c_off + [pos], dtype=np.int64)
+        self._u_off = np.array(u_off + [u], dtype=np.int64)
+
+    def _inflate(self, f, k: int) -> bytes:
+        import zlib
+        f.seek(int(self._c_off[k]))
+        raw = f.read(int(self._c_off[k + 1] - self._c_off[k]))
+        xlen = int.from_bytes(raw[10:12], "little")
+        return zlib.decompress(raw[12 + xlen:-8], -15)
+
+    def chunks(self):
+        """(offset of the chunk in the text, uint8 array) over the whole text."""
+        if self.kind == "gzip":
+            yield 0, self._whole
+        elif self.kind == "plain":
+            with open(self.fname, "rb") as f:
+                off = 0
+                while True:
+                    raw = f.read(self.CHUNK)
+                    if not raw:
+                        break
+                    yield off, np.frombuffer(raw, dtype=np.uint8)
+                    off += len(raw)
+        else:
+            with open(self.fname, "rb") as f:
+                k, nb = 0, len(self._c_off) - 1
+                while k < nb:
+                    parts, off, size = [], int(self._u_off[k]), 0
+                    while k < nb and size < self.CHUNK:
+                        parts.append(self._inflate(f, k))
+                        size += len(parts[-1])
+                        k += 1
+                    yield off, np.frombuffer(b"".join(parts), dtype=np.uint8)
+
+    def read(self, lo: int, hi: int) -> np.ndarray:
+        """Text bytes [lo, hi)."""
+        if hi <= lo:
+            return np.zeros(0, np.uint8)
+        if self.kind == "gzip":
+            return self._whole[lo:hi]
+        if self.kind == "plain":
+            with open(self.fname, "rb") as f:
+                f.seek(lo)
+                return np.frombuffer(f.read(hi - lo), dtype=np.uint8)
+        k0 = int(np.searchsorted(self._u_off, lo, side="right") - 1)
+        k1 = int(np.searchsorted(self._u_off, hi, side="left"))
+        with open(self.fname, "rb") as f:
+            data = b"".join(self._inflate(f, k) for k in range(k0, k1))
+        base = int(self._u_off[k0])
+        return np.frombuffer(data, dtype=np.uint8)[lo - base:hi - base]
+
+
 class VCF:
+    """One-contig VCF (plain, gzip or bgzip) with position-indexed access, standing in for the pysam/tabix-backed class
+    of variant.py:622-830.  Construction streams the file once and keeps only an index - 24 bytes per record (line start,
+    line end, POS) - so a 2504-sample chromosome VCF (tens of GB of text) is never resident; a fetch reads just the bytes
+    of the records it returns."""
+
     def __init__(self, fname: str, verbosity: int = 0, debug: bool = True, vcfidx: Optional[str] = "") -> None:
         self._debug, self._verbosity = debug, verbosity
         if not os.path.isfile(fname):
             exception_handler(FileNotFoundError, f"Cannot find input VCF {fname}", os.EX_DATAERR, debug)
         self._fname = fname
-        with open(fname, "rb") as f:
-            magic = f.read(2)
-        opener = gzip.open if magic == b"\x1f\x8b" else open
-        with opener(fname, "rb") as f:
-            raw = f.read()
-        buf = np.frombuffer(raw, dtype=np.uint8)
-        nl = np.flatnonzero(buf == 10)
-        if len(buf) and (len(nl) == 0 or nl[-1] != len(buf) - 1):  # unterminated last line
-            buf = np.concatenate((buf, np.array([10], np.uint8)))
-            nl = np.flatnonzero(buf == 10)
-        starts = np.concatenate(([0], nl[:-1] + 1)).astype(np.int64) if len(nl) else np.zeros(0, np.int64)
-        is_hdr = buf[starts] == ord("#") if len(starts) else np.zeros(0, bool)
-        header = [bytes(buf[s:e]).decode() for s, e in zip(starts[is_hdr], nl[is_hdr])]
-        if not header or not header[-1].startswith("#CHROM"):
-            exception_handler(ValueError, f"Input VCF {fname} has no #CHROM header line", os.EX_DATAERR, debug)
-        self._samples = header[-1].strip().split()[9:]  # variant.py:657
-        self._buf = buf
-        body = ~is_hdr & (nl - starts > 0)
-        self._starts, self._ends = starts[body], nl[body] + 1
-        # CHROM and POS of every record: the first two tab-separated fields
-        self._pos = np.zeros(len(self._starts), dtype=np.int64)
+        self._src = _TextSource(fname)
+        starts_l, ends_l, pos_l = [], [], []
         contigs = set()
-        for i, s in enumerate(self._starts):
-            head = bytes(buf[s:s + 64]).split(b"\t", 2)
-            contigs.add(head[0].decode())
-            self._pos[i] = int(head[1])
+        header_last = None
+        carry = np.zeros(0, np.uint8)
+        carry_off = 0
+        total = 0
+        for off, chunk in self._src.chunks():
+            total = off + len(chunk)
+            buf = np.concatenate((carry, chunk)) if len(carry) else chunk
+            base = off - len(carry)
+            nl = np.flatnonzero(buf == 10)
+            if len(nl) == 0:
+                carry, carry_off = buf, base
+                continue
+            starts = np.concatenate(([0], nl[:-1] + 1)).astype(np.int64)
+            self._index_lines(buf, base, starts, nl, starts_l, ends_l, pos_l, contigs)
+            hdr = starts[buf[starts] == ord("#")]
+            if len(hdr):
+                k = int(np.searchsorted(starts, hdr[-1]))
+                header_last = bytes(buf[starts[k]:nl[k]]).decode()
+            carry, carry_off = buf[nl[-1] + 1:].copy(), base + int(nl[-1]) + 1
+        if len(carry):  # unterminated last line
+            buf = np.concatenate((carry, np.array([10], np.uint8)))
+            self._index_lines(buf, carry_off, np.zeros(1, np.int64), np.array([len(buf) - 1]), starts_l, ends_l, pos_l, contigs)
+            if buf[0] == ord("#"):
+                header_last = bytes(buf[:-1]).decode()
+            self._tail_fix = total  # reads past the file end are clipped; the missing newline is re-added on fetch
+        if header_last is None or not header_last.startswith("#CHROM"):
+            exception_handler(ValueError, f"Input VCF {fname} has no #CHROM header line", os.EX_DATAERR, debug)
+        self._samples = header_last.strip().split()[9:]  # variant.py:657
+        self._total = total
+        self._starts = np.concatenate(starts_l) if starts_l else np.zeros(0, np.int64)
+        self._ends = np.concatenate(ends_l) if ends_l else np.zeros(0, np.int64)
+        self._pos = np.concatenate(pos_l) if pos_l else np.zeros(0, np.int64)
         if len(contigs) > 1:  # variant.py:650-656: one contig per VCF
             exception_handler(ValueError, f"Input VCF {fname} store variants belonging to multiple contigs", os.EX_DATAERR, debug)
         self._contig = next(iter(contigs)) if contigs else ""
@@ -205,8 +309,49 @@ class VCF:
             exception_handler(ValueError, f"Input VCF {fname} is not sorted by position", os.EX_DATAERR, debug)
         self._phased = False  # variant.py:700-708: decided by the first record's first genotype
         if len(self._starts):
-            first = bytes(buf[self._starts[0]:self._ends[0]]).decode().strip().split()
+            first = bytes(self._read(int(self._starts[0]), int(self._ends[0]))).decode().strip().split()
             self._phased = len(first) > 9 and "|" in first[9]
+
+    def _index_lines(self, buf, base, starts, nl, starts_l, ends_l, pos_l, contigs) -> None:
+        """CHROM and POS of every body line of a chunk, without a Python loop: the first 64 bytes of each line as a matrix,
+        the first two tabs by argmax, POS from its digit columns."""
+        body = (buf[starts] != ord("#")) & (nl - starts > 0)
+        st, en = starts[body], nl[body] + 1
+        if len(st) == 0:
+            return
+        W = 64
+        idx = np.minimum(st[:, None] + np.arange(W)[None, :], len(buf) - 1)
+        head = buf[idx]
+        istab = head == 9
+        t1 = istab.argmax(axis=1)
+        rest = istab.copy()
+        rest[np.arange(len(st)), t1] = False
+        t2 = rest.argmax(axis=1)
+        ok = istab.any(axis=1) & rest.any(axis=1) & (t2 > t1 + 1)
+        if not ok.all():
+            exception_handler(ValueError, f"Malformed VCF record near byte {base + int(st[np.flatnonzero(~ok)[0]])} of {self._fname}",
+                              os.EX_DATAERR, self._debug)
+        col = np.arange(W)[None, :]
+        digit = (col > t1[:, None]) & (col < t2[:, None])
+        vals = np.where(digit, head.astype(np.int64) - 48, 0)
+        if np.any(digit & ((vals < 0) | (vals > 9))):
+            exception_handler(ValueError, f"Non-numeric POS in {self._fname}", os.EX_DATAERR, self._debug)
+        power = np.where(digit, 10 ** np.clip(t2[:, None] - 1 - col, 0, 18), 0)
+        pos_l.append((vals * power).sum(axis=1))
+        starts_l.append(st + base)
+        ends_l.append(en + base)
+        # contig names: distinct first fields (one per VCF as a rule: compare against the first line's)
+        first = bytes(head[0, :t1[0]])
+        same = (t1 == t1[0]) & (head[:, :t1[0]] == head[0, :t1[0]]).all(axis=1)
+        contigs.add(first.decode())
+        for i in np.flatnonzero(~same).tolist():
+            contigs.add(bytes(head[i, :t1[i]]).decode())
+
+    def _read(self, lo: int, hi: int) -> np.ndarray:
+        data = self._src.read(lo, min(hi, self._total))
+        if hi > self._total:  # the file's last line had no newline
+            data = np.concatenate((data, np.full(hi - self._total, 10, np.uint8)))
+        return data
 
     def _range(self, coordinate: Coordinate) -> Tuple[int, int]:
         if self._contig != coordinate.contig and self._contig.replace("chr", "") != coordinate.contig.replace("chr", ""):
@@ -220,9 +365,13 @@ class VCF:
     def fetch(self, coordinate: Coordinate) -> List[VariantRecord]:  # variant.py:710-760
         a, b = self._range(coordinate)
         out = []
+        if a == b:
+            return out
+        s0 = int(self._starts[a])
+        text = self._read(s0, int(self._ends[b - 1]))
         for s, e in zip(self._starts[a:b], self._ends[a:b]):
             v = VariantRecord(self._debug)
-            v.read_vcf_line(bytes(self._buf[s:e]).decode().strip().split(), self._samples, self._phased)
+            v.read_vcf_line(bytes(text[int(s) - s0:int(e) - s0]).decode().strip().split(), self._samples, self._phased)
             out.append(v)
         return out
 
@@ -231,7 +380,7 @@ class VCF:
         if a == b:
             return VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         s0, e1 = int(self._starts[a]), int(self._ends[b - 1])
-        text = self._buf[s0:e1]
+        text = self._read(s0, e1)
         line_off = np.concatenate((self._starts[a:b] - s0, [e1 - s0])).astype(np.uint64)
         gt_off = np.zeros(b - a, dtype=np.uint64)
         fixed = []
@@ -261,9 +410,29 @@ def write_vcf(path: str, contig: str, samples: List[str], rows: List[List[str]],
             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples)]
     data = ("\n".join(head + ["\t".join(r) for r in rows]) + "\n").encode()
-    if compress:
+    if compress == "bgzf":
+        write_bgzf(path, data)
+    elif compress:
         with gzip.open(path, "wb") as f:
             f.write(data)
     else:
         with open(path, "wb") as f:
             f.write(data)
+
+
+def write_bgzf(path: str, data: bytes, block: int = 0xff00) -> None:
+    """bgzip's container: independent deflate members of <= 64 KB of text each, the member size in a BC extra field,
+    an empty member as the end marker (SAM spec §4.1)."""
+    import struct
+    import zlib
+
+    def member(chunk: bytes) -> bytes:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize) + body +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    with open(path, "wb") as f:
+        for i in range(0, len(data), block):
+            f.write(member(data[i:i + block]))
+        f.write(member(b""))

@@ -221,4 +221,4 @@ def test_sharded_genome_index_partitions_the_hits():
         parts.append(idx.scan_arrays(guides, pam, False, 3)[0])
     key = lambda h: sorted(zip(h["guide"].tolist(), h["row"].tolist(), h["q"].tolist(), h["strand"].tolist(), h["mm"].tolist()))
     merged = {k: np.concatenate([p[k] for p in parts]) for k in whole}
-    assert key(merged) == key(whole) and len(whole["guide"]) > 100
+    assert key(merged) == key(whole) and len(whole["guide"]) >= 5  # ~1 spacer in 16 is followed by NGG and is its own on-target

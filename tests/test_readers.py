@@ -53,7 +53,7 @@ def test_bed_errors(tmp_path):
         readers.Bed(str(p), 100)
 
 
-@pytest.mark.parametrize("compress", [False, True])
+@pytest.mark.parametrize("compress", [False, True, "bgzf"])
 def test_vcf_fetch_matches_in_memory_records(tmp_path, compress):
     reg = synth.make_region(9111, "chrF", 9000, 2000, 7000)
     synth.add_phased_variants(reg, 9112, 80, 6)
@@ -277,3 +277,37 @@ def test_multiallelic_sites_expand_like_the_host_builder(tmp_path):
         h = by_seq[s]
         assert sorted(inf.samples) == sorted(h.samples.split(",")), s[:40]
         assert np.array_equal(ds.host_meta[r].seg.full(), h.segments.full())
+
+
+def test_vcf_index_streams_and_reads_only_what_it_returns(tmp_path, monkeypatch):
+    """The reader keeps an index, not the text: a file spanning many index chunks and many BGZF blocks, with
+    an unterminated last line; every fetch must equal the eager parse, and a bgzip fetch must inflate only the blocks
+    its records lie in."""
+    reg = synth.make_region(9401, "chrB", 260_000, 5_000, 255_000)
+    synth.add_phased_variants(reg, 9402, 3000, 40, af_min=0.05, af_max=0.5)
+    rows = [reg.vcf_fields(v) for v in reg.variants]
+    plain, bg = str(tmp_path / "p.vcf"), str(tmp_path / "b.vcf.gz")
+    readers.write_vcf(plain, reg.contig, reg.samples, rows, False)
+    data = open(plain, "rb").read()[:-1]  # drop the final newline
+    open(plain, "wb").write(data)
+    readers.write_bgzf(bg, data, block=4096)
+    monkeypatch.setattr(readers._TextSource, "CHUNK", 50_000)  # many chunks: lines straddle chunk borders
+    vp, vb = readers.VCF(plain), readers.VCF(bg)
+    assert vb._src.kind == "bgzf" and len(vb._src._c_off) > 100 and vp._src.kind == "plain"
+    assert np.array_equal(vp._pos, [int(r[1]) for r in rows]) and np.array_equal(vb._pos, vp._pos)
+    assert vp.samples == reg.samples and vb.phased and vp.contig == "chrB"
+    inflated = []
+    orig = readers._TextSource._inflate
+    monkeypatch.setattr(readers._TextSource, "_inflate", lambda self, f, k: (inflated.append(k), orig(self, f, k))[1])
+    from crisprhawk_hip.coordinate import Coordinate
+    for lo, hi in ((5_000, 9_000), (100_000, 101_000), (250_000, 255_000), (1, 260_000)):
+        c = Coordinate("chrB", lo, hi, 0)
+        want = [r for r in rows if lo < int(r[1]) <= hi]
+        inflated.clear()
+        for v in (vp, vb):
+            got = v.fetch(c)
+            assert [(g.position, g.ref, g.alt) for g in got] == [(int(r[1]), r[3], r[4].split(",")) for r in want]
+            blk = v.fetch_block(c)
+            assert len(blk) == len(want) and (len(want) == 0 or bytes(blk.text[-1:]) == b"\n")
+        if hi - lo < 10_000:
+            assert 0 < len(set(inflated)) < 0.2 * (len(vb._src._c_off) - 1)
