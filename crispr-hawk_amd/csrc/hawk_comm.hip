@@ -9,6 +9,7 @@
 // than a padded all-gather: xGMI is point to point, every peer has its own link into the destination, and the
 // tables differ in length.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstring>
 #include <new>
@@ -35,6 +36,15 @@ struct Rccl {
 };
 Rccl g_rccl;
 thread_local char g_comm_err[256] = "";
+
+// RCCL prints a version banner on STDOUT when its first communicator comes up ("RCCL version : ...", five lines).  A
+// caller whose stdout is a protocol (bench.py prints exactly one JSON line) must not get that: while RCCL initialises,
+// file descriptor 1 points at stderr.
+struct StdoutToStderr {
+  int saved;
+  StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+  ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+};
 
 int rccl_load() {
   if (g_rccl.h) return HAWK_OK;
@@ -89,7 +99,11 @@ int hawk_comm_unique_id(uint8_t* id128) {
   int rc = rccl_load();
   if (rc) return rc;
   NcclId id;
-  NCCLCHK(g_rccl.GetUniqueId(&id));
+  {
+    StdoutToStderr quiet;
+    const int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) { snprintf(g_comm_err, sizeof(g_comm_err), "ncclGetUniqueId: %s", g_rccl.GetErrorString(r)); return HAWK_E_COMM; }
+  }
   memcpy(id128, id.internal, 128);
   return HAWK_OK;
 }
@@ -104,7 +118,11 @@ int hawk_comm_init(hawk_ctx* ctx, int world, int rank, const uint8_t* id128, haw
   c->ctx = ctx; c->world = world; c->rank = rank; c->nccl = nullptr;
   NcclId id;
   memcpy(id.internal, id128, 128);
-  int r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+  int r;
+  {
+    StdoutToStderr quiet;
+    r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+  }
   if (r != 0) {
     snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommInitRank(world %d, rank %d): %s", world, rank, g_rccl.GetErrorString(r));
     delete c;

@@ -12,7 +12,7 @@ from crisprhawk_hip.workload import expand_on_device
 pytestmark = pytest.mark.gpu
 
 
-def test_rccl_world_of_one_gathers_a_table_onto_itself():
+def test_rccl_world_of_one_gathers_a_table_onto_itself(capfd):
     reg = synth.make_region(9101, "chrR", 30_000, 1_000, 28_000)
     synth.add_phased_variants(reg, 9102, 300, 5, af_min=0.2, af_max=0.7)
     pam = PAM("NGG", False, True)
@@ -35,6 +35,8 @@ def test_rccl_world_of_one_gathers_a_table_onto_itself():
     assert np.array_equal(np.isnan(merged.cfdon), np.isnan(tab.cfdon))
     assert np.array_equal(np.nan_to_num(merged.cfdon), np.nan_to_num(tab.cfdon))
     comm.close()
+    # RCCL's start-up banner must not reach stdout: bench.py's stdout is one JSON line
+    assert "RCCL version" not in capfd.readouterr().out
 
 
 def test_stale_table_is_refused():
