@@ -165,3 +165,35 @@ def test_dense_carried_variants_overflow_the_staged_range():
         n = (int(host.hap_len[i]) + 31) // 32
         assert ds.hap_len[r] == host.hap_len[i]
         assert np.array_equal(pd_[:, r, :n], ph[:, i, :n]), (i, r)
+
+
+def test_tiled_equals_one_piece_at_megabase_scale():
+    """C4's mechanism at a size the oracle does not reach (1.5 Mb x 300 samples, 46 k sites, four tiles, block-generated
+    genotypes): the tiled pipeline's report must equal the one-piece device search's report row for row - every column but
+    the haplotype ids, which name per-tile rows - and the per-tile candidate counts must add up to the one-piece count
+    over REF (the one haplotype every tile shares unchanged)."""
+    from crisprhawk_hip.workload import hap_labels
+    seq, panel = synth.contig_panel(4601, "chrW", 1_500_000, 0, 300, sites_per_mb=31_000)
+    contig = seq.tobytes().decode()
+    startp, stopp = 1, 1_500_000
+    pam = PAM("NGG", False, True)
+    pam.encode(0)
+    mm, pt = synth.cfd_tables()
+    fetch = lambda lo, hi: seq[lo - 1:hi]
+    target = "chrW:101-1499900"
+    trs = TiledRegionSearch(fetch, "chrW", startp, stopp, panel, pam, 20, False, tile_nt=400_000)
+    assert len(trs.tiles) == 4
+    mg = trs.run(cfd=(mm, pt))
+    df_t = reports.report_from_groups(mg.groups(), mg.labels, pam, "chrW", target)
+    # one piece: the same panel as a single tile spanning the region
+    one = TiledRegionSearch(fetch, "chrW", startp, stopp, panel, pam, 20, False, tile_nt=10_000_000)
+    assert len(one.tiles) == 1
+    mg1 = one.run(cfd=(mm, pt))
+    df_1 = reports.report_from_groups(mg1.groups(), mg1.labels, pam, "chrW", target)
+    assert len(df_1) == len(df_t) > 300_000
+    cols = [c for c in df_1.columns if c != "haplotype_id"]
+    for c in cols:
+        assert (df_1[c].values == df_t[c].values).all(), c
+    ref_rows_t = int((df_t["origin"] == "ref").sum())
+    assert ref_rows_t == int((df_1["origin"] == "ref").sum())
+    assert sum(st["rows"] for st in mg.stats) >= sum(st["rows"] for st in mg1.stats) * 0.99
