@@ -135,7 +135,7 @@ class DeviceHapSet:
         self.set_meta(haps)
 
     def set_meta(self, haps: Sequence[HostHaplotype]) -> None:
-        is_ref, ss, se, seg_off, seg_rel, seg_gen, self.ref_index = _meta_arrays(haps)
+        is_ref, ss, se, seg_off, seg_rel, seg_gen, self.ref_index = haps.meta_arrays() if hasattr(haps, "meta_arrays") else _meta_arrays(haps)
         self.is_ref = is_ref
         _lib.check(self._L.hawk_hapset_set_meta(self._h, _p(is_ref), _p(ss), _p(se), _p(seg_off), _p(seg_rel), _p(seg_gen),
                                                 self.ref_index), "hawk_hapset_set_meta")
@@ -225,7 +225,7 @@ class ExpansionPlan:
         self.is_ref = None
 
     def set_meta(self, haps: Sequence["HostHaplotype"]) -> None:
-        is_ref, ss, se, seg_off, seg_rel, seg_gen, ref_index = _meta_arrays(haps)
+        is_ref, ss, se, seg_off, seg_rel, seg_gen, ref_index = haps.meta_arrays() if hasattr(haps, "meta_arrays") else _meta_arrays(haps)
         _lib.check(self._L.hawk_xplan_set_meta(self._x, _p(is_ref), _p(ss), _p(se), _p(seg_off), _p(seg_rel), _p(seg_gen), ref_index),
                    "hawk_xplan_set_meta")
         self.ref_index, self.is_ref = ref_index, is_ref

@@ -157,6 +157,71 @@ def _scan_for(seg: PosSegments, startp: int, stopp: int, pamlen: int, own: Optio
     return lo, max(lo, hi)
 
 
+class RowMeta:
+    """Position maps and scan ranges of the rows of an expanded set, as flat arrays (CSR segments) - what
+    hawk_hapset_set_meta takes - with list-like access to per-row `HostHaplotype` views for the few callers that want one
+    (labels keep `host_meta[r].seg`).  Replaces 5009 Python objects and as many numpy calls per expansion."""
+
+    def __init__(self, seg_start: np.ndarray, seg_rel: np.ndarray, seg_gen: np.ndarray, hap_len: np.ndarray, alias: np.ndarray, startp: int):
+        self.seg_start, self.seg_rel, self.seg_gen = seg_start, seg_rel, seg_gen
+        self.hap_len, self.alias, self.startp = np.asarray(hap_len, dtype=np.int64), alias, startp
+        self.n = len(hap_len)
+        self.scan_lo = np.zeros(self.n, dtype=np.int64)
+        self.scan_hi = np.zeros(self.n, dtype=np.int64)
+
+    def __len__(self):
+        return self.n
+
+    def seg(self, r: int) -> PosSegments:
+        a, b = int(self.seg_start[r]), int(self.seg_start[r + 1])
+        return PosSegments(self.seg_rel[a:b], self.seg_gen[a:b], int(self.hap_len[r]))
+
+    def __getitem__(self, r: int) -> HostHaplotype:
+        return HostHaplotype(b"", self.seg(r), r == 0, (int(self.scan_lo[r]), int(self.scan_hi[r])))
+
+    def __iter__(self):
+        return (self[r] for r in range(self.n))
+
+    def _rev_all(self, g: int) -> np.ndarray:
+        """posmap_rev[g] of every row at once: the last relative position whose genomic position is g, -1 where g is
+        deleted (the reference rebuilds the reverse dict by overwrite, haplotype.py:159)."""
+        ends = np.empty(len(self.seg_rel), dtype=np.int64)
+        ends[:-1] = self.seg_rel[1:]
+        ends[self.seg_start[1:] - 1] = self.hap_len          # a row's last segment runs to the row's end
+        last_gen = self.seg_gen + (ends - self.seg_rel.astype(np.int64)) - 1
+        hit = (self.seg_gen <= g) & (g <= last_gen)
+        k = np.where(hit, np.arange(len(hit)), -1)
+        lastk = np.maximum.reduceat(k, self.seg_start[:-1])
+        rel = self.seg_rel[np.maximum(lastk, 0)].astype(np.int64) + (g - self.seg_gen[np.maximum(lastk, 0)])
+        return np.where(lastk >= 0, rel, -1)
+
+    def compute_scans(self, startp: int, stopp: int, pamlen: int, own: Optional["ScanOwnership"]) -> None:
+        """compute_scan_start_stop (search_guides.py:49-84), or a tile's ownership range, for every live row; rows whose
+        boundary position is deleted (rare) take the per-row walk of `_scan_for`."""
+        live = self.alias == np.arange(self.n)
+        lo_g = startp + 100 if (own is None or own.own_lo is None) else own.own_lo
+        hi_g = stopp - 100 if (own is None or own.own_hi is None) else own.own_hi
+        lo, hi = self._rev_all(lo_g), self._rev_all(hi_g)
+        if own is None or own.own_hi is None:
+            hi = np.where(hi >= 0, hi - pamlen + 1, hi)
+        slow = live & ((lo < 0) | (hi < 0))
+        if own is not None and own.own_lo is not None and np.any(live & (lo >= 0) & (lo < own.guard)):
+            raise ValueError("tile flank too small: a guide window at the seam would leave the tile (left)")
+        if own is not None and own.own_hi is not None and np.any(live & (hi >= 0) & (hi + own.guard > self.hap_len)):
+            raise ValueError("tile flank too small: a guide window at the seam would leave the tile (right)")
+        self.scan_lo = np.where(live, lo, 0)
+        self.scan_hi = np.where(live, hi if own is None else np.maximum(lo, hi), 0)
+        for r in np.flatnonzero(slow).tolist():
+            a, b = _scan_for(self.seg(r), startp, stopp, pamlen, own)
+            self.scan_lo[r], self.scan_hi[r] = a, b
+
+    def meta_arrays(self):
+        is_ref = np.zeros(self.n, dtype=np.uint8)
+        is_ref[0] = 1
+        return (is_ref, self.scan_lo.astype(np.int32), self.scan_hi.astype(np.int32), self.seg_start.astype(np.uint32),
+                np.ascontiguousarray(self.seg_rel, dtype=np.uint32), np.ascontiguousarray(self.seg_gen, dtype=np.int64), 0)
+
+
 def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, samples: List[str], tab, live: np.ndarray,
                  counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device,
                  own: Optional[ScanOwnership] = None, keep_plan: bool = False):
@@ -196,35 +261,50 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     plan = ExpansionPlan(xh, hap_len, device)
     ds, hashes, ms_val = plan.run(want_hash=True)
     ms = C.c_float(ms_val)
-    # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes) ----------------
-    key = [bytes(hashes[i]) for i in range(n_hap)]
-    first: Dict[bytes, int] = {key[0]: 0}
-    info: List[Optional[HapInfo]] = [HapInfo(["REF"], ())] + [None] * (n_hap - 1)
+    # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes), for all rows at once -----------
+    # entries in the reference's order (haplotypes.py:297-368): samples in panel order, copy 0 then copy 1; a sample
+    # whose two copies hold the same sequence contributes one "1|1" entry; a copy without variants is the REF sequence
+    _, key_id = np.unique(hashes, axis=0, return_inverse=True)
+    key_id = key_id.reshape(-1)
+    ns = len(samples)
+    row_of_col = np.zeros(2 * ns, dtype=np.int64)          # 0 = "no row" (the copy carries nothing: it IS REF)
+    row_of_col[np.asarray(live, dtype=np.int64)] = np.arange(1, n_hap)
+    r_a, r_b = row_of_col[0::2], row_of_col[1::2]           # rows of copy 0 / copy 1 per sample (0: none)
+    k_a, k_b = key_id[r_a], key_id[r_b]                     # row 0 is REF, so "none" reads REF's key
+    present = (r_a > 0) | (r_b > 0)
+    homo = present & (k_a == k_b)
     alias = np.arange(n_hap)
-    row_of_col = {int(cc): i + 1 for i, cc in enumerate(live)}
-    for si in range(len(samples)):
-        rows = [row_of_col.get(2 * si), row_of_col.get(2 * si + 1)]
-        if rows[0] is None and rows[1] is None:
-            continue
-        keys = [key[r] if r is not None else key[0] for r in rows]  # a copy without variants is the REF sequence
-        name = samples[si]
-        if keys[0] == keys[1]:
-            entries = [(rows[0], f"{name}:1|1")]
-            if rows[1] is not None and rows[0] is not None:
-                alias[rows[1]] = rows[0]
+    alias[(key_id == key_id[0]) & (alias > 0)] = 0          # a copy whose variants reproduce the REF sequence
+    both = homo & (r_a > 0) & (r_b > 0)
+    # entry list: (sample, row, genotype code 0 = 1|1, 1 = 1|0, 2 = 0|1), rows that do not exist dropped
+    e_s = np.concatenate((np.flatnonzero(homo), np.flatnonzero(present & ~homo), np.flatnonzero(present & ~homo)))
+    e_r = np.concatenate((r_a[homo], r_a[present & ~homo], r_b[present & ~homo]))
+    e_g = np.concatenate((np.zeros(int(homo.sum()), np.int64), np.ones(int((present & ~homo).sum()), np.int64),
+                          np.full(int((present & ~homo).sum()), 2, np.int64)))
+    ok = e_r > 0
+    e_s, e_r, e_g = e_s[ok], e_r[ok], e_g[ok]
+    order = np.lexsort((e_g, e_s))                          # sample order, then 1|1 / 1|0 before 0|1
+    e_s, e_r, e_g = e_s[order], e_r[order], e_g[order]
+    # the first row seen with a key owns it (REF owns its own key); later rows with that key alias onto the owner
+    e_k = key_id[e_r]
+    owner_of_key = np.full(int(key_id.max()) + 1, -1, dtype=np.int64)
+    uk, first_pos = np.unique(e_k, return_index=True)
+    owner_of_key[uk] = e_r[first_pos]
+    owner_of_key[key_id[0]] = 0
+    e_owner = owner_of_key[e_k]
+    alias[e_r] = e_owner
+    alias[r_b[both]] = alias[r_a[both]]                     # the second copy of a homozygous sample follows the first
+    gts = ("1|1", "1|0", "0|1")
+    labels_e = [f"{samples[si]}:{gts[g]}" for si, g in zip(e_s.tolist(), e_g.tolist())]
+    info: List[Optional[HapInfo]] = [HapInfo(["REF"], ())] + [None] * (n_hap - 1)
+    hv_off_i = hv_off.astype(np.int64)
+    for lab, r, o in zip(labels_e, e_r.tolist(), e_owner.tolist()):
+        if o == 0:
+            continue  # collapses onto REF, which keeps samples == "REF" (haplotypes.py:255-258)
+        if info[o] is None:
+            info[o] = HapInfo([lab], hv_idx[hv_off_i[o]:hv_off_i[o + 1]])
         else:
-            entries = [(rows[0], f"{name}:1|0"), (rows[1], f"{name}:0|1")]
-        for r, label in entries:
-            if r is None:
-                continue  # collapses onto REF, which keeps samples == "REF" (haplotypes.py:255-258)
-            j = first.get(key[r])
-            if j is None:
-                first[key[r]] = r
-                info[r] = HapInfo([label], hv_idx[int(hv_off[r]):int(hv_off[r + 1])])
-            else:
-                alias[r] = j
-                if j != 0:
-                    info[j].samples.append(label)
+            info[o].samples.append(lab)
     # ---- position-map segments + scan bounds per row ------------------------------------------
     # all rows at once: every carried deletion opens one segment behind it, every carried insertion of n bases
     # opens n + 1 (the inserted bases all map to the anchor position, haplotype.py:106-159)
@@ -245,23 +325,26 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     seg_row_all = row_i[rep]
     keep = seg_rel_all < hap_len[seg_row_all].astype(np.int64)
     seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[keep], seg_gen_all[keep], seg_row_all[keep]
-    srt = np.lexsort((seg_rel_all, seg_row_all))        # rows are already ascending; order each row by rel
-    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[srt], seg_gen_all[srt], seg_row_all[srt]
-    seg_cnt = np.bincount(seg_row_all, minlength=n_hap)
-    seg_start = np.concatenate(([0], np.cumsum(seg_cnt)))
-    haps = []
-    zero_rel, first_gen = np.zeros(1, np.uint32), np.array([startp], np.int64)
-    for r in range(n_hap):
-        if alias[r] != r:
-            haps.append(HostHaplotype(b"", PosSegments.identity(startp, int(hap_len[r])), False, (0, 0)))
-            continue
-        a, b = int(seg_start[r]), int(seg_start[r + 1])
-        if a == b:
-            seg = PosSegments.identity(startp, int(hap_len[r]))
-        else:
-            seg = PosSegments(np.concatenate((zero_rel, seg_rel_all[a:b].astype(np.uint32))),
-                              np.concatenate((first_gen, seg_gen_all[a:b])), int(hap_len[r]))
-        haps.append(HostHaplotype(b"", seg, r == 0, _scan_for(seg, startp, stopp, pamlen, own)))
+    # rows collapsed onto another keep the identity map only; every row starts with the identity segment (rel 0 ->
+    # startp).  The rows' own segments come out in (row, rel) order already - list entries are ordered by row, then by
+    # variant, and output positions grow with the variant - so the identity segments are slotted in, not sorted in.
+    live_seg = alias[seg_row_all] == seg_row_all
+    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[live_seg], seg_gen_all[live_seg], seg_row_all[live_seg]
+    if len(seg_rel_all) > 1:
+        same = seg_row_all[1:] == seg_row_all[:-1]
+        if np.any(same & (seg_rel_all[1:] <= seg_rel_all[:-1])) or np.any(seg_row_all[1:] < seg_row_all[:-1]):
+            srt = np.lexsort((seg_rel_all, seg_row_all))
+            seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[srt], seg_gen_all[srt], seg_row_all[srt]
+    own_cnt = np.bincount(seg_row_all, minlength=n_hap)
+    seg_start = np.concatenate(([0], np.cumsum(own_cnt + 1)))
+    dst = np.arange(len(seg_rel_all)) + seg_row_all + 1    # own segment i of row r lands behind r + 1 identity segments
+    rel_m = np.zeros(int(seg_start[-1]), dtype=np.int64)
+    gen_m = np.full(int(seg_start[-1]), startp, dtype=np.int64)
+    rel_m[dst] = seg_rel_all
+    gen_m[dst] = seg_gen_all
+    seg_rel_all, seg_gen_all = rel_m, gen_m
+    haps = RowMeta(seg_start, seg_rel_all.astype(np.uint32), seg_gen_all, hap_len, alias, startp)
+    haps.compute_scans(startp, stopp, pamlen, own)
     ds.set_meta(haps)
     if own is not None and own.partner is not None:
         _lib.check(L.hawk_hapset_set_ref_partner_range(ds._h, int(own.partner[0]), int(own.partner[1])), "hawk_hapset_set_ref_partner_range")
@@ -275,7 +358,7 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
         ds.plan = plan
     else:
         plan.close()
-    kept = [i for i in range(n_hap) if alias[i] == i]
+    kept = np.flatnonzero(alias == np.arange(n_hap)).tolist()
     return ds, [info[i] for i in kept], float(ms.value), kept
 
 
@@ -308,21 +391,36 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
         return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
     tab = _variant_table(np.array([v.pos for v in reg.variants]), [v.ref for v in reg.variants], [v.alt for v in reg.variants], seq, startp)
     r0, span, chain = tab[0], tab[1], tab[2]
-    # which variants each chromosome copy carries, from the in-memory genotype matrix (`sample_range`: this rank's block
-    # of the panel - haplotypes shard across GPUs, REF is on every rank)
-    G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
-    cols, sites = np.nonzero(G.T)                             # sorted by column, then site
-    counts = np.bincount(cols, minlength=G.shape[1])
+    # which variants each chromosome copy carries: the in-memory genotype matrix goes to the device as allele codes and
+    # is inverted there (hawk_gt_lists, the kernels of the VCF path) - a host-side nonzero scan of the 155 MB matrix
+    # took 0.4 s of C3's expansion (`sample_range`: this rank's block of the panel - haplotypes shard across GPUs, REF
+    # is on every rank)
+    import ctypes as C
+    from . import _lib
+    from .hapset import _p
+    G = np.ascontiguousarray(np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants]), dtype=np.uint8)  # [site, 2*sample]
+    n_cols = G.shape[1]
+    L = _lib.lib()
+    g = C.c_void_p()
+    _lib.check(L.hawk_gt_from_codes(ref_set._ctx, _p(G), C.c_uint64(len(G)), n_cols // 2, C.byref(g)), "hawk_gt_from_codes")
+    try:
+        nv = len(G)
+        col_off = np.zeros(n_cols + 1, dtype=np.uint64)
+        col_delta = np.zeros(n_cols, dtype=np.int64)
+        ms_l = C.c_float(0)
+        _lib.check(L.hawk_gt_lists(g, _p(np.arange(nv, dtype=np.uint32)), _p(np.ones(nv, dtype=np.uint8)),
+                                   _p(np.ascontiguousarray(r0, dtype=np.int32)), _p(np.ascontiguousarray(chain, dtype=np.int32)), nv,
+                                   _p(col_off), _p(col_delta), C.byref(ms_l)), "hawk_gt_lists")
+        ne = int(col_off[-1])
+        hv_idx = np.zeros(max(ne, 1), dtype=np.uint32)
+        hv_o = np.zeros(max(ne, 1), dtype=np.int32)
+        _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
+        hv_idx, hv_o = hv_idx[:ne], hv_o[:ne]
+    finally:
+        L.hawk_gt_destroy(g)
+    counts = np.diff(col_off.astype(np.int64))
     live = np.flatnonzero(counts)
-    hv_idx = sites.astype(np.uint32)
-    c = chain[hv_idx]
-    excl = np.cumsum(c) - c
-    row_of = np.repeat(np.arange(len(live)), counts[live])
-    starts = (np.cumsum(counts[live]) - counts[live]).astype(np.int64)
-    excl -= excl[starts][row_of] if len(starts) else 0
-    hv_o = (r0[hv_idx] + excl).astype(np.int32)
-    tot = np.zeros(len(live), dtype=np.int64)
-    np.add.at(tot, row_of, c)
+    tot = col_delta[live]
     if len(live) == 0:
         ref_set.alias = np.zeros(1, dtype=np.int64)
         return ref_set, [HapInfo(["REF"], ())], 0.0, [0]

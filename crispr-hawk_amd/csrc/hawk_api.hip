@@ -1303,6 +1303,24 @@ int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const u
   return HAWK_OK;
 }
 
+int hawk_gt_from_codes(hawk_ctx* ctx, const uint8_t* codes, uint64_t n_lines, uint32_t n_samples, hawk_gt** out) {
+  if (!ctx || !out || !n_samples || (n_lines && !codes)) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  hawk_gt* g = new (std::nothrow) hawk_gt();
+  if (!g) return HAWK_E_INVALID;
+  g->ctx = ctx; g->n_lines = n_lines; g->n_samples = n_samples; g->n_var = 0; g->n_entries = 0;
+  g->d_codes = nullptr; g->d_flags = nullptr; g->d_col_off = nullptr; g->d_idx = nullptr; g->d_o = nullptr; g->d_delta = nullptr;
+  const size_t ncode = std::max<size_t>((size_t)n_lines * 2 * n_samples, 1);
+  POOLCHK(&g->d_codes, ncode); POOLCHK(&g->d_flags, std::max<size_t>(n_lines, 1));
+  if (n_lines) {
+    HIPCHK(hipMemcpyAsync(g->d_codes, codes, (size_t)n_lines * 2 * n_samples, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(g->d_flags, 0, n_lines, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  *out = g;
+  return HAWK_OK;
+}
+
 void hawk_gt_destroy(hawk_gt* g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->device);

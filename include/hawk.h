@@ -276,6 +276,9 @@ int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst,
 typedef struct hawk_gt hawk_gt;
 int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const uint64_t* line_off, const uint64_t* gt_off,
                   uint64_t n_lines, uint32_t n_samples, hawk_gt** out, float* kernel_ms);
+/* The same object from an allele-code matrix the caller already holds (codes[n_lines][2*n_samples], host): genotypes that
+ * never were VCF text (an in-memory panel) enter the device inversion (hawk_gt_lists) without a host-side nonzero scan. */
+int hawk_gt_from_codes(hawk_ctx* ctx, const uint8_t* codes, uint64_t n_lines, uint32_t n_samples, hawk_gt** out);
 void hawk_gt_destroy(hawk_gt* g);
 int hawk_gt_codes(hawk_gt* g, uint8_t* codes, uint8_t* line_flags);
 int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allele, const int32_t* var_r0, const int32_t* var_chain,
