@@ -27,7 +27,7 @@ import numpy as np
 
 from . import parallel
 from .hapset import GroupTable
-from .workload import HapInfo, RowLabel, ScanOwnership, _expand_rows, _ref_only_set, _variant_table
+from .workload import HapInfo, RowLabel, ScanOwnership, _expand_rows, _ref_only_set, _variant_table, carried_lists_on_device
 
 PADDING = 100  # region_constructor.py:21
 
@@ -38,6 +38,9 @@ class DenseGenotypes:
     def __init__(self, G: np.ndarray):
         self.G = np.asarray(G, dtype=np.uint8)
         self.n_cols = self.G.shape[1]
+
+    def dense(self, var_lo: int, var_hi: int, col_lo: int, col_hi: int) -> np.ndarray:
+        return self.G[var_lo:var_hi, col_lo:col_hi]
 
     def carried(self, var_lo: int, var_hi: int, col_lo: int, col_hi: int):
         """-> (counts[col_hi - col_lo], variant indices relative to var_lo, ordered by column then variant)"""
@@ -174,20 +177,15 @@ class TiledRegionSearch:
             v_hi -= 1
         if v_hi <= v_lo:
             return self._keep(t, PreparedTile(tile, ref_set, None, [ref_label], 1))
-        counts, hv_idx = p.genotypes.carried(v_lo, v_hi, 2 * slo, 2 * shi)
+        tab = _variant_table(p.pos[v_lo:v_hi], p.ref[v_lo:v_hi], p.alt[v_lo:v_hi], seq, tile.seq_lo)
+        r0, chain = tab[0], tab[2]
+        # the tile's genotype rectangle is inverted into per-copy carried lists on the device (hawk_gt_lists)
+        col_off, col_delta, hv_idx, hv_o = carried_lists_on_device(ref_set._ctx, p.genotypes.dense(v_lo, v_hi, 2 * slo, 2 * shi), r0, chain)
+        counts = np.diff(col_off.astype(np.int64))
         live = np.flatnonzero(counts)
         if len(live) == 0:
             return self._keep(t, PreparedTile(tile, ref_set, None, [ref_label], 1))
-        tab = _variant_table(p.pos[v_lo:v_hi], p.ref[v_lo:v_hi], p.alt[v_lo:v_hi], seq, tile.seq_lo)
-        r0, chain = tab[0], tab[2]
-        c = chain[hv_idx]
-        excl = np.cumsum(c) - c
-        row_of = np.repeat(np.arange(len(live)), counts[live])
-        starts = (np.cumsum(counts[live]) - counts[live]).astype(np.int64)
-        excl -= excl[starts][row_of]
-        hv_o = (r0[hv_idx] + excl).astype(np.int32)
-        tot = np.zeros(len(live), dtype=np.int64)
-        np.add.at(tot, row_of, c)
+        tot = col_delta[live]
         ds, info, _ms, kept = _expand_rows(ref_set, seq, tile.seq_lo, tile.seq_hi, pamlen, p.samples[slo:shi], tab, live, counts[live],
                                            hv_idx, hv_o, tot, self.device, own=own, keep_plan=keep_plan)
         ref_set.close()

@@ -376,6 +376,36 @@ def _ref_only_set(seq, startp: int, stopp: int, pamlen: int, device, own: Option
     return ds
 
 
+def carried_lists_on_device(ctx, G: np.ndarray, r0: np.ndarray, chain: np.ndarray):
+    """A 0/1 genotype matrix G[variant, chromosome copy] -> per-copy carried-variant lists, on the device: the matrix goes
+    up as allele codes (hawk_gt_from_codes) and is inverted by the kernels of the VCF path (hawk_gt_lists).
+    -> (col_off[n_cols + 1], col_delta[n_cols], hv_idx, hv_o)"""
+    import ctypes as C
+    from . import _lib
+    from .hapset import _p
+    G = np.ascontiguousarray(G, dtype=np.uint8)
+    nv, n_cols = G.shape
+    if n_cols % 2:
+        raise ValueError("genotype matrix needs two columns per sample")
+    L = _lib.lib()
+    g = C.c_void_p()
+    _lib.check(L.hawk_gt_from_codes(ctx, _p(G), C.c_uint64(nv), n_cols // 2, C.byref(g)), "hawk_gt_from_codes")
+    try:
+        col_off = np.zeros(n_cols + 1, dtype=np.uint64)
+        col_delta = np.zeros(n_cols, dtype=np.int64)
+        ms_l = C.c_float(0)
+        _lib.check(L.hawk_gt_lists(g, _p(np.arange(nv, dtype=np.uint32)), _p(np.ones(nv, dtype=np.uint8)),
+                                   _p(np.ascontiguousarray(r0, dtype=np.int32)), _p(np.ascontiguousarray(chain, dtype=np.int32)), nv,
+                                   _p(col_off), _p(col_delta), C.byref(ms_l)), "hawk_gt_lists")
+        ne = int(col_off[-1])
+        hv_idx = np.zeros(max(ne, 1), dtype=np.uint32)
+        hv_o = np.zeros(max(ne, 1), dtype=np.int32)
+        _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
+    finally:
+        L.hawk_gt_destroy(g)
+    return col_off, col_delta, hv_idx[:ne], hv_o[:ne]
+
+
 def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None, sample_range: Optional[Tuple[int, int]] = None,
                      keep_plan: bool = False):
     """build_phased_haplotypes() with the sequence work done by hawk_hapset_expand: the host only
@@ -395,29 +425,8 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     # is inverted there (hawk_gt_lists, the kernels of the VCF path) - a host-side nonzero scan of the 155 MB matrix
     # took 0.4 s of C3's expansion (`sample_range`: this rank's block of the panel - haplotypes shard across GPUs, REF
     # is on every rank)
-    import ctypes as C
-    from . import _lib
-    from .hapset import _p
-    G = np.ascontiguousarray(np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants]), dtype=np.uint8)  # [site, 2*sample]
-    n_cols = G.shape[1]
-    L = _lib.lib()
-    g = C.c_void_p()
-    _lib.check(L.hawk_gt_from_codes(ref_set._ctx, _p(G), C.c_uint64(len(G)), n_cols // 2, C.byref(g)), "hawk_gt_from_codes")
-    try:
-        nv = len(G)
-        col_off = np.zeros(n_cols + 1, dtype=np.uint64)
-        col_delta = np.zeros(n_cols, dtype=np.int64)
-        ms_l = C.c_float(0)
-        _lib.check(L.hawk_gt_lists(g, _p(np.arange(nv, dtype=np.uint32)), _p(np.ones(nv, dtype=np.uint8)),
-                                   _p(np.ascontiguousarray(r0, dtype=np.int32)), _p(np.ascontiguousarray(chain, dtype=np.int32)), nv,
-                                   _p(col_off), _p(col_delta), C.byref(ms_l)), "hawk_gt_lists")
-        ne = int(col_off[-1])
-        hv_idx = np.zeros(max(ne, 1), dtype=np.uint32)
-        hv_o = np.zeros(max(ne, 1), dtype=np.int32)
-        _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
-        hv_idx, hv_o = hv_idx[:ne], hv_o[:ne]
-    finally:
-        L.hawk_gt_destroy(g)
+    G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
+    col_off, col_delta, hv_idx, hv_o = carried_lists_on_device(ref_set._ctx, G, r0, chain)
     counts = np.diff(col_off.astype(np.int64))
     live = np.flatnonzero(counts)
     tot = col_delta[live]
