@@ -218,7 +218,8 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   hawk_pool_free(hs->d_seg_rel); hawk_pool_free(hs->d_seg_gen); hawk_pool_free(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
-                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits};
+                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
+                    &hs->big};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   for (auto& b : hs->crep) b.release();
@@ -338,6 +339,8 @@ int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* 
   hs->scan_start.assign(scan_start, scan_start + n);
   hs->scan_stop.assign(scan_stop, scan_stop + n);
   hs->ref_index = ref_index;
+  hs->n_ref_rows = 0;
+  for (uint32_t h = 0; h < n; ++h) hs->n_ref_rows += is_ref[h] ? 1u : 0u;
   hs->has_meta = true;
   hs->refbits_valid = false;
   ++hs->cols_gen;  // tables written under the old metadata are stale
@@ -556,9 +559,13 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   // HAWK_LIST_EMIT=0 keeps the recompute-everything emit pass (A/B measurements).
   static const bool list_emit = [] { const char* e = getenv("HAWK_LIST_EMIT"); return !(e && e[0] == '0'); }();
   uint32_t* d_lists = nullptr;
+  unsigned long long* d_big = nullptr;
   if (list_emit) {
-    if ((rc = hs->lists.reserve(ntile * HAWK_LIST_CAP * 4))) return rc;
+    // a REF tile takes one work-list entry per 512 survivors (<= 128 per tile), any other big tile one
+    const uint64_t n_ref_tiles = (uint64_t)sp.bph * hs->n_ref_rows;
+    if ((rc = hs->lists.reserve(ntile * HAWK_LIST_CAP * 4)) || (rc = hs->big.reserve((ntile + 128 * n_ref_tiles) * 8 + 16))) return rc;
     d_lists = hs->lists.as<uint32_t>();
+    d_big = hs->big.as<unsigned long long>();
   }
   if (p->score_cfdon) {  // the tables go up once; later searches with the same tables find them in HBM
     if (hs->cfd_host.size() != 336 || memcmp(hs->cfd_host.data(), p->cfd_mm, 320 * 8) != 0 ||
@@ -573,6 +580,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   HIPCHK(hipMemsetAsync(hs->misc.p, 0, 512 * 8 + 64, ctx->stream));
   unsigned long long* d_shards = hs->misc.as<unsigned long long>();          // [256][2] candidate / hit partial sums
   int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 512 * 8);
+  uint32_t* d_big_count = reinterpret_cast<uint32_t*>(hs->misc.as<char>() + 512 * 8 + 16);  // zeroed with misc
   GuideParams gp;
   gp.pamlen = sp.pamlen; gp.guidelen = sp.guidelen; gp.right = sp.right; gp.L = sp.L;
   gp.score_cfdon = (int32_t)p->score_cfdon;  // 1: a non-ACGT base under a lookup is HAWK_E_CFD; 2: it scores NaN ("NA")
@@ -613,7 +621,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists);
+  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists, d_big_count, d_big);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
   hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
                     hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
@@ -636,7 +644,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     if ((rc = hawk_reserve_cols(hs->colsA, hs->cols_cap, &ca))) return rc;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                       hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
+                       hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5]);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
@@ -660,7 +668,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     hs->cols_cap = ca.cap;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                                  hs->offsets.as<uint64_t>(), ca, d_status, d_lists, ev[5]);
+                                  hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5]);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1055,6 +1063,7 @@ struct hawk_xplan {
   int64_t ref_startp, min_gen, max_gen;
   bool has_partner = false;
   int32_t partner_start = 0, partner_stop = 0;
+  uint32_t n_ref_rows = 0;
 };
 
 void hawk_xplan_destroy(hawk_xplan* x) {
@@ -1184,6 +1193,8 @@ int hawk_xplan_set_meta(hawk_xplan* x, const uint8_t* is_ref, const int32_t* sca
   x->min_gen = mn; x->max_gen = mx;
   x->scan_start.assign(scan_start, scan_start + n);
   x->scan_stop.assign(scan_stop, scan_stop + n);
+  x->n_ref_rows = 0;
+  for (uint32_t h = 0; h < n; ++h) x->n_ref_rows += is_ref[h] ? 1u : 0u;
   x->has_meta = true;
   return HAWK_OK;
 }
@@ -1228,7 +1239,7 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
     if (e == hipSuccess) e = hipMemcpyAsync(hs->d_tile_meta, x->m_tile.p, (size_t)n * x->bph * sizeof(TileMeta), hipMemcpyDeviceToDevice, st);
     hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
     hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
-    hs->ref_index = x->ref_index; hs->has_meta = true;
+    hs->ref_index = x->ref_index; hs->has_meta = true; hs->n_ref_rows = x->n_ref_rows;
     hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
   }
   if (e == hipSuccess && (hash_out || kernel_ms)) e = hipStreamSynchronize(st);

@@ -128,7 +128,8 @@ void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, co
                            const uint64_t* offsets, uint64_t n_fwd_total, uint32_t* hits_fwd, uint32_t* hits_rev);
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
-                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, hipEvent_t mid = nullptr);
+                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, uint32_t* big_count,
+                        unsigned long long* big_list, hipEvent_t mid = nullptr);
 size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit);
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
                          int flank_up, int flank_down, int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,

@@ -69,6 +69,7 @@ struct hawk_hapset {
   uint32_t *d_seg_off, *d_seg_rel;
   int64_t* d_seg_gen;
   int32_t ref_index;
+  uint32_t n_ref_rows = 0;           // rows flagged REF (their tiles take one emit work-list entry per 512 survivors)
   bool has_meta;
   bool has_partner = false;          // hawk_hapset_set_ref_partner_range
   int32_t partner_start = 0, partner_stop = 0;
@@ -84,6 +85,7 @@ struct hawk_hapset {
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
   DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
+  DevBuf big;                 // tiles whose rows exceed the hand-over list (k_search_emit's work list)
   DevBuf refbits;             // REF's candidate-window bitmaps, one per strand (k_ref_bits)
   bool refbits_valid = false;
   uint64_t refbits_key[6] = {0, 0, 0, 0, 0, 0};

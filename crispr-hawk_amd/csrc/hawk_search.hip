@@ -104,7 +104,8 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
                                             const TileMeta* __restrict__ tmeta, uint32_t* __restrict__ counts,
                                             unsigned long long* __restrict__ shards,
                                             const uint64_t* __restrict__ offsets, const GuideCols& out, int* status,
-                                            uint32_t* __restrict__ lists) {
+                                            uint32_t* __restrict__ lists, const uint32_t tile, uint32_t* __restrict__ big_count,
+                                            unsigned long long* __restrict__ big_list, const int round_only) {
   __shared__ __attribute__((aligned(16))) uint32_t s_pl[PASS == 1 ? HAWK_PLANES : 1][PASS == 1 ? LDS_ROW : 8];
   __shared__ uint32_t s_list[PASS == 1 ? CAP : 1];
   // count pass: every thread's survivor bits (4 words per strand) and packed exclusive offsets, so that phase C
@@ -118,7 +119,6 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
   __shared__ uint32_t s_acc[4];
   const ScanParams& p = p_in;
   const uint32_t tid = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
   // list mode: the count pass hands the valid survivors of small tiles to k_emit_list; this kernel's emit
   // pass then only serves the tiles whose list did not fit (REF tiles, very dense tiles)
   const bool list_mode = PASS == 0 && lists != nullptr;
@@ -257,7 +257,9 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
   } else if (T) {  // workgroup-uniform
     const int nloc = (int)s_acc[3];
     const size_t refbase = ri.index >= 0 ? (size_t)ri.index * hs.S : 0;
-    uint64_t row_base = PASS == 1 ? offsets[tile] : 0;
+    // PASS 1 on one round of a REF tile (round_only >= 0): every survivor of a REF tile is a row, so round b starts
+    // b * CAP rows into the tile and the rounds of one tile can run in different workgroups
+    uint64_t row_base = PASS == 1 ? offsets[tile] + (round_only >= 0 ? (uint64_t)round_only * CAP : 0ull) : 0;
     const int L = p.L;
     const int W = L + 2 * HAWK_PAD;
     const uint32_t mlo = L >= 32 ? 0xffffffffu : ((1u << L) - 1u), mhi = L <= 32 ? 0u : ((1u << (L - 32)) - 1u);
@@ -265,7 +267,9 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
     const int ncfd = gp.guidelen < 20 ? gp.guidelen : 20;
     const uint32_t cfdmask = (1u << ncfd) - 1u;
 
-    for (uint32_t base = 0; base < T; base += CAP) {
+    const uint32_t base_lo = (PASS == 1 && round_only >= 0) ? (uint32_t)round_only * CAP : 0u;
+    const uint32_t base_hi = (PASS == 1 && round_only >= 0) ? (base_lo + CAP < T ? base_lo + CAP : T) : T;
+    for (uint32_t base = base_lo; base < base_hi; base += CAP) {
       // ---- phase B (emit pass): survivors -> LDS list, strand 0 first, each in position order ------
       // (the count pass needs no list: its phase C looks survivor number i up in s_ex / s_kw)
       if (PASS == 1) {
@@ -508,6 +512,16 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
 #pragma unroll
       for (int wv = 0; wv < HAWK_BLOCK / WAVE; ++wv) { a0 += s_w[wv]; a1 += s_kw[0][wv] & 0xffffu; a2 += s_kw[0][wv] >> 16; }
       counts[tile] = a0;
+      // tiles whose rows do not fit the hand-over list (REF tiles, very dense ones) are named for k_search_emit, which
+      // then runs over them alone instead of launching one workgroup per tile to find out
+      // (a REF tile - thousands of rows, none ever dropped - is named once per round of CAP survivors, so that its rounds
+      // spread over workgroups: 31 REF tiles of ~4000 rows were a 50 us critical path of their own)
+      if (list_mode && a0 > LIST_CAP) {
+        const uint32_t nr = isref ? (T + CAP - 1) / CAP : 1u;
+        const uint32_t at = atomicAdd(big_count, nr);
+        for (uint32_t r = 0; r < nr; ++r)
+          big_list[at + r] = (unsigned long long)tile | ((unsigned long long)(isref ? r + 1u : 0u) << 32);
+      }
       if (a1 | a2) {
         atomicAdd(&shards[(tile & 255u) * 2 + 0], (unsigned long long)a1);
         atomicAdd(&shards[(tile & 255u) * 2 + 1], (unsigned long long)a2);
@@ -521,14 +535,24 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
 __global__ __launch_bounds__(HAWK_BLOCK) __attribute__((amdgpu_waves_per_eu(COUNT_WAVES, 8)))
 void k_search_count(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri, const TileMeta* __restrict__ tmeta,
                     uint32_t* __restrict__ counts, unsigned long long* __restrict__ shards, int* status,
-                    uint32_t* __restrict__ lists) {
-  search_tile<0>(hs, p, gp, ri, tmeta, counts, shards, nullptr, GuideCols{}, status, lists);
+                    uint32_t* __restrict__ lists, uint32_t* __restrict__ big_count, unsigned long long* __restrict__ big_list) {
+  search_tile<0>(hs, p, gp, ri, tmeta, counts, shards, nullptr, GuideCols{}, status, lists, blockIdx.x, big_count, big_list, -1);
 }
 __global__ __launch_bounds__(HAWK_BLOCK)
 void k_search_emit(HapSetDev hs, ScanParams p, GuideParams gp, RefInfo ri, const TileMeta* __restrict__ tmeta,
                    uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets, GuideCols out, int* status,
-                   uint32_t* __restrict__ lists) {
-  search_tile<1>(hs, p, gp, ri, tmeta, counts, nullptr, offsets, out, status, lists);
+                   uint32_t* __restrict__ lists, const uint32_t* __restrict__ big_count, const unsigned long long* __restrict__ big_list) {
+  if (lists == nullptr) {  // no hand-over lists: every tile recomputes and emits here
+    search_tile<1>(hs, p, gp, ri, tmeta, counts, nullptr, offsets, out, status, lists, blockIdx.x, nullptr, nullptr, -1);
+    return;
+  }
+  const uint32_t n_big = *big_count;
+#pragma unroll 1
+  for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {  // workgroup-uniform
+    const unsigned long long e = big_list[i];
+    search_tile<1>(hs, p, gp, ri, tmeta, counts, nullptr, offsets, out, status, lists, (uint32_t)e, nullptr, nullptr, (int)(e >> 32) - 1);
+    __syncthreads();  // the tile's LDS staging is rewritten by the next one
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -708,15 +732,18 @@ void hawk_launch_ref_bits(hipStream_t st, const HapSetDev& hs, const ScanParams&
 
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
-                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, hipEvent_t mid) {
-  const dim3 grid(hs.n_hap * p.bph), block(HAWK_BLOCK);
+                        const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, uint32_t* big_count,
+                        unsigned long long* big_list, hipEvent_t mid) {
+  const uint32_t ntile = hs.n_hap * p.bph;
+  const dim3 grid(ntile), block(HAWK_BLOCK);
   if (pass == 0) {
-    hipLaunchKernelGGL(k_search_count, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, status, lists);
+    hipLaunchKernelGGL(k_search_count, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, status, lists, big_count, big_list);
   } else {
-    // lists != nullptr: small tiles are assembled from their hand-over lists, the rest recompute
+    // lists != nullptr: small tiles are assembled from their hand-over lists, the named big ones recompute
     if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, lists, out, status);
     if (mid) (void)hipEventRecord(mid, st);  // timing: k_emit_list ends here
-    hipLaunchKernelGGL(k_search_emit, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, out, status, lists);
+    const dim3 egrid(lists ? (ntile < 2048u ? ntile : 2048u) : ntile);
+    hipLaunchKernelGGL(k_search_emit, egrid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, out, status, lists, big_count, big_list);
   }
 }
 
