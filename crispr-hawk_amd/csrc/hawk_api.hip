@@ -134,6 +134,7 @@ int hawk_init(int device, hawk_ctx** out) {
   ctx->device = device;
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipHostMalloc(&ctx->pinned, 256, hipHostMallocDefault));
   *out = ctx;
   return HAWK_OK;
 }
@@ -144,6 +145,7 @@ void hawk_destroy(hawk_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& e : ctx->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
 }
 
@@ -552,7 +554,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   ++hs->cols_gen;  // the columns are about to be rewritten: earlier tables of this set become stale
   const uint64_t ntile = (uint64_t)hs->n_hap * sp.bph;
   if ((rc = hs->counts.reserve(ntile * 4)) || (rc = hs->offsets.reserve((ntile + 1) * 8)) ||
-      (rc = hs->totals.reserve(sizeof(ScanTotals))) || (rc = hs->misc.reserve(512 * 8 + 64)) ||
+      (rc = hs->misc.reserve(512 * 8 + 64)) ||
       (rc = hs->cfd.reserve(336 * 8)) || (rc = hs->partial.reserve((ntile / 1024 + 2) * 8)))
     return rc;
   // hand-over lists (2 KB per tile): the count pass leaves each small tile's valid survivors for the emit pass.
@@ -581,6 +583,11 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   unsigned long long* d_shards = hs->misc.as<unsigned long long>();          // [256][2] candidate / hit partial sums
   int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 512 * 8);
   uint32_t* d_big_count = reinterpret_cast<uint32_t*>(hs->misc.as<char>() + 512 * 8 + 16);  // zeroed with misc
+  // status (4 B) | work-list count | totals share one 64-byte block: a single copy into page-locked memory per search
+  static_assert(sizeof(ScanTotals) == 32, "status block layout");
+  ScanTotals* d_totals = reinterpret_cast<ScanTotals*>(hs->misc.as<char>() + 512 * 8 + 32);
+  const char* d_block = hs->misc.as<char>() + 512 * 8;
+  char* h_block = static_cast<char*>(ctx->pinned);
   GuideParams gp;
   gp.pamlen = sp.pamlen; gp.guidelen = sp.guidelen; gp.right = sp.right; gp.L = sp.L;
   gp.score_cfdon = (int32_t)p->score_cfdon;  // 1: a non-ACGT base under a lookup is HAWK_E_CFD; 2: it scores NaN ("NA")
@@ -624,7 +631,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists, d_big_count, d_big);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
   hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
-                    hs->offsets.as<uint64_t>(), hs->totals.as<ScanTotals>());
+                    hs->offsets.as<uint64_t>(), d_totals);
   HIPCHK(hipEventRecord(ev[2], ctx->stream));
   HIPCHK(hipGetLastError());
   ScanTotals tot;
@@ -647,15 +654,17 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
                        hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5]);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(&tot, h_block + 32, sizeof(tot));
+    memcpy(&status, h_block, 4);
     nrows = tot.n_keep;
     emitted = nrows <= hs->cols_cap;
     if (!emitted) { status = 0; HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream)); }
   } else {
-    HIPCHK(hipMemcpyAsync(&tot, hs->totals.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(&tot, h_block + 32, sizeof(tot));
     nrows = tot.n_keep;
   }
   if (count_only) {  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
@@ -671,8 +680,9 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
                                   hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5]);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_block, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(&status, h_block, 4);
   }
   if (timing) {
     memset(timing, 0, sizeof(*timing));

@@ -25,6 +25,7 @@ struct hawk_ctx {
   int device;
   hipStream_t stream;
   hipEvent_t ev[8];
+  void* pinned = nullptr;  // 256 B of page-locked host memory: the per-search totals + status come back in one copy
 };
 
 // Caching device allocator, one per device: a freed block goes to a free list and is handed to the next request of a
