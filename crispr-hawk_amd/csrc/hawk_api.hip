@@ -1063,7 +1063,7 @@ struct hawk_xplan {
   std::vector<uint32_t> hap_len;
   uint32_t* ref_plane[4];  // the REF region's code planes, copied: the plan does not depend on the life of ref_set
   uint32_t ref_S;
-  DevBuf r0, span, ao, al, codes, off, idx, o, wk0, wn, hash;
+  DevBuf recs, tiles, codes, off, hlen, hash;  // 32 B per carried variant, 16 B per (row, tile): hawk_expand.hip
   // metadata of the produced rows (hawk_xplan_set_meta)
   bool has_meta;
   std::vector<int32_t> scan_start, scan_stop;
@@ -1081,7 +1081,7 @@ void hawk_xplan_destroy(hawk_xplan* x) {
   (void)hipSetDevice(x->ctx->device);
   (void)hipStreamSynchronize(x->ctx->stream);
   for (auto& p : x->ref_plane) hawk_pool_free(p);
-  DevBuf* bufs[] = {&x->r0, &x->span, &x->ao, &x->al, &x->codes, &x->off, &x->idx, &x->o, &x->wk0, &x->wn, &x->hash,
+  DevBuf* bufs[] = {&x->recs, &x->tiles, &x->codes, &x->off, &x->hlen, &x->hash,
                     &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile};
   for (auto* b : bufs) b->release();
   delete x;
@@ -1129,43 +1129,61 @@ int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0
   x->ref_S = ref_set->S;
   x->S = ((maxlen + 31) / 32 + 2 + 3) / 4 * 4;  // the stride hapset_create_impl will choose
   x->bph = (x->S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
-  const size_t nwg = (size_t)n_hap * ((x->S + HAWK_BLOCK - 1) / HAWK_BLOCK);
+  const size_t nwg = (size_t)n_hap * hawk_hx_tiles_per_row(x->S);
   const size_t nv = std::max<size_t>(n_var, 1), nc = std::max<size_t>(ncar, 1);
   int rc = HAWK_OK;
   for (int p = 0; p < 4 && !rc; ++p) rc = hawk_pool_alloc((void**)&x->ref_plane[p], (size_t)x->ref_S * 4);
-  if (!rc) rc = x->r0.reserve(nv * 4);
-  if (!rc) rc = x->span.reserve(nv * 4);
-  if (!rc) rc = x->ao.reserve(nv * 4);
-  if (!rc) rc = x->al.reserve(nv * 4);
+  // the per-variant and per-carried-variant tables only feed the record / tile kernels: temporaries of this call
+  DevBuf t_r0, t_span, t_ao, t_al, t_am, t_idx, t_o;
+  DevBuf* temps[] = {&t_r0, &t_span, &t_ao, &t_al, &t_am, &t_idx, &t_o};
+  if (!rc) rc = t_r0.reserve(nv * 4);
+  if (!rc) rc = t_span.reserve(nv * 4);
+  if (!rc) rc = t_ao.reserve(nv * 4);
+  if (!rc) rc = t_al.reserve(nv * 4);
+  if (!rc) rc = t_am.reserve(nv * 16);
+  if (!rc) rc = t_idx.reserve(nc * 4);
+  if (!rc) rc = t_o.reserve(nc * 4);
+  if (!rc) rc = x->recs.reserve(nc * hawk_hx_record_bytes());
+  if (!rc) rc = x->tiles.reserve(nwg * hawk_hx_tile_bytes());
   if (!rc) rc = x->codes.reserve(std::max<size_t>(alt_codes_len, 1));
   if (!rc) rc = x->off.reserve((size_t)(n_hap + 1) * 8);
-  if (!rc) rc = x->idx.reserve(nc * 4);
-  if (!rc) rc = x->o.reserve(nc * 4);
-  if (!rc) rc = x->wk0.reserve(nwg * 4);
-  if (!rc) rc = x->wn.reserve(nwg * 4);
+  if (!rc) rc = x->hlen.reserve((size_t)n_hap * 4);
   if (!rc) rc = x->hash.reserve((size_t)n_hap * 16);
-  if (rc) { hawk_xplan_destroy(x); return rc; }
+  if (rc) { for (auto* b : temps) b->release(); hawk_xplan_destroy(x); return rc; }
   hipStream_t st = ctx->stream;
   hipError_t e = hipSuccess;
+  // every variant's first 32 alt bases as plane bits (A, C, G, T): the build kernel shifts them into place instead of
+  // walking the allele text (which only insertions longer than a word still need)
+  std::vector<uint32_t> am(nv * 4, 0);
+  for (uint32_t i = 0; i < n_var; ++i)
+    for (uint32_t j = 0; j < v_alt_len[i] && j < 32; ++j) {
+      const uint8_t c = alt_codes[v_alt_off[i] + j];
+      for (int pl = 0; pl < 4; ++pl) am[(size_t)i * 4 + pl] |= (uint32_t)((c >> pl) & 1u) << j;
+    }
   for (int p = 0; p < 4 && e == hipSuccess; ++p)
     e = hipMemcpyAsync(x->ref_plane[p], ref_set->plane[p], (size_t)x->ref_S * 4, hipMemcpyDeviceToDevice, st);
   if (n_var && e == hipSuccess) {
-    e = hipMemcpyAsync(x->r0.p, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(x->span.p, v_span, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(x->ao.p, v_alt_off, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(x->al.p, v_alt_len, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    e = hipMemcpyAsync(t_r0.p, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t_span.p, v_span, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t_ao.p, v_alt_off, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t_al.p, v_alt_len, (size_t)n_var * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(x->codes.p, alt_codes, alt_codes_len, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t_am.p, am.data(), (size_t)n_var * 16, hipMemcpyHostToDevice, st);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(x->off.p, hv_off, (size_t)(n_hap + 1) * 8, hipMemcpyHostToDevice, st);
   if (ncar && e == hipSuccess) {
-    e = hipMemcpyAsync(x->idx.p, hv_idx, ncar * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(x->o.p, hv_o, ncar * 4, hipMemcpyHostToDevice, st);
+    e = hipMemcpyAsync(t_idx.p, hv_idx, ncar * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t_o.p, hv_o, ncar * 4, hipMemcpyHostToDevice, st);
   }
+  if (e == hipSuccess) e = hipMemcpyAsync(x->hlen.p, hap_len, (size_t)n_hap * 4, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
-    hawk_launch_hx_index(st, x->off.as<uint64_t>(), x->o.as<int32_t>(), n_hap, x->S, x->wk0.as<int32_t>(), x->wn.as<uint32_t>());
+    hawk_launch_hx_prepare(st, x->off.as<uint64_t>(), t_idx.as<uint32_t>(), t_o.as<int32_t>(), ncar, t_r0.as<uint32_t>(),
+                           t_span.as<uint32_t>(), t_ao.as<uint32_t>(), t_al.as<uint32_t>(), t_am.p, x->hlen.as<uint32_t>(), n_hap, x->S,
+                           x->recs.p, x->tiles.p);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
+  for (auto* b : temps) b->release();
   if (e != hipSuccess) {
     snprintf(g_hip_err, sizeof(g_hip_err), "hawk_xplan_create: %s", hipGetErrorString(e));
     hawk_xplan_destroy(x);
@@ -1227,9 +1245,8 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
   hipError_t e = hipMemsetAsync(x->hash.p, 0, (size_t)x->n_hap * 16, st);
   if (e == hipSuccess) e = hipEventRecord(ctx->ev[0], st);
   if (e == hipSuccess) {
-    hawk_launch_hx_build(st, x->ref_plane, x->r0.as<uint32_t>(), x->span.as<uint32_t>(), x->ao.as<uint32_t>(), x->al.as<uint32_t>(),
-                         x->codes.as<uint8_t>(), x->off.as<uint64_t>(), x->idx.as<uint32_t>(), x->o.as<int32_t>(), hs->d_hap_len,
-                         x->n_hap, hs->S, hs->plane, x->wk0.as<int32_t>(), x->wn.as<uint32_t>());
+    hawk_launch_hx_build(st, x->ref_plane, x->ref_S, x->recs.p, x->codes.as<uint8_t>(), x->off.as<uint64_t>(), hs->d_hap_len, x->n_hap,
+                         hs->S, hs->plane, x->tiles.p);
     if (hash_out) hawk_launch_hx_hash(st, hs->plane, x->n_hap, hs->S, x->hash.as<unsigned long long>());
     e = hipEventRecord(ctx->ev[1], st);
   }

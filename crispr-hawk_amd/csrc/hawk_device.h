@@ -156,10 +156,14 @@ void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t 
 void hawk_launch_gbt(hipStream_t st, const double* feats, uint64_t n, uint32_t nf, uint32_t n_trees, const int32_t* tree_off,
                      const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold, const double* value,
                      double init, double lr, int cast_f32, double* out);
-void hawk_launch_hx_index(hipStream_t st, const uint64_t* hv_off, const int32_t* hv_o, uint32_t n_hap, uint32_t S, int32_t* wg_k0,
-                          uint32_t* wg_n);
-void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
-                          const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
-                          const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,
-                          uint32_t* const* plane, int32_t* wg_k0, uint32_t* wg_n);
+uint32_t hawk_hx_tiles_per_row(uint32_t S);
+size_t hawk_hx_record_bytes();
+size_t hawk_hx_tile_bytes();
+void hawk_launch_hx_prepare(hipStream_t st, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o, uint64_t ncar,
+                            const uint32_t* v_r0, const uint32_t* v_span, const uint32_t* v_alt_off, const uint32_t* v_alt_len,
+                            const void* v_am /* uint4 per variant */, const uint32_t* hap_len, uint32_t n_hap, uint32_t S, void* recs,
+                            void* tiles);
+void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, uint32_t ref_S, const void* recs, const uint8_t* alt_codes,
+                          const uint64_t* hv_off, const uint32_t* hap_len, uint32_t n_hap, uint32_t S, uint32_t* const* plane,
+                          const void* tiles);
 void hawk_launch_hx_hash(hipStream_t st, uint32_t* const* plane, uint32_t n_hap, uint32_t S, unsigned long long* hash);

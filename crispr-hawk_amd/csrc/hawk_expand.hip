@@ -9,134 +9,275 @@
 // planes (funnel shift), alt alleles are written from their IUPAC codes with the V bit set
 // (the reference lower-cases every alt base, haplotype.py:120: a deletion's anchor is marked
 // even though it equals REF).
-//   k_hx_build  one thread per output word; the row's variants overlapping the workgroup's 8192
-//               positions are staged in LDS first
+//   once per plan (hawk_xplan_create):
+//   k_hx_records one 32-byte record per carried variant of every row: where it starts in the row, where REF resumes
+//               behind it, its first 32 alt bases as plane bits
+//   k_hx_index  per (row, tile of 32768 output positions): the row's records the tile needs, the REF words it reads
+//   every run (hawk_xplan_run):
+//   k_hx_build  one thread per four consecutive output words; the tile's records and its image in the REF planes
+//               are staged in LDS first (two independent coalesced loads), then no thread waits on global memory
 //   k_hx_hash   128-bit position-tagged content hash per row (for collapse_haplotypes,
 //               haplotypes.py:274-294, and the homozygous test 326-333, done by the caller)
 #include "hawk_bits.h"
 
-#define HX_MAXV 192  // carried variants staged per workgroup (8192 output positions)
+#define HX_TW 1024        // output words a workgroup builds: 32768 positions, four consecutive words per thread
+#define HX_MAXV 160       // carried variants staged per workgroup (32 B each)
+#define HX_RW (HX_TW + 64)  // REF words staged per plane: the tile's image in REF plus up to 2048 net deleted bases
 
-struct HxVar { int32_t o; uint32_t r0; uint32_t span; uint32_t alt_len; uint32_t alt_off; };
+// o: output start; rs = r0 + span: where REF resumes behind the alt allele; m: the first 32 alt bases as plane bits
+struct __attribute__((aligned(16))) HxVar { int32_t o; uint32_t rs; uint32_t alt_len; uint32_t alt_off; uint32_t m[4]; };
+// what a workgroup of k_hx_build starts from: one 16-byte scalar load
+struct __attribute__((aligned(16))) HxTile {
+  uint32_t first_lo, first_hi;  // index (over all rows) of the first record to stage
+  uint32_t n_flags;             // records to stage | HX_FITS | HX_ALL
+  uint32_t ws;                  // first REF word of the staged window (a multiple of 4)
+};
+#define HX_FITS (1u << 31)  // the tile's REF image fits the staged window
+#define HX_ALL (1u << 30)   // every record the tile needs is staged
+#define HX_HEAD (1u << 29)  // the first staged record starts at or before the tile (otherwise the tile starts in unmodified REF)
 
-// Which of a row's carried variants a workgroup of k_hx_build needs: the last one starting at or before the
-// workgroup's first output position (its alt allele / the copy behind it may reach in) and every one starting
-// inside its 8192 positions.  One thread per (row, workgroup): the two binary searches are dependent global
-// loads, cheap when 6 x 10^5 of them run side by side, but 5 us of serial latency when lane 0 of every
-// k_hx_build workgroup does them with 255 lanes waiting (the first version: 2.4 ms instead of 0.9 ms).
-__global__ __launch_bounds__(256) void k_hx_index(const uint64_t* __restrict__ hv_off, const int32_t* __restrict__ hv_o, uint32_t n_hap,
-                                                  uint32_t wpr, int32_t* __restrict__ wg_k0, uint32_t* __restrict__ wg_n) {
+__global__ __launch_bounds__(256) void k_hx_records(const uint32_t* __restrict__ hv_idx, const int32_t* __restrict__ hv_o, uint64_t ncar,
+                                                    const uint32_t* __restrict__ v_r0, const uint32_t* __restrict__ v_span,
+                                                    const uint32_t* __restrict__ v_alt_off, const uint32_t* __restrict__ v_alt_len,
+                                                    const uint4* __restrict__ v_am, HxVar* __restrict__ recs) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncar) return;
+  const uint32_t vi = hv_idx[i];
+  const uint4 m = v_am[vi];
+  HxVar v;
+  v.o = hv_o[i]; v.rs = v_r0[vi] + v_span[vi]; v.alt_len = v_alt_len[vi]; v.alt_off = v_alt_off[vi];
+  v.m[0] = m.x; v.m[1] = m.y; v.m[2] = m.z; v.m[3] = m.w;
+  recs[i] = v;
+}
+
+// Per (row, tile), before any plane is built: which of the row's carried variants the tile needs - the last one
+// starting at or before the tile's first output position (its alt allele / the copy behind it may reach in) and every
+// one starting inside its 32768 positions - and which REF words its copies read.  One thread per (row, tile): the
+// binary searches are dependent global loads, cheap when 10^5 of them run side by side, but microseconds of serial
+// latency when lane 0 of every k_hx_build workgroup does them with 255 lanes waiting (the first version: 2.4 ms
+// instead of 0.9 ms).
+__global__ __launch_bounds__(256) void k_hx_index(const uint64_t* __restrict__ hv_off, const HxVar* __restrict__ recs,
+                                                  const uint32_t* __restrict__ hap_len, uint32_t n_hap, uint32_t wpr,
+                                                  HxTile* __restrict__ tiles) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (uint64_t)n_hap * wpr) return;
   const uint32_t h = (uint32_t)(i / wpr), wb = (uint32_t)(i % wpr);
   const uint64_t lo = hv_off[h];
   const int K = (int)(hv_off[h + 1] - lo);
-  const int32_t p_lo = (int32_t)(wb * HAWK_BLOCK * 32u), p_hi = p_lo + HAWK_BLOCK * 32;
+  const int32_t p_lo = (int32_t)(wb * HX_TW * 32u), p_hi = p_lo + HX_TW * 32;
   int a = 0, b = K;  // first index with o > p_lo
-  while (a < b) { const int m = (a + b) >> 1; if (hv_o[lo + m] <= p_lo) a = m + 1; else b = m; }
+  while (a < b) { const int m = (a + b) >> 1; if (recs[lo + m].o <= p_lo) a = m + 1; else b = m; }
   int c = a, d = K;  // first index with o >= p_hi
-  while (c < d) { const int m = (c + d) >> 1; if (hv_o[lo + m] < p_hi) c = m + 1; else d = m; }
+  while (c < d) { const int m = (c + d) >> 1; if (recs[lo + m].o < p_hi) c = m + 1; else d = m; }
   const int first = a - 1 < 0 ? 0 : a - 1;
-  int n = c - first;
-  wg_k0[i] = a - 1;
-  wg_n[i] = (uint32_t)(n < 0 ? 0 : (n > HX_MAXV ? HX_MAXV : n));
+  const int want = c - first;
+  const int n = want < 0 ? 0 : (want > HX_MAXV ? HX_MAXV : want);
+  // REF position an output position maps to under variant k's stretch (k < 0: unmodified REF); inside the alt allele:
+  // where the copy behind it starts.  Copies read REF in ascending order over the tile, so the first and the last
+  // output position bound what is read.
+  auto refpos = [&](int k, int32_t p) -> uint32_t {
+    if (k < 0) return (uint32_t)p;
+    const int32_t e = recs[lo + k].o + (int32_t)recs[lo + k].alt_len;
+    return recs[lo + k].rs + (uint32_t)(p > e ? p - e : 0);
+  };
+  const int32_t len = (int32_t)hap_len[h];
+  const int32_t plast = (p_hi < len ? p_hi : len) - 1;
+  uint32_t ws = 0, flags = HX_FITS;
+  if (plast >= p_lo) {
+    ws = (refpos(a - 1, p_lo) >> 5) & ~3u;                 // 16-byte loads stage the window
+    const uint32_t we = (refpos(c - 1, plast) >> 5) + 2;  // a 32-bit read at bit r touches words r >> 5 and (r >> 5) + 1
+    if (we - ws > HX_RW) flags = 0;
+  }
+  if (n == want || want < 0) flags |= HX_ALL;
+  if (a - 1 >= 0) flags |= HX_HEAD;
+  const uint64_t f = lo + (uint64_t)first;
+  tiles[i] = HxTile{(uint32_t)f, (uint32_t)(f >> 32), (uint32_t)n | flags, ws};
 }
 
-__global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(const uint32_t* __restrict__ refA, const uint32_t* __restrict__ refC,
-                                                          const uint32_t* __restrict__ refG, const uint32_t* __restrict__ refT,
-                                                          const uint32_t* __restrict__ v_r0, const uint32_t* __restrict__ v_span,
-                                                          const uint32_t* __restrict__ v_alt_off, const uint32_t* __restrict__ v_alt_len,
-                                                          const uint8_t* __restrict__ alt_codes, const uint64_t* __restrict__ hv_off,
-                                                          const uint32_t* __restrict__ hv_idx, const int32_t* __restrict__ hv_o,
-                                                          const uint32_t* __restrict__ hap_len, uint32_t S, uint32_t wpr /*workgroups per row*/,
-                                                          const int32_t* __restrict__ wg_k0, const uint32_t* __restrict__ wg_n,
-                                                          uint32_t* pA, uint32_t* pC, uint32_t* pG, uint32_t* pT, uint32_t* pV) {
-  __shared__ HxVar s_v[HX_MAXV];
-  const uint32_t h = blockIdx.x / wpr, wb = blockIdx.x % wpr;
-  const uint32_t w = wb * HAWK_BLOCK + threadIdx.x;
-  const uint64_t lo = hv_off[h], hi = hv_off[h + 1];
-  const int K = (int)(hi - lo);
-  const int32_t p_lo = (int32_t)(wb * HAWK_BLOCK * 32u), p_hi = p_lo + HAWK_BLOCK * 32;
-  const int32_t len = (int32_t)hap_len[h];
-  const int s_k0 = wg_k0[blockIdx.x];  // k_hx_index
-  const int n = (int)wg_n[blockIdx.x];
-  const int k0 = s_k0 < 0 ? 0 : s_k0;  // row-local index of the first staged variant
-  for (int i = threadIdx.x; i < n; i += HAWK_BLOCK) {
-    const uint32_t vi = hv_idx[lo + k0 + i];
-    s_v[i] = HxVar{hv_o[lo + k0 + i], v_r0[vi], v_span[vi], v_alt_len[vi], v_alt_off[vi]};
-  }
-  __syncthreads();
-  if (w >= S) return;
-  // more carried variants start inside this workgroup's 8192 positions than LDS holds (> HX_MAXV, i.e. one every
-  // ~40 nt): the ones beyond the staged range are read from global memory (workgroup-uniform flag, rare)
-  const bool overflow = k0 + n < K && hv_o[lo + k0 + n] < p_hi;
-  // variant kk of the row (0 <= kk < K): staged copy when there is one
-  auto getv = [&](int kk) -> HxVar {
-    if (kk >= k0 && kk < k0 + n) return s_v[kk - k0];
-    const uint32_t vi = hv_idx[lo + kk];
-    return HxVar{hv_o[lo + kk], v_r0[vi], v_span[vi], v_alt_len[vi], v_alt_off[vi]};
+// Staged REF word i of a plane lives at (i & 3) * HX_RW / 4 + (i >> 2): a thread owns four consecutive output words, so
+// the lanes of a wave read words 4 apart - a 4-way bank conflict in the natural layout, consecutive banks in this one.
+__device__ __forceinline__ uint32_t hx_slot(uint32_t i) { return (i & 3u) * (HX_RW / 4) + (i >> 2); }
+__device__ __forceinline__ uint32_t hx_low(int n) { return n >= 32 ? 0xffffffffu : (n > 0 ? (1u << n) - 1u : 0u); }
+
+struct HxArgs {
+  const uint32_t* ref[4];
+  uint32_t ref_S;
+  const HxVar* recs;
+  const uint8_t* alt_codes;
+};
+
+// The four words of one thread.  FAST: every record the tile needs and its whole REF image are in LDS (the usual
+// tile); otherwise records beyond the staged ones and / or the REF words come from global memory.  Records are
+// addressed tile-locally: j = 0 is the first staged one, the row's records [row_lo, row_hi) sit around it.
+//
+// A word is written as: REF copied under the mapping in force at its first position (the allele of variant k reaching
+// into the word first, if it does), then one round per variant starting inside the word - its alt bases shifted out of
+// the record's plane bits over what is there, and only when the variant changes the mapping (an indel; a SNV does not)
+// the rest of the word copied again.  A round is ~40 instructions; the first version looped over pieces (copy, allele,
+// copy ...: three rounds of both branches per variant, 1000 vector instructions per wave).
+template <bool FAST>
+__device__ __forceinline__ void hx_words(const HxArgs& g, const HxVar* __restrict__ s_v, const uint32_t (*__restrict__ s_ref)[HX_RW],
+                                         const HxVar* __restrict__ first, int n, int j_end /* records of the row from `first` on */,
+                                         bool head, bool staged, uint32_t ws, int32_t p0, int32_t len,
+                                         uint32_t (&oA)[4], uint32_t (&oC)[4], uint32_t (&oG)[4], uint32_t (&oT)[4], uint32_t (&oV)[4]) {
+  auto getv = [&](int j) -> HxVar { return FAST || j < n ? s_v[j] : first[j]; };
+  // FAST: a variant behind the staged ones starts behind the tile - all that matters about it
+  auto geto = [&](int j) -> int32_t {
+    if (FAST) return j < n ? s_v[j].o : 0x7fffffff;
+    return j < n ? s_v[j].o : (j < j_end ? first[j].o : 0x7fffffff);
   };
-  auto geto = [&](int kk) -> int32_t { return kk >= k0 && kk < k0 + n ? s_v[kk - k0].o : hv_o[lo + kk]; };
-  uint32_t oA = 0, oC = 0, oG = 0, oT = 0, oV = 0;
-  const int32_t p0 = (int32_t)(w * 32u);
-  if (p0 < len) {
-    const int32_t pend = p0 + 32 < len ? p0 + 32 : len;
-    // k: row-local index of the last carried variant with o <= p0 (-1: none, the word starts in unmodified REF).
-    // Variants before k0 start before the workgroup's first position and before variant k0 (or there is none <= p_lo),
-    // so the search range is [k0, k0 + n), extended to the rest of the row in overflow mode.
-    int a = k0, b = overflow ? K : k0 + n;
-    while (a < b) { const int m = (a + b) >> 1; if (geto(m) <= p0) a = m + 1; else b = m; }
-    int k = a - 1;
-    int32_t cur = p0;
-    while (cur < pend) {  // every iteration advances cur or k; k only while variants start inside the word
-      const bool havev = k >= 0;
-      HxVar v = HxVar{0, 0, 0, 0, 0};
-      if (havev) v = getv(k);
-      const int32_t next_o = k + 1 < K ? geto(k + 1) : 0x7fffffff;  // output start of the following variant
-      if (havev && cur < v.o + (int32_t)v.alt_len) {
-        // alt allele bases [cur - o, ...)
-        const int32_t e = v.o + (int32_t)v.alt_len < pend ? v.o + (int32_t)v.alt_len : pend;
-        for (int32_t q = cur; q < e; ++q) {
-          const uint32_t c = alt_codes[v.alt_off + (uint32_t)(q - v.o)], bit = 1u << (q - p0);
-          if (c & 1u) oA |= bit; if (c & 2u) oC |= bit; if (c & 4u) oG |= bit; if (c & 8u) oT |= bit;
-          oV |= bit;
-        }
-        cur = e;
-      } else {
-        // copy REF: r = position in REF of output position cur
-        const uint32_t r = havev ? v.r0 + v.span + (uint32_t)(cur - (v.o + (int32_t)v.alt_len)) : (uint32_t)cur;
-        const int32_t e = pend < next_o ? pend : next_o;
-        const int nb = e - cur;
-        if (nb > 0) {
-          const uint32_t m = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
-          const int sh = cur - p0;
-          oA |= (ext_glb(refA, r).lo & m) << sh; oC |= (ext_glb(refC, r).lo & m) << sh;
-          oG |= (ext_glb(refG, r).lo & m) << sh; oT |= (ext_glb(refT, r).lo & m) << sh;
-          cur = e;
+  // 32 bits of REF plane pl from bit r.  A read under a mapping that a later variant of the word replaces, or of bits
+  // past the end of the row, may point outside what exists: the word index is clamped, the bits are overwritten / masked.
+  auto ref32 = [&](int pl, uint32_t r) -> uint32_t {
+    if (FAST || staged) {
+      uint32_t w = (r >> 5) - ws;
+      w = w < HX_RW - 2 ? w : HX_RW - 2;
+      return fsh(s_ref[pl][hx_slot(w)], s_ref[pl][hx_slot(w + 1)], r & 31u);
+    }
+    const uint32_t w = (r >> 5) < g.ref_S - 3 ? (r >> 5) : g.ref_S - 3;
+    return ext_glb(g.ref[pl], (w << 5) | (r & 31u)).lo;
+  };
+  // k: tile-local index of the last carried variant with o <= p0 (-1: none; only possible when the tile starts in
+  // unmodified REF).  Records before the first staged one start before it.
+  int a = head ? 1 : 0, b = FAST ? n : j_end;
+  while (a < b) { const int m = (a + b) >> 1; if (geto(m) <= p0) a = m + 1; else b = m; }
+  int k = a - 1;
+  // the stretch in force, reloaded when k moves: alt allele [v.o, v_end), behind it REF copied with r = r_base + p
+  HxVar v;
+  v.o = 0; v.rs = 0; v.alt_len = 0; v.alt_off = 0; v.m[0] = v.m[1] = v.m[2] = v.m[3] = 0;
+  int32_t v_end = 0, r_base = 0, next_o = 0x7fffffff;  // k < 0: an empty allele at position 0, REF copied 1:1
+  auto load = [&]() {
+    if (k >= 0) {
+      v = getv(k);
+      v_end = v.o + (int32_t)v.alt_len;
+      r_base = (int32_t)v.rs - v_end;
+    }
+    next_o = geto(k + 1);  // output start of the following variant
+  };
+  load();
+#pragma unroll
+  for (int wi = 0; wi < 4; ++wi) {
+    const int32_t wp0 = p0 + 32 * wi;
+    const int32_t wend = wp0 + 32 < len ? wp0 + 32 : len;
+    if (next_o <= wp0) { ++k; load(); }  // a variant starting exactly at the word
+    uint32_t xA = 0, xC = 0, xG = 0, xT = 0, xV = 0;
+    int32_t cs = 0;  // first bit of the word the REF copy fills
+    if (wp0 < v_end) {  // the allele of variant k reaches into (or starts at) the word
+      const int src = wp0 - v.o, na = v_end - wp0;
+      const uint32_t am = hx_low(na);
+      if (v.alt_len <= 32u) {
+        xA = (v.m[0] >> src) & am; xC = (v.m[1] >> src) & am; xG = (v.m[2] >> src) & am; xT = (v.m[3] >> src) & am;
+      } else {  // an insertion longer than a word: base by base from the allele text
+        for (int32_t q = wp0; q < v_end && q < wend; ++q) {
+          const uint32_t c = g.alt_codes[v.alt_off + (uint32_t)(q - v.o)], bit = 1u << (q - wp0);
+          if (c & 1u) xA |= bit; if (c & 2u) xC |= bit; if (c & 4u) xG |= bit; if (c & 8u) xT |= bit;
         }
       }
-      if (cur >= next_o) ++k;  // the next variant starts here
+      xV = am;
+      cs = na;
+    }
+    if (cs < 32) {
+      const uint32_t r = (uint32_t)(r_base + wp0 + cs);
+      xA |= ref32(0, r) << cs; xC |= ref32(1, r) << cs; xG |= ref32(2, r) << cs; xT |= ref32(3, r) << cs;
+    }
+    while (next_o < wend) {  // one round per variant starting inside the word
+      const int32_t rb_prev = r_base;
+      ++k; load();
+      const int s = v.o - wp0;  // 1 .. 31
+      const uint32_t am = hx_low((int)v.alt_len) << s;
+      if (v.alt_len <= 32u) {
+        xA = (xA & ~am) | (v.m[0] << s); xC = (xC & ~am) | (v.m[1] << s); xG = (xG & ~am) | (v.m[2] << s); xT = (xT & ~am) | (v.m[3] << s);
+      } else {
+        xA &= ~am; xC &= ~am; xG &= ~am; xT &= ~am;
+        for (int32_t q = v.o; q < wend; ++q) {  // the allele covers the rest of the word
+          const uint32_t c = g.alt_codes[v.alt_off + (uint32_t)(q - v.o)], bit = 1u << (q - wp0);
+          if (c & 1u) xA |= bit; if (c & 2u) xC |= bit; if (c & 4u) xG |= bit; if (c & 8u) xT |= bit;
+        }
+      }
+      xV |= am;
+      const int e = v_end - wp0;  // where REF resumes
+      if (r_base != rb_prev && e < 32) {  // an indel: the rest of the word maps elsewhere
+        const uint32_t cm = 0xffffffffu << e, r = v.rs;
+        xA = (xA & ~cm) | (ref32(0, r) << e); xC = (xC & ~cm) | (ref32(1, r) << e);
+        xG = (xG & ~cm) | (ref32(2, r) << e); xT = (xT & ~cm) | (ref32(3, r) << e);
+      }
+    }
+    const uint32_t wm = hx_low(wend - wp0);  // the row ends inside (or before) the word
+    oA[wi] = xA & wm; oC[wi] = xC & wm; oG[wi] = xG & wm; oT[wi] = xT & wm; oV[wi] = xV & wm;
+  }
+}
+
+__global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(HxArgs g, const uint64_t* __restrict__ hv_off, const uint32_t* __restrict__ hap_len,
+                                                          uint32_t S, uint32_t wpr /*tiles per row*/, const HxTile* __restrict__ tiles,
+                                                          uint32_t* pA, uint32_t* pC, uint32_t* pG, uint32_t* pT, uint32_t* pV) {
+  __shared__ HxVar s_v[HX_MAXV];
+  __shared__ uint32_t s_ref[4][HX_RW];
+  const uint32_t h = blockIdx.x / wpr, wb = blockIdx.x % wpr;
+  const uint32_t w0 = wb * HX_TW + threadIdx.x * 4u;
+  const HxTile t = tiles[blockIdx.x];  // k_hx_index
+  const int32_t len = (int32_t)hap_len[h];
+  const int n = (int)(t.n_flags & 0xffffu);
+  const bool staged = (t.n_flags & HX_FITS) != 0, all = (t.n_flags & HX_ALL) != 0, head = (t.n_flags & HX_HEAD) != 0;
+  const uint32_t ws = t.ws;
+  const HxVar* first = g.recs + (((uint64_t)t.first_hi << 32) | t.first_lo);
+  // both stagings are independent coalesced loads, in flight together
+  if (staged) {  // the REF words the tile's copies read: 16-byte loads, each word to its swizzled slot
+    for (uint32_t i = threadIdx.x; i < HX_RW / 4; i += HAWK_BLOCK) {
+      const uint32_t w = ws + 4 * i + 4 <= g.ref_S ? ws + 4 * i : g.ref_S - 4;  // rows are whole 16-byte quads
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) {
+        const uint4 q = *reinterpret_cast<const uint4*>(g.ref[pl] + w);
+        s_ref[pl][i] = q.x; s_ref[pl][HX_RW / 4 + i] = q.y; s_ref[pl][2 * (HX_RW / 4) + i] = q.z; s_ref[pl][3 * (HX_RW / 4) + i] = q.w;
+      }
     }
   }
-  const size_t o = (size_t)h * S + w;
-  pA[o] = oA; pC[o] = oC; pG[o] = oG; pT[o] = oT; pV[o] = oV;
+  if ((int)threadIdx.x < n) s_v[threadIdx.x] = first[threadIdx.x];  // n <= HX_MAXV < workgroup size
+  __syncthreads();
+  if (w0 >= S) return;
+  uint32_t oA[4] = {0, 0, 0, 0}, oC[4] = {0, 0, 0, 0}, oG[4] = {0, 0, 0, 0}, oT[4] = {0, 0, 0, 0}, oV[4] = {0, 0, 0, 0};
+  const int32_t p0 = (int32_t)(w0 * 32u);
+  if (p0 < len) {
+    if (staged && all) {
+      hx_words<true>(g, s_v, s_ref, first, n, n, head, true, ws, p0, len, oA, oC, oG, oT, oV);
+    } else {  // more records than LDS holds start inside the tile (one every 200 nt over all of it), or a long REF image
+      const int j_end = (int)(g.recs + hv_off[h + 1] - first);
+      hx_words<false>(g, s_v, s_ref, first, n, j_end, head, staged, ws, p0, len, oA, oC, oG, oT, oV);
+    }
+  }
+  const size_t o = (size_t)h * S + w0;  // S and w0 are multiples of 4: one 16-byte store per plane
+  *reinterpret_cast<uint4*>(pA + o) = make_uint4(oA[0], oA[1], oA[2], oA[3]);
+  *reinterpret_cast<uint4*>(pC + o) = make_uint4(oC[0], oC[1], oC[2], oC[3]);
+  *reinterpret_cast<uint4*>(pG + o) = make_uint4(oG[0], oG[1], oG[2], oG[3]);
+  *reinterpret_cast<uint4*>(pT + o) = make_uint4(oT[0], oT[1], oT[2], oT[3]);
+  *reinterpret_cast<uint4*>(pV + o) = make_uint4(oV[0], oV[1], oV[2], oV[3]);
 }
 
-void hawk_launch_hx_index(hipStream_t st, const uint64_t* hv_off, const int32_t* hv_o, uint32_t n_hap, uint32_t S, int32_t* wg_k0,
-                          uint32_t* wg_n) {
-  const uint32_t wpr = (S + HAWK_BLOCK - 1) / HAWK_BLOCK;
+uint32_t hawk_hx_tiles_per_row(uint32_t S) { return (S + HX_TW - 1) / HX_TW; }
+size_t hawk_hx_record_bytes() { return sizeof(HxVar); }
+size_t hawk_hx_tile_bytes() { return sizeof(HxTile); }
+
+// plan creation: records of all carried variants, then the per-tile index over them
+void hawk_launch_hx_prepare(hipStream_t st, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o, uint64_t ncar,
+                            const uint32_t* v_r0, const uint32_t* v_span, const uint32_t* v_alt_off, const uint32_t* v_alt_len,
+                            const void* v_am, const uint32_t* hap_len, uint32_t n_hap, uint32_t S, void* recs, void* tiles) {
+  if (ncar)
+    hipLaunchKernelGGL(k_hx_records, dim3((unsigned)((ncar + 255) / 256)), dim3(256), 0, st, hv_idx, hv_o, ncar, v_r0, v_span, v_alt_off,
+                       v_alt_len, (const uint4*)v_am, (HxVar*)recs);
+  const uint32_t wpr = hawk_hx_tiles_per_row(S);
   const uint64_t nwg = (uint64_t)n_hap * wpr;
-  hipLaunchKernelGGL(k_hx_index, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, hv_off, hv_o, n_hap, wpr, wg_k0, wg_n);
+  hipLaunchKernelGGL(k_hx_index, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, st, hv_off, (const HxVar*)recs, hap_len, n_hap, wpr,
+                     (HxTile*)tiles);
 }
 
-void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, const uint32_t* v_r0, const uint32_t* v_span,
-                          const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, const uint64_t* hv_off,
-                          const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* hap_len, uint32_t n_hap, uint32_t S,
-                          uint32_t* const* plane, int32_t* wg_k0, uint32_t* wg_n) {
-  const uint32_t wpr = (S + HAWK_BLOCK - 1) / HAWK_BLOCK;
-  hipLaunchKernelGGL(k_hx_build, dim3(n_hap * wpr), dim3(HAWK_BLOCK), 0, st, ref[0], ref[1], ref[2], ref[3], v_r0, v_span, v_alt_off,
-                     v_alt_len, alt_codes, hv_off, hv_idx, hv_o, hap_len, S, wpr, wg_k0, wg_n, plane[0], plane[1], plane[2], plane[3],
-                     plane[4]);
+void hawk_launch_hx_build(hipStream_t st, const uint32_t* const* ref, uint32_t ref_S, const void* recs, const uint8_t* alt_codes,
+                          const uint64_t* hv_off, const uint32_t* hap_len, uint32_t n_hap, uint32_t S, uint32_t* const* plane,
+                          const void* tiles) {
+  const uint32_t wpr = hawk_hx_tiles_per_row(S);
+  HxArgs g;
+  for (int p = 0; p < 4; ++p) g.ref[p] = ref[p];
+  g.ref_S = ref_S; g.recs = (const HxVar*)recs; g.alt_codes = alt_codes;
+  hipLaunchKernelGGL(k_hx_build, dim3(n_hap * wpr), dim3(HAWK_BLOCK), 0, st, g, hv_off, hap_len, S, wpr, (const HxTile*)tiles, plane[0],
+                     plane[1], plane[2], plane[3], plane[4]);
 }
 
 __device__ __forceinline__ uint64_t fmix64(uint64_t k) {

@@ -210,6 +210,49 @@ def test_device_expansion_matches_host_expansion_200kb():
         assert ds.host_meta[r].scan == haps[j].scan
 
 
+def test_device_expansion_crowded_tiles_and_long_deletions():
+    # what the expansion kernel stages per tile of 32768 output positions has a capacity: 256 carried variants and the
+    # tile's image in REF plus 2048 net deleted bases.  Here one tile carries a SNV every 25 nt (the variants beyond the
+    # staged ones come from global memory), another loses 4 x 1500 nt to deletions (its REF image does not fit: copies
+    # read global memory), and a 400-nt insertion crosses a word-quad boundary.
+    from crisprhawk_hip.workload import build_phased_haplotypes, expand_on_device
+    reg = synth.make_region(7351, "chrK", 170_000, 5_000, 165_000)
+    rng = np.random.default_rng(7352)
+    seq = reg.contig_seq
+    n_samples = 3
+    reg.samples = [f"S{i:04d}" for i in range(n_samples)]
+    sites = []
+    def gt(p):
+        g = (rng.random((n_samples, 2)) < p).astype(np.uint8)
+        g[0, 0] = 1
+        return g
+    for pos in range(20_000, 60_000, 25):
+        refb = seq[pos - 1]
+        if refb not in "ACGT":
+            continue
+        sites.append(synth.VariantSite(pos, refb, "ACGT"[("ACGT".index(refb) + 1) % 4], 0.7, gt(0.7)))
+    for pos in (70_000, 76_000, 82_000, 88_000):
+        sites.append(synth.VariantSite(pos, seq[pos - 1:pos + 1500], seq[pos - 1], 0.5, gt(0.5)))
+    pos = 120_000
+    sites.append(synth.VariantSite(pos, seq[pos - 1], seq[pos - 1] + "".join("ACGT"[b] for b in rng.integers(0, 4, 400)), 0.5, gt(0.5)))
+    for pos in range(130_000, 160_000, 700):
+        refb = seq[pos - 1]
+        if refb not in "ACGT":
+            continue
+        sites.append(synth.VariantSite(pos, refb, "ACGT"[("ACGT".index(refb) + 2) % 4], 0.3, gt(0.3)))
+    reg.variants = sites
+    haps, info_h = build_phased_haplotypes(reg, 3)
+    ds, info_d, ms, kept = expand_on_device(reg, 3)
+    assert len(kept) == len(haps) and [sorted(i.samples) for i in info_d] == [sorted(i.samples) for i in info_h]
+    want = DeviceHapSet(haps).planes()
+    got = ds.planes()
+    for j, r in enumerate(kept):
+        n = (len(haps[j].seq) + 31) // 32
+        assert np.array_equal(got[:, r, :n], want[:, j, :n])
+        assert not got[:, r, n:].any()
+        assert np.array_equal(ds.host_meta[r].seg.rel, haps[j].seg.rel) and np.array_equal(ds.host_meta[r].seg.gen, haps[j].seg.gen)
+
+
 def _dense_region(seed, sites, samples):
     reg = synth.make_region(seed, "chrX", 75_000, 2_000, 72_000)
     synth.add_phased_variants(reg, seed + 1, sites, samples, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.6, af_max=0.95)
