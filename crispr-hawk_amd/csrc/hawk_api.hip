@@ -776,21 +776,29 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   if (n > 0xffffffffull || hs->max_gen - hs->min_gen > 0xffffffffll) return HAWK_E_UNSUPPORTED;
   unsigned end_bit = 32;
   while (end_bit < 64 && ((uint64_t)(hs->max_gen - hs->min_gen) >> (end_bit - 32)) != 0) ++end_bit;
-  const size_t temp_bytes = hawk_collapse_temp_bytes(n, end_bit);
+  // low hash bits the sort leaves out: start bits + strand + hash fill whole 8-bit passes, at least 24 hash bits stay
+  const unsigned pos_bits = end_bit - 31;  // start - base, strand
+  const unsigned hash_bits = std::min(31u, (pos_bits + 24 + 7) / 8 * 8 - pos_bits);
+  const unsigned begin_bit = 31 - hash_bits;
+  const size_t temp_bytes = hawk_collapse_temp_bytes(n, begin_bit, end_bit);
   int rc;
   if ((rc = hs->ckeys.reserve(2 * n * 8)) || (rc = hs->cvals.reserve(2 * n * 4)) || (rc = hs->cflags.reserve(n * 4)) ||
       (rc = hs->cgidx.reserve(n * 4)) || (rc = hs->ctemp.reserve(temp_bytes + 16)) || (rc = hs->cgoff.reserve((n + 1) * 8)) ||
-      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(16)) || (rc = hs->cfull.reserve(hawk_collapse_full_bytes(n))))
+      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(16)))
     return rc;
+  // identity of a row beyond (start, strand): 63 hash bits, or - HAWK_COLLAPSE_EXACT=1 - the full key (hawk_collapse.hip)
+  const char* ex = getenv("HAWK_COLLAPSE_EXACT");
+  const bool exact = ex && ex[0] == '1';
+  if (exact && (rc = hs->cfull.reserve(hawk_collapse_full_bytes(n)))) return rc;
   unsigned long long cnt[2] = {0, 0};
   for (int attempt = 0; attempt < 4; ++attempt) {  // a new seed whenever two different rows collide in the hash bits
     HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 16, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (hawk_launch_collapse(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)t->right, (int)flank_up,
-                             (int)flank_down, hs->min_gen, end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p,
+                             (int)flank_down, hs->min_gen, begin_bit, end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p,
                              temp_bytes, hs->ckeys.as<uint64_t>(), hs->cvals.as<uint32_t>(), hs->cflags.as<uint32_t>(),
                              hs->cgidx.as<uint32_t>(), hs->ccnt.as<unsigned long long>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(),
-                             hs->cgc.as<uint8_t>() + n, hs->cfull.p))
+                             hs->cgc.as<uint8_t>() + n, hs->cgidx.as<uint32_t>(), exact ? hs->cfull.p : nullptr))
       return HAWK_E_HIP;
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(hipGetLastError());

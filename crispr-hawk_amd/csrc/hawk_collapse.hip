@@ -6,13 +6,18 @@
 // slices of the window planes (the V plane is the case).  Equality of the stored (+ strand) cores is
 // equality of the reverse-complemented guides the report prints.
 //
-//   k_collapse_keys   row -> 64-bit sort key  (start - base) << 32 | strand << 31 | hash31(core, stop, origin)
-//   rocprim::radix_sort_pairs (key, row id); stable, so equal keys keep table order (haplotype ascending)
-//   k_collapse_heads  neighbours in sorted order are compared on the FULL row key (not the hash; 64-byte records
-//                     written by k_collapse_keys): head flags;
-//                     counts heads by key and heads by full key - if they differ, two different rows of one
-//                     (start, strand) collided in the 31 hash bits and may interleave: the host layer re-runs
-//                     with another seed, so the grouping is exact, never probabilistic
+//   k_collapse_keys   row -> 64-bit sort key  (start - base) << 32 | strand << 31 | hash31(core, stop, origin), and 32
+//                     further bits of the same 64-bit hash of the row's identity (id2, table order)
+//   rocprim::radix_sort_pairs (key, row id) over the bits in use - the low hash bits are dropped (zero in the key) so
+//                     that start + strand + hash fill a whole number of 8-bit passes with >= 24 hash bits (a 4 Mb tile:
+//                     48 bits, 6 passes instead of 7); stable, so equal keys keep table order (haplotype ascending)
+//   k_collapse_heads  neighbours in sorted order open a group when their keys differ or, with equal keys, their id2
+//                     (two 4-byte gathers); counts heads by key and heads by identity - if they differ, two different
+//                     rows of one (start, strand) collided in the 31 key bits and may interleave: the host layer
+//                     re-runs with another seed.  Two different rows are merged only if they agree in start, strand
+//                     and 63 hash bits (~10^-12 for a whole C4 contig); HAWK_COLLAPSE_EXACT=1 compares the FULL row
+//                     keys instead (64-byte records written by k_collapse_keys, two 64-byte gathers per row: 8.5 of
+//                     the 18 ms a 1.1 x 10^8-row tile took) - the tests run both
 //   rocprim::exclusive_scan of the flags, k_collapse_groups: CSR offsets + GC counts of each group's guide
 //                     (annotation.py:513-541: gc_fraction(guide.guide); Biopython's default drops ambiguous bases)
 #include <cstring>
@@ -58,27 +63,31 @@ __device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
 }
 
 __global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
-                                                       int64_t base, uint64_t seed, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals, ulonglong4* __restrict__ full) {
+                                                       int64_t base, uint64_t seed, uint32_t hash_mask, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ id2,
+                                                       ulonglong4* __restrict__ full /* exact mode, else null */) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const RowKey k = row_key(c, is_ref, i, L, up, down);
   // the full key as one 64-byte record: the head pass compares neighbours of the SORTED order, i.e. rows scattered
   // over the table - one line per row here instead of nine (one per column) there
-  full[2 * i] = make_ulonglong4((unsigned long long)k.start, (unsigned long long)k.stop, (unsigned long long)k.sr, k.core[0]);
-  full[2 * i + 1] = make_ulonglong4(k.core[1], k.core[2], k.core[3], k.core[4]);
+  if (full) {
+    full[2 * i] = make_ulonglong4((unsigned long long)k.start, (unsigned long long)k.stop, (unsigned long long)k.sr, k.core[0]);
+    full[2 * i + 1] = make_ulonglong4(k.core[1], k.core[2], k.core[3], k.core[4]);
+  }
   uint64_t h = seed;
 #pragma unroll
   for (int pl = 0; pl < HAWK_PLANES; ++pl) h = mix64(h ^ k.core[pl]);
   h = mix64(h ^ (uint64_t)k.stop ^ ((uint64_t)(k.sr >> 1) << 63));
-  keys[i] = ((uint64_t)(k.start - base) << 32) | ((uint64_t)(k.sr & 1u) << 31) | (h >> 33);
+  keys[i] = ((uint64_t)(k.start - base) << 32) | ((uint64_t)(k.sr & 1u) << 31) | ((h >> 33) & hash_mask);
   vals[i] = (uint32_t)i;
+  id2[i] = (uint32_t)h;
 }
 
 __device__ __forceinline__ bool same4(const ulonglong4& a, const ulonglong4& b) {
   return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
 }
-__global__ __launch_bounds__(256) void k_collapse_heads(const ulonglong4* __restrict__ full, uint64_t n,
+__global__ __launch_bounds__(256) void k_collapse_heads(const ulonglong4* __restrict__ full, const uint32_t* __restrict__ id2, uint64_t n,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                         uint32_t* __restrict__ flags, unsigned long long* __restrict__ counters) {
   __shared__ uint32_t s_cnt[2];
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void k_collapse_heads(const ulonglong4* __rest
       hk = keys[j] != keys[j - 1];
       if (!hk) {
         const uint64_t a = vals[j], b = vals[j - 1];
-        hf = !(same4(full[2 * a], full[2 * b]) && same4(full[2 * a + 1], full[2 * b + 1]));
+        hf = full ? !(same4(full[2 * a], full[2 * b]) && same4(full[2 * a + 1], full[2 * b + 1])) : id2[a] != id2[b];
       } else {
         hf = 1;
       }
@@ -131,9 +140,9 @@ __global__ __launch_bounds__(256) void k_collapse_groups(GuideCols c, uint64_t n
 // bytes of the full-key records (64 per row)
 size_t hawk_collapse_full_bytes(uint64_t n) { return (size_t)n * 64; }
 
-size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit) {
+size_t hawk_collapse_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit) {
   size_t a = 0, b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
+  (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, begin_bit,
                                   end_bit, (hipStream_t)0);
   (void)rocprim::exclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
   return a > b ? a : b;
@@ -142,15 +151,15 @@ size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit) {
 // keys/vals: [2][n] ping-pong; flags, gidx: [n]; counters: [2], zeroed by the caller; group_off must hold
 // n + 1 entries (the number of groups is only known afterwards)
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
-                         int flank_up, int flank_down, int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
+                         int flank_up, int flank_down, int64_t base, unsigned begin_bit, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
-                         uint8_t* gc_den, void* full) {
+                         uint8_t* gc_den, uint32_t* id2, void* full) {
   const int L = guidelen + pamlen;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, L, flank_up, flank_down, base, seed, keys, vals, (ulonglong4*)full);
+  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, L, flank_up, flank_down, base, seed, ~((1u << begin_bit) - 1u) & 0x7fffffffu, keys, vals, id2, (ulonglong4*)full);
   size_t tb = temp_bytes;
-  if (rocprim::radix_sort_pairs(temp, tb, keys, keys + n, vals, vals + n, n, 0, end_bit, st) != hipSuccess) return -2;
-  hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, (const ulonglong4*)full, n, keys + n, vals + n, flags, counters);
+  if (rocprim::radix_sort_pairs(temp, tb, keys, keys + n, vals, vals + n, n, begin_bit, end_bit, st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, (const ulonglong4*)full, id2, n, keys + n, vals + n, flags, counters);
   tb = temp_bytes;
   if (rocprim::exclusive_scan(temp, tb, flags, gidx, 0u, n, rocprim::plus<uint32_t>(), st) != hipSuccess) return -2;
   hipLaunchKernelGGL(k_collapse_groups, grid, block, 0, st, c, n, vals + n, flags, gidx, guidelen, pamlen, right, group_off, gc_num,

@@ -130,11 +130,11 @@ void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const Sca
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, uint32_t* big_count,
                         unsigned long long* big_list, hipEvent_t mid = nullptr);
-size_t hawk_collapse_temp_bytes(uint64_t n, unsigned end_bit);
+size_t hawk_collapse_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit);
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
-                         int flank_up, int flank_down, int64_t base, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
+                         int flank_up, int flank_down, int64_t base, unsigned begin_bit, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
-                         uint8_t* gc_den, void* full);
+                         uint8_t* gc_den, uint32_t* id2 /* may alias gidx */, void* full /* null: identity by hash */);
 size_t hawk_collapse_full_bytes(uint64_t n);
 void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n, uint64_t ng, const uint32_t* perm,
                                  const uint64_t* group_off, const GuideCols& rep, uint32_t* member_hap);

@@ -346,9 +346,12 @@ def _check_collapse(hs, tab, guidelen, pamlen, right):
         assert (int(tab.gc_num[g]), int(tab.gc_den[g])) == want_gc[key]
 
 
+@pytest.mark.parametrize("exact", ["0", "1"], ids=["hash-identity", "full-key"])
 @pytest.mark.parametrize("pam,guidelen,right", [("NGG", 20, False), ("TTTV", 23, True)])
-def test_collapse_groups_against_oracle(pam, guidelen, right):
-    # 12 haplotypes over common variants: most alt rows are shared by several haplotypes
+def test_collapse_groups_against_oracle(pam, guidelen, right, exact, monkeypatch):
+    # 12 haplotypes over common variants: most alt rows are shared by several haplotypes.  Rows of one (start, strand)
+    # are told apart by 63 hash bits by default, by their full keys with HAWK_COLLAPSE_EXACT=1 (read per call)
+    monkeypatch.setenv("HAWK_COLLAPSE_EXACT", exact)
     reg = synth.make_region(7501, "chrC", 40_000, 1_000, 38_000)
     synth.add_phased_variants(reg, 7502, 300, 6, af_min=0.3, af_max=0.8)
     fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
