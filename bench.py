@@ -367,7 +367,17 @@ def gather_once(R: Ranks, ds, step, n_hap_total):
 
 def end_to_end(args, R: Ranks, reg, pam, mm, pt, info, kept, c1):
     """in-memory records -> device expansion -> search + CFDon -> collapse -> D2H of the report groups,
-    wall clock (rank 0, N = 1).  With --report the guide report (f2) is assembled from the groups as well."""
+    wall clock (rank 0, N = 1).  With --report the guide report (f2) is assembled from the groups as well.
+    The pipeline runs twice: the first pass pays for whatever HBM the library's allocator does not hold yet (hipMalloc of
+    the 2 GB of guide columns alone is ~50 ms) and is reported as `first_run_wall_s`; `wall_s` is the second pass."""
+    first = _end_to_end_once(args, R, reg, pam, mm, pt, c1, False)
+    res = _end_to_end_once(args, R, reg, pam, mm, pt, c1, True)
+    res["first_run_wall_s"] = first["wall_s"]
+    res["first_run_stages_s"] = first["stages_s"]
+    return res
+
+
+def _end_to_end_once(args, R: Ranks, reg, pam, mm, pt, c1, extras):
     from crisprhawk_hip.workload import expand_on_device
     t0 = time.perf_counter()
     ds, info2, ems, kept2 = expand_on_device(reg, len(pam), device=R.device)
@@ -387,7 +397,7 @@ def end_to_end(args, R: Ranks, reg, pam, mm, pt, info, kept, c1):
            "rows": tab.n_rows, "groups": g.n_groups, "d2h_bytes": int(d2h),
            "what": "in-memory variant records + genotype matrix -> hawk_xplan_create/run -> hawk_search -> hawk_table_collapse -> "
                    "hawk_table_collapse_export; FASTA/VCF text ingest (f3) is timed by --vcf"}
-    if args.report and not c1:
+    if extras and args.report and not c1:
         from crisprhawk_hip import reports
         from crisprhawk_hip.workload import hap_labels
         t4 = time.perf_counter()
@@ -401,7 +411,7 @@ def end_to_end(args, R: Ranks, reg, pam, mm, pt, info, kept, c1):
                                  "+ reports.to_tsv"}
         res["wall_with_report_s"] = t6 - t0
         del txt
-    if args.vcf and not c1:
+    if extras and args.vcf and not c1:
         res["vcf_ingest"] = time_vcf_ingest(reg, ds, len(pam), R.device)
     tab.close()
     ds.close()

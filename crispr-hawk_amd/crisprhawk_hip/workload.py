@@ -241,23 +241,29 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     hv_off[2:] = np.cumsum(counts_live)
     hv_idx = np.ascontiguousarray(hv_idx, dtype=np.uint32)
     hv_o = np.ascontiguousarray(hv_o, dtype=np.int32)
-    row_of = np.repeat(np.arange(len(live)), counts_live)
     hap_len = np.concatenate(([n_ref], n_ref + np.asarray(tot_live, dtype=np.int64))).astype(np.uint32)
-    if len(hv_idx):
+    if len(hv_idx) and own is None:
         # the reference's clamp (haplotype.py:199-201) would fire.  It compares with the REGION's original length, which a
         # tile of a larger region cannot know (the shift accumulated before the tile): tiled searches do not reproduce
-        # that end-of-region error (divergences).
-        if own is None and np.any(hv_o.astype(np.int64) + span[hv_idx] > n_ref):
+        # that end-of-region error (divergences).  Only entries within the longest REF allele of the region's
+        # end can trip it: one comparison over the lists, the gather over the few that pass.
+        near = np.flatnonzero(hv_o > n_ref - int(span.max()))
+        if len(near) and np.any(hv_o[near].astype(np.int64) + span[hv_idx[near]] > n_ref):
             raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
-        same_row = row_of[1:] == row_of[:-1]
-        if np.any(same_row & (r0[hv_idx[1:]] < r0[hv_idx[:-1]] + span[hv_idx[:-1]])):
-            raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
     L = _lib.lib()
     xh = C.c_void_p()
     u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
     arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(alt_codes)]
-    _lib.check(L.hawk_xplan_create(ref_set._h, nv, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), len(alt_codes),
-                                   n_hap, _p(hv_off), _p(hv_idx), _p(hv_o), _p(hap_len), C.byref(xh)), "hawk_xplan_create")
+    rc = L.hawk_xplan_create(ref_set._h, nv, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), len(alt_codes),
+                             n_hap, _p(hv_off), _p(hv_idx), _p(hv_o), _p(hap_len), C.byref(xh))
+    if rc == _lib.HAWK_E_INVALID and len(hv_idx) > 1:
+        # the library validates every list it is given (ascending, non-overlapping, prefix sums consistent); say which
+        # rule of the reference a refused input broke (haplotype.py:214-252 raises on overlapping variants of one copy)
+        row_of = np.repeat(np.arange(len(live)), counts_live)
+        same_row = row_of[1:] == row_of[:-1]
+        if np.any(same_row & (r0[hv_idx[1:]] < r0[hv_idx[:-1]] + span[hv_idx[:-1]])):
+            raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
+    _lib.check(rc, "hawk_xplan_create")
     plan = ExpansionPlan(xh, hap_len, device)
     ds, hashes, ms_val = plan.run(want_hash=True)
     ms = C.c_float(ms_val)
@@ -308,13 +314,11 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     # ---- position-map segments + scan bounds per row ------------------------------------------
     # all rows at once: every carried deletion opens one segment behind it, every carried insertion of n bases
     # opens n + 1 (the inserted bases all map to the anchor position, haplotype.py:106-159)
-    ch_all = chain[hv_idx]
-    ind = np.flatnonzero(ch_all != 0)
-    row_all = row_of + 1  # device row of every list entry (row 0 is REF)
+    ind = np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])  # the carried indels: one byte-table gather over the lists
     o_i = hv_o[ind].astype(np.int64)
     pos_i = r0[hv_idx[ind]] + startp
-    ch_i = ch_all[ind]
-    row_i = row_all[ind]
+    ch_i = chain[hv_idx[ind]]
+    row_i = np.searchsorted(hv_off[1:].astype(np.int64), ind, side="right")  # device row of the entry (row 0 is REF)
     nseg_i = np.where(ch_i < 0, 1, ch_i + 1)
     rep = np.repeat(np.arange(len(ind)), nseg_i)
     first_of = np.cumsum(nseg_i) - nseg_i

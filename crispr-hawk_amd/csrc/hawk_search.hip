@@ -123,8 +123,10 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
   // pass then only serves the tiles whose list did not fit (REF tiles, very dense tiles)
   const bool list_mode = PASS == 0 && lists != nullptr;
   if (PASS == 1 && lists != nullptr && counts[tile] <= LIST_CAP) return;
-  const TileMeta tm = tmeta[tile];  // one scalar load: every haplotype / tile scalar the workgroup needs
-  const uint32_t h = tm.h, blk = tm.blk;
+  // The tile's row and index within the row are arithmetic (tmeta is laid out [row][tile]), so the plane loads below do
+  // not wait for the TileMeta record: both go out together and one level of memory latency leaves the wave's lifetime.
+  const uint32_t h = tile / p.bph, blk = tile - h * p.bph;
+  const TileMeta tm = tmeta[tile];  // one scalar load: every other haplotype / tile scalar the workgroup needs
   const uint32_t u = blk * HAWK_BLOCK + tid;
   const bool active = u < hs.S / 4;
   const size_t rowbase = (size_t)h * hs.S;
@@ -151,8 +153,8 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
   if (ldmask & 2u) load6_issue(hs.plane[1] + rowbase, u, hs.S, active, lc);
   if (ldmask & 4u) load6_issue(hs.plane[2] + rowbase, u, hs.S, active, lg);
   if (ldmask & 8u) load6_issue(hs.plane[3] + rowbase, u, hs.S, active, lt);
-  if (!isref) load6_issue(hs.plane[4] + rowbase, u, hs.S, active, lv);  // workgroup-uniform: REF windows are never filtered
-  else if (lds_planes && active) lv.v = *reinterpret_cast<const uint4*>(hs.plane[4] + rowbase + 4 * (size_t)u);
+  // REF windows are never filtered, but whether this is a REF row is TileMeta's to say: the V plane is fetched either way
+  load6_issue(hs.plane[4] + rowbase, u, hs.S, active, lv);
   uint32_t halo = 0, seg_r = 0xffffffffu;
   int64_t seg_g = 0;
   bool seg_in = false, ovf = false;
