@@ -823,10 +823,51 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_mscan3(const uint32_t* __restric
   }
 }
 
+// k_mscan2 + k_mscan3 in one launch while the partials are few: every workgroup adds up the partials before its own
+// (<= 4096 values out of L2) instead of waiting for a single-workgroup scan kernel in between; the last workgroup
+// leaves the totals, workgroup 0 the shard sums
+__global__ __launch_bounds__(HAWK_BLOCK) void k_mscan23(const uint32_t* __restrict__ counts, uint64_t n,
+                                                         const unsigned long long* __restrict__ partial, uint32_t nb,
+                                                         const unsigned long long* __restrict__ shards, uint64_t* __restrict__ offsets,
+                                                         ScanTotals* __restrict__ totals) {
+  __shared__ uint32_t s_w[HAWK_BLOCK / WAVE];
+  __shared__ unsigned long long s_sum[3];
+  if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long pre = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += HAWK_BLOCK) pre += partial[j];
+  pre = (unsigned long long)wave_sum((uint32_t)pre) + ((unsigned long long)wave_sum((uint32_t)(pre >> 32)) << 32);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && pre) atomicAdd(&s_sum[0], pre);
+  if (blockIdx.x == 0 && shards) {  // 256 (candidates, hits) partial sums of the count pass
+    atomicAdd(&s_sum[1], shards[2 * threadIdx.x]);
+    atomicAdd(&s_sum[2], shards[2 * threadIdx.x + 1]);
+  }
+  const uint64_t i0 = (uint64_t)blockIdx.x * MS_TILE + threadIdx.x * 4;
+  uint32_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = i0 + k < n ? counts[i0 + k] : 0u;
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(c[0] + c[1] + c[2] + c[3], s_w, &tot);  // has the barrier s_sum needs
+  uint64_t run = s_sum[0] + ex;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < n) offsets[i0 + k] = run;
+    run += c[k];
+  }
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == nb - 1) { totals->n_keep = s_sum[0] + tot; totals->n_keep_fwd = 0; }
+    if (blockIdx.x == 0) { totals->n_cand = s_sum[1]; totals->n_hits = s_sum[2]; }
+  }
+}
+
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals) {
   const uint32_t nb = (uint32_t)((n + MS_TILE - 1) / MS_TILE);
   hipLaunchKernelGGL(k_mscan1, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial);
+  if (nb <= 4096 && shards) {
+    hipLaunchKernelGGL(k_mscan23, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial, nb, shards, offsets, totals);
+    return;
+  }
   hipLaunchKernelGGL(k_mscan2, dim3(1), dim3(1024), 0, st, partial, (uint64_t)nb, shards, totals);
   hipLaunchKernelGGL(k_mscan3, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial, offsets);
 }
