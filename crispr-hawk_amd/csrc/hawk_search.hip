@@ -744,7 +744,8 @@ void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const Sca
     // lists != nullptr: small tiles are assembled from their hand-over lists, the named big ones recompute
     if (lists) hipLaunchKernelGGL(k_emit_list, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, lists, out, status);
     if (mid) (void)hipEventRecord(mid, st);  // timing: k_emit_list ends here
-    const dim3 egrid(lists ? (ntile < 2048u ? ntile : 2048u) : ntile);
+    // list mode: a walk over the work list (<= 128 entries per REF tile, usually ~8; one per other big tile)
+    const dim3 egrid(lists ? (ntile * 8u < 2048u ? ntile * 8u : 2048u) : ntile);
     hipLaunchKernelGGL(k_search_emit, egrid, block, 0, st, hs, p, gp, ri, tmeta, counts, offsets, out, status, lists, big_count, big_list);
   }
 }
@@ -860,8 +861,43 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_mscan23(const uint32_t* __restri
   }
 }
 
+// a small region (<= 2048 tiles; C1 has one): the whole scan in ONE workgroup and one launch - thread t owns a run of
+// consecutive counts, the runs' sums are scanned across the workgroup.  (Runs of 19 - one rank's eighth of C3 in one
+// workgroup - were tried: 25 us of dependent loads against 14 us for the two-launch scan.)
+__global__ __launch_bounds__(1024) void k_mscan_one(const uint32_t* __restrict__ counts, uint32_t n, uint32_t ipt,
+                                                     const unsigned long long* __restrict__ shards, uint64_t* __restrict__ offsets,
+                                                     ScanTotals* __restrict__ totals) {
+  __shared__ uint32_t s_w[1024 / WAVE];
+  __shared__ unsigned long long s_aux[2];
+  const uint32_t t = threadIdx.x;
+  if (t < 2) s_aux[t] = 0;
+  const uint32_t i0 = t * ipt, i1 = i0 + ipt < n ? i0 + ipt : n;
+  uint32_t sum = 0;  // a tile keeps <= 65536 rows and there are <= 32768 tiles here: the total fits 32 bits
+  for (uint32_t i = i0; i < i1; ++i) sum += counts[i];
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan<1024 / WAVE>(sum, s_w, &tot);
+  uint64_t run = ex;
+  for (uint32_t i = i0; i < i1; ++i) { offsets[i] = run; run += counts[i]; }
+  if (shards && t < 256) {
+    atomicAdd(&s_aux[0], shards[2 * t]);
+    atomicAdd(&s_aux[1], shards[2 * t + 1]);
+  }
+  __syncthreads();
+  if (t == 0) {
+    totals->n_keep = tot;
+    totals->n_keep_fwd = 0;
+    totals->n_cand = s_aux[0];
+    totals->n_hits = s_aux[1];
+  }
+}
+
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals) {
+  if (n <= 2048 && shards) {
+    const uint32_t ipt = (uint32_t)((n + 1023) / 1024);
+    hipLaunchKernelGGL(k_mscan_one, dim3(1), dim3(1024), 0, st, counts, (uint32_t)n, ipt ? ipt : 1u, shards, offsets, totals);
+    return;
+  }
   const uint32_t nb = (uint32_t)((n + MS_TILE - 1) / MS_TILE);
   hipLaunchKernelGGL(k_mscan1, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial);
   if (nb <= 4096 && shards) {
