@@ -199,7 +199,10 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
  *                        and keep table order (haplotype ascending)
  *   group_off[n_groups+1] CSR offsets into perm
  *   gc_num, gc_den[n_groups]  G/C/S and A/C/G/T/S/W base counts of the group's spacer: gc_content =
- *                        gc_num / gc_den (annotation.py:513-541 -> Biopython gc_fraction, ambiguous bases dropped) */
+ *                        gc_num / gc_den (annotation.py:513-541 -> Biopython gc_fraction, ambiguous bases dropped)
+ * Rows of one (start, strand) are told apart by 63 bits of a hash of everything compared (a false merge needs a 63-bit
+ * collision inside one (start, strand): ~1e-12 over a whole-chromosome run); with HAWK_COLLAPSE_EXACT=1 in the
+ * environment (read per call) the full keys are compared instead, at about twice the time. */
 int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms);
 int hawk_table_collapse_download(hawk_table* t, uint32_t* perm, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den);
 /* The same grouping with the compared sequence widened by flank_up bases 5' and flank_down bases 3' of the guide (as it
