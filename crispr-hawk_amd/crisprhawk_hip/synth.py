@@ -61,6 +61,7 @@ class SynthRegion:
     bed_stop: int
     samples: List[str] = field(default_factory=list)
     variants: List[VariantSite] = field(default_factory=list)
+    gt_matrix: Optional[np.ndarray] = None  # uint8 [len(variants), 2 * n_samples]: the records' genotypes as one matrix
 
     @property
     def startp(self) -> int:  # padded start (reference Coordinate.start)
@@ -130,6 +131,7 @@ def add_phased_variants(
     seq = reg.contig_seq
     reg.samples = [f"S{i:04d}" for i in range(n_samples)]
     out: List[VariantSite] = []
+    ks: List[int] = []  # row of gt_all behind every record of `out`
     gt_all = np.empty((n_sites, n_hap), dtype=np.uint8)
     for k0 in range(0, n_sites, 4096):  # chunked: 31k x 5008 float64 would be 1.2 GB at once
         k1 = min(n_sites, k0 + 4096)
@@ -142,6 +144,7 @@ def add_phased_variants(
         if refb not in "ACGT":
             continue  # no variant on an ambiguous reference base
         gt = gt_all[k].reshape(n_samples, 2)
+        ks.append(k)
         if kinds[k] < frac_snv:
             altb = "ACGT"[("ACGT".index(refb) + int(alt_pick[k])) % 4]
             out.append(VariantSite(pos, refb, altb, float(afs[k]), gt))
@@ -161,8 +164,10 @@ def add_phased_variants(
         ins_len = np.array([max(0, v.chain) for v in out], dtype=np.int64)
         ins_rows = np.flatnonzero(ins_len > 0)  # gt_all: [site, hap]
         guard = int((ins_len[ins_rows, None] * gt_all[ins_rows].astype(np.int64)).sum(axis=0).max()) if len(ins_rows) else 0
-        out = [v for v in out if v.pos + len(v.ref) + guard <= reg.stopp]
+        keep = [i for i, v in enumerate(out) if v.pos + len(v.ref) + guard <= reg.stopp]
+        out, ks = [out[i] for i in keep], [ks[i] for i in keep]
     reg.variants = out
+    reg.gt_matrix = gt_all[np.asarray(ks, dtype=np.int64)] if ks else None
     return reg
 
 

@@ -429,7 +429,12 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     # is inverted there (hawk_gt_lists, the kernels of the VCF path) - a host-side nonzero scan of the 155 MB matrix
     # took 0.4 s of C3's expansion (`sample_range`: this rank's block of the panel - haplotypes shard across GPUs, REF
     # is on every rank)
-    G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
+    gm = getattr(reg, "gt_matrix", None)
+    if gm is not None and gm.shape == (len(reg.variants), 2 * len(reg.samples)) and \
+            all(np.array_equal(gm[i], reg.variants[i].gt.reshape(-1)) for i in (0, len(reg.variants) // 2, -1)):
+        G = gm if (slo, shi) == (0, len(reg.samples)) else gm[:, 2 * slo:2 * shi]  # the panel already is one matrix
+    else:
+        G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
     col_off, col_delta, hv_idx, hv_o = carried_lists_on_device(ref_set._ctx, G, r0, chain)
     counts = np.diff(col_off.astype(np.int64))
     live = np.flatnonzero(counts)

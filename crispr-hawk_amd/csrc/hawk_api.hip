@@ -220,7 +220,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   hawk_pool_free(hs->d_seg_rel); hawk_pool_free(hs->d_seg_gen); hawk_pool_free(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
-                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
+                    &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->ctable, &hs->cocc, &hs->cdense, &hs->cgkey, &hs->cgslot, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
                     &hs->big};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
@@ -790,6 +790,55 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   const char* ex = getenv("HAWK_COLLAPSE_EXACT");
   const bool exact = ex && ex[0] == '1';
   if (exact && (rc = hs->cfull.reserve(hawk_collapse_full_bytes(n)))) return rc;
+  // ---- grouping through a hash table (hawk_collapse.hip) when groups are expected to be far fewer than rows: the sort
+  // below then only orders (group number, row).  HAWK_COLLAPSE_MODE=sort / hash overrides the choice; a table that turns
+  // out too small, or an unlucky seed twice, falls through to the sort.
+  {
+    const char* md = getenv("HAWK_COLLAPSE_MODE");
+    const bool force_hash = md && md[0] == 'h', force_sort = md && md[0] == 's';
+    const uint64_t g_est = hs->last_groups ? hs->last_groups + hs->last_groups / 4 : n / 16;
+    uint64_t C = 1024;
+    while (C < 2 * g_est) C <<= 1;  // at most half full (with the 25 % head room of g_est)
+    const bool fits = C <= (1ull << 26) && hs->max_gen - hs->min_gen < 0xffffffffll;
+    const bool want = !exact && !force_sort && fits && (force_hash || (n >= (1u << 20) && (hs->last_groups == 0 || hs->last_groups * 8 <= n)));
+    if (want) {
+      const size_t tb = hawk_collapse_hash_temp_bytes(n, (uint32_t)C);
+      if ((rc = hs->ctable.reserve(C * 16)) || (rc = hs->cocc.reserve(C * 4)) || (rc = hs->cdense.reserve(C * 4)) ||
+          (rc = hs->cgkey.reserve(2 * C * 8)) || (rc = hs->cgslot.reserve(2 * C * 4)) || (rc = hs->ctemp.reserve(std::max(tb, temp_bytes) + 16)) ||
+          (rc = hs->ccnt.reserve(32)))
+        return rc;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        unsigned long long hc[3] = {0, 0, 0};
+        HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 32, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+        if (hawk_launch_collapse_hash1(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)flank_up, (int)flank_down,
+                                       hs->min_gen, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p, tb, hs->ctable.p, (uint32_t)C,
+                                       hs->cocc.as<uint32_t>(), hs->cdense.as<uint32_t>(), hs->cgkey.as<uint64_t>(), hs->cgslot.as<uint32_t>(),
+                                       hs->cflags.as<uint32_t>(), hs->ccnt.as<unsigned long long>()))
+          return HAWK_E_HIP;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hc, hs->ccnt.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (hc[1]) { hs->last_groups = n; break; }   // no room: sort now, a larger table (or the sort) next time
+        if (hc[0]) continue;                         // two identities under one key: another seed
+        const uint64_t ng = hc[2];
+        if (hawk_launch_collapse_hash2(ctx->stream, t->cols, n, (uint32_t)ng, (int)t->guidelen, (int)t->pamlen, (int)t->right, end_bit, hs->ctemp.p, tb,
+                                       hs->cgkey.as<uint64_t>(), hs->cgslot.as<uint32_t>(), (uint32_t)C, hs->cocc.as<uint32_t>(),
+                                       hs->cflags.as<uint32_t>(), hs->ckeys.as<uint32_t>(), hs->cvals.as<uint32_t>(), hs->cgoff.as<uint64_t>(),
+                                       hs->cgc.as<uint8_t>(), hs->cgc.as<uint8_t>() + n))
+          return HAWK_E_HIP;
+        HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (kernel_ms) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); *kernel_ms += ms; }
+        hs->last_groups = ng;
+        t->n_groups = ng; t->collapsed = true;
+        *n_groups = ng;
+        return HAWK_OK;
+      }
+    }
+  }
   unsigned long long cnt[2] = {0, 0};
   for (int attempt = 0; attempt < 4; ++attempt) {  // a new seed whenever two different rows collide in the hash bits
     HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 16, ctx->stream));
@@ -811,6 +860,7 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   const uint64_t ng = cnt[1];
   HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  hs->last_groups = ng;
   t->n_groups = ng; t->collapsed = true;
   *n_groups = ng;
   return HAWK_OK;

@@ -192,3 +192,140 @@ void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n,
   const uint64_t m = n > ng ? n : ng;
   hipLaunchKernelGGL(k_collapse_export, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, c, n, ng, perm, group_off, rep, member_hap);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grouping through a hash table instead of a sort of all rows: when groups are far fewer than rows (a C4 tile: 1.1 x 10^8
+// rows in 8.9 x 10^5 groups) the table (16 B per slot, a few MB) lives in the memory-side cache, every row finds its
+// group with one or two probes, and what is sorted afterwards is (group number, row) on ~20 bits instead of the 48-bit
+// row keys.  Same key, same identity test (63 hash bits; a 31-bit collision inside one (start, strand) is counted and
+// answered with another seed) and the SAME output as the sort path: groups in key order, members in table order.
+//   k_cg_insert  row -> key, identity; claim / find the key's slot (CAS), keep the smallest (identity, row) per slot
+//   k_cg_occ + rocprim::exclusive_scan + k_cg_pack   occupied slots -> dense (key, slot) pairs, their number
+//   rocprim::radix_sort_pairs (key, slot); k_cg_rank: slot -> position of its key = group number
+//   k_cg_rowgid  row -> group number;  rocprim::radix_sort_pairs (group number, row);  k_cg_groups: CSR offsets + GC
+struct CgSlot { unsigned long long key, idrow; };
+#define CG_EMPTY 0xffffffffffffffffull
+#define CG_MAXPROBE 256
+
+__global__ __launch_bounds__(256) void k_cg_insert(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
+                                                   int64_t base, uint64_t seed, CgSlot* __restrict__ T, uint32_t mask,
+                                                   uint32_t* __restrict__ slot_of_row, unsigned long long* __restrict__ counters) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const RowKey k = row_key(c, is_ref, i, L, up, down);
+  uint64_t h = seed;
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) h = mix64(h ^ k.core[pl]);
+  h = mix64(h ^ (uint64_t)k.stop ^ ((uint64_t)(k.sr >> 1) << 63));
+  const unsigned long long key = ((uint64_t)(k.start - base) << 32) | ((uint64_t)(k.sr & 1u) << 31) | (h >> 33);
+  const unsigned long long idr = ((unsigned long long)(uint32_t)h << 32) | (uint32_t)i;
+  uint32_t s = (uint32_t)mix64(key) & mask;
+  for (int probe = 0; probe < CG_MAXPROBE; ++probe, s = (s + 1) & mask) {
+    // One 16-byte read of the slot: the usual row finds its key and a smaller row of its identity there and is done.  A
+    // plain load - what it returns may be stale, and every decision taken on it is either confirmed by an atomic (an
+    // empty slot is claimed by CAS, a larger minimum replaced by atomicMin, both of which answer with the truth) or
+    // stays right when the slot has moved on (keys never change; the minimum only falls; any earlier minimum is a row of
+    // the same key to compare identities with).
+    const ulonglong2 sl = *reinterpret_cast<const ulonglong2*>(&T[s]);
+    unsigned long long cur = sl.x, old = sl.y;
+    if (cur == CG_EMPTY) {
+      const unsigned long long prev = atomicCAS(&T[s].key, CG_EMPTY, key);
+      cur = prev == CG_EMPTY ? key : prev;
+    }
+    if (cur != key) continue;
+    // the slot's (identity, row) minimum: rows arrive roughly in table order, so most leave without an atomic
+    if (old == CG_EMPTY || old > idr) old = atomicMin(&T[s].idrow, idr);
+    if (old != CG_EMPTY && (uint32_t)(old >> 32) != (uint32_t)(idr >> 32)) atomicAdd(&counters[0], 1ull);  // two identities, one key
+    slot_of_row[i] = s;
+    return;
+  }
+  atomicAdd(&counters[1], 1ull);  // table too full: the caller falls back to the sort
+  slot_of_row[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_cg_occ(const CgSlot* __restrict__ T, uint32_t C, uint32_t* __restrict__ flags) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s < C) flags[s] = T[s].key != CG_EMPTY ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_cg_pack(const CgSlot* __restrict__ T, uint32_t C, const uint32_t* __restrict__ flags,
+                                                 const uint32_t* __restrict__ dense, uint64_t* __restrict__ gkey,
+                                                 uint32_t* __restrict__ gslot, unsigned long long* __restrict__ counters) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= C) return;
+  if (flags[s]) { gkey[dense[s]] = T[s].key; gslot[dense[s]] = s; }
+  if (s == C - 1) counters[2] = (unsigned long long)dense[s] + flags[s];
+}
+__global__ __launch_bounds__(256) void k_cg_rank(const uint32_t* __restrict__ gslot_sorted, uint32_t G, uint32_t* __restrict__ slot2rank) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p < G) slot2rank[gslot_sorted[p]] = p;
+}
+__global__ __launch_bounds__(256) void k_cg_rowgid(const uint32_t* __restrict__ slot_of_row, const uint32_t* __restrict__ slot2rank, uint64_t n,
+                                                   uint32_t* __restrict__ gid, uint32_t* __restrict__ vals) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { gid[i] = slot2rank[slot_of_row[i]]; vals[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void k_cg_groups(GuideCols c, uint64_t n, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ gid,
+                                                   int guidelen, int pamlen, int right, uint64_t* __restrict__ group_off,
+                                                   uint8_t* __restrict__ gc_num, uint8_t* __restrict__ gc_den) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t g = gid[j];
+  if (j && gid[j - 1] == g) return;
+  group_off[g] = j;
+  const uint64_t r = vals[j];  // the group's first member in table order
+  const bool pamfirst = (right != 0) != (c.strand[r] != 0);
+  const int sh = HAWK_PAD + (pamfirst ? pamlen : 0);
+  const uint64_t m = guidelen >= 64 ? ~0ull : ((1ull << guidelen) - 1ull);
+  const uint64_t A = (c.win[r] >> sh) & m, C = (c.win[c.cap + r] >> sh) & m, G = (c.win[2 * c.cap + r] >> sh) & m,
+                 T = (c.win[3 * c.cap + r] >> sh) & m;
+  const uint64_t gc = (C | G) & ~(A | T), at = (A | T) & ~(C | G);
+  gc_num[g] = (uint8_t)__popcll(gc);
+  gc_den[g] = (uint8_t)__popcll(gc | at);
+}
+
+size_t hawk_collapse_hash_temp_bytes(uint64_t n, uint32_t C) {
+  size_t a = 0, b = 0, d = 0;
+  (void)rocprim::exclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)C, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)C, 0, 64,
+                                  (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
+                                  (hipStream_t)0);
+  return std::max(a, std::max(b, d));
+}
+
+// stage 1: rows into the table, occupied slots packed; counters[0] = identity collisions, [1] = rows that found no
+// slot, [2] = groups - read by the host before stage 2.  table: C slots (a power of two), flags / dense: C words each,
+// gkey: 2 * C, gslot: 2 * C (sort ping-pong)
+int hawk_launch_collapse_hash1(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
+                               int flank_down, int64_t base, uint64_t seed, void* temp, size_t temp_bytes, void* table, uint32_t C,
+                               uint32_t* flags, uint32_t* dense, uint64_t* gkey, uint32_t* gslot, uint32_t* slot_of_row,
+                               unsigned long long* counters) {
+  const int L = guidelen + pamlen;
+  if (hipMemsetAsync(table, 0xff, (size_t)C * sizeof(CgSlot), st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_cg_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, is_ref, n, L, flank_up, flank_down, base, seed,
+                     (CgSlot*)table, C - 1, slot_of_row, counters);
+  const dim3 cg((C + 255) / 256);
+  hipLaunchKernelGGL(k_cg_occ, cg, dim3(256), 0, st, (const CgSlot*)table, C, flags);
+  size_t tb = temp_bytes;
+  if (rocprim::exclusive_scan(temp, tb, flags, dense, 0u, (size_t)C, rocprim::plus<uint32_t>(), st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_cg_pack, cg, dim3(256), 0, st, (const CgSlot*)table, C, flags, dense, gkey, gslot, counters);
+  return 0;
+}
+
+// stage 2: groups in key order, rows by (group, row).  slot2rank: C words (may be `flags` of stage 1); gid: 2 * n, vals: 2 * n
+int hawk_launch_collapse_hash2(hipStream_t st, const GuideCols& c, uint64_t n, uint32_t G, int guidelen, int pamlen, int right, unsigned key_end_bit,
+                               void* temp, size_t temp_bytes, uint64_t* gkey, uint32_t* gslot, uint32_t C, uint32_t* slot2rank,
+                               const uint32_t* slot_of_row, uint32_t* gid, uint32_t* vals, uint64_t* group_off, uint8_t* gc_num,
+                               uint8_t* gc_den) {
+  size_t tb = temp_bytes;
+  if (rocprim::radix_sort_pairs(temp, tb, gkey, gkey + C, gslot, gslot + C, (size_t)G, 0, key_end_bit, st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_cg_rank, dim3((G + 255) / 256), dim3(256), 0, st, gslot + C, G, slot2rank);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipLaunchKernelGGL(k_cg_rowgid, grid, dim3(256), 0, st, slot_of_row, slot2rank, n, gid, vals);
+  unsigned gbits = 1;
+  while (gbits < 32 && (G >> gbits) != 0) ++gbits;
+  tb = temp_bytes;
+  if (rocprim::radix_sort_pairs(temp, tb, gid, gid + n, vals, vals + n, (size_t)n, 0, gbits, st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_cg_groups, grid, dim3(256), 0, st, c, n, vals + n, gid + n, guidelen, pamlen, right, group_off, gc_num, gc_den);
+  return 0;
+}

@@ -136,6 +136,15 @@ int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_r
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
                          uint8_t* gc_den, uint32_t* id2 /* may alias gidx */, void* full /* null: identity by hash */);
 size_t hawk_collapse_full_bytes(uint64_t n);
+size_t hawk_collapse_hash_temp_bytes(uint64_t n, uint32_t C);
+int hawk_launch_collapse_hash1(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
+                               int flank_down, int64_t base, uint64_t seed, void* temp, size_t temp_bytes, void* table, uint32_t C,
+                               uint32_t* flags, uint32_t* dense, uint64_t* gkey, uint32_t* gslot, uint32_t* slot_of_row,
+                               unsigned long long* counters);
+int hawk_launch_collapse_hash2(hipStream_t st, const GuideCols& c, uint64_t n, uint32_t G, int guidelen, int pamlen, int right, unsigned key_end_bit,
+                               void* temp, size_t temp_bytes, uint64_t* gkey, uint32_t* gslot, uint32_t C, uint32_t* slot2rank,
+                               const uint32_t* slot_of_row, uint32_t* gid, uint32_t* vals, uint64_t* group_off, uint8_t* gc_num,
+                               uint8_t* gc_den);
 void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n, uint64_t ng, const uint32_t* perm,
                                  const uint64_t* group_off, const GuideCols& rep, uint32_t* member_hap);
 void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* line_off, const uint64_t* gt_off, uint64_t n_lines,

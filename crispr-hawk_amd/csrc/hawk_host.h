@@ -85,6 +85,8 @@ struct hawk_hapset {
   // workspace reused across searches
   DevBuf keepF, keepR, counts, offsets, totals, misc, cfd, partial, sites, hits, guides, lists;
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
+  DevBuf ctable, cocc, cdense, cgkey, cgslot;                          // ... its hash-table path
+  uint64_t last_groups = 0;   // groups of the last collapse on this set (sizes the table of the next one)
   DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
   DevBuf big;                 // tiles whose rows exceed the hand-over list (k_search_emit's work list)
   DevBuf refbits;             // REF's candidate-window bitmaps, one per strand (k_ref_bits)

@@ -99,6 +99,22 @@ def test_search_is_deterministic_and_additive(c3):
     assert (np.diff(perm)[inner[1:]] > 0).all()
 
 
+def test_collapse_hash_table_path_equals_sort_path(c3, monkeypatch):
+    # 2.8 x 10^7 rows in 2.2 x 10^5 groups: what hawk_table_collapse does through its hash table (groups numbered in key
+    # order, then a sort of (group, row)) must be the sort path's output array for array
+    ds, pam = c3["ds"], c3["pam"]
+    t = ds.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, c3["mm"], c3["pt"], download=False)
+    out = {}
+    for mode in ("hash", "sort"):
+        monkeypatch.setenv("HAWK_COLLAPSE_MODE", mode)
+        t.collapse()
+        out[mode] = (t.n_groups, t.group_perm.copy(), t.group_off.copy(), t.gc_num.copy(), t.gc_den.copy(), t.collapse_ms)
+    assert out["hash"][0] == out["sort"][0] == c3["tab"].n_groups
+    for a, b in zip(out["hash"][1:5], out["sort"][1:5]):
+        assert np.array_equal(a, b)
+    t.close()
+
+
 @pytest.mark.parametrize("sample", [0, 1251, 2503])
 def test_sampled_haplotypes_match_the_oracle_exactly(c3, sample):
     """Rows of one sample's chromosome copies, cut out of the full table, against the oracle run on REF + that sample

@@ -346,12 +346,14 @@ def _check_collapse(hs, tab, guidelen, pamlen, right):
         assert (int(tab.gc_num[g]), int(tab.gc_den[g])) == want_gc[key]
 
 
-@pytest.mark.parametrize("exact", ["0", "1"], ids=["hash-identity", "full-key"])
+@pytest.mark.parametrize("exact,mode", [("0", "sort"), ("0", "hash"), ("1", "sort")], ids=["hash-identity", "hash-table", "full-key"])
 @pytest.mark.parametrize("pam,guidelen,right", [("NGG", 20, False), ("TTTV", 23, True)])
-def test_collapse_groups_against_oracle(pam, guidelen, right, exact, monkeypatch):
+def test_collapse_groups_against_oracle(pam, guidelen, right, exact, mode, monkeypatch):
     # 12 haplotypes over common variants: most alt rows are shared by several haplotypes.  Rows of one (start, strand)
-    # are told apart by 63 hash bits by default, by their full keys with HAWK_COLLAPSE_EXACT=1 (read per call)
+    # are told apart by 63 hash bits by default, by their full keys with HAWK_COLLAPSE_EXACT=1; grouping runs through a
+    # sort of all rows or (large tables by default, here forced) through a hash table (both read per call)
     monkeypatch.setenv("HAWK_COLLAPSE_EXACT", exact)
+    monkeypatch.setenv("HAWK_COLLAPSE_MODE", mode)
     reg = synth.make_region(7501, "chrC", 40_000, 1_000, 38_000)
     synth.add_phased_variants(reg, 7502, 300, 6, af_min=0.3, af_max=0.8)
     fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
