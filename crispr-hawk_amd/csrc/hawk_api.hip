@@ -819,7 +819,7 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hc, hs->ccnt.p, 24, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (hc[1]) { hs->last_groups = n; break; }   // no room: sort now, a larger table (or the sort) next time
+        if (hc[1]) { hs->last_groups = n; if (hs->plan_groups) *hs->plan_groups = n; break; }   // no room: sort now, a larger table (or the sort) next time
         if (hc[0]) continue;                         // two identities under one key: another seed
         const uint64_t ng = hc[2];
         if (hawk_launch_collapse_hash2(ctx->stream, t->cols, n, (uint32_t)ng, (int)t->guidelen, (int)t->pamlen, (int)t->right, end_bit, hs->ctemp.p, tb,
@@ -833,6 +833,7 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (kernel_ms) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); *kernel_ms += ms; }
         hs->last_groups = ng;
+        if (hs->plan_groups) *hs->plan_groups = ng;
         t->n_groups = ng; t->collapsed = true;
         *n_groups = ng;
         return HAWK_OK;
@@ -861,6 +862,7 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hs->last_groups = ng;
+  if (hs->plan_groups) *hs->plan_groups = ng;
   t->n_groups = ng; t->collapsed = true;
   *n_groups = ng;
   return HAWK_OK;
@@ -1132,6 +1134,7 @@ struct hawk_xplan {
   bool has_partner = false;
   int32_t partner_start = 0, partner_stop = 0;
   uint32_t n_ref_rows = 0;
+  std::shared_ptr<uint64_t> groups = std::make_shared<uint64_t>(0);  // groups the last collapse of a set of this plan found
 };
 
 void hawk_xplan_destroy(hawk_xplan* x) {
@@ -1325,6 +1328,7 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
     hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
     hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
     hs->ref_index = x->ref_index; hs->has_meta = true; hs->n_ref_rows = x->n_ref_rows;
+    hs->plan_groups = x->groups; hs->last_groups = *x->groups;
     hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
   }
   if (e == hipSuccess && (hash_out || kernel_ms)) e = hipStreamSynchronize(st);

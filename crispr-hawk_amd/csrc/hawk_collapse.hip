@@ -205,13 +205,15 @@ void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n,
 //   k_cg_rowgid  row -> group number;  rocprim::radix_sort_pairs (group number, row);  k_cg_groups: CSR offsets + GC
 struct CgSlot { unsigned long long key, idrow; };
 #define CG_EMPTY 0xffffffffffffffffull
-#define CG_MAXPROBE 256
+#define CG_MAXPROBE 64
 
 __global__ __launch_bounds__(256) void k_cg_insert(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
                                                    int64_t base, uint64_t seed, CgSlot* __restrict__ T, uint32_t mask,
                                                    uint32_t* __restrict__ slot_of_row, unsigned long long* __restrict__ counters) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  // the table has turned out too small (far more groups than expected): the call is going to the sort path anyway
+  if (__hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4096ull) return;
   const RowKey k = row_key(c, is_ref, i, L, up, down);
   uint64_t h = seed;
 #pragma unroll

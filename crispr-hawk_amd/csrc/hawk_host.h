@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <memory>
 #include <vector>
 
 #include "../../include/hawk.h"
@@ -87,6 +88,7 @@ struct hawk_hapset {
   DevBuf ckeys, cvals, cflags, cgidx, ctemp, cgoff, cgc, ccnt, cfull;  // hawk_table_collapse
   DevBuf ctable, cocc, cdense, cgkey, cgslot;                          // ... its hash-table path
   uint64_t last_groups = 0;   // groups of the last collapse on this set (sizes the table of the next one)
+  std::shared_ptr<uint64_t> plan_groups;  // ... shared with the expansion plan the set came from: the next run of the plan starts from it
   DevBuf otoff, otcode, otid, othit;  // hawk_offtarget_scan: bucketed guides, gathered hit sites
   DevBuf big;                 // tiles whose rows exceed the hand-over list (k_search_emit's work list)
   DevBuf refbits;             // REF's candidate-window bitmaps, one per strand (k_ref_bits)
