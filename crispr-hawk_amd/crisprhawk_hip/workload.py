@@ -224,7 +224,7 @@ class RowMeta:
 
 def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, samples: List[str], tab, live: np.ndarray,
                  counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device,
-                 own: Optional[ScanOwnership] = None, keep_plan: bool = False):
+                 own: Optional[ScanOwnership] = None, keep_plan: bool = False, indel_entries: Optional[np.ndarray] = None):
     """Common tail of the device expansions: rows = REF + every chromosome copy (column) with a non-empty carried
     list, in column order.  Builds the expansion plan (hawk_xplan_create), runs it, then labels / homozygous merge /
     collapse on the 16-byte content hashes (haplotypes.py:232-368) and the position-map segments + scan bounds of every
@@ -314,19 +314,22 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     # ---- position-map segments + scan bounds per row ------------------------------------------
     # all rows at once: every carried deletion opens one segment behind it, every carried insertion of n bases
     # opens n + 1 (the inserted bases all map to the anchor position, haplotype.py:106-159)
-    ind = np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])  # the carried indels: one byte-table gather over the lists
+    # the carried indels: listed by the device inversion (hawk_gt_lists_indels), else one byte-table gather over the lists
+    ind = indel_entries.astype(np.int64) if indel_entries is not None else np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])
     o_i = hv_o[ind].astype(np.int64)
     pos_i = r0[hv_idx[ind]] + startp
     ch_i = chain[hv_idx[ind]]
     row_i = np.searchsorted(hv_off[1:].astype(np.int64), ind, side="right")  # device row of the entry (row 0 is REF)
     nseg_i = np.where(ch_i < 0, 1, ch_i + 1)
-    rep = np.repeat(np.arange(len(ind)), nseg_i)
     first_of = np.cumsum(nseg_i) - nseg_i
-    k_in = np.arange(len(rep)) - first_of[rep]           # 0..n within an insertion's run, 0 for a deletion
-    is_del = ch_i[rep] < 0
-    seg_rel_all = o_i[rep] + 1 + k_in
-    seg_gen_all = np.where(is_del, pos_i[rep] + 1 - ch_i[rep], np.where(k_in < ch_i[rep], pos_i[rep], pos_i[rep] + 1))
-    seg_row_all = row_i[rep]
+    k_in = np.arange(int(nseg_i.sum())) - np.repeat(first_of, nseg_i)  # 0..n within an insertion's run, 0 for a deletion
+    # one repeat per per-indel quantity (not a gather per use): a deletion's single segment starts behind the deleted
+    # bases; an insertion's n + 1 segments repeat the anchor position n times, then move on
+    base_i = np.where(ch_i < 0, pos_i + 1 - ch_i, pos_i)
+    bump_at = np.where(ch_i < 0, np.iinfo(np.int64).max, ch_i)
+    seg_rel_all = np.repeat(o_i + 1, nseg_i) + k_in
+    seg_gen_all = np.repeat(base_i, nseg_i) + (k_in >= np.repeat(bump_at, nseg_i))
+    seg_row_all = np.repeat(row_i, nseg_i)
     keep = seg_rel_all < hap_len[seg_row_all].astype(np.int64)
     seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[keep], seg_gen_all[keep], seg_row_all[keep]
     # rows collapsed onto another keep the identity map only; every row starts with the identity segment (rel 0 ->
@@ -380,10 +383,10 @@ def _ref_only_set(seq, startp: int, stopp: int, pamlen: int, device, own: Option
     return ds
 
 
-def carried_lists_on_device(ctx, G: np.ndarray, r0: np.ndarray, chain: np.ndarray):
+def carried_lists_on_device(ctx, G: np.ndarray, r0: np.ndarray, chain: np.ndarray, want_indels: bool = False):
     """A 0/1 genotype matrix G[variant, chromosome copy] -> per-copy carried-variant lists, on the device: the matrix goes
     up as allele codes (hawk_gt_from_codes) and is inverted by the kernels of the VCF path (hawk_gt_lists).
-    -> (col_off[n_cols + 1], col_delta[n_cols], hv_idx, hv_o)"""
+    -> (col_off[n_cols + 1], col_delta[n_cols], hv_idx, hv_o[, entry indices of the carried indels])"""
     import ctypes as C
     from . import _lib
     from .hapset import _p
@@ -405,8 +408,17 @@ def carried_lists_on_device(ctx, G: np.ndarray, r0: np.ndarray, chain: np.ndarra
         hv_idx = np.zeros(max(ne, 1), dtype=np.uint32)
         hv_o = np.zeros(max(ne, 1), dtype=np.int32)
         _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
+        indel = None
+        if want_indels:
+            ni = C.c_uint64(0)
+            _lib.check(L.hawk_gt_lists_indels(g, None, C.c_uint64(0), C.byref(ni)), "hawk_gt_lists_indels")
+            indel = np.zeros(max(ni.value, 1), dtype=np.uint32)
+            _lib.check(L.hawk_gt_lists_indels(g, _p(indel), C.c_uint64(ni.value), C.byref(ni)), "hawk_gt_lists_indels")
+            indel = indel[:ni.value]
     finally:
         L.hawk_gt_destroy(g)
+    if want_indels:
+        return col_off, col_delta, hv_idx[:ne], hv_o[:ne], indel
     return col_off, col_delta, hv_idx[:ne], hv_o[:ne]
 
 
@@ -435,7 +447,7 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
         G = gm if (slo, shi) == (0, len(reg.samples)) else gm[:, 2 * slo:2 * shi]  # the panel already is one matrix
     else:
         G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
-    col_off, col_delta, hv_idx, hv_o = carried_lists_on_device(ref_set._ctx, G, r0, chain)
+    col_off, col_delta, hv_idx, hv_o, indel = carried_lists_on_device(ref_set._ctx, G, r0, chain, want_indels=True)
     counts = np.diff(col_off.astype(np.int64))
     live = np.flatnonzero(counts)
     tot = col_delta[live]
@@ -443,7 +455,7 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
         ref_set.alias = np.zeros(1, dtype=np.int64)
         return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
     return _expand_rows(ref_set, seq, startp, stopp, pamlen, reg.samples[slo:shi], tab, live, counts[live], hv_idx, hv_o, tot, device,
-                        keep_plan=keep_plan)
+                        keep_plan=keep_plan, indel_entries=indel)
 
 
 class VcfVariants:

@@ -1366,6 +1366,8 @@ struct hawk_gt {
   uint8_t* d_flags;   // [n_lines]
   uint64_t n_entries; // carried-variant entries over all columns (valid after hawk_gt_lists)
   uint64_t* d_col_off; uint32_t* d_idx; int32_t* d_o; int64_t* d_delta;
+  uint64_t n_indel = 0;          // entries whose variant changes the length (var_chain != 0)
+  uint32_t* d_indel = nullptr;   // their entry indices, ascending
 };
 
 int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const uint64_t* line_off, const uint64_t* gt_off,
@@ -1429,6 +1431,7 @@ void hawk_gt_destroy(hawk_gt* g) {
   if (g->d_idx) hawk_pool_free(g->d_idx);
   if (g->d_o) hawk_pool_free(g->d_o);
   if (g->d_delta) hawk_pool_free(g->d_delta);
+  if (g->d_indel) hawk_pool_free(g->d_indel);
   delete g;
 }
 
@@ -1454,7 +1457,8 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   if (g->d_idx) { hawk_pool_free(g->d_idx); g->d_idx = nullptr; }
   if (g->d_o) { hawk_pool_free(g->d_o); g->d_o = nullptr; }
   if (g->d_delta) { hawk_pool_free(g->d_delta); g->d_delta = nullptr; }
-  g->n_var = n_var; g->n_entries = 0;
+  if (g->d_indel) { hawk_pool_free(g->d_indel); g->d_indel = nullptr; }
+  g->n_var = n_var; g->n_entries = 0; g->n_indel = 0;
   if (kernel_ms) *kernel_ms = 0.f;
   std::vector<uint64_t> off(n_cols + 1, 0);
   if (n_var == 0) {
@@ -1465,7 +1469,9 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   uint32_t *d_vl = nullptr, *d_cnt = nullptr; uint8_t* d_va = nullptr; int32_t *d_r0 = nullptr, *d_ch = nullptr;
   unsigned long long* d_bal = nullptr;
   POOLCHK(&d_vl, (size_t)n_var * 4); POOLCHK(&d_va, n_var); POOLCHK(&d_r0, (size_t)n_var * 4);
-  POOLCHK(&d_ch, (size_t)n_var * 4); POOLCHK(&d_cnt, (size_t)n_cols * 4);
+  POOLCHK(&d_ch, (size_t)n_var * 4); POOLCHK(&d_cnt, (size_t)n_cols * 2 * 4);
+  uint64_t* d_ioff = nullptr;
+  POOLCHK(&d_ioff, (size_t)(n_cols + 1) * 8);
   POOLCHK(&d_bal, (size_t)n_cols * n_chunk * 8);
   POOLCHK(&g->d_col_off, (size_t)(n_cols + 1) * 8); POOLCHK(&g->d_delta, (size_t)n_cols * 8);
   HIPCHK(hipMemcpyAsync(d_vl, var_line, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
@@ -1473,17 +1479,23 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   HIPCHK(hipMemcpyAsync(d_r0, var_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_ch, var_chain, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hawk_launch_gt_count(st, g->d_codes, n_cols, d_vl, d_va, n_var, d_bal, d_cnt);
+  hawk_launch_gt_count(st, g->d_codes, n_cols, d_vl, d_va, d_ch, n_var, d_bal, d_cnt);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  std::vector<uint32_t> cnt(n_cols);
-  HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n_cols * 4, hipMemcpyDeviceToHost, st));
+  std::vector<uint32_t> cnt(2 * (size_t)n_cols);
+  HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n_cols * 2 * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (uint32_t c = 0; c < n_cols; ++c) off[c + 1] = off[c] + cnt[c];  // 2 * n_samples values: a host prefix sum
-  const uint64_t ne = off[n_cols];
+  std::vector<uint64_t> ioff(n_cols + 1, 0);
+  for (uint32_t c = 0; c < n_cols; ++c) {  // 2 * n_samples values: host prefix sums
+    off[c + 1] = off[c] + cnt[c];
+    ioff[c + 1] = ioff[c] + cnt[n_cols + c];
+  }
+  const uint64_t ne = off[n_cols], ni = ioff[n_cols];
   POOLCHK(&g->d_idx, std::max<size_t>(ne, 1) * 4); POOLCHK(&g->d_o, std::max<size_t>(ne, 1) * 4);
+  POOLCHK(&g->d_indel, std::max<size_t>(ni, 1) * 4);
   HIPCHK(hipMemcpyAsync(g->d_col_off, off.data(), (size_t)(n_cols + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_ioff, ioff.data(), (size_t)(n_cols + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(ctx->ev[2], st));
-  hawk_launch_gt_fill(st, n_cols, d_r0, d_ch, n_var, d_bal, g->d_col_off, g->d_idx, g->d_o, g->d_delta);
+  hawk_launch_gt_fill(st, n_cols, d_r0, d_ch, n_var, d_bal, g->d_col_off, g->d_idx, g->d_o, g->d_delta, d_ioff, g->d_indel);
   HIPCHK(hipEventRecord(ctx->ev[3], st));
   HIPCHK(hipGetLastError());
   if (col_delta) HIPCHK(hipMemcpyAsync(col_delta, g->d_delta, (size_t)n_cols * 8, hipMemcpyDeviceToHost, st));
@@ -1495,7 +1507,20 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   }
   memcpy(col_off, off.data(), (size_t)(n_cols + 1) * 8);
   g->n_entries = ne;
+  g->n_indel = ni;
   hawk_pool_free(d_vl); hawk_pool_free(d_va); hawk_pool_free(d_r0); hawk_pool_free(d_ch); hawk_pool_free(d_cnt); hawk_pool_free(d_bal);
+  hawk_pool_free(d_ioff);
+  return HAWK_OK;
+}
+
+int hawk_gt_lists_indels(hawk_gt* g, uint32_t* entry_idx, uint64_t cap, uint64_t* n_indel) {
+  if (!g || !n_indel) return HAWK_E_INVALID;
+  *n_indel = g->n_indel;
+  const uint64_t k = std::min<uint64_t>(cap, g->n_indel);
+  if (!k || !entry_idx) return HAWK_OK;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpyAsync(entry_idx, g->d_indel, k * 4, hipMemcpyDefault, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
   return HAWK_OK;
 }
 

@@ -150,9 +150,10 @@ void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n,
 void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* line_off, const uint64_t* gt_off, uint64_t n_lines,
                           uint32_t n_samples, uint8_t* codes, uint8_t* flags);
 void hawk_launch_gt_count(hipStream_t st, const uint8_t* codes, uint32_t n_cols, const uint32_t* var_line, const uint8_t* var_allele,
-                          uint32_t n_var, unsigned long long* ballots, uint32_t* col_count);
+                          const int32_t* var_chain, uint32_t n_var, unsigned long long* ballots, uint32_t* col_count /* [2 * n_cols] */);
 void hawk_launch_gt_fill(hipStream_t st, uint32_t n_cols, const int32_t* var_r0, const int32_t* var_chain, uint32_t n_var,
-                         const unsigned long long* ballots, const uint64_t* col_off, uint32_t* hv_idx, int32_t* hv_o, int64_t* col_delta);
+                         const unsigned long long* ballots, const uint64_t* col_off, uint32_t* hv_idx, int32_t* hv_o, int64_t* col_delta,
+                         const uint64_t* indel_off, uint32_t* indel_entry);
 #define HAWK_LIST_CAP 512  // entries per tile in the count pass -> emit pass hand-over list (hawk_search.hip LIST_CAP)
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals);

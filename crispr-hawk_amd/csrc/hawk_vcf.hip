@@ -91,13 +91,14 @@ __global__ __launch_bounds__(256) void k_gt_parse(const uint8_t* __restrict__ te
 }
 
 // one wave per column: ballots[col][chunk] = which of variants 64*chunk .. +63 the column carries
+// col_count[col], col_count[n_cols + col]: carried variants, carried indels (var_chain != 0) of the column
 __global__ __launch_bounds__(256) void k_gt_count(const uint8_t* __restrict__ codes, uint32_t n_cols, const uint32_t* __restrict__ var_line,
-                                                  const uint8_t* __restrict__ var_allele, uint32_t n_var, uint32_t n_chunk,
-                                                  unsigned long long* __restrict__ ballots, uint32_t* __restrict__ col_count) {
+                                                  const uint8_t* __restrict__ var_allele, const int32_t* __restrict__ var_chain, uint32_t n_var,
+                                                  uint32_t n_chunk, unsigned long long* __restrict__ ballots, uint32_t* __restrict__ col_count) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (col >= n_cols) return;  // wave-uniform
-  uint32_t cnt = 0;
+  uint32_t cnt = 0, cnt_indel = 0;
   for (uint32_t ch = 0; ch < n_chunk; ++ch) {
     const uint32_t j = ch * 64u + lane;
     bool carried = false;
@@ -105,18 +106,21 @@ __global__ __launch_bounds__(256) void k_gt_count(const uint8_t* __restrict__ co
     const unsigned long long b = __ballot(carried);
     if (lane == 0) ballots[(size_t)col * n_chunk + ch] = b;
     cnt += (uint32_t)__popcll(b);
+    if (b) cnt_indel += (uint32_t)__popcll(__ballot(carried && var_chain[j] != 0));
   }
-  if (lane == 0) col_count[col] = cnt;
+  if (lane == 0) { col_count[col] = cnt; col_count[n_cols + col] = cnt_indel; }
 }
 
 __global__ __launch_bounds__(256) void k_gt_fill(uint32_t n_cols, const int32_t* __restrict__ var_r0, const int32_t* __restrict__ var_chain,
                                                  uint32_t n_var, uint32_t n_chunk, const unsigned long long* __restrict__ ballots,
                                                  const uint64_t* __restrict__ col_off, uint32_t* __restrict__ hv_idx,
-                                                 int32_t* __restrict__ hv_o, int64_t* __restrict__ col_delta) {
+                                                 int32_t* __restrict__ hv_o, int64_t* __restrict__ col_delta,
+                                                 const uint64_t* __restrict__ indel_off, uint32_t* __restrict__ indel_entry) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (col >= n_cols) return;
   uint64_t o = col_off[col];
+  uint64_t io = indel_off[col];  // where this column's carried indels are listed (by entry index: position-map segments come from them)
   int64_t run = 0;  // sum of the length changes of the variants already placed
   for (uint32_t ch = 0; ch < n_chunk; ++ch) {
     const unsigned long long b = ballots[(size_t)col * n_chunk + ch];
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(256) void k_gt_fill(uint32_t n_cols, const int32_t*
       hv_idx[o + rank] = j;
       hv_o[o + rank] = (int32_t)((int64_t)var_r0[j] + run + (int64_t)(int32_t)(inc - (uint32_t)chn));
     }
+    const unsigned long long bi = __ballot(chn != 0);
+    if (chn != 0) indel_entry[io + (uint32_t)__popcll(bi & ((1ull << lane) - 1ull))] = (uint32_t)(o + rank);
+    io += (uint64_t)__popcll(bi);
     run += (int64_t)(int32_t)__builtin_amdgcn_readlane((int)inc, 63);
     o += (uint64_t)__popcll(b);
   }
@@ -141,14 +148,15 @@ void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* l
   if (n_lines) hipLaunchKernelGGL(k_gt_parse, dim3((unsigned)n_lines), dim3(256), 0, st, text, line_off, gt_off, n_samples, codes, flags);
 }
 void hawk_launch_gt_count(hipStream_t st, const uint8_t* codes, uint32_t n_cols, const uint32_t* var_line, const uint8_t* var_allele,
-                          uint32_t n_var, unsigned long long* ballots, uint32_t* col_count) {
+                          const int32_t* var_chain, uint32_t n_var, unsigned long long* ballots, uint32_t* col_count /* [2 * n_cols] */) {
   const uint32_t n_chunk = (n_var + 63u) / 64u;
-  hipLaunchKernelGGL(k_gt_count, dim3((n_cols + 3u) / 4u), dim3(256), 0, st, codes, n_cols, var_line, var_allele, n_var, n_chunk, ballots,
-                     col_count);
+  hipLaunchKernelGGL(k_gt_count, dim3((n_cols + 3u) / 4u), dim3(256), 0, st, codes, n_cols, var_line, var_allele, var_chain, n_var, n_chunk,
+                     ballots, col_count);
 }
 void hawk_launch_gt_fill(hipStream_t st, uint32_t n_cols, const int32_t* var_r0, const int32_t* var_chain, uint32_t n_var,
-                         const unsigned long long* ballots, const uint64_t* col_off, uint32_t* hv_idx, int32_t* hv_o, int64_t* col_delta) {
+                         const unsigned long long* ballots, const uint64_t* col_off, uint32_t* hv_idx, int32_t* hv_o, int64_t* col_delta,
+                         const uint64_t* indel_off, uint32_t* indel_entry) {
   const uint32_t n_chunk = (n_var + 63u) / 64u;
   hipLaunchKernelGGL(k_gt_fill, dim3((n_cols + 3u) / 4u), dim3(256), 0, st, n_cols, var_r0, var_chain, n_var, n_chunk, ballots, col_off,
-                     hv_idx, hv_o, col_delta);
+                     hv_idx, hv_o, col_delta, indel_off, indel_entry);
 }

@@ -287,6 +287,10 @@ int hawk_gt_codes(hawk_gt* g, uint8_t* codes, uint8_t* line_flags);
 int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allele, const int32_t* var_r0, const int32_t* var_chain,
                   uint32_t n_var, uint64_t* col_off, int64_t* col_delta, float* kernel_ms);
 int hawk_gt_lists_download(hawk_gt* g, uint32_t* hv_idx, int32_t* hv_o);
+/* The entries of those lists whose variant changes the haplotype's length (var_chain != 0), as ascending entry indices:
+ * what the position-map segments are built from (haplotype.py:90-159) without a pass over all entries on the host.
+ * *n_indel is always set; up to cap indices are copied (cap = 0 / NULL: ask for the number first). */
+int hawk_gt_lists_indels(hawk_gt* g, uint32_t* entry_idx, uint64_t cap, uint64_t* n_indel);
 
 /* ---- K7: off-target enumeration, replacing the external `crispritz.py search ... -mm M -bDNA 0
  * -bRNA 0` of offtargets.py:222-293 (CRISPRitz 2.6.6 is a third-party binary the reference shells
