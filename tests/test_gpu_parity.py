@@ -367,6 +367,19 @@ def test_collapse_groups_against_oracle(pam, guidelen, right, exact, mode, monke
     _check_collapse(hs, tab, guidelen, len(pam), right)
 
 
+def test_collapse_hash_table_too_small_falls_back_to_the_sort(monkeypatch):
+    # an all-N stretch: every position is a PAM hit on both strands and every row its own group, 16 x what the hash-table
+    # path sizes its first table for - rows find no slot, the call must come back through the sort path with the same groups
+    seq = "ACGT" * 50 + "N" * 12_000 + "ACGT" * 50
+    ds = DeviceHapSet([HostHaplotype(seq, PosSegments.identity(1, len(seq)), True, (100, len(seq) - 100))])
+    bits, bitsrc, _, _ = ora.pam_encode("NGG")
+    monkeypatch.setenv("HAWK_COLLAPSE_MODE", "hash")
+    tab = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
+    assert tab.n_rows > 20_000 and tab.n_groups == tab.n_rows
+    hs = ora.HapSet([seq], [np.arange(1, len(seq) + 1, dtype=np.int64)], [True], [(100, len(seq) - 100)])
+    _check_collapse(hs, tab, 20, 3, False)
+
+
 def test_collapse_empty_and_single():
     seq = "ACGT" * 100
     ds = DeviceHapSet([HostHaplotype(seq, PosSegments.identity(1, len(seq)), True, (100, 300))])
