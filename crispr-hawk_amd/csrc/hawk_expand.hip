@@ -21,7 +21,7 @@
 #include "hawk_bits.h"
 
 #define HX_TW 1024        // output words a workgroup builds: 32768 positions, four consecutive words per thread
-#define HX_MAXV 160       // carried variants staged per workgroup (32 B each)
+#define HX_MAXV 96        // carried variants staged per workgroup (32 B each; more: the rest from global memory)
 #define HX_RW (HX_TW + 64)  // REF words staged per plane: the tile's image in REF plus up to 2048 net deleted bases
 
 // o: output start; rs = r0 + span: where REF resumes behind the alt allele; m: the first 32 alt bases as plane bits
@@ -207,7 +207,7 @@ __device__ __forceinline__ void hx_words(const HxArgs& g, const HxVar* __restric
   }
 }
 
-__global__ __launch_bounds__(HAWK_BLOCK) void k_hx_build(HxArgs g, const uint64_t* __restrict__ hv_off, const uint32_t* __restrict__ hap_len,
+__global__ __launch_bounds__(HAWK_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_hx_build(HxArgs g, const uint64_t* __restrict__ hv_off, const uint32_t* __restrict__ hap_len,
                                                           uint32_t S, uint32_t wpr /*tiles per row*/, const HxTile* __restrict__ tiles,
                                                           uint32_t* pA, uint32_t* pC, uint32_t* pG, uint32_t* pT, uint32_t* pV) {
   __shared__ HxVar s_v[HX_MAXV];
