@@ -184,6 +184,14 @@ def test_device_carried_lists_against_oracle():
         _lib.check(L.hawk_gt_lists_download(g, _p(idx), _p(off)), "hawk_gt_lists_download")
         w_off, w_idx, w_o, w_delta = ora.carried_lists(codes, var_line, var_allele, var_r0, var_chain)
         assert np.array_equal(col_off, w_off) and np.array_equal(idx, w_idx) and np.array_equal(off, w_o) and np.array_equal(delta, w_delta)
+        # the carried indels, as entry indices of those lists (hawk_gt_lists_indels): asked for in two steps
+        ni = C.c_uint64(0)
+        _lib.check(L.hawk_gt_lists_indels(g, None, C.c_uint64(0), C.byref(ni)), "hawk_gt_lists_indels")
+        want_ind = np.flatnonzero(var_chain[w_idx] != 0)
+        assert ni.value == len(want_ind) > 0
+        ind = np.zeros(ni.value, np.uint32)
+        _lib.check(L.hawk_gt_lists_indels(g, _p(ind), C.c_uint64(ni.value), C.byref(ni)), "hawk_gt_lists_indels")
+        assert np.array_equal(ind, want_ind)
     finally:
         _lib.lib().hawk_gt_destroy(g)
 
