@@ -222,6 +222,67 @@ class RowMeta:
                 np.ascontiguousarray(self.seg_rel, dtype=np.uint32), np.ascontiguousarray(self.seg_gen, dtype=np.int64), 0)
 
 
+def build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp: int, hap_len, alias):
+    """Position-map segments of all rows of an expansion as CSR arrays (seg_start[n + 1], seg_rel u32, seg_gen i64) from the
+    carried indels `ind` (entry indices into hv_idx / hv_o, ascending): the library's host helper
+    (hawk_host_build_segments; one pass over the ~10 % of list entries that are indels).  `build_segments_numpy` is the
+    same in numpy - what ran before, kept as the cross-check of tests/test_host_logic.py."""
+    import ctypes as C
+    from . import _lib
+    from .hapset import _p
+    L = _lib.lib()
+    n = len(hap_len)
+    ind = np.ascontiguousarray(ind, dtype=np.uint32)
+    hv_idx = np.ascontiguousarray(hv_idx, dtype=np.uint32)
+    hv_o = np.ascontiguousarray(hv_o, dtype=np.int32)
+    hv_off = np.ascontiguousarray(hv_off, dtype=np.uint64)
+    r0_, ch_ = np.ascontiguousarray(r0, dtype=np.int64), np.ascontiguousarray(chain, dtype=np.int64)
+    hl, al = np.ascontiguousarray(hap_len, dtype=np.uint32), np.ascontiguousarray(alias, dtype=np.int64)
+    seg_start = np.zeros(n + 1, dtype=np.uint64)
+    args = (_p(ind), C.c_uint64(len(ind)), _p(hv_idx), _p(hv_o), _p(hv_off), C.c_uint32(n), _p(r0_), _p(ch_), C.c_int64(int(startp)), _p(hl), _p(al),
+            _p(seg_start))
+    _lib.check(L.hawk_host_build_segments(*args, None, None, C.c_uint64(0)), "hawk_host_build_segments")
+    tot = int(seg_start[-1])
+    seg_rel = np.zeros(tot, dtype=np.uint32)
+    seg_gen = np.zeros(tot, dtype=np.int64)
+    _lib.check(L.hawk_host_build_segments(*args, _p(seg_rel), _p(seg_gen), C.c_uint64(tot)), "hawk_host_build_segments")
+    return seg_start.astype(np.int64), seg_rel, seg_gen
+
+
+def build_segments_numpy(ind, hv_idx, hv_o, hv_off, r0, chain, startp: int, hap_len, alias):
+    """build_segments in numpy (all rows at once): every carried deletion opens one segment behind it, every carried
+    insertion of n bases opens n + 1 (the inserted bases all map to the anchor position, haplotype.py:106-159)."""
+    n_hap = len(hap_len)
+    ind = np.asarray(ind, dtype=np.int64)
+    o_i = hv_o[ind].astype(np.int64)
+    pos_i = r0[hv_idx[ind]] + startp
+    ch_i = chain[hv_idx[ind]]
+    row_i = np.searchsorted(np.asarray(hv_off[1:], dtype=np.int64), ind, side="right")  # row of the entry (row 0 is REF)
+    nseg_i = np.where(ch_i < 0, 1, ch_i + 1)
+    first_of = np.cumsum(nseg_i) - nseg_i
+    k_in = np.arange(int(nseg_i.sum())) - np.repeat(first_of, nseg_i)  # 0..n within an insertion's run, 0 for a deletion
+    base_i = np.where(ch_i < 0, pos_i + 1 - ch_i, pos_i)
+    bump_at = np.where(ch_i < 0, np.iinfo(np.int64).max, ch_i)
+    seg_rel_all = np.repeat(o_i + 1, nseg_i) + k_in
+    seg_gen_all = np.repeat(base_i, nseg_i) + (k_in >= np.repeat(bump_at, nseg_i))
+    seg_row_all = np.repeat(row_i, nseg_i)
+    keep = seg_rel_all < np.asarray(hap_len)[seg_row_all].astype(np.int64)
+    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[keep], seg_gen_all[keep], seg_row_all[keep]
+    # rows collapsed onto another keep the identity map only; every row starts with the identity segment (rel 0 ->
+    # startp).  The rows' own segments come out in (row, rel) order already - list entries are ordered by row, then by
+    # variant, and output positions grow with the variant - so the identity segments are slotted in, not sorted in.
+    live_seg = np.asarray(alias)[seg_row_all] == seg_row_all
+    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[live_seg], seg_gen_all[live_seg], seg_row_all[live_seg]
+    own_cnt = np.bincount(seg_row_all, minlength=n_hap)
+    seg_start = np.concatenate(([0], np.cumsum(own_cnt + 1)))
+    dst = np.arange(len(seg_rel_all)) + seg_row_all + 1    # own segment i of row r lands behind r + 1 identity segments
+    rel_m = np.zeros(int(seg_start[-1]), dtype=np.int64)
+    gen_m = np.full(int(seg_start[-1]), startp, dtype=np.int64)
+    rel_m[dst] = seg_rel_all
+    gen_m[dst] = seg_gen_all
+    return seg_start, rel_m.astype(np.uint32), gen_m
+
+
 def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, samples: List[str], tab, live: np.ndarray,
                  counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device,
                  own: Optional[ScanOwnership] = None, keep_plan: bool = False, indel_entries: Optional[np.ndarray] = None):
@@ -312,44 +373,9 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
         else:
             info[o].samples.append(lab)
     # ---- position-map segments + scan bounds per row ------------------------------------------
-    # all rows at once: every carried deletion opens one segment behind it, every carried insertion of n bases
-    # opens n + 1 (the inserted bases all map to the anchor position, haplotype.py:106-159)
     # the carried indels: listed by the device inversion (hawk_gt_lists_indels), else one byte-table gather over the lists
-    ind = indel_entries.astype(np.int64) if indel_entries is not None else np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])
-    o_i = hv_o[ind].astype(np.int64)
-    pos_i = r0[hv_idx[ind]] + startp
-    ch_i = chain[hv_idx[ind]]
-    row_i = np.searchsorted(hv_off[1:].astype(np.int64), ind, side="right")  # device row of the entry (row 0 is REF)
-    nseg_i = np.where(ch_i < 0, 1, ch_i + 1)
-    first_of = np.cumsum(nseg_i) - nseg_i
-    k_in = np.arange(int(nseg_i.sum())) - np.repeat(first_of, nseg_i)  # 0..n within an insertion's run, 0 for a deletion
-    # one repeat per per-indel quantity (not a gather per use): a deletion's single segment starts behind the deleted
-    # bases; an insertion's n + 1 segments repeat the anchor position n times, then move on
-    base_i = np.where(ch_i < 0, pos_i + 1 - ch_i, pos_i)
-    bump_at = np.where(ch_i < 0, np.iinfo(np.int64).max, ch_i)
-    seg_rel_all = np.repeat(o_i + 1, nseg_i) + k_in
-    seg_gen_all = np.repeat(base_i, nseg_i) + (k_in >= np.repeat(bump_at, nseg_i))
-    seg_row_all = np.repeat(row_i, nseg_i)
-    keep = seg_rel_all < hap_len[seg_row_all].astype(np.int64)
-    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[keep], seg_gen_all[keep], seg_row_all[keep]
-    # rows collapsed onto another keep the identity map only; every row starts with the identity segment (rel 0 ->
-    # startp).  The rows' own segments come out in (row, rel) order already - list entries are ordered by row, then by
-    # variant, and output positions grow with the variant - so the identity segments are slotted in, not sorted in.
-    live_seg = alias[seg_row_all] == seg_row_all
-    seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[live_seg], seg_gen_all[live_seg], seg_row_all[live_seg]
-    if len(seg_rel_all) > 1:
-        same = seg_row_all[1:] == seg_row_all[:-1]
-        if np.any(same & (seg_rel_all[1:] <= seg_rel_all[:-1])) or np.any(seg_row_all[1:] < seg_row_all[:-1]):
-            srt = np.lexsort((seg_rel_all, seg_row_all))
-            seg_rel_all, seg_gen_all, seg_row_all = seg_rel_all[srt], seg_gen_all[srt], seg_row_all[srt]
-    own_cnt = np.bincount(seg_row_all, minlength=n_hap)
-    seg_start = np.concatenate(([0], np.cumsum(own_cnt + 1)))
-    dst = np.arange(len(seg_rel_all)) + seg_row_all + 1    # own segment i of row r lands behind r + 1 identity segments
-    rel_m = np.zeros(int(seg_start[-1]), dtype=np.int64)
-    gen_m = np.full(int(seg_start[-1]), startp, dtype=np.int64)
-    rel_m[dst] = seg_rel_all
-    gen_m[dst] = seg_gen_all
-    seg_rel_all, seg_gen_all = rel_m, gen_m
+    ind = indel_entries if indel_entries is not None else np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])
+    seg_start, seg_rel_all, seg_gen_all = build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp, hap_len, alias)
     haps = RowMeta(seg_start, seg_rel_all.astype(np.uint32), seg_gen_all, hap_len, alias, startp)
     haps.compute_scans(startp, stopp, pamlen, own)
     ds.set_meta(haps)

@@ -234,4 +234,50 @@ int hawk_host_group_samples(const uint64_t* member_off, const uint32_t* member_h
   return HAWK_OK;
 }
 
+// Position-map segments of every row of an expansion (haplotype.py:90-159 as unit-slope segments), from the carried
+// indels alone: row r's list entries are [hv_off[r], hv_off[r+1]); indel_entry = the ascending entry indices whose
+// variant changes the length (hawk_gt_lists_indels).  A carried deletion opens one segment behind the deleted bases, a
+// carried insertion of n bases n + 1 (the inserted bases all map to the anchor position); every row starts with the
+// identity segment (rel 0 -> startp); rows that alias another row (collapsed onto it) keep only that one; segments
+// starting at or behind the row's end are dropped.  seg_start[n_rows + 1] is always written (so a first call with
+// cap = 0 tells the size), seg_rel / seg_gen when they hold seg_start[n_rows] entries.
+int hawk_host_build_segments(const uint32_t* indel_entry, uint64_t n_indel, const uint32_t* hv_idx, const int32_t* hv_o,
+                             const uint64_t* hv_off, uint32_t n_rows, const int64_t* var_r0, const int64_t* var_chain, int64_t startp,
+                             const uint32_t* hap_len, const int64_t* alias, uint64_t* seg_start, uint32_t* seg_rel, int64_t* seg_gen,
+                             uint64_t cap) {
+  if (!hv_off || !hap_len || !alias || !seg_start || !n_rows || (n_indel && (!indel_entry || !hv_idx || !hv_o || !var_r0 || !var_chain)))
+    return HAWK_E_INVALID;
+  for (int pass = 0; pass < 2; ++pass) {
+    uint64_t e = 0, at = 0;
+    for (uint32_t r = 0; r < n_rows; ++r) {
+      if (pass == 0) seg_start[r] = at;
+      if (pass == 1) { seg_rel[at] = 0; seg_gen[at] = startp; }
+      ++at;
+      const bool own = alias[r] == (int64_t)r;
+      const int64_t len = (int64_t)hap_len[r];
+      for (; e < n_indel && indel_entry[e] < hv_off[r + 1]; ++e) {
+        if (indel_entry[e] < hv_off[r]) return HAWK_E_INVALID;  // entries must ascend with the rows
+        if (!own) continue;
+        const uint32_t v = hv_idx[indel_entry[e]];
+        const int64_t o = hv_o[indel_entry[e]], pos = var_r0[v] + startp, ch = var_chain[v];
+        const int64_t nseg = ch < 0 ? 1 : ch + 1;
+        for (int64_t k = 0; k < nseg; ++k) {
+          const int64_t rel = o + 1 + k;
+          if (rel >= len) break;
+          if (pass == 1) {
+            seg_rel[at] = (uint32_t)rel;
+            seg_gen[at] = ch < 0 ? pos + 1 - ch : (k < ch ? pos : pos + 1);
+          }
+          ++at;
+        }
+      }
+    }
+    if (pass == 0) {
+      seg_start[n_rows] = at;
+      if (!seg_rel || !seg_gen || cap < at) return cap ? HAWK_E_CAPACITY : HAWK_OK;
+    }
+  }
+  return HAWK_OK;
+}
+
 }  // extern "C"

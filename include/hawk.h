@@ -242,6 +242,13 @@ int hawk_host_group_samples(const uint64_t* member_off, const uint32_t* member_h
                             const uint16_t* ent_a2, const uint8_t* ent_ok, uint64_t n_entries, const uint8_t* name_pool,
                             const uint64_t* name_off, uint64_t n_samples, const uint8_t* ent_pool, const uint64_t* ent_pool_off,
                             uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint8_t* group_flags);
+/* Position-map segments (haplotype.py:90-159 as unit-slope segments) of all rows of an expansion from its carried
+ * indels (hawk_gt_lists_indels): CSR seg_start[n_rows + 1] (always written: call with cap = 0 for the size), seg_rel,
+ * seg_gen.  Rows aliasing another row keep the identity segment only. */
+int hawk_host_build_segments(const uint32_t* indel_entry, uint64_t n_indel, const uint32_t* hv_idx, const int32_t* hv_o,
+                             const uint64_t* hv_off, uint32_t n_rows, const int64_t* var_r0, const int64_t* var_chain, int64_t startp,
+                             const uint32_t* hap_len, const int64_t* alias, uint64_t* seg_start, uint32_t* seg_rel, int64_t* seg_gen,
+                             uint64_t cap);
 
 /* ---- the one exchange of a multi-GPU job.  One process per GPU, haplotypes block-partitioned with REF
  * on every rank (search_guides.py:111-131, 530-547 loop over independent haplotypes), no collective on the search

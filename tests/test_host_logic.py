@@ -48,3 +48,32 @@ def test_expand_errors():
     out, seg = expand_haplotype(ref, 100, [(105, b"C", b"CAA")])
     assert out.tobytes() == b"ACGTAcaaGTACGTACGTACGT" and seg.full().tolist()[4:9] == [104, 105, 105, 105, 106]
     assert seg.rev(105) == 7
+
+
+def test_segment_builder_helper_matches_numpy():
+    """hawk_host_build_segments (the library's host pass over the carried indels) against the numpy formulation it
+    replaced, on random carried lists: deletions, insertions, rows aliased onto others, segments cut by the row's end."""
+    from crisprhawk_hip.workload import build_segments, build_segments_numpy
+    rng = np.random.default_rng(4242)
+    nv, n_rows, startp = 400, 60, 1000
+    r0 = np.sort(rng.choice(np.arange(10, 50_000), nv, replace=False)).astype(np.int64)
+    chain = rng.choice([0, 0, 0, -1, -3, 1, 2, 5], nv).astype(np.int64)
+    counts = np.concatenate(([0], rng.integers(0, 40, n_rows - 1)))
+    hv_off = np.concatenate(([0], np.cumsum(counts))).astype(np.uint64)
+    hv_idx = np.concatenate([np.sort(rng.choice(nv, c, replace=False)) for c in counts]).astype(np.uint32)
+    hv_o = np.empty(len(hv_idx), dtype=np.int32)
+    hap_len = np.empty(n_rows, dtype=np.uint32)
+    for r in range(n_rows):
+        a, b = int(hv_off[r]), int(hv_off[r + 1])
+        ch = chain[hv_idx[a:b]]
+        hv_o[a:b] = r0[hv_idx[a:b]] + np.concatenate(([0], np.cumsum(ch)[:-1])) if b > a else []
+        hap_len[r] = 50_100 + int(ch.sum())
+    hap_len[7] = int(hv_o[int(hv_off[7]) + 3]) + 2 if counts[7] > 3 else hap_len[7]  # a row ending inside its own list
+    alias = np.arange(n_rows, dtype=np.int64)
+    alias[[5, 11, 12]] = [2, 0, 11]
+    ind = np.flatnonzero(chain[hv_idx] != 0)
+    got = build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp, hap_len, alias)
+    want = build_segments_numpy(ind, hv_idx, hv_o, hv_off, r0, chain, startp, hap_len, alias)
+    for g, w in zip(got, want):
+        assert np.array_equal(np.asarray(g, dtype=np.int64), np.asarray(w, dtype=np.int64))
+    assert got[0][1] == 1 and got[1][0] == 0 and got[2][0] == startp  # REF: the identity segment alone
