@@ -367,6 +367,40 @@ def test_collapse_groups_against_oracle(pam, guidelen, right, exact, mode, monke
     _check_collapse(hs, tab, guidelen, len(pam), right)
 
 
+def test_collapse_with_scorer_flanks_splits_groups_and_both_paths_agree(monkeypatch):
+    # with the model scorers' 4 + 3 flanking bases in the key (hawk_table_collapse_ex; reports.py:978-1003) rows whose
+    # spacer+PAM agree but whose flanks differ stay apart: never fewer groups than without, and the same arrays from the
+    # sort and the hash-table path
+    reg = synth.make_region(7511, "chrC", 40_000, 1_000, 38_000)
+    synth.add_phased_variants(reg, 7512, 600, 6, af_min=0.3, af_max=0.8)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, 3) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    bits, bitsrc, _, _ = ora.pam_encode("NGG")
+    tab = device_set(hs).search(bits, bitsrc, 3, 20, False, download=False)
+    monkeypatch.setenv("HAWK_COLLAPSE_MODE", "sort")
+    tab.collapse()
+    plain = tab.n_groups
+    out = {}
+    for mode in ("sort", "hash"):
+        monkeypatch.setenv("HAWK_COLLAPSE_MODE", mode)
+        tab.collapse(flank=(4, 3))
+        out[mode] = (tab.n_groups, tab.group_perm.copy(), tab.group_off.copy(), tab.gc_num.copy(), tab.gc_den.copy())
+    assert out["sort"][0] == out["hash"][0] > plain
+    for a, b in zip(out["sort"][1:], out["hash"][1:]):
+        assert np.array_equal(a, b)
+    # every group of the flank-aware collapse agrees on the widened window
+    tab.download()
+    wins = tab.windows()
+    perm, off = out["hash"][1].astype(np.int64), out["hash"][2].astype(np.int64)
+    for g in range(0, out["hash"][0], 7):
+        rows = perm[off[g]:off[g + 1]]
+        keys = {(wins[r][10 - 4:-10 + 3] if tab.strand[r] == 0 else wins[r][10 - 3:-10 + 4]) for r in rows.tolist()}
+        assert len(keys) == 1
+
+
 def test_collapse_hash_table_too_small_falls_back_to_the_sort(monkeypatch):
     # an all-N stretch: every position is a PAM hit on both strands and every row its own group, 16 x what the hash-table
     # path sizes its first table for - rows find no slot, the call must come back through the sort path with the same groups
