@@ -102,10 +102,18 @@ def _variant_table(pos: np.ndarray, refs: List[str], alts: List[str], seq: str, 
         raise HaplotypeBuildError("device expansion handles SNVs, deletions (alt of one base) and insertions")
     if np.any(r0 < 0) or np.any(r0 + span > n_ref):
         raise HaplotypeBuildError("variant outside the region")
-    for i in range(nv):  # REF allele must match (haplotype.py:203-208)
-        a, sp = int(r0[i]), int(span[i])
-        if len(refs[i]) < sp or seq[a:a + sp].upper() != refs[i][:sp].upper():
-            raise HaplotypeBuildError(f"Mismatching reference alleles at position {int(pos[i])}")
+    # REF allele must match (haplotype.py:203-208): its first base for all records at once, the rest of a deletion's
+    # span (the few records with span > 1) one by one
+    if nv:
+        seq_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8) if isinstance(seq, str) else np.asarray(seq, dtype=np.uint8)
+        first = np.frombuffer("".join(x[:1] or "\0" for x in refs).encode("ascii"), dtype=np.uint8)
+        bad = np.flatnonzero(((seq_u8[r0] ^ first) & 0xDF) != 0)  # case-insensitive (letters only)
+        if len(bad):
+            raise HaplotypeBuildError(f"Mismatching reference alleles at position {int(pos[int(bad[0])])}")
+        for i in np.flatnonzero(span > 1).tolist():
+            a, sp = int(r0[i]), int(span[i])
+            if len(refs[i]) < sp or seq[a:a + sp].upper() != refs[i][:sp].upper():
+                raise HaplotypeBuildError(f"Mismatching reference alleles at position {int(pos[i])}")
     alt_blob = "".join(alts).encode("ascii")
     alt_codes = _NIB[np.frombuffer(alt_blob, dtype=np.uint8)] if alt_blob else np.zeros(0, np.uint8)
     alt_off = np.zeros(nv, dtype=np.int64)
@@ -184,7 +192,21 @@ class RowMeta:
 
     def _rev_all(self, g: int) -> np.ndarray:
         """posmap_rev[g] of every row at once: the last relative position whose genomic position is g, -1 where g is
-        deleted (the reference rebuilds the reverse dict by overwrite, haplotype.py:159)."""
+        deleted (the reference rebuilds the reverse dict by overwrite, haplotype.py:159).  One pass over the segments in
+        the library's host helper; `_rev_all_numpy` is the same in numpy (cross-check of tests/test_host_logic.py)."""
+        import ctypes as C
+        from . import _lib
+        from .hapset import _p
+        ss = np.ascontiguousarray(self.seg_start, dtype=np.uint64)
+        sr = np.ascontiguousarray(self.seg_rel, dtype=np.uint32)
+        sg = np.ascontiguousarray(self.seg_gen, dtype=np.int64)
+        hl = np.ascontiguousarray(self.hap_len, dtype=np.uint32)
+        out = np.empty(self.n, dtype=np.int64)
+        _lib.check(_lib.lib().hawk_host_posmap_rev(_p(ss), _p(sr), _p(sg), _p(hl), C.c_uint32(self.n), C.c_int64(int(g)), _p(out)),
+                   "hawk_host_posmap_rev")
+        return out
+
+    def _rev_all_numpy(self, g: int) -> np.ndarray:
         ends = np.empty(len(self.seg_rel), dtype=np.int64)
         ends[:-1] = self.seg_rel[1:]
         ends[self.seg_start[1:] - 1] = self.hap_len          # a row's last segment runs to the row's end

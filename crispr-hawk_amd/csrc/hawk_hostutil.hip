@@ -247,35 +247,56 @@ int hawk_host_build_segments(const uint32_t* indel_entry, uint64_t n_indel, cons
                              uint64_t cap) {
   if (!hv_off || !hap_len || !alias || !seg_start || !n_rows || (n_indel && (!indel_entry || !hv_idx || !hv_o || !var_r0 || !var_chain)))
     return HAWK_E_INVALID;
-  for (int pass = 0; pass < 2; ++pass) {
-    uint64_t e = 0, at = 0;
-    for (uint32_t r = 0; r < n_rows; ++r) {
-      if (pass == 0) seg_start[r] = at;
-      if (pass == 1) { seg_rel[at] = 0; seg_gen[at] = startp; }
-      ++at;
-      const bool own = alias[r] == (int64_t)r;
-      const int64_t len = (int64_t)hap_len[r];
-      for (; e < n_indel && indel_entry[e] < hv_off[r + 1]; ++e) {
-        if (indel_entry[e] < hv_off[r]) return HAWK_E_INVALID;  // entries must ascend with the rows
-        if (!own) continue;
-        const uint32_t v = hv_idx[indel_entry[e]];
-        const int64_t o = hv_o[indel_entry[e]], pos = var_r0[v] + startp, ch = var_chain[v];
-        const int64_t nseg = ch < 0 ? 1 : ch + 1;
-        for (int64_t k = 0; k < nseg; ++k) {
-          const int64_t rel = o + 1 + k;
-          if (rel >= len) break;
-          if (pass == 1) {
-            seg_rel[at] = (uint32_t)rel;
-            seg_gen[at] = ch < 0 ? pos + 1 - ch : (k < ch ? pos : pos + 1);
-          }
-          ++at;
+  for (uint64_t e = 1; e < n_indel; ++e)
+    if (indel_entry[e] <= indel_entry[e - 1]) return HAWK_E_INVALID;  // ascending: a row's indels are one run of the list
+  if (n_indel && indel_entry[n_indel - 1] >= hv_off[n_rows]) return HAWK_E_INVALID;
+  // one row's segments: the identity segment, then those of its carried indels (entries [hv_off[r], hv_off[r + 1]) of the
+  // list, found by bisection so that rows can be walked by several threads); `at` = where the row's segments go, or
+  // nullptr to count them
+  auto row = [&](uint32_t r, uint64_t at, bool write) -> uint64_t {
+    uint64_t cnt = 1;
+    if (write) { seg_rel[at] = 0; seg_gen[at] = startp; }
+    if (alias[r] != (int64_t)r) return cnt;
+    const uint32_t* lo = std::lower_bound(indel_entry, indel_entry + n_indel, hv_off[r],
+                                          [](uint32_t a, uint64_t b) { return (uint64_t)a < b; });
+    const int64_t len = (int64_t)hap_len[r];
+    for (const uint32_t* p = lo; p < indel_entry + n_indel && *p < hv_off[r + 1]; ++p) {
+      const uint32_t v = hv_idx[*p];
+      const int64_t o = hv_o[*p], pos = var_r0[v] + startp, ch = var_chain[v];
+      const int64_t nseg = ch < 0 ? 1 : ch + 1;
+      for (int64_t k = 0; k < nseg; ++k) {
+        const int64_t rel = o + 1 + k;
+        if (rel >= len) break;
+        if (write) {
+          seg_rel[at + cnt] = (uint32_t)rel;
+          seg_gen[at + cnt] = ch < 0 ? pos + 1 - ch : (k < ch ? pos : pos + 1);
         }
+        ++cnt;
       }
     }
-    if (pass == 0) {
-      seg_start[n_rows] = at;
-      if (!seg_rel || !seg_gen || cap < at) return cap ? HAWK_E_CAPACITY : HAWK_OK;
+    return cnt;
+  };
+  par_groups(n_rows, [&](uint64_t a, uint64_t b) { for (uint64_t r = a; r < b; ++r) seg_start[r + 1] = row((uint32_t)r, 0, false); });
+  seg_start[0] = 0;
+  for (uint32_t r = 0; r < n_rows; ++r) seg_start[r + 1] += seg_start[r];
+  if (!seg_rel || !seg_gen || cap < seg_start[n_rows]) return cap ? HAWK_E_CAPACITY : HAWK_OK;
+  par_groups(n_rows, [&](uint64_t a, uint64_t b) { for (uint64_t r = a; r < b; ++r) (void)row((uint32_t)r, seg_start[r], true); });
+  return HAWK_OK;
+}
+
+// posmap_rev[g] of every row (the reference rebuilds the reverse dict by overwrite, haplotype.py:159): the LAST relative
+// position whose genomic position is g, -1 where g is deleted from the row or outside it.  Segments as built above.
+int hawk_host_posmap_rev(const uint64_t* seg_start, const uint32_t* seg_rel, const int64_t* seg_gen, const uint32_t* hap_len,
+                         uint32_t n_rows, int64_t g, int64_t* out) {
+  if (!seg_start || !seg_rel || !seg_gen || !hap_len || !out) return HAWK_E_INVALID;
+  for (uint32_t r = 0; r < n_rows; ++r) {
+    int64_t best = -1;
+    for (uint64_t k = seg_start[r]; k < seg_start[r + 1]; ++k) {
+      const int64_t end = k + 1 < seg_start[r + 1] ? (int64_t)seg_rel[k + 1] : (int64_t)hap_len[r];
+      const int64_t last_gen = seg_gen[k] + (end - (int64_t)seg_rel[k]) - 1;
+      if (seg_gen[k] <= g && g <= last_gen) best = (int64_t)seg_rel[k] + (g - seg_gen[k]);  // later segments overwrite
     }
+    out[r] = best;
   }
   return HAWK_OK;
 }

@@ -249,6 +249,10 @@ int hawk_host_build_segments(const uint32_t* indel_entry, uint64_t n_indel, cons
                              const uint64_t* hv_off, uint32_t n_rows, const int64_t* var_r0, const int64_t* var_chain, int64_t startp,
                              const uint32_t* hap_len, const int64_t* alias, uint64_t* seg_start, uint32_t* seg_rel, int64_t* seg_gen,
                              uint64_t cap);
+/* posmap_rev[g] (haplotype.py:159: the last relative position whose genomic position is g; -1 where g is deleted) of every
+ * row of such a segment table at once: what compute_scan_start_stop (search_guides.py:49-84) looks up per haplotype. */
+int hawk_host_posmap_rev(const uint64_t* seg_start, const uint32_t* seg_rel, const int64_t* seg_gen, const uint32_t* hap_len,
+                         uint32_t n_rows, int64_t g, int64_t* out);
 
 /* ---- the one exchange of a multi-GPU job.  One process per GPU, haplotypes block-partitioned with REF
  * on every rank (search_guides.py:111-131, 530-547 loop over independent haplotypes), no collective on the search
