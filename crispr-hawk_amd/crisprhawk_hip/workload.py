@@ -513,11 +513,29 @@ class VcfVariants:
     def __init__(self, block, contig: Optional[str] = None):
         from .variant import adjust_multiallelic
         pos, ref, alt, vid, af, line, allele = [], [], [], [], [], [], []
+        nan = float("nan")
         for i, f in enumerate(block.fixed):
-            chrom, p, r, alts, info = f[0], int(f[1]), f[3], f[4].split(","), f[7]
-            afs = [float("nan")] * len(alts)
+            chrom, p, r, alt_s, info = f[0], int(f[1]), f[3], f[4], f[7]
             k = info.find("AF=")
-            if k != -1:  # variant.py:188-206
+            if "," not in alt_s:  # one ALT allele: the usual record, no per-allele loop
+                a1 = nan
+                if k != -1:  # variant.py:188-206
+                    e = info.find(";", k + 3)
+                    a_s = info[k + 3: len(info) if e == -1 else e]
+                    if "," in a_s:
+                        raise ValueError(f"AF number does not match the alleles number ({a_s.count(',') + 1} - 1)")
+                    a1 = float(a_s)
+                if len(r) == 1 and len(alt_s) == 1:
+                    r_, a_, p_ = r, alt_s, p
+                else:
+                    r_, a_, p_ = adjust_multiallelic(r, alt_s, p)
+                pos.append(p_); ref.append(r_); alt.append(a_); af.append(a1)
+                vid.append(f"{chrom}-{p}-{r}/{alt_s}")
+                line.append(i); allele.append(1)
+                continue
+            alts = alt_s.split(",")
+            afs = [nan] * len(alts)
+            if k != -1:
                 e = info.find(";", k + 3)
                 afs = [float(x) for x in info[k + 3: len(info) if e == -1 else e].split(",")]
                 if len(afs) != len(alts):
@@ -582,12 +600,17 @@ def expand_from_vcf(region_seq: str, startp: int, stopp: int, block, samples: Li
         hv_o = np.zeros(max(ne, 1), dtype=np.int32)
         _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
         hv_idx, hv_o = hv_idx[:ne], hv_o[:ne]
+        ni = C.c_uint64(0)  # the carried indels (position-map segments are built from them)
+        _lib.check(L.hawk_gt_lists_indels(g, None, C.c_uint64(0), C.byref(ni)), "hawk_gt_lists_indels")
+        indel = np.zeros(max(ni.value, 1), dtype=np.uint32)
+        _lib.check(L.hawk_gt_lists_indels(g, _p(indel), C.c_uint64(ni.value), C.byref(ni)), "hawk_gt_lists_indels")
+        indel = indel[:ni.value]
     finally:
         L.hawk_gt_destroy(g)
     counts = np.diff(col_off.astype(np.int64))
     live = np.flatnonzero(counts)
     ds, info, ms_expand, kept = _expand_rows(ref_set, region_seq, startp, stopp, pamlen, samples, tab, live, counts[live], hv_idx,
-                                             hv_o, col_delta[live], device)
+                                             hv_o, col_delta[live], device, indel_entries=indel)
     return ds, info, {"parse": float(ms_parse.value), "lists": float(ms_lists.value), "expand": ms_expand}, kept, vt
 
 
