@@ -197,12 +197,13 @@ class RowMeta:
         import ctypes as C
         from . import _lib
         from .hapset import _p
+        from .reports import _host_lib
         ss = np.ascontiguousarray(self.seg_start, dtype=np.uint64)
         sr = np.ascontiguousarray(self.seg_rel, dtype=np.uint32)
         sg = np.ascontiguousarray(self.seg_gen, dtype=np.int64)
         hl = np.ascontiguousarray(self.hap_len, dtype=np.uint32)
         out = np.empty(self.n, dtype=np.int64)
-        _lib.check(_lib.lib().hawk_host_posmap_rev(_p(ss), _p(sr), _p(sg), _p(hl), C.c_uint32(self.n), C.c_int64(int(g)), _p(out)),
+        _lib.check(_host_lib().hawk_host_posmap_rev(_p(ss), _p(sr), _p(sg), _p(hl), C.c_uint32(self.n), C.c_int64(int(g)), _p(out)),
                    "hawk_host_posmap_rev")
         return out
 
@@ -252,7 +253,8 @@ def build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp: int, hap_len, a
     import ctypes as C
     from . import _lib
     from .hapset import _p
-    L = _lib.lib()
+    from .reports import _host_lib
+    L = _host_lib()  # libhawk_hip.so, or the sanitizer build of the host helpers (HAWK_HOSTUTIL_LIB)
     n = len(hap_len)
     ind = np.ascontiguousarray(ind, dtype=np.uint32)
     hv_idx = np.ascontiguousarray(hv_idx, dtype=np.uint32)
