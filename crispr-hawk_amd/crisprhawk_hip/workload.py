@@ -327,13 +327,14 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     hv_idx = np.ascontiguousarray(hv_idx, dtype=np.uint32)
     hv_o = np.ascontiguousarray(hv_o, dtype=np.int32)
     hap_len = np.concatenate(([n_ref], n_ref + np.asarray(tot_live, dtype=np.int64))).astype(np.uint32)
-    if len(hv_idx) and own is None:
+    # the carried indels: listed by the device inversion (hawk_gt_lists_indels), else one byte-table gather over the lists
+    ind = indel_entries if indel_entries is not None else np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])
+    if len(ind) and own is None:
         # the reference's clamp (haplotype.py:199-201) would fire.  It compares with the REGION's original length, which a
         # tile of a larger region cannot know (the shift accumulated before the tile): tiled searches do not reproduce
-        # that end-of-region error (divergences).  Only entries within the longest REF allele of the region's
-        # end can trip it: one comparison over the lists, the gather over the few that pass.
-        near = np.flatnonzero(hv_o > n_ref - int(span.max()))
-        if len(near) and np.any(hv_o[near].astype(np.int64) + span[hv_idx[near]] > n_ref):
+        # that end-of-region error (divergences).  Only INDELS can trip it: the reference applies a copy's SNVs
+        # first (haplotype.py:494-512), while the position map is still the identity.
+        if np.any(hv_o[ind].astype(np.int64) + span[hv_idx[ind]] > n_ref):
             raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
     L = _lib.lib()
     xh = C.c_void_p()
@@ -397,8 +398,6 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
         else:
             info[o].samples.append(lab)
     # ---- position-map segments + scan bounds per row ------------------------------------------
-    # the carried indels: listed by the device inversion (hawk_gt_lists_indels), else one byte-table gather over the lists
-    ind = indel_entries if indel_entries is not None else np.flatnonzero((chain != 0).astype(np.uint8)[hv_idx])
     seg_start, seg_rel_all, seg_gen_all = build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp, hap_len, alias)
     haps = RowMeta(seg_start, seg_rel_all.astype(np.uint32), seg_gen_all, hap_len, alias, startp)
     haps.compute_scans(startp, stopp, pamlen, own)

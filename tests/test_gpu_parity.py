@@ -253,6 +253,35 @@ def test_device_expansion_crowded_tiles_and_long_deletions():
         assert np.array_equal(ds.host_meta[r].seg.rel, haps[j].seg.rel) and np.array_equal(ds.host_meta[r].seg.gen, haps[j].seg.gen)
 
 
+def test_clamp_error_is_for_indels_only():
+    # haplotype.py:199-201 compares a variant's span with the region's ORIGINAL length after upstream length changes; the
+    # reference applies a copy's SNVs first, on the untouched sequence (494-512), so a SNV pushed past that length by an
+    # upstream insertion is fine and only an indel there raises (found by tools/stress_parity.py: the device path refused
+    # the SNV case too, the host builder did not)
+    from crisprhawk_hip.expand import HaplotypeBuildError
+    from crisprhawk_hip.workload import build_phased_haplotypes, expand_on_device
+    reg = synth.make_region(7361, "chrQ", 30_000, 2_000, 28_000)
+    seq, n = reg.contig_seq, len(reg.sequence)
+    reg.samples = ["S0000", "S0001"]
+    gt = np.array([[1, 0], [1, 1]], dtype=np.uint8)
+    p_ins, p_snv = reg.startp + 500, reg.startp + n - 40
+    ins = synth.VariantSite(p_ins, seq[p_ins - 1], seq[p_ins - 1] + "ACGT" * 20, 0.5, gt)
+    snv = synth.VariantSite(p_snv, seq[p_snv - 1], "ACGT"[("ACGT".index(seq[p_snv - 1]) + 1) % 4], 0.5, gt)
+    reg.variants = [ins, snv]
+    haps, _ = build_phased_haplotypes(reg, 3)
+    ds, _info, _ms, kept = expand_on_device(reg, 3)
+    want, got = DeviceHapSet(haps).planes(), ds.planes()
+    for j, r in enumerate(kept):
+        w = (len(haps[j].seq) + 31) // 32
+        assert np.array_equal(got[:, r, :w], want[:, j, :w])
+    p_del = reg.startp + n - 40
+    reg.variants = [ins, synth.VariantSite(p_del, seq[p_del - 1:p_del + 2], seq[p_del - 1], 0.5, gt)]
+    with pytest.raises(HaplotypeBuildError):
+        build_phased_haplotypes(reg, 3)
+    with pytest.raises(HaplotypeBuildError):
+        expand_on_device(reg, 3)
+
+
 def _dense_region(seed, sites, samples):
     reg = synth.make_region(seed, "chrX", 75_000, 2_000, 72_000)
     synth.add_phased_variants(reg, seed + 1, sites, samples, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.6, af_max=0.95)
