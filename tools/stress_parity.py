@@ -23,16 +23,17 @@ import test_gpu_parity as T
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+big = len(sys.argv) > 3 and sys.argv[3] == "big"  # 0.5-2 Mb x 20-100 samples: many tiles per row, tables of millions of rows
 rng = np.random.default_rng(seed)
 PAMS = [("NGG", 20, False), ("NGG", 23, False), ("TTTV", 23, True), ("NNGRRT", 21, False), ("NAG", 18, False), ("TTN", 25, True)]
 t0 = time.time()
 rounds = 0
 while time.time() - t0 < budget:
     rounds += 1
-    rlen = int(rng.integers(40_000, 300_000))
-    dens = float(np.exp(rng.uniform(np.log(15), np.log(3000))))       # nt per variant site
+    rlen = int(rng.integers(500_000, 2_000_000)) if big else int(rng.integers(40_000, 300_000))
+    dens = float(np.exp(rng.uniform(np.log(60 if big else 15), np.log(3000))))       # nt per variant site
     sites = max(5, int(rlen / dens))
-    samples = int(rng.integers(2, 13))
+    samples = int(rng.integers(20, 101)) if big else int(rng.integers(2, 13))
     fs = float(rng.uniform(0.2, 0.95)); fd = float(rng.uniform(0, 1 - fs))
     mi = int(rng.choice([2, 5, 12, 40]))
     pam, gl, right = PAMS[int(rng.integers(len(PAMS)))]
