@@ -162,8 +162,9 @@ def add_phased_variants(
     # largest total inserted length any one haplotype carries.
     if out:
         ins_len = np.array([max(0, v.chain) for v in out], dtype=np.int64)
-        ins_rows = np.flatnonzero(ins_len > 0)  # gt_all: [site, hap]
-        guard = int((ins_len[ins_rows, None] * gt_all[ins_rows].astype(np.int64)).sum(axis=0).max()) if len(ins_rows) else 0
+        ins_rows = np.flatnonzero(ins_len > 0)
+        ins_gt = gt_all[np.asarray(ks, dtype=np.int64)[ins_rows]]  # [kept insertion, hap] (sites on ambiguous REF bases were skipped)
+        guard = int((ins_len[ins_rows, None] * ins_gt.astype(np.int64)).sum(axis=0).max()) if len(ins_rows) else 0
         keep = [i for i, v in enumerate(out) if v.pos + len(v.ref) + guard <= reg.stopp]
         out, ks = [out[i] for i in keep], [ks[i] for i in keep]
     reg.variants = out
