@@ -50,6 +50,7 @@ READ_BYTES_PER_POS = 0.625
 ROW_BYTES = 74
 LIST_BYTES = 4  # one u32 hand-over entry per guide row (count pass writes it, k_emit_list reads it)
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
+REFERENCE_TIMING = os.path.join(ROOT, "profiles", "r02_reference_python_timing.json")  # tools/time_reference.py, build container
 
 
 def log(msg):
@@ -305,6 +306,12 @@ def run_region(args, R: Ranks):
             out["end_to_end"] = end_to_end(args, R, reg, pam, mm, pt, info, kept, c1)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reg, pam, args, mm, pt)
+            if not c1 and os.path.exists(REFERENCE_TIMING):
+                # NOT measured here: the reference's own Python path, timed in the build container (it cannot travel to the
+                # GPU box) on C3 restricted to a few haplotypes - the committed number, quoted for scale
+                ext = json.load(open(REFERENCE_TIMING)).get("extrapolation_to_c3", {})
+                out["reference_python"] = {"candidates_per_s": ext.get("c3_candidates_per_s"), "c3_seconds_extrapolated": ext.get("c3_seconds_5009_haplotypes"),
+                                           "measured": "build container, 8 vCPU, single thread (profiles/r02_reference_python_timing.json); not on this host"}
             if not c1 and not args.no_cpu_all_cores:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
     ds.close()
