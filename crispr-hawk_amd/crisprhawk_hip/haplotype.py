@@ -110,12 +110,18 @@ class Haplotype(Region):
         va: Dict[int, List[Tuple[str, str, int]]] = {}
         off = 0                          # length change of the indels already applied (they come last, by position)
         deleted: List[Tuple[int, int]] = []
+        # _initialize_posmap (haplotype.py:90-104) sizes the position map for the FINAL length: a variant whose relative
+        # position is not among its keys yet - a SNV in the last N bases of a stretch that loses N bases in total - raises
+        # KeyError in the look-up, which the unphased insert swallows (274-277): the variant is listed but never applied
+        map_keys = len(self.sequence.sequence) + sum(len(v.alt[0]) - len(v.ref) for v in variants)
         for v in variants:
             pos, ref, alt = v.position, v.ref, v.alt[0]
             if any(a < pos <= b for a, b in deleted):
                 continue                 # position removed by a previous deletion (haplotype.py:262-265)
             chain = len(alt) - len(ref)
             posrel = pos - start + off
+            if posrel >= map_keys:
+                continue                 # not in the position map: skipped, like the deleted positions
             stop = posrel + abs(chain) + 1 if chain < 0 else posrel + 1
             ref_seq = self.sequence.sequence
             refnt = "".join(cur.get(pos + i, ref_seq[pos - start + i: pos - start + i + 1]) for i in range(stop - posrel))

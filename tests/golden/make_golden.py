@@ -414,13 +414,24 @@ def g7_all():
 
 
 # ---------------------------------------------------------------------------- G4 (unphased)
-def g4_unphased():
+G4_CASES = {  # fixture name -> (synth parameters, PAM, guide length, right); tests rebuild the inputs from the stored parameters
+    "g4_unphased": (dict(region=[4001, "chrU", 5000, 1000, 4000], variants=[4002, 40, 3],
+                         kw=dict(frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.2, af_max=0.6)), "NGG", 20, False),
+    "g4_unphased_cpf1": (dict(region=[4011, "chrV", 7000, 1500, 5500], variants=[4012, 70, 4],
+                              kw=dict(frac_snv=0.6, frac_del=0.2, max_indel=5, af_min=0.2, af_max=0.7)), "TTTV", 23, True),
+    "g4_unphased_dense": (dict(region=[4021, "chrW", 4000, 800, 3200], variants=[4022, 110, 6],
+                               kw=dict(frac_snv=0.7, frac_del=0.15, max_indel=8, af_min=0.15, af_max=0.8)), "NGG", 20, False),
+}
+
+
+def g4_unphased(name="g4_unphased"):
     """Unphased VCF: the reference encodes heterozygous SNVs as lower-case IUPAC letters, builds one
     200-bp window haplotype per indel, and search() expands every candidate through resolve_guide
     (search_guides.py:163-257, 473-480).  The haplotypes are built by the reference's own
     add_variants_unphased body (haplotypes.py:672-712, VCF object replaced by its sample list)."""
-    reg = synth.make_region(4001, "chrU", 5000, 1000, 4000)
-    synth.add_phased_variants(reg, 4002, 40, 3, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.2, af_max=0.6)
+    sp, pam_s, guidelen, right = G4_CASES[name]
+    reg = synth.make_region(*sp["region"])
+    synth.add_phased_variants(reg, *sp["variants"], **sp["kw"])
     region = _ref_region(reg)
     haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
     records = []
@@ -439,7 +450,6 @@ def g4_unphased():
             haps.extend(R_haps.create_indels_haplotype_unphased(indel, snvs, region, False, True))
     for i, h in enumerate(haps):
         h.id = f"hap_{i:08d}"
-    pam_s, guidelen, right = "NGG", 20, False
     pam = R_pam.PAM(pam_s, right, True)
     pam.encode(0)
     bits = [R_encoder.encode(h.sequence.sequence, 0, True) for h in haps]
@@ -451,7 +461,8 @@ def g4_unphased():
                      coord=[h.coordinates.startp, h.coordinates.stopp, h.coordinates.start, h.coordinates.stop],
                      posmap_breaks=_posmap_breaks(h.posmap), posmap_len=len(h.posmap),
                      variant_alleles={str(k): [list(t) for t in v] for k, v in h.variant_alleles.items()}) for h in haps]
-    dump("g4_unphased.json.gz", dict(
+    dump(f"{name}.json.gz", dict(
+        synth=sp,
         contig=reg.contig, bed_start=reg.bed_start, bed_stop=reg.bed_stop, startp=region.start, stopp=region.stop,
         region_seq=reg.sequence, pam=pam_s, guidelen=guidelen, right=right, haplotypes=out_haps, scan=scan,
         hits=[[list(f), list(r)] for f, r in hits],
@@ -559,7 +570,8 @@ if __name__ == "__main__":
     if "g3" in which:
         g3_all()
     if "g4" in which:
-        g4_unphased()
+        for _name in G4_CASES:
+            g4_unphased(_name)
     if "g5" in which:
         g5_cfd()
     if "g6" in which:

@@ -153,11 +153,15 @@ def test_azimuth_against_sklearn_gbr():
     assert np.max(np.abs(got - gbr.predict(ora.azimuth_features(test)))) < 1e-9
 
 
-def test_unphased_search_resolves_iupac_like_the_reference():
+G4_FIXTURES = ["g4_unphased", "g4_unphased_cpf1", "g4_unphased_dense"]
+
+
+@pytest.mark.parametrize("fixture", G4_FIXTURES)
+def test_unphased_search_resolves_iupac_like_the_reference(fixture):
     """haplotypes built by the reference from an unphased VCF (lower-case IUPAC letters at
     heterozygous SNVs, one window haplotype per indel) -> search() with resolve_guide expansion."""
     from util import posmap_from_breaks
-    fx = load_golden("g4_unphased.json.gz")
+    fx = load_golden(f"{fixture}.json.gz")
     region = Region(Sequence(fx["region_seq"], True), Coordinate(fx["contig"], fx["bed_start"], fx["bed_stop"], 100))
     haps = []
     for i, gh in enumerate(fx["haplotypes"]):
@@ -180,13 +184,14 @@ def test_unphased_search_resolves_iupac_like_the_reference():
     assert got == fx["guides"]
 
 
-def test_unphased_vcf_records_to_guides_end_to_end():
+@pytest.mark.parametrize("fixture", G4_FIXTURES)
+def test_unphased_vcf_records_to_guides_end_to_end(fixture):
     """Unphased VCF records -> haplotypes.add_variants_unphased (mirror) -> device search -> resolve_guide: the
     guide list the reference produced from its own haplotypes for the same records (g4_unphased)."""
     from test_host_objects import _unphased_inputs
     from crisprhawk_hip import haplotypes as H
-    fx = load_golden("g4_unphased.json.gz")
-    reg, region, recs = _unphased_inputs()
+    fx = load_golden(f"{fixture}.json.gz")
+    reg, region, recs = _unphased_inputs(fx)
     haps = [Haplotype(Sequence(region.sequence.sequence, True), region.coordinates, False, 0, True)]
     haps = H.add_variants_unphased(haps, region, reg.samples, recs, False, True)
     for i, h in enumerate(haps):
