@@ -429,7 +429,13 @@ def g4_unphased(name="g4_unphased"):
     200-bp window haplotype per indel, and search() expands every candidate through resolve_guide
     (search_guides.py:163-257, 473-480).  The haplotypes are built by the reference's own
     add_variants_unphased body (haplotypes.py:672-712, VCF object replaced by its sample list)."""
-    sp, pam_s, guidelen, right = G4_CASES[name]
+    obj = g4_unphased_case(*G4_CASES[name])
+    dump(f"{name}.json.gz", obj)
+    print(f"   unphased: {len(obj['haplotypes'])} haplotypes, {sum(len(f)+len(r) for f, r in obj['hits'])} hits, {len(obj['guides'])} guides")
+
+
+def g4_unphased_case(sp, pam_s, guidelen, right):
+    """One unphased case as a fixture dict (also what tools/campaign_unphased_fixtures.py collects)."""
     reg = synth.make_region(*sp["region"])
     synth.add_phased_variants(reg, *sp["variants"], **sp["kw"])
     region = _ref_region(reg)
@@ -461,13 +467,12 @@ def g4_unphased(name="g4_unphased"):
                      coord=[h.coordinates.startp, h.coordinates.stopp, h.coordinates.start, h.coordinates.stop],
                      posmap_breaks=_posmap_breaks(h.posmap), posmap_len=len(h.posmap),
                      variant_alleles={str(k): [list(t) for t in v] for k, v in h.variant_alleles.items()}) for h in haps]
-    dump(f"{name}.json.gz", dict(
+    return dict(
         synth=sp,
         contig=reg.contig, bed_start=reg.bed_start, bed_stop=reg.bed_stop, startp=region.start, stopp=region.stop,
         region_seq=reg.sequence, pam=pam_s, guidelen=guidelen, right=right, haplotypes=out_haps, scan=scan,
         hits=[[list(f), list(r)] for f, r in hits],
-        guides=[[g.start, g.stop, g.strand, g.sequence, hapidx[g.hapid], bool(g.right), g.samples] for g in guides]))
-    print(f"   unphased: {len(haps)} haplotypes, {sum(len(f)+len(r) for f, r in hits)} hits, {len(guides)} guides")
+        guides=[[g.start, g.stop, g.strand, g.sequence, hapidx[g.hapid], bool(g.right), g.samples] for g in guides])
 
 
 # ---------------------------------------------------------------------------- G5
