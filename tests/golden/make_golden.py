@@ -385,6 +385,8 @@ def g7_report(name, reg, pam_s, guidelen, right, cfd=True, unphased=False):
         unphased=unphased,
         rows_before_collapse=n_rows, report_tsv=tsv,
     )
+    if name is None:  # tools/campaign_report_fixtures.py collects the dicts
+        return obj
     dump(f"g7_report_{name}.json.gz", obj)
     print(f"   {name}: {len(haps)} haplotypes, {n_rows} guide rows -> {len(df)} report rows")
 
