@@ -3,7 +3,7 @@
 the REFERENCE wrote for the same inputs (tools/campaign_report_fixtures.py).  Unphased cases: haplotype ids are matched by
 count (the reference numbers window haplotypes in set order).
 
-    python tools/stress_report_files_gpu.py tools/_campaign/reports.json.gz
+    python tools/stress_report_files_gpu.py tools/_campaign/reports.json.gz [--force-host-builder]
 """
 import gzip
 import io
@@ -17,6 +17,12 @@ import pandas as pd
 from crisprhawk_hip import pipeline, readers, synth
 
 cases = json.load(gzip.open(sys.argv[1], "rt"))
+if "--force-host-builder" in sys.argv:  # phased records through the fallback the pipeline takes when the device expansion declines them
+    from crisprhawk_hip.expand import HaplotypeBuildError
+
+    def _refuse(*a, **k):
+        raise HaplotypeBuildError("forced: host haplotype builder")
+    pipeline.expand_from_vcf = _refuse
 n_ok = 0
 with tempfile.TemporaryDirectory() as tmp:
     for k, fx in enumerate(cases):
