@@ -159,6 +159,7 @@ class TiledRegionSearch:
             seq = seq.tobytes().decode("ascii")
         if len(seq) != tile.seq_hi - tile.seq_lo + 1:
             raise ValueError("fetch() returned a string of the wrong length")
+        seq = seq.upper()  # soft-masked genomes: the reference upper-cases every region (sequence.py:49); lower case means "variant" here
         # the region's scan range in this tile's REF coordinates (REF's position map is the identity)
         reg_lo = self.startp + PADDING - tile.seq_lo
         reg_hi = (self.stopp - PADDING) - pamlen + 1 - tile.seq_lo

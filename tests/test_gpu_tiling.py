@@ -197,3 +197,21 @@ def test_tiled_equals_one_piece_at_megabase_scale():
     ref_rows_t = int((df_t["origin"] == "ref").sum())
     assert ref_rows_t == int((df_1["origin"] == "ref").sum())
     assert sum(st["rows"] for st in mg.stats) >= sum(st["rows"] for st in mg1.stats) * 0.99
+
+
+def test_soft_masked_reference_is_upper_cased_like_the_reference_does():
+    """A genome FASTA with lower-case (soft-masked) stretches: the reference upper-cases every region it reads
+    (sequence.py:49), so a tiled search over a fetch() that returns the masked text must give the groups of the unmasked one."""
+    reg = synth.make_region(4491, "chrM", 16_000, 1_000, 14_000)
+    synth.add_phased_variants(reg, 4492, 200, 4, frac_snv=0.7, frac_del=0.15, af_min=0.2, af_max=0.6)
+    pam = PAM("NGG", False, True)
+    pam.encode(0)
+    masked = reg.contig_seq[:3000] + reg.contig_seq[3000:9000].lower() + reg.contig_seq[9000:]
+    out = []
+    for text in (reg.contig_seq, masked):
+        trs = TiledRegionSearch(lambda lo, hi, t=text: t[lo - 1:hi], reg.contig, reg.startp, reg.stopp, VariantPanel.from_region(reg), pam, 20, False,
+                                tile_nt=4000, flank=400)
+        mg = trs.run(cfd=synth.cfd_tables())
+        out.append(_tiled_groups(mg))
+    assert len(out[0]) > 500 and out[0].keys() == out[1].keys()
+    assert all(out[0][k][0] == out[1][k][0] and _same(out[0][k][1], out[1][k][1]) for k in out[0])
