@@ -4,7 +4,7 @@ search -> annotation -> CFDon -> report chain (as tests/golden/make_golden.py:g7
 of inputs and the TSV text the reference produced, for tools/stress_report_files_gpu.py on the GPU box.  Campaign data,
 not a committed fixture.
 
-    python tools/campaign_report_fixtures.py N seed out.json.gz
+    python tools/campaign_report_fixtures.py N seed out.json.gz [--iupac]
 """
 import gzip
 import importlib.util
@@ -30,7 +30,8 @@ while len(cases) < n and tries < 20 * n:
     tries += 1
     rlen = int(rng.integers(800, 8000))
     b0 = int(rng.integers(200, 1500))
-    reg = synth.make_region(int(rng.integers(1 << 30)), "chrR", b0 + rlen + int(rng.integers(200, 1500)), b0, b0 + rlen)
+    reg = synth.make_region(int(rng.integers(1 << 30)), "chrR", b0 + rlen + int(rng.integers(200, 1500)), b0, b0 + rlen,
+                            iupac_frac=float(rng.choice([0.0, 0.0, 0.003])) if "--iupac" in sys.argv else 0.0)
     sites = max(2, int(rlen / float(np.exp(rng.uniform(np.log(20), np.log(400))))))
     unphased = bool(rng.random() < 0.35)
     try:
