@@ -42,5 +42,13 @@ class CrisprHawkDeepCpf1ScoreError(CrisprHawkScoreError):
     pass
 
 
+class CrisprHawkElevationScoreError(CrisprHawkScoreError):
+    pass
+
+
+class CrisprHawkAnnotationError(CrisprHawkError):
+    pass
+
+
 class CrisprHawkOffTargetsError(CrisprHawkError):
     pass

@@ -3,7 +3,7 @@
 (offtargets.py:328-363) computed in one GPU batch.  The scan's hits are rendered as
 CRISPRitz-format report lines so that ``Offtarget`` parsing, the per-guide counts and the global
 CFD ``100 / (100 + sum(cfd))`` (offtargets.py:561-627) keep the reference's semantics.
-BED annotation of the off-target table and Elevation are out of scope (DESIGN.md §8)."""
+BED annotation of the off-target table and Elevation are out of scope (DESIGN.md §9)."""
 import os
 from typing import Dict, List, Set
 
@@ -55,18 +55,57 @@ def _compute_cfd_score(offtargets: List[Offtarget], verbosity: int, debug: bool)
     return offtargets
 
 
-def report_offtargets(lines: List[str], region: Region, pam: PAM, guidelen: int, right: bool, outdir: str, verbosity: int,
-                      debug: bool) -> List[Offtarget]:
-    offtargets = [Offtarget(line, pam.pam, right, debug) for line in lines]
+def _read_offtargets(crispritz_targets, pam: PAM, right: bool, debug: bool) -> List[Offtarget]:
+    """offtargets.py:296-325.  `crispritz_targets`: the path of a CRISPRitz `*.targets.txt` (first line = header,
+    skipped) or the scan's report lines themselves."""
+    try:
+        if isinstance(crispritz_targets, (str, os.PathLike)):
+            with open(crispritz_targets) as infile:
+                infile.readline()
+                return [Offtarget(line, pam.pam, right, debug) for line in infile]
+        return [Offtarget(line, pam.pam, right, debug) for line in crispritz_targets]
+    except Exception as e:
+        exception_handler(CrisprHawkOffTargetsError, f"Failed retrieving CRISPRitz off-targets in {crispritz_targets}", os.EX_DATAERR, debug, e)
+
+
+def _tsv_float(x: str) -> str:
+    """A score as pandas writes it after the reference's read_csv / to_csv round trip (offtargets.py:540-548): the text
+    is parsed to float64 and written with repr(), NaN as NA."""
+    return "NA" if x == "NA" else repr(float(x))
+
+
+def offtargets_table(offtargets: List[Offtarget]) -> str:
+    """The text of offtargets_*.tsv: header, rows sorted by (chrom, position) - pandas' two-key sort_values is a stable
+    lexsort, ties keep file order -, a trailing newline.  A column without a single number (elevation; cfd for PAMs
+    outside SpCas9 / xCas9) comes back from read_csv as all-NaN and is written NA throughout."""
+    rows = sorted(offtargets, key=lambda o: (o.chrom, o.position))
+    out = ["\t".join(OTREPCNAMES)]
+    for o in rows:
+        f = o.report_line().split("\t")
+        f[9], f[10] = _tsv_float(f[9]), _tsv_float(f[10])
+        out.append("\t".join(f))
+    return "\n".join(out) + "\n"
+
+
+def report_offtargets(crispritz_targets_file, region: Region, pam: PAM, guidelen: int, annotations: List[str], anncolnames: List[str],
+                      compute_elevation: bool, right: bool, outdir: str, verbosity: int, debug: bool) -> List[Offtarget]:
+    """offtargets.py:486-558, same arguments.  CFD for SpCas9 / xCas9 PAMs in one device batch; BED annotation of the
+    table and Elevation are outside the path and refused, not skipped."""
+    if annotations:
+        from .crisprhawk_error import CrisprHawkAnnotationError
+        exception_handler(CrisprHawkAnnotationError, "BED annotation of the off-targets table is not part of the GPU path", os.EX_DATAERR, debug)
+    if compute_elevation and guidelen + len(pam) == 23 and not right:
+        from .crisprhawk_error import CrisprHawkElevationScoreError
+        exception_handler(CrisprHawkElevationScoreError, "Elevation is not part of the GPU scoring path", os.EX_DATAERR, debug)
+    offtargets = _read_offtargets(crispritz_targets_file, pam, right, debug)
     if pam.cas_system in (SPCAS9, XCAS9):
         offtargets = _compute_cfd_score(offtargets, verbosity, debug)
+    print_verbosity("Writing off-targets report", verbosity, VERBOSITYLVL[1])
     if outdir:
         fname = os.path.join(outdir, f"offtargets_{region.contig}_{region.start + PADDING}_{region.stop - PADDING}.tsv")
         try:
-            rows = sorted(offtargets, key=lambda o: (o.chrom, o.position))  # offtargets.py:541
             with open(fname, "w") as f:
-                f.write("\t".join(OTREPCNAMES) + "\n")
-                f.write("\n".join(o.report_line() for o in rows) + ("\n" if rows else ""))
+                f.write(offtargets_table(offtargets))
         except OSError as e:
             exception_handler(CrisprHawkOffTargetsError, f"Failed writing off-targets report for region {region}", os.EX_IOERR, debug, e)
     return offtargets
@@ -92,14 +131,51 @@ def annotate_guides_offtargets(offtargets: List[Offtarget], guides: List[Guide],
     return guides
 
 
-def estimate_offtargets(guides: List[Guide], pam: PAM, genome: GenomeIndex, region: Region, mm: int, bdna: int, brna: int,
-                        guidelen: int, right: bool, outdir: str, verbosity: int, debug: bool) -> List[Guide]:
-    """offtargets.py:630-722"""
+def _genome_index(crispritz_index, guidelen: int, pamlen: int) -> GenomeIndex:
+    """What stands where the reference passes a CRISPRitz index directory: a GenomeIndex, a {contig: sequence} dict or a
+    FASTA path."""
+    if isinstance(crispritz_index, GenomeIndex):
+        return crispritz_index
+    if isinstance(crispritz_index, (str, os.PathLike)):
+        from .genome import read_fasta
+        crispritz_index = read_fasta(str(crispritz_index))
+    return GenomeIndex(crispritz_index, guidelen, pamlen)
+
+
+def offtargets_by_spacer(offtargets: List[Offtarget], spacers) -> Dict[str, tuple]:
+    """{SPACER: (number of rows, global CFD as the report prints it)} - what annotate_guides_offtargets leaves on every
+    guide with that spacer (offtargets.py:597-627; Guide.cfd stores str(round(100 / (100 + sum), 4)), guide.py:723-744)."""
+    from .utils import round_score
+    rows: Dict[str, List[Offtarget]] = {sp.upper(): [] for sp in spacers}
+    for ot in offtargets:
+        rows[ot.grna_.upper().replace("-", "")].append(ot)
+    return {sp: (len(r), str(round_score(_calculate_global_cfd(r)))) for sp, r in rows.items()}
+
+
+def estimate_offtargets_spacers(spacers, pam: PAM, crispritz_index, region, mm: int, bdna: int, brna: int, guidelen: int, right: bool,
+                                outdir: str, verbosity: int, debug: bool) -> Dict[str, tuple]:
+    """estimate_offtargets for the columnar report (pipeline.search_files): the same stage - unique spacers -> device scan
+    -> CFD -> offtargets_*.tsv -> per-spacer aggregates - without Guide objects."""
+    if bdna or brna:
+        exception_handler(CrisprHawkOffTargetsError, "DNA/RNA bulges are not supported by the GPU off-target scan", os.EX_DATAERR, debug)
+    uniq = sorted({sp.upper() for sp in spacers})
+    lines = search(_genome_index(crispritz_index, guidelen, len(pam)), uniq, pam, right, mm, verbosity, debug) if uniq else []
+    ots = report_offtargets(lines, region, pam, guidelen, [], [], False, right, outdir, verbosity, debug)
+    return offtargets_by_spacer(ots, uniq)
+
+
+def estimate_offtargets(guides: List[Guide], pam: PAM, crispritz_index, region: Region, crispritz_config, mm: int, bdna: int, brna: int,
+                        annotations: List[str], anncolnames: List[str], guidelen: int, compute_elevation: bool, right: bool,
+                        threads: int, outdir: str, verbosity: int, debug: bool) -> List[Guide]:
+    """offtargets.py:630-722 with the reference's seventeen arguments in the reference's order.  `crispritz_index` is the
+    genome (see _genome_index); `crispritz_config` (the conda environment of the external tool) and `threads` have no
+    meaning on the device path and are ignored."""
     if bdna or brna:
         exception_handler(CrisprHawkOffTargetsError, "DNA/RNA bulges are not supported by the GPU off-target scan",
                           os.EX_DATAERR, debug)
     guides_seqs = sorted(_filter_guides(guides))
     print_verbosity("Estimating off-targets for found guides", verbosity, VERBOSITYLVL[3])
+    genome = _genome_index(crispritz_index, guidelen, len(pam))
     lines = search(genome, guides_seqs, pam, right, mm, verbosity, debug)
-    offtargets = report_offtargets(lines, region, pam, guidelen, right, outdir, verbosity, debug)
+    offtargets = report_offtargets(lines, region, pam, guidelen, annotations, anncolnames, compute_elevation, right, outdir, verbosity, debug)
     return annotate_guides_offtargets(offtargets, guides, verbosity)

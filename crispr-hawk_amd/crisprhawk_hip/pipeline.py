@@ -40,7 +40,14 @@ def _labels(ds, info: List[HapInfo], kept: List[int], vt) -> List[Optional[RowLa
     return out
 
 
-def _search_host_built(coord, seq: str, vcf, phased: bool, pam: PAM, guidelen: int, right: bool, outdir: str, mm, pt, debug: bool) -> str:
+def _offtargets(spacers, pam: PAM, ot, coord, guidelen: int, right: bool, outdir: str, debug: bool):
+    """--estimate-offtargets for one region: {SPACER: (count, global CFD)} + offtargets_{contig}_{start}_{stop}.tsv."""
+    from .offtargets import estimate_offtargets_spacers
+    return estimate_offtargets_spacers(spacers, pam, ot["genome"], coord, ot["mm"], ot["bdna"], ot["brna"], guidelen, right, outdir, 0, debug)
+
+
+def _search_host_built(coord, seq: str, vcf, phased: bool, pam: PAM, guidelen: int, right: bool, outdir: str, mm, pt, debug: bool,
+                       ot=None) -> str:
     """One BED interval with the haplotypes built on the host by the mirror of the reference's own construction
     (haplotypes.py:106-368 phased, 370-712 unphased) - the route of unphased VCFs (IUPAC haplotypes + indel windows,
     resolve_guide on the host, search_guides.py:163-257) and the fallback for phased records the device expansion
@@ -74,7 +81,12 @@ def _search_host_built(coord, seq: str, vcf, phased: bool, pam: PAM, guidelen: i
                 g.reverse_complement()
             assert g.sequence == w and g.right == r
     bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING
-    df = reports.report_from_guides(guides, haps, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", cfd)
+    otmap = None
+    if ot is not None:  # spacers as reverse_guides would leave them (annotation.py:27-51)
+        from .utils import _RC_TRANS
+        cores = [g.sequence[10:-10][::-1].translate(_RC_TRANS) if g.strand == 1 else g.sequence[10:-10] for g in guides]
+        otmap = _offtargets([c[len(pam):] if right else c[:guidelen] for c in cores], pam, ot, coord, guidelen, right, outdir, debug)
+    df = reports.report_from_guides(guides, haps, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", cfd, otmap)
     path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
     with open(path, "w") as f:
         f.write(reports.to_tsv(df))
@@ -83,11 +95,26 @@ def _search_host_built(coord, seq: str, vcf, phased: bool, pam: PAM, guidelen: i
 
 def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidelen: int, right: bool, outdir: str,
                  cfd_tables=None, azimuth_model=None, deepcpf1_weights=None, device: Optional[int] = None,
-                 debug: bool = True) -> Dict[str, str]:
+                 debug: bool = True, estimate_offtargets=None, mm: int = 4, bdna: int = 0, brna: int = 0) -> Dict[str, str]:
     """One report per BED interval; returns {str(coordinate): path}.  `cfd_tables = (mm[20,4,4], pam[16])` adds the
     CFDon column for SpCas9-class PAMs (scoring.py:352-387); `azimuth_model` (a fitted sklearn GBR or the flattened
     dict of scoring.azimuth_model_from_sklearn) and `deepcpf1_weights` (scoring.set_deepcpf1_weights layout) switch
-    their score columns on - the reference reads those parameters from files it downloads."""
+    their score columns on - the reference reads those parameters from files it downloads.  `estimate_offtargets` (the
+    reference's --estimate-offtargets with its --crispritz-index: a genome.GenomeIndex, a {contig: sequence} dict or a
+    FASTA path) runs the off-target stage per region: the `offtargets` / `cfd` columns of the guide report
+    (reports.py:292-333, 612-660) and offtargets_{contig}_{start}_{stop}.tsv next to it (offtargets.py:486-558); `mm`,
+    `bdna`, `brna` as on the reference's command line (bulges are refused).  The per-site CFD needs `cfd_tables`."""
+    ot = None
+    if estimate_offtargets is not None:
+        from .genome import GenomeIndex, read_fasta
+        genome = estimate_offtargets
+        if isinstance(genome, (str, os.PathLike)):
+            genome = read_fasta(str(genome))
+        if isinstance(genome, dict):
+            genome = GenomeIndex(genome, guidelen, len(pam_seq), device=device)  # once for all regions
+        ot = dict(genome=genome, mm=mm, bdna=bdna, brna=brna)
+        if cfd_tables is not None:
+            scoring.set_cfd_tables(*cfd_tables)
     if azimuth_model is not None:
         scoring.set_azimuth_model(azimuth_model)
     if deepcpf1_weights is not None:
@@ -101,15 +128,15 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         v = VCF(f, 0, debug)
         vcf_by_contig[v.contig] = v
     score = cfd_tables is not None and pam.cas_system in (SPCAS9, XCAS9) and not right
-    mm, pt = cfd_tables if score else (None, None)
+    mmt, pt = cfd_tables if score else (None, None)
     os.makedirs(outdir, exist_ok=True)
     paths = {}
     for coord in Bed(bedfile, PADDING, debug):
         seq = fastas[coord.contig].fetch(coord).sequence
         v = vcf_by_contig.get(coord.contig)
         if v is not None and not v.phased:
-            paths[str(coord)] = _search_host_built(coord, seq, v, False, pam, guidelen, right, outdir, mm if score else None,
-                                                   pt if score else None, debug)
+            paths[str(coord)] = _search_host_built(coord, seq, v, False, pam, guidelen, right, outdir, mmt if score else None,
+                                                   pt if score else None, debug, ot)
             continue
         from .readers import VcfBlock
         blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
@@ -119,10 +146,10 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         except HaplotypeBuildError:
             # records the device expansion does not take (overlapping records on one chromosome copy, deletions with a
             # multi-base alt): the host builder mirrors the reference's own construction, the search stays on the device
-            paths[str(coord)] = _search_host_built(coord, seq, v, True, pam, guidelen, right, outdir, mm if score else None,
-                                                   pt if score else None, debug)
+            paths[str(coord)] = _search_host_built(coord, seq, v, True, pam, guidelen, right, outdir, mmt if score else None,
+                                                   pt if score else None, debug, ot)
             continue
-        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mm, pt, download=False)
+        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mmt, pt, download=False)
         labels = hap_labels(coord.contig, vt, ds, info, kept)
         bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041
         # With a model scorer on, the reference's groupby includes its score column (reports.py:978-1003): rows that
@@ -141,8 +168,9 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
                 scores["score_azimuth"] = np.asarray(scoring.azimuth(kmers, debug), dtype=np.float64)
             if deepcpf1_on:
                 scores["score_deepcpf1"] = np.asarray(scoring.deepcpf1(kmers, debug), dtype=np.float64)
+        otcb = None if ot is None else (lambda spacers: _offtargets(spacers, pam, ot, coord, guidelen, right, outdir, debug))
         df = reports.report_from_groups(groups, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score,
-                                        is_ref_hap=np.asarray(ds.is_ref, dtype=bool))
+                                        is_ref_hap=np.asarray(ds.is_ref, dtype=bool), offtargets=otcb)
         ds.close()
         path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
         with open(path, "w") as f:

@@ -118,14 +118,28 @@ def collapse_haplotype_ids(hapids: Sequence[str]) -> str:  # reports.py:845-857
     return "" if not len(hapids) else ",".join(sorted(set(",".join(hapids).split(","))))
 
 
-def select_reportcols(pam: PAM, right: bool) -> List[str]:
-    """Final column order (reports.py:612-660) without the optional annotation / off-target / Elevation columns."""
+def select_reportcols(pam: PAM, right: bool, estimate_offtargets: bool = False) -> List[str]:
+    """Final column order (reports.py:612-660) without the optional annotation / Elevation columns.  With
+    --estimate-offtargets: `offtargets` (+ `cfd` for SpCas9 / xCas9 PAMs, reports.py:384-404) between `af` and `target`."""
     cols = (REPORTCOLS[:3] + REPORTCOLS[4:5] + REPORTCOLS[3:4] + REPORTCOLS[5:7]) if right else REPORTCOLS[:7]
     if pam.cas_system in (SPCAS9, XCAS9):
         cols = cols + REPORTCOLS[7:12] + REPORTCOLS[13:14]
     elif pam.cas_system == CPF1:
         cols = cols + REPORTCOLS[12:13]
-    return cols + REPORTCOLS[15:20] + REPORTCOLS[20:22]
+    cols = cols + REPORTCOLS[15:20]
+    if estimate_offtargets:
+        cols = cols + REPORTCOLS[22:23] + (REPORTCOLS[23:24] if pam.cas_system in (SPCAS9, XCAS9) else [])
+    return cols + REPORTCOLS[20:22]
+
+
+def _offtarget_columns(spacers: Sequence[str], offtargets: Dict[str, tuple], with_cfd: bool):
+    """Per report row: Guide.offtargets / Guide.cfd of its spacer (offtargets.py:597-627 sets both per guide from the
+    upper-cased spacer alone, so every row with that spacer carries the same pair; reports.py:292-333)."""
+    pairs = [offtargets[sp.upper()] for sp in spacers]
+    out = {"offtargets": np.array([str(n) for n, _ in pairs], dtype=object)}
+    if with_cfd:
+        out["cfd"] = np.array([c for _, c in pairs], dtype=object)
+    return out
 
 
 class _SampleIndex:
@@ -205,12 +219,12 @@ def scorer_kmers(inp: ReportInput):
 
 
 def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
-                 with_cfdon: bool = True):
+                 with_cfdon: bool = True, offtargets: Optional[Dict[str, tuple]] = None):
     """The collapsed, sorted report of one region as a pandas DataFrame (what reports.report_guides hands to
     to_csv).  `haplotypes[i]` needs .samples .variants .afs .id and .segments (PosSegments); `scores` may map a
     score column name to a per-row float array (NaN -> "NA")."""
     import pandas as pd
-    cols = select_reportcols(pam, inp.right)
+    cols = select_reportcols(pam, inp.right, offtargets is not None)
     L = inp.guidelen + inp.pamlen
     pamclass = compute_pam_class(pam)
     parsed_cache: Dict[int, Dict[int, List]] = {}
@@ -275,6 +289,8 @@ def report_frame(inp: ReportInput, haplotypes, pam: PAM, contig: str, target: st
         rec["af"] = af
         rec["target"] = target
         rec["haplotype_id"] = agg[1]
+        if offtargets is not None:
+            rec["offtargets"], rec["cfd"] = str(offtargets[guideseq.upper()][0]), offtargets[guideseq.upper()][1]
         recs.append(rec)
     if not recs:
         return pd.DataFrame({c: [] for c in cols})
@@ -655,11 +671,11 @@ def group_kmers(G) -> List[str]:
 
 
 def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
-                       with_cfdon: bool = True, is_ref_hap: Optional[np.ndarray] = None):
+                       with_cfdon: bool = True, is_ref_hap: Optional[np.ndarray] = None, offtargets=None):
     """report_frame's result from group-level inputs (hapset.GroupTable, tiling.MergedGroups.groups(), ReportGroups),
     assembled column by column: same DataFrame, same order, same strings.  `scores[c]` is per GROUP here."""
     import pandas as pd
-    cols = select_reportcols(pam, G.right)
+    cols = select_reportcols(pam, G.right, offtargets is not None)
     ng = G.n_groups
     if ng == 0:
         return pd.DataFrame({c: [] for c in cols})
@@ -706,6 +722,10 @@ def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores
     data["af"] = np.array(af_col, dtype=object)
     data["target"] = np.full(ng, target, dtype=object)
     data["haplotype_id"] = np.array(_hapids_column(member_off, member_hap, lab.ids), dtype=object)
+    if offtargets is not None:  # a dict {SPACER: (count, cfd)} or a callable that builds it from the rows' spacers
+        if callable(offtargets):
+            offtargets = offtargets(sorted(set(np.char.upper(data["sgRNA_sequence"]).tolist())))
+        data.update(_offtarget_columns(data["sgRNA_sequence"].tolist(), offtargets, pam.cas_system in (SPCAS9, XCAS9)))
     # pandas groupby(sort=True) order over the group columns (reports.py:978-1003), then _format_report's stable sort on
     # (start, stop): one lexsort with (start, stop) as the leading keys
     gcols = REPORTCOLS[:5]
@@ -726,7 +746,8 @@ def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores
     return pd.DataFrame({c: data[c][order] for c in cols})
 
 
-def report_from_guides(guides, haplotypes, pam: PAM, contig: str, target: str, cfdon: Optional[Sequence[float]] = None):
+def report_from_guides(guides, haplotypes, pam: PAM, contig: str, target: str, cfdon: Optional[Sequence[float]] = None,
+                       offtargets: Optional[Dict[str, tuple]] = None):
     """The report of a Guide list as search() returns it (windows still on the + strand, i.e. BEFORE
     annotation.reverse_guides) - the route of unphased inputs, whose guides are resolved on the host
     (search_guides.resolve_guide) and therefore are not rows of the device table.  Rows the report merges are grouped
@@ -763,4 +784,4 @@ def report_from_guides(guides, haplotypes, pam: PAM, contig: str, target: str, c
         den.append(gc + sum(spacer.count(c) for c in "ATWUatwu"))
     inp = ReportInput(start, stop, strand, hap, pos, wins, cfd, np.array(perm, dtype=np.int64), np.array(off, dtype=np.int64),
                       np.array(num), np.array(den), guidelen, pamlen, right)
-    return report_frame(inp, haplotypes, pam, contig, target, with_cfdon=cfd is not None)
+    return report_frame(inp, haplotypes, pam, contig, target, with_cfdon=cfd is not None, offtargets=offtargets)

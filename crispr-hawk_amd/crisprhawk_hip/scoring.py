@@ -85,21 +85,30 @@ def group_guides_position(guides: List[Guide], debug: bool):
 
 
 def compute_cfd_batch(wt: List[str], sg: List[str], pam2: List[str], debug: bool) -> np.ndarray:
-    """compute_cfd (cfdscore.py:53-95) for n (wildtype, sgRNA, PAM[-2:]) triples on the GPU."""
+    """compute_cfd (cfdscore.py:53-95) for n (wildtype, sgRNA, PAM[-2:]) triples on the GPU.  Triples of one length go
+    up as one batch; off-target rows with a bulge are one base longer than the rest and form a batch of their own."""
     mm, pt = _tables(debug)
     n = len(wt)
-    if n == 0:
-        return np.zeros(0)
-    ln = len(wt[0])
-    if any(len(x) != ln for x in wt) or any(len(x) != ln for x in sg) or any(len(p) != 2 for p in pam2):
-        exception_handler(CrisprHawkCfdScoreError, "CFDon score calculation failed", os.EX_DATAERR, debug)
     out = np.empty(n, dtype=np.float64)
-    rc = _lib.lib().hawk_cfd(_lib.context(), "".join(wt).encode("ascii"), "".join(sg).encode("ascii"), ln,
-                             "".join(pam2).encode("ascii"), C.c_uint64(n), mm.ctypes.data_as(C.c_void_p),
-                             pt.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
-    if rc == _lib.HAWK_E_CFD:
+    if n == 0:
+        return out
+    if any(len(a) != len(b) for a, b in zip(wt, sg)) or any(len(p) != 2 for p in pam2):
         exception_handler(CrisprHawkCfdScoreError, "CFDon score calculation failed", os.EX_DATAERR, debug)
-    _lib.check(rc, "hawk_cfd")
+    lens = np.fromiter((len(x) for x in wt), dtype=np.int64, count=n)
+    for ln in np.unique(lens):
+        idx = np.flatnonzero(lens == ln)
+        part = np.empty(len(idx), dtype=np.float64)
+        whole = len(idx) == n
+        w = wt if whole else [wt[i] for i in idx]
+        g = sg if whole else [sg[i] for i in idx]
+        p = pam2 if whole else [pam2[i] for i in idx]
+        rc = _lib.lib().hawk_cfd(_lib.context(), "".join(w).encode("ascii"), "".join(g).encode("ascii"), int(ln),
+                                 "".join(p).encode("ascii"), C.c_uint64(len(idx)), mm.ctypes.data_as(C.c_void_p),
+                                 pt.ctypes.data_as(C.c_void_p), part.ctypes.data_as(C.c_void_p))
+        if rc == _lib.HAWK_E_CFD:
+            exception_handler(CrisprHawkCfdScoreError, "CFDon score calculation failed", os.EX_DATAERR, debug)
+        _lib.check(rc, "hawk_cfd")
+        out[idx] = part
     return out
 
 
@@ -361,8 +370,8 @@ def rs3(guides: List[str], debug: bool = True) -> List[float]:
 
 
 def rs3_score(guides: List[Guide], threads: int, verbosity: int, debug: bool) -> List[Guide]:
-    """scoring.py:261-300 (one device batch; ``threads`` is ignored).  Without a model every guide keeps "NA"."""
-    if not guides or _RS3 is None:
+    """scoring.py:261-300 (one device batch; ``threads`` is ignored).  Without a model rs3() raises CrisprHawkRs3ScoreError."""
+    if not guides:
         return guides
     print_verbosity("Computing RS3 score", verbosity, VERBOSITYLVL[3])
     for g, s in zip(guides, rs3(_extract_guide_sequences(guides), debug)):
@@ -405,16 +414,54 @@ def load_models(models_dir: str, debug: bool = True) -> Dict[str, bool]:
     return have
 
 
+# Scorers the reference calls that have no counterpart here (external checkpoints / conda environments).
+# Their columns keep "NA"; they are listed so that scoring_guides documents, in code, what it leaves out.
+OUT_OF_SCOPE_SCORERS = ("plmcrispr", "crispron", "sgdesigner")
+_SKIP: set = set()
+
+
+def skip_scorers(*names: str) -> None:
+    """Opt out of in-scope scorers by name ("azimuth", "rs3", "cfdon", "deepcpf1") for callers that do not hold their
+    parameters.  Nothing is skipped by default: like the reference, scoring_guides calls every scorer of the Cas system
+    and a scorer without its model raises its CrisprHawk*ScoreError.  skip_scorers() with no argument clears the set."""
+    bad = set(names) - {"azimuth", "rs3", "cfdon", "deepcpf1"}
+    if bad:
+        raise ValueError(f"unknown scorer(s): {sorted(bad)}")
+    _SKIP.clear()
+    _SKIP.update(names)
+
+
+def _scoring_guides_cas9(guides_list: List[Guide], cas_system: int, scoring_envs, threads: int, verbosity: int, debug: bool) -> List[Guide]:
+    """scoring.py:749-792: azimuth, rs3, (plm-crispr), cfdon, (crispron, sgdesigner) - in that order; cfdon_score
+    returns the guides in group order (scoring.py:383), so the list order changes there exactly as in the reference."""
+    if "azimuth" not in _SKIP:
+        guides_list = azimuth_score(guides_list, threads, verbosity, debug)
+    if "rs3" not in _SKIP:
+        guides_list = rs3_score(guides_list, threads, verbosity, debug)
+    if "cfdon" not in _SKIP:
+        guides_list = cfdon_score(guides_list, verbosity, debug)
+    return guides_list
+
+
+def _scoring_guides_cpf1(guides_list: List[Guide], threads: int, verbosity: int, debug: bool) -> List[Guide]:
+    """scoring.py:795-813"""
+    if "deepcpf1" in _SKIP:
+        return guides_list
+    return deepcpf1_score(guides_list, threads, verbosity, debug)
+
+
 def scoring_guides(guides: Dict, pam: PAM, scoring_envs, args) -> Dict:
-    """scoring.py:816-867, restricted to the scorers whose parameters can be supplied offline:
-    Azimuth / RS3 (when a model is set) + CFDon for SpCas9/xCas9 PAMs (749-792), DeepCpf1 for Cpf1 PAMs with --right (795-813)."""
+    """scoring.py:816-867: SpCas9 / xCas9 PAMs -> azimuth, rs3, cfdon; Cpf1 PAMs -> deepcpf1; any other PAM -> no score.
+    A scorer whose parameters were never supplied raises its own error class, as the reference's does when its model
+    file is missing; Elevation-on (an external package with its own checkpoints) is refused rather than left at NA."""
+    print_verbosity("Scoring guides", args.verbosity, VERBOSITYLVL[1])
     for region, guides_list in guides.items():
         if pam.cas_system in (SPCAS9, XCAS9):
-            if _AZIMUTH_MODEL is not None:
-                guides_list = azimuth_score(guides_list, args.threads, args.verbosity, args.debug)
-            guides_list = rs3_score(guides_list, args.threads, args.verbosity, args.debug)
-            guides_list = cfdon_score(guides_list, args.verbosity, args.debug)
-        elif pam.cas_system == CPF1 and _DEEPCPF1_W is not None:
-            guides_list = deepcpf1_score(guides_list, args.threads, args.verbosity, args.debug)
+            guides_list = _scoring_guides_cas9(guides_list, pam.cas_system, scoring_envs, args.threads, args.verbosity, args.debug)
+        elif pam.cas_system == CPF1:
+            guides_list = _scoring_guides_cpf1(guides_list, args.threads, args.verbosity, args.debug)
+        if getattr(args, "compute_elevation", False) and (args.guidelen + len(pam) == 23 and not args.right):
+            from .crisprhawk_error import CrisprHawkElevationScoreError
+            exception_handler(CrisprHawkElevationScoreError, "Elevation-on is not part of the GPU scoring path", os.EX_DATAERR, args.debug)
         guides[region] = guides_list
     return guides

@@ -17,8 +17,11 @@ def offtargets_search(guides: Dict[Region, List[Guide]], pam: PAM, args) -> Dict
     if isinstance(genome, str):
         genome = read_fasta(genome)
     if isinstance(genome, dict):
-        genome = GenomeIndex(genome, args.guidelen, len(pam))
+        genome = GenomeIndex(genome, args.guidelen, len(pam))  # once for all regions
     for region, guides_list in guides.items():
-        guides[region] = estimate_offtargets(guides_list, pam, genome, region, args.mm, args.bdna, args.brna, args.guidelen,
-                                             args.right, getattr(args, "outdir", ""), args.verbosity, args.debug)
+        guides[region] = estimate_offtargets(  # search_offtargets.py:44-62: the reference's call, argument for argument
+            guides_list, pam, genome, region, getattr(args, "crispritz_config", None), args.mm, args.bdna, args.brna,
+            getattr(args, "offtargets_annotations", []), getattr(args, "offtargets_annotation_colnames", []), args.guidelen,
+            getattr(args, "compute_elevation", False), args.right, getattr(args, "threads", 1), getattr(args, "outdir", ""),
+            args.verbosity, args.debug)
     return guides

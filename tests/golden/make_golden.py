@@ -25,6 +25,14 @@ Fixtures:
   g6_deepcpf1.json.gz   SeqDeepCpf1 forward on random 34-mers, seeded synthetic weights
   g8_vcf_lines.json.gz  VariantRecord.read_vcf_line / split() on multi-allelic, missing-allele and
                         extra-FORMAT records
+  g9_azimuth.json.gz    scores/azimuth: features/featurization.featurize_data + util.concatenate_feature_sets with the
+                        learn_options save_final_model_V3(include_position=False) pickles (model_comparison.py:474-497) on
+                        random 30-mers -> the 627-column matrix; model_comparison.predict driven with a locally fitted
+                        GradientBoostingRegressor (100 x depth 3, lr 0.1: models/ensembles.py:28-30).  Biopython is absent:
+                        Tm_NN is a restatement (columns 623-626 and whatever the trees read of them stay unpinned)
+  g10_offtargets.json.gz  the off-target host stage (offtargets.py:486-627, offtarget.py:77-129): report_offtargets on a
+                        CRISPRitz-format targets.txt, annotate_guides_offtargets, and the guide report with the
+                        offtargets / cfd columns (reports.py:292-333, 384-404, 612-660, 877-906)
   g7_report_*.json.gz   the guide report: search -> _annotate_variants -> annotate_variants_afs ->
                         reverse_guides -> gc -> CFDon -> reports._process_data -> _collapse_report_entries ->
                         _format_report, stored as the TSV text the reference would write.  gc_content comes from
@@ -568,8 +576,284 @@ def g8_vcf_lines():
     dump("g8_vcf_lines.json.gz", dict(samples=samples, records=out))
 
 
+# ---------------------------------------------------------------------------- G9 (Azimuth / Rule Set 2)
+def _tm_nn_restated(seq, **kw):
+    """Biopython 1.83 Bio.SeqUtils.MeltingTemp.Tm_NN(seq) with its defaults (nn_table DNA_NN3 = Allawi & SantaLucia
+    1997, dnac1 = dnac2 = 25 nM, Na = 50 mM, saltcorr = 5, no mismatches / dangling ends), restated from the published
+    algorithm because Biopython is not installed: whatever passes through it is UNPINNED."""
+    import math
+    seq = str(seq).upper()
+    nn = {"AA": (-7.9, -22.2), "AT": (-7.2, -20.4), "TA": (-7.2, -21.3), "CA": (-8.5, -22.7), "GT": (-8.4, -22.4),
+          "CT": (-7.8, -21.0), "GA": (-8.2, -22.2), "CG": (-10.6, -27.2), "GC": (-9.8, -24.4), "GG": (-8.0, -19.9)}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    dh = ds = 0.0
+    for end in (seq[0], seq[-1]):  # init_A/T (2.3, 4.1), init_G/C (0.1, -2.8); the other init terms of DNA_NN3 are zero
+        if end in "AT":
+            dh += 2.3
+            ds += 4.1
+        else:
+            dh += 0.1
+            ds += -2.8
+    for i in range(len(seq) - 1):
+        pair = seq[i:i + 2]
+        if pair not in nn:  # the table lists one strand of every complementary pair
+            pair = comp[pair[1]] + comp[pair[0]]
+        dh += nn[pair][0]
+        ds += nn[pair][1]
+    k = (25.0 - 25.0 / 2.0) * 1e-9
+    ds += 0.368 * (len(seq) - 1) * math.log(50.0 * 1e-3)
+    return (1000.0 * dh) / (ds + 1.987 * math.log(k)) - 273.15
+
+
+def _azimuth_modules():
+    """features/featurization.py, util.py and model_comparison.py imported from where they lie, as members of their
+    package (their relative imports resolve to the reference's own files) but without running the package __init__s,
+    which pull rs3 / elevation / h5py.  matplotlib, pylab and Biopython are absent: plotting is never reached, and the
+    one Biopython function on the path (Tm_NN) is the restatement above."""
+    import importlib
+
+    class _Any:
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    def shell(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__getattr__ = lambda k: _Any()
+        sys.modules[name] = m
+        return m
+
+    for n in ("matplotlib", "matplotlib.pylab", "matplotlib.pyplot", "pylab"):
+        shell(n)
+    bio = shell("Bio", __path__=[])
+    for n in ("SeqUtils", "Seq", "Entrez", "SeqIO"):
+        setattr(bio, n, shell(f"Bio.{n}"))
+    bio.SeqUtils.__path__ = []
+    bio.SeqUtils.MeltingTemp = shell("Bio.SeqUtils.MeltingTemp", Tm_NN=_tm_nn_restated)
+    for pk in ("crisprhawk.scores", "crisprhawk.scores.azimuth", "crisprhawk.scores.azimuth.features", "crisprhawk.scores.azimuth.models"):
+        m = types.ModuleType(pk)
+        m.__path__ = [os.path.join(REF, *pk.split("."))]
+        m.__package__ = pk
+        sys.modules[pk] = m
+    feat = importlib.import_module("crisprhawk.scores.azimuth.features.featurization")
+    util = importlib.import_module("crisprhawk.scores.azimuth.util")
+    mc = importlib.import_module("crisprhawk.scores.azimuth.model_comparison")
+    return feat, util, mc
+
+
+def g9_azimuth():
+    import pandas
+    from sklearn.ensemble import GradientBoostingRegressor
+    from crisprhawk_hip.scoring import azimuth_model_from_sklearn
+    feat, util, mc = _azimuth_modules()
+    # what save_final_model_V3(include_position=False) pickles beside the model (model_comparison.py:474-497), plus the
+    # keys run_models / setup add that featurize_data reads (order 2: model_comparison.py:499; one process)
+    learn_options = {
+        "V": 3, "testing_non_binary_target_name": "ranks", "include_pi_nuc_feat": True, "gc_features": True,
+        "nuc_features": True, "include_gene_position": False, "include_NGGX_interaction": True, "include_Tm": True,
+        "include_strand": False, "include_gene_feature": False, "include_gene_guide_feature": 0, "extra pairs": False,
+        "weighted": None, "training_metric": "spearmanr", "NDGC_k": 10, "cv": "gene", "include_gene_effect": False,
+        "include_drug": False, "include_sgRNAscore": False, "adaboost_loss": "ls", "adaboost_alpha": 0.5,
+        "normalize_features": False, "adaboost_CV": False,
+        "order": 2, "num_proc": 1, "include_known_pairs": False, "include_microhomology": False,
+    }
+    rng = np.random.default_rng(9009)
+    seqs = [synth.random_sequence(rng, 30) for _ in range(1200)]
+    seqs[0] = "A" * 30
+    seqs[1] = "G" * 30
+    seqs[2] = "ACGT" * 7 + "AC"
+    seqs[3] = seqs[3][:4] + "GC" * 10 + seqs[3][24:]  # GC count 20
+    seqs[4] = seqs[4][:4] + "AT" * 10 + seqs[4][24:]  # GC count 0
+    seqs[5] = seqs[5][:4] + "G" * 10 + "A" * 10 + seqs[5][24:]  # GC count exactly 10: neither flag
+    arr = np.array(seqs)
+    Xdf = pandas.DataFrame(columns=["30mer", "Strand"], data=list(zip(arr, ["NA"] * len(arr))))
+    gene_position = pandas.DataFrame(columns=["Percent Peptide", "Amino Acid Cut position"],
+                                     data=list(zip(np.ones(len(arr)) * -1, np.ones(len(arr)) * -1)))
+    fs = feat.featurize_data(Xdf, dict(learn_options), pandas.DataFrame(), gene_position, pam_audit=False, length_audit=False)
+    inputs, dim, dimsum, names = util.concatenate_feature_sets(fs)
+    assert inputs.shape == (len(seqs), 627), inputs.shape
+    head = inputs[:, :623]
+    assert np.array_equal(head, np.rint(head)) and head.min() >= 0 and head.max() <= 30
+    # the predict() plumbing (model_comparison.py:507-585) with a model of the shipped shape fitted on random targets
+    y = rng.normal(0.5, 0.2, size=len(seqs)) + 0.05 * inputs[:, 606] - 0.02 * inputs[:, 623] / 10.0
+    gbr = GradientBoostingRegressor(n_estimators=100, max_depth=3, learning_rate=0.1, random_state=1)
+    gbr.fit(inputs[:800], y[:800])
+    preds = mc.predict(arr, None, None, model=(gbr, dict(learn_options)), pam_audit=False, length_audit=False)
+    flat = azimuth_model_from_sklearn(gbr)
+    uses_tm = sorted(set(int(f) for f in flat["feature"] if f >= 623))
+    dump("g9_azimuth.json.gz", dict(
+        seqs=seqs, dim={k: int(v) for k, v in dim.items()}, names=[str(n) for n in names],
+        features_int=head.astype(int).ravel().tolist(), tm=inputs[:, 623:].tolist(), tm_source="restated: Biopython absent, unpinned",
+        model={k: (np.asarray(v).tolist() if not np.isscalar(v) else float(v)) for k, v in flat.items()},
+        model_uses_tm_features=uses_tm, predictions=[float(p) for p in preds]))
+    print(f"   azimuth: {len(seqs)} 30-mers, {dimsum} features in {len(dim)} sets; trees read Tm columns {uses_tm}")
+
+
+# ---------------------------------------------------------------------------- G10 (off-target host stage, SURVEY row a23)
+def _brute_force_targets(genome, guides_seqs, pam_s, right, mm_max):
+    """CRISPRitz-format rows (offtarget.py:89-101 reads fields 0,1,2,3,4,6,7,8) for every genome window, both strands,
+    whose PAM positions IUPAC-match and whose spacer differs from a guide in <= mm_max positions: the INPUT of the stage
+    under test, enumerated here independently of the package (CRISPRitz itself is absent)."""
+    iupac = {"A": "A", "C": "C", "G": "G", "T": "T", "N": "ACGT", "R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT",
+             "M": "AC", "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG"}
+    comp = str.maketrans("ACGTN", "TGCAN")
+    pl, rows = len(pam_s), []
+    for contig, seq in genome.items():
+        for strand in "+-":
+            for g in guides_seqs:
+                gl = len(g)
+                L = gl + pl
+                for p in range(len(seq) - L + 1):
+                    w = seq[p:p + L]
+                    if strand == "-":
+                        w = w[::-1].translate(comp)
+                    sp, pm = (w[pl:], w[:pl]) if right else (w[:gl], w[gl:])
+                    if any(b not in iupac[q] for b, q in zip(pm, pam_s)) or "N" in sp:
+                        continue
+                    nmm = sum(a != b for a, b in zip(sp, g))
+                    if nmm > mm_max:
+                        continue
+                    dsp = "".join(t if t == q else t.lower() for t, q in zip(sp, g))
+                    cr = ("N" * pl + g) if right else (g + "N" * pl)
+                    dna = (pm + dsp) if right else (dsp + pm)
+                    rows.append(f"X\t{cr}\t{dna}\t{contig}\t{p}\t{p}\t{strand}\t{nmm}\t0\t{nmm}")
+    return rows
+
+
+def g10_offtargets():
+    import tempfile
+    import importlib
+    from crisprhawk import annotation as R_ann
+    from crisprhawk import reports as R_rep
+    # crisprhawk.scores' __init__ imports rs3 / elevation / ...: register the package without running it, and give
+    # offtargets.py the one name it imports from crisprhawk_scores (elevation: never called, compute_elevation=False)
+    if "crisprhawk.scores" not in sys.modules:
+        m = types.ModuleType("crisprhawk.scores")
+        m.__path__ = [os.path.join(REF, "crisprhawk", "scores")]
+        sys.modules["crisprhawk.scores"] = m
+    cs = types.ModuleType("crisprhawk.scores.crisprhawk_scores")
+    cs.elevation = None
+    sys.modules["crisprhawk.scores.crisprhawk_scores"] = cs
+    R_off = importlib.import_module("crisprhawk.offtargets")
+    mm, pt = synth.cfd_tables()
+    mmd, pamd = synth.cfd_tables_as_dicts(mm, pt)
+    R_off.load_mismatch_pam_scores = lambda debug: (mmd, pamd)  # the tables are input data (the pickles are not downloadable)
+
+    out = {}
+    for name, pam_s, guidelen, right, seedbase in (("ngg", "NGG", 20, False, 10010), ("cpf1", "TTTV", 23, True, 10020)):
+        rng = np.random.default_rng(seedbase)
+        reg = synth.make_region(seedbase + 1, "chrO", 2400, 600, 1500)
+        synth.add_phased_variants(reg, seedbase + 2, 25, 3, frac_snv=0.7, frac_del=0.15, af_min=0.2, af_max=0.6)
+        region = _ref_region(reg)
+        haps, variants_present, phased = _ref_haplotypes(reg, region)
+        for i, h in enumerate(haps):
+            h.id = f"hap_{i:08d}"
+        pam = R_pam.PAM(pam_s, right, True)
+        pam.encode(0)
+        bits = [R_encoder.encode(h.sequence.sequence, 0, True) for h in haps]
+        guides = R_search.search(pam, region, haps, bits, guidelen, right, variants_present, phased, 0, True)
+        guides = R_ann._annotate_variants(guides, 0, True)
+        guides = R_ann.annotate_variants_afs(guides, 0)
+        guides = R_ann.reverse_guides(guides, 0)
+        for g in guides:
+            g.gc = _gc_fraction_restated(g.guide)
+        cfdon = pam_s == "NGG"
+        if cfdon:
+            groups = R_search.group_guides_position(guides, True)
+            outg = []
+            for _, grp in groups.items():
+                gref, members = grp[0], grp[1]
+                for sg in members:
+                    sg.cfdon_score = float("nan") if gref is None else float(
+                        R_cfd.compute_cfd(gref.guide, sg.guide, sg.pam[-2:], mmd, pamd, True))
+                    outg.append(sg)
+            guides = outg
+        # genome: the region's own contig (on-target rows) + two decoys with near-copies of some guide sites planted
+        uniq = sorted(R_off._filter_guides(guides))
+        decoys = {}
+        for cn, n in (("chrD1", 5000), ("chrD2", 4000)):
+            s = list(synth.random_sequence(rng, n))
+            for _ in range(40):
+                g = guides[int(rng.integers(0, len(guides)))]
+                site = list((g.pam + g.guide if right else g.guide + g.pam).upper())
+                sp0 = len(pam_s) if right else 0
+                for q in rng.integers(0, guidelen, size=int(rng.integers(0, 6))):
+                    site[sp0 + int(q)] = "ACGT"[int(rng.integers(0, 4))]
+                if rng.random() < 0.5:
+                    site = list("".join(site)[::-1].translate(str.maketrans("ACGT", "TGCA")))
+                at = int(rng.integers(0, n - len(site)))
+                s[at:at + len(site)] = site
+            decoys[cn] = "".join(s)
+        genome = {reg.contig: reg.contig_seq, **decoys}
+        mm_max = 4
+        rows = _brute_force_targets(genome, uniq, pam_s, right, mm_max)
+        rng.shuffle(rows)  # CRISPRitz writes in thread order: report_offtargets sorts
+        # hand-made bulge rows on real guides: a DNA bulge has '-' in the crRNA, an RNA bulge '-' in the DNA
+        pl = len(pam_s)
+        for k, g in enumerate(uniq[:6]):
+            cut = 5 + k
+            site = synth.random_sequence(rng, 1)
+            if k % 2 == 0:
+                crsp, dsp, bt = g[:cut] + "-" + g[cut:], g[:cut] + site.lower() + g[cut:], "DNA"
+            else:
+                crsp, dsp, bt = g, g[:cut] + "-" + g[cut + 1:], "RNA"
+            obs = "".join("ACGT"[int(rng.integers(0, 4))] if c == "N" else c for c in pam_s.replace("V", "A").replace("R", "A"))
+            cr = ("N" * pl + crsp) if right else (crsp + "N" * pl)
+            dna = (obs + dsp) if right else (dsp + obs)
+            rows.insert(int(rng.integers(0, len(rows))), f"{bt}\t{cr}\t{dna}\tchrD1\t{100 + 37 * k}\t{100 + 37 * k}\t{'+-'[k % 2]}\t{k % 3}\t1\t{k % 3 + 1}")
+        header = "#Bulge_type\tcrRNA\tDNA\tChromosome\tPosition\tCluster Position\tDirection\tMismatches\tBulge_Size\tTotal"
+        targets_txt = header + "\n" + "\n".join(rows) + "\n"
+        with tempfile.TemporaryDirectory() as td:
+            tf = os.path.join(td, "x.targets.txt")
+            with open(tf, "w") as f:
+                f.write(targets_txt)
+            ots = R_off.report_offtargets(tf, region, pam, guidelen, [], [], False, right, td, 0, True)
+            rep = os.path.join(td, f"offtargets_{region.contig}_{region.start + 100}_{region.stop - 100}.tsv")
+            with open(rep) as f:
+                ot_tsv = f.read()
+        guides = R_off.annotate_guides_offtargets(ots, guides, 0)
+        per_guide = [[g.guide, int(g.offtargets), g.cfd] for g in guides]
+        case = dict(
+            contig=reg.contig, bed_start=reg.bed_start, bed_stop=reg.bed_stop, startp=region.start, stopp=region.stop,
+            region_seq=reg.sequence, samples=reg.samples,
+            variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants],
+            pam=pam_s, guidelen=guidelen, right=right, cfdon=cfdon, mm=mm_max, target=str(region.coordinates),
+            haplotypes=[dict(id=h.id, samples=h.samples, variants=h.variants, start=h.coordinates.start,
+                             afs={k: (None if v != v else v) for k, v in h.afs.items()}) for h in haps],
+            genome=genome, unique_spacers=uniq, targets_txt=targets_txt, offtargets_tsv=ot_tsv, per_guide=per_guide,
+            offtarget_objects=[[o.grna_, o.grna, o.spacer, o.cfd, o.elevation] for o in ots[:200]])
+        def guide_report():
+            try:  # the guide report with the offtargets / cfd columns
+                df = R_rep._process_data(region, guides, pam, [], [], [], [], True, False)
+                df = R_rep._collapse_report_entries(df, pam, [], [], True)
+                df = R_rep._format_report(df, pam, right, [], [], True)
+                return df.to_csv(sep="\t", index=False), None
+            except Exception as e:  # recorded as the reference's behaviour for this PAM class
+                return None, f"{type(e).__name__}: {e}"
+        case["report_tsv"], case["report_error"] = guide_report()
+        # the same stage on the bulge-free rows alone: what a search with -bDNA 0 -bRNA 0 (the reference's default) returns
+        plain = header + "\n" + "\n".join(r for r in rows if r.startswith("X\t")) + "\n"
+        with tempfile.TemporaryDirectory() as td:
+            tf = os.path.join(td, "x.targets.txt")
+            with open(tf, "w") as f:
+                f.write(plain)
+            ots = R_off.report_offtargets(tf, region, pam, guidelen, [], [], False, right, td, 0, True)
+            with open(os.path.join(td, f"offtargets_{region.contig}_{region.start + 100}_{region.stop - 100}.tsv")) as f:
+                case["nobulge_offtargets_tsv"] = f.read()
+        guides = R_off.annotate_guides_offtargets(ots, guides, 0)
+        case["nobulge_per_guide"] = [[g.guide, int(g.offtargets), g.cfd] for g in guides]
+        case["nobulge_report_tsv"], _ = guide_report()
+        out[name] = case
+        print(f"   offtargets {name}: {len(uniq)} spacers, {len(rows)} target rows, {len(guides)} guides, report: "
+              f"{'ok' if case['report_tsv'] else case['report_error']}")
+    dump("g10_offtargets.json.gz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     if "g1" in which:
         g1_tables()
     if "g2" in which:
@@ -587,3 +871,7 @@ if __name__ == "__main__":
         g7_all()
     if "g8" in which:
         g8_vcf_lines()
+    if "g10" in which:  # before g9: g9 re-registers crisprhawk.scores' sub-packages
+        g10_offtargets()
+    if "g9" in which:
+        g9_azimuth()

@@ -124,12 +124,16 @@ def test_load_models_reads_converted_files(tmp_path):
     assert scoring.load_models(str(d2))["cfd"] and np.allclose(scoring._CFD_TABLES[1], pt)
 
 
-def test_rs3_boundary_without_model_leaves_na():
+def test_rs3_boundary_without_model_raises():
+    """The reference's rs3_score ends in CrisprHawkRs3ScoreError when the scorer cannot run (scoring.py:261-300)."""
+    from crisprhawk_hip.crisprhawk_error import CrisprHawkRs3ScoreError
     from crisprhawk_hip.guide import Guide
     scoring._RS3 = None
     g = Guide(1, 24, "C" * 10 + "AGCTTAGCTAGCTAGCTAGCTAG" + "C" * 10, 20, 3, 0, "REF", "NA", {}, {i: i for i in range(43)}, True, False, "hap1")
-    assert scoring.rs3_score([g], 1, 0, True)[0].rs3_score == "NA"
-    with pytest.raises(Exception):
+    with pytest.raises(CrisprHawkRs3ScoreError):
+        scoring.rs3_score([g], 1, 0, True)
+    assert g.rs3_score == "NA" and scoring.rs3_score([], 1, 0, True) == []
+    with pytest.raises(CrisprHawkRs3ScoreError):
         scoring.rs3(["A" * 30], True)
 
 
