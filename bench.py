@@ -49,7 +49,9 @@ VALU_PEAK_LANE_OPS = 78.6e12  # 256 CUs x 4 SIMDs x 32 lanes/cycle x 2.4 GHz (MI
 READ_BYTES_PER_POS = 0.625
 ROW_BYTES = 74
 LIST_BYTES = 4  # one u32 hand-over entry per guide row (count pass writes it, k_emit_list reads it)
+REC_BYTES = 32  # one record per carried variant of a chromosome copy (hawk_hx.h HxVar): what the fused step reads instead of planes
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
+PROFILE_TRAFFIC_R3 = os.path.join(ROOT, "profiles", "r03_traffic.json")
 REFERENCE_TIMING = os.path.join(ROOT, "profiles", "r02_reference_python_timing.json")  # tools/time_reference.py, build container
 
 
@@ -182,6 +184,40 @@ def search_roofline(pam, positions, rows, count_ms, emit_list_ms, emit_ms, traff
             "step_level": {"algorithmic_bytes": step_bytes, "what": "planes read once (0.625 B/position) + rows written once (74 B)"}}
 
 
+def plan_carried(ds) -> int:
+    """Carried-variant records of the set's expansion plan (one 32-byte record each)."""
+    return int(getattr(ds.plan, "n_records", 0))
+
+
+def vsearch_roofline(rows, records, positions, count_ms, emit_ms, traffic_key=None):
+    """The fused step's two kernels (hawk_vsearch.hip).  What they have to move through HBM: every carried-variant record in
+    (32 B, both passes) and every guide row out (74 B, the emit pass) - the haplotype positions themselves are never
+    materialised, so pricing the launch at SURVEY §8(d)'s 0.75 B per scanned position would describe a different
+    algorithm; that figure is reported as `survey_priced` (effective GB/s at the survey's price), not as the fraction."""
+    emit_bytes = ROW_BYTES * rows + REC_BYTES * records
+    count_bytes = REC_BYTES * records
+    cands = [("k_vsearch<1>", emit_ms, emit_bytes), ("k_vsearch<0>", count_ms, count_bytes)]
+    cands.sort(key=lambda c: -c[1])
+    (dom, dom_ms, dom_bytes), (oth, oth_ms, oth_bytes) = cands
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+    traffic = None
+    if traffic_key and os.path.exists(PROFILE_TRAFFIC_R3):
+        tk = json.load(open(PROFILE_TRAFFIC_R3)).get(traffic_key, {}).get(dom)
+        traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]
+    step_bytes = ROW_BYTES * rows + 2 * REC_BYTES * records
+    survey = 0.75 * positions + ROW_BYTES * rows
+    tot_ms = count_ms + emit_ms
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes, "row_bytes": ROW_BYTES,
+            "record_bytes": REC_BYTES, "records": records,
+            "other_kernel": {"kernel": oth, "launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_bytes,
+                             "frac": (oth_bytes / (oth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if oth_ms else None,
+                             "note": "no table output: bound by instruction issue and LDS / L2 latency, not by HBM"},
+            "survey_priced": {"bytes": survey, "what": "0.75 B per scanned haplotype position (SURVEY 8d, K2) + 74 B per guide row",
+                              "effective_GBps_both_kernels": survey / (tot_ms * 1e-3) / 1e9 if tot_ms else None},
+            "step_level": {"algorithmic_bytes": step_bytes, "what": "records read by both passes (32 B each) + rows written once (74 B)"}}
+
+
 def pam_scan_kernel(ds, pam):
     """The K2 PAM-scan kernel on its own (what `pam_search` runs): north_star's >= 40 % of HBM peak target."""
     import ctypes as C
@@ -227,16 +263,23 @@ def run_region(args, R: Ranks):
     n_samples = len(reg.samples)
     slo, shi = (0, n_samples) if (args.weak or c1) else shard_range(n_samples, R.rank, R.world)
     t1 = time.time()
-    ds, info, expand_ms, kept = expand_on_device(reg, len(pam), device=R.device, sample_range=(slo, shi))
+    ds, info, expand_ms, kept = expand_on_device(reg, len(pam), device=R.device, sample_range=(slo, shi), keep_plan=True)
     region_nt = int(ds.hap_len[0])
     log(f"workload: {ds.n_hap} haplotype rows x {region_nt} nt (samples {slo}..{shi} of {n_samples}), {len(reg.variants)} sites; "
         f"synthesised in {t1 - t0:.1f}s, expanded on the device in {time.time() - t1:.1f}s (kernels {expand_ms:.2f} ms, "
         f"{5 * ds.n_hap * ds.stride * 4 / 1e9:.2f} GB of planes)")
     score = (not args.right) and pam.cas_system in (3, 4)  # scoring.py:749-792: CFDon for SpCas9/xCas9 PAMs
     mm, pt = synth.cfd_tables() if score else (None, None)
+    plan = getattr(ds, "plan", None)
+    # The step SURVEY §8(d) defines: encode + search + reverse_guides + CFDon.  What is resident when the clock starts is the
+    # INPUT of encode - REF's planes and every chromosome copy's variant records (the expansion plan) - not the haplotype
+    # planes: a view of the plan (hawk_xplan_view) goes from there to the finished guide table without writing a plane.
+    # `--planes` times the round-2 step instead (hawk_search over planes already materialised in HBM).
+    fused = plan is not None and not args.planes
+    target = plan.view() if fused else ds
 
     def step(keep=False):
-        tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+        tab = target.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
         if not keep:
             tab.close()
         return tab
@@ -272,14 +315,38 @@ def run_region(args, R: Ranks):
                          "variant_sites": len(reg.variants), "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
                          "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all})
         tkey = "c3" if workload.startswith("C3") and R.world == 1 else None
-        out["roofline"] = search_roofline(pam, positions, rows, avg("count_ms"), avg("emit_list_ms"), avg("emit_ms"), tkey)
+        out["config"]["step"] = ("encode + search + CFDon from the expansion plan (REF planes + variant records resident; no haplotype plane written)"
+                                 if fused else "hawk_search over haplotype planes resident in HBM")
+        if fused:
+            out["roofline"] = vsearch_roofline(rows, int(plan_carried(ds)), positions, avg("v_count_ms"), avg("v_emit_ms"), tkey)
+        else:
+            out["roofline"] = search_roofline(pam, positions, rows, avg("count_ms"), avg("emit_list_ms"), avg("emit_ms"), tkey)
         sl = out["roofline"]["step_level"]
         sl["ms"] = avg("total_ms")
         sl["frac"] = sl["algorithmic_bytes"] / (sl["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sl["ms"] else None
         out["kernels_ms"] = {"count": avg("count_ms"), "offsets": avg("offsets_ms"), "emit": avg("emit_ms"), "emit_list": avg("emit_list_ms"),
-                             "device_total": avg("total_ms")}
+                             "vsearch_count": avg("v_count_ms"), "vsearch_emit": avg("v_emit_ms"), "device_total": avg("total_ms")}
         out["pam_scan_kernel"] = pam_scan_kernel(ds, pam)
-        out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap, "where": "device (hawk_xplan_run), outside the timed steps"}
+        out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap,
+                                      "where": "device (hawk_xplan_run); not part of the fused step, which writes no planes" if fused
+                                      else "device (hawk_xplan_run), outside the timed steps"}
+        if fused:  # the materialised alternative, for scale: planes written (hawk_xplan_run) and then searched (round 2's kernels)
+            k = max(3, min(10, args.steps))
+            R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+            t_a = time.perf_counter()
+            tms = []
+            for _ in range(k):
+                tb = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+                tms.append(tb.timing)
+                tb.close()
+            R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+            dt = (time.perf_counter() - t_a) / k
+            out["search_on_resident_planes"] = {
+                "ms_per_step": dt * 1e3, "candidates_per_s": cand / dt,
+                "kernels_ms": {kk: float(np.mean([t[kk] for t in tms])) for kk in ("count_ms", "offsets_ms", "emit_list_ms", "emit_ms", "total_ms")},
+                "plus_expansion_ms": expand_ms, "candidates_per_s_with_expansion": cand / (dt + expand_ms * 1e-3),
+                "what": "round 2's step: hawk_search over planes hawk_xplan_run has already written; with the expansion kernels added it is "
+                        "the same work as the fused step"}
     for t in tabs:
         t.close()
 
@@ -293,7 +360,7 @@ def run_region(args, R: Ranks):
             if R.rank == 0:
                 out["gather"] = {"error": f"no completion within {args.gather_timeout} s (watchdog)"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)  # the measured line is out, but a hung exchange is a failed run: every rank ends non-zero
         wd = threading.Timer(args.gather_timeout, _bail)
         wd.daemon = True
         wd.start()
@@ -314,6 +381,8 @@ def run_region(args, R: Ranks):
                                            "measured": "build container, 8 vCPU, single thread (profiles/r02_reference_python_timing.json); not on this host"}
             if not c1 and not args.no_cpu_all_cores:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
+    if plan is not None:
+        plan.close()
     ds.close()
     return out
 
@@ -326,11 +395,23 @@ def gather_once(R: Ranks, ds, step, n_hap_total):
     if R.backend != "rccl":
         return {"skipped": f"backend {R.backend}: the RCCL exchange needs one GPU per rank"}
     res = {}
+    # every rank says over the TCP control plane whether it can enter the exchange at all (librccl loads, its table exists)
+    # BEFORE anybody calls into RCCL: one rank failing on its own must not strand the others in a collective
+    ok, why = 1, ""
+    try:
+        tab = step(keep=True)
+        R._lib.check(R._lib.lib().hawk_comm_unique_id(np.zeros(128, dtype=np.uint8).ctypes.data_as(__import__("ctypes").c_void_p)), "hawk_comm_unique_id")
+    except Exception as e:
+        ok, why, tab = 0, f"{type(e).__name__}: {e}", None
+    oks = R.ctl.allgather_i64([ok])[:, 0]
+    if not oks.all():
+        if tab is not None:
+            tab.close()
+        return {"error": f"rank(s) {np.flatnonzero(oks == 0).tolist()} cannot enter the exchange" + (f" ({why})" if why else "")}
     try:
         comm = parallel.RcclComm(R.ctl, R.device)
         n_all = R.ctl.allgather_i64([ds.n_hap])[:, 0]
         hap_off = int(n_all[:R.rank].sum() - R.rank)  # rows of the earlier ranks, their REF rows not counted
-        tab = step(keep=True)
         comm.barrier()
         t0 = time.perf_counter()
         merged, ms = comm.gather_table(tab, hap_off, 0)
@@ -756,6 +837,7 @@ def build_parser():
     ap.add_argument("--guides", type=int, default=10_000, help="c5: unique spacers")
     ap.add_argument("--mm", type=int, default=4)
     ap.add_argument("--cpu-haps", type=int, default=1280, help="haplotypes in the cpu_baseline sample (about 12 s of single-thread oracle work on C3)")
+    ap.add_argument("--planes", action="store_true", help="c3: time round 2's step (hawk_search over materialised planes) instead of the fused step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")

@@ -241,7 +241,29 @@ class ExpansionPlan:
         ds.ref_index, ds.is_ref = self.ref_index, self.is_ref
         return ds, hashes, (ms.value if (timed or want_hash) else None)
 
+    def view(self) -> "DeviceHapSet":
+        """hawk_xplan_view: the plan's rows as a set WITHOUT planes.  `search()` on it runs encode + search in one step from
+        REF + the rows' variant records (hawk_vsearch.hip) and returns the same table as on `run()`'s set; whatever reads
+        planes (pam_scan, planes(), the off-target scan) is refused.  Cached: one view per plan; it keeps the plan alive."""
+        v = getattr(self, "_view", None)
+        if v is None or v._h is None:
+            handle = C.c_void_p()
+            _lib.check(self._L.hawk_xplan_view(self._x, C.byref(handle)), "hawk_xplan_view")
+            v = DeviceHapSet.from_handle(handle, self.hap_len, self.device)
+            v.ref_index, v.is_ref = self.ref_index, self.is_ref
+            v._plan_ref = self
+            for k in ("alias", "host_meta"):
+                if hasattr(self, k):
+                    setattr(v, k, getattr(self, k))
+            self._view = v
+        return v
+
     def close(self) -> None:
+        v = getattr(self, "_view", None)
+        if v is not None:
+            v._plan_ref = None
+            v.close()  # the view reads the plan's buffers: it goes first
+            self._view = None
         if getattr(self, "_x", None):
             self._L.hawk_xplan_destroy(self._x)
             self._x = None

@@ -351,6 +351,7 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
             raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
     _lib.check(rc, "hawk_xplan_create")
     plan = ExpansionPlan(xh, hap_len, device)
+    plan.n_records = int(len(hv_idx))
     ds, hashes, ms_val = plan.run(want_hash=True)
     ms = C.c_float(ms_val)
     # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes), for all rows at once -----------

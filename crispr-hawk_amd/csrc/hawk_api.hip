@@ -157,7 +157,7 @@ int hawk_sync(hawk_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------- hapset
-static int hapset_create_impl(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, bool zero_planes, hawk_hapset** out) {
+static int hapset_create_impl(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, bool zero_planes, hawk_hapset** out, bool alloc_planes = true) {
   if (!ctx || !n_hap || !hap_len || !out) return HAWK_E_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   hawk_hapset* hs = new (std::nothrow) hawk_hapset();
@@ -182,7 +182,7 @@ static int hapset_create_impl(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap
   hs->ref_index = -1;
   hs->has_meta = false;
   int rc = HAWK_OK;
-  for (int p = 0; p < HAWK_PLANES && !rc; ++p) rc = hawk_pool_alloc((void**)&hs->plane[p], words * 4);
+  for (int p = 0; p < HAWK_PLANES && !rc && alloc_planes; ++p) rc = hawk_pool_alloc((void**)&hs->plane[p], words * 4);
   if (!rc) rc = hawk_pool_alloc((void**)&hs->d_hap_len, (size_t)n_hap * 4);
   if (!rc) rc = hawk_pool_alloc((void**)&hs->d_is_ref, n_hap);
   if (!rc) rc = hawk_pool_alloc((void**)&hs->d_scan_start, (size_t)n_hap * 4);
@@ -190,7 +190,7 @@ static int hapset_create_impl(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap
   if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_off, (size_t)(n_hap + 1) * 4);
   if (!rc) rc = hawk_pool_alloc((void**)&hs->d_tile_meta, (size_t)n_hap * hs->bph * sizeof(TileMeta));
   if (rc) { hawk_hapset_destroy(hs); return rc; }
-  if (zero_planes)
+  if (zero_planes && alloc_planes)
     for (int p = 0; p < HAWK_PLANES; ++p) HIPCHK(hipMemsetAsync(hs->plane[p], 0, words * 4, ctx->stream));
   HIPCHK(hipMemcpyAsync(hs->d_hap_len, hap_len, (size_t)n_hap * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -214,14 +214,14 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   if (!hs) return;
   (void)hipSetDevice(hs->ctx->device);
   (void)hipStreamSynchronize(hs->ctx->stream);
-  for (int p = 0; p < HAWK_PLANES; ++p) hawk_pool_free(hs->plane[p]);
+  if (!hs->vplan) for (int p = 0; p < HAWK_PLANES; ++p) hawk_pool_free(hs->plane[p]);  // a view reads its plan's REF planes
   hawk_pool_free(hs->d_hap_len); hawk_pool_free(hs->d_is_ref); hawk_pool_free(hs->d_scan_start);
   hawk_pool_free(hs->d_scan_stop); hawk_pool_free(hs->d_seg_off);
   hawk_pool_free(hs->d_seg_rel); hawk_pool_free(hs->d_seg_gen); hawk_pool_free(hs->d_tile_meta);
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
                     &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->ctable, &hs->cocc, &hs->cdense, &hs->cgkey, &hs->cgslot, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
-                    &hs->big};
+                    &hs->big, &hs->refhp, &hs->vcnt0};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   for (auto& b : hs->crep) b.release();
@@ -236,6 +236,7 @@ int hawk_hapset_stride(const hawk_hapset* hs, uint32_t* stride_words) {
 
 int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* seq_off, uint64_t* bad_index) {
   if (!hs || !seqs || !seq_off) return HAWK_E_INVALID;
+  if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
   hs->refbits_valid = false;
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -315,7 +316,7 @@ static int meta_build(uint32_t n, const std::vector<uint32_t>& hap_len, uint32_t
 
 int hawk_hapset_set_meta(hawk_hapset* hs, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
                          const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index) {
-  if (!hs) return HAWK_E_INVALID;
+  if (!hs || hs->vplan) return HAWK_E_INVALID;  // a view takes its metadata from the plan (hawk_xplan_set_meta)
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t n = hs->n_hap;
@@ -360,6 +361,7 @@ int hawk_hapset_set_ref_partner_range(hawk_hapset* hs, int32_t start, int32_t st
 
 int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words) {
   if (!hs || plane < 0 || plane >= HAWK_PLANES || !out_words) return HAWK_E_INVALID;
+  if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
   HIPCHK(hipSetDevice(hs->ctx->device));
   HIPCHK(hipStreamSynchronize(hs->ctx->stream));
   HIPCHK(hipMemcpy(out_words, hs->plane[plane], (size_t)hs->n_hap * hs->S * 4, hipMemcpyDeviceToHost));
@@ -368,6 +370,7 @@ int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words) 
 
 int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes) {
   if (!hs || !planes) return HAWK_E_INVALID;
+  if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
   hs->refbits_valid = false;
   HIPCHK(hipSetDevice(hs->ctx->device));
   const size_t words = (size_t)hs->n_hap * hs->S;
@@ -418,6 +421,7 @@ static int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pa
 int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t* hits_fwd,
                   uint32_t* hits_rev, uint64_t cap_fwd, uint64_t cap_rev, uint64_t* off_fwd, uint64_t* off_rev) {
   if (!hs || !hs->has_meta || !off_fwd || !off_rev) return HAWK_E_INVALID;
+  if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   ScanParams sp;
@@ -462,6 +466,7 @@ int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t 
 int hawk_pam_scan_time(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t reps, float* avg_ms,
                        uint64_t* scanned_positions) {
   if (!hs || !hs->has_meta || !avg_ms || !reps) return HAWK_E_INVALID;
+  if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   ScanParams sp;
@@ -559,13 +564,19 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     return rc;
   // hand-over lists (2 KB per tile): the count pass leaves each small tile's valid survivors for the emit pass.
   // HAWK_LIST_EMIT=0 keeps the recompute-everything emit pass (A/B measurements).
-  static const bool list_emit = [] { const char* e = getenv("HAWK_LIST_EMIT"); return !(e && e[0] == '0'); }();
+  static const bool list_emit_env = [] { const char* e = getenv("HAWK_LIST_EMIT"); return !(e && e[0] == '0'); }();
+  // A view of an expansion plan (hawk_xplan_view) holds no planes: its REF row runs through the plane kernels below on the
+  // plan's REF planes (without hand-over lists: a handful of tiles), every other row through hawk_vsearch.hip.
+  const hawk_xplan* vx = hs->vplan;
+  const bool list_emit = list_emit_env;
+  const uint32_t plane_tiles = vx ? sp.bph * (hs->ref_index == 0 ? 1u : 0u) : (uint32_t)ntile;  // tiles the plane kernels take
+  if (vx && (hs->ref_index != 0 || hs->n_ref_rows != 1)) return HAWK_E_INVALID;                 // a plan's rows: REF first, once
   uint32_t* d_lists = nullptr;
   unsigned long long* d_big = nullptr;
   if (list_emit) {
     // a REF tile takes one work-list entry per 512 survivors (<= 128 per tile), any other big tile one
     const uint64_t n_ref_tiles = (uint64_t)sp.bph * hs->n_ref_rows;
-    if ((rc = hs->lists.reserve(ntile * HAWK_LIST_CAP * 4)) || (rc = hs->big.reserve((ntile + 128 * n_ref_tiles) * 8 + 16))) return rc;
+    if ((rc = hs->lists.reserve((size_t)plane_tiles * HAWK_LIST_CAP * 4 + 16)) || (rc = hs->big.reserve(((size_t)plane_tiles + 128 * n_ref_tiles) * 8 + 16))) return rc;
     d_lists = hs->lists.as<uint32_t>();
     d_big = hs->big.as<unsigned long long>();
   }
@@ -618,17 +629,32 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     ri.bits[0] = hs->refbits.as<uint32_t>();
     ri.bits[1] = hs->refbits.as<uint32_t>() + hs->S;
     ri.n_bits = hs->S * 32u;
+    if (vx && ((rc = hs->refhp.reserve(((size_t)hs->S + 1) * 8 * 2)) || (rc = hs->vcnt0.reserve(ntile * 4)))) return rc;
     if (!hs->refbits_valid || memcmp(hs->refbits_key, key, sizeof(key)) != 0) {
       hawk_launch_ref_bits(ctx->stream, d, sp, ri, hs->refbits.as<uint32_t>(), hs->refbits.as<uint32_t>() + hs->S);
+      // REF's PAM hits + prefix counts: what the clean stretches of a plan's rows are counted from
+      if (vx) hawk_launch_ref_hits(ctx->stream, d, sp, hs->ref_index, hs->refhp.p, hs->refhp.as<uint2>() + hs->S + 1);
       HIPCHK(hipGetLastError());
       memcpy(hs->refbits_key, key, sizeof(key));
       hs->refbits_valid = true;
     }
   }
+  VcArgs va;
+  memset(&va, 0, sizeof(va));
+  if (vx) {
+    for (int pl = 0; pl < 4; ++pl) va.ref[pl] = vx->ref5[pl].as<uint32_t>();
+    va.ref_S = hs->S;
+    va.recs_ = vx->recs.p; va.alt_codes = vx->codes.as<uint8_t>(); va.hv_off = vx->off.as<uint64_t>(); va.tiles_ = vx->tiles.p;
+    va.hpF = hs->refhp.as<uint2>(); va.hpR = hs->refhp.as<uint2>() + hs->S + 1;
+  }
+  const uint32_t v_tiles = vx ? (uint32_t)ntile - plane_tiles : 0u;
   GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists, d_big_count, d_big);
+  hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists, d_big_count, d_big,
+                     nullptr, plane_tiles);
+  if (vx) HIPCHK(hipEventRecord(ev[6], ctx->stream));
+  if (vx) hawk_launch_vsearch(ctx->stream, 0, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, nullptr, none, d_status, plane_tiles, v_tiles);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
   hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
                     hs->offsets.as<uint64_t>(), d_totals);
@@ -651,7 +677,10 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     if ((rc = hawk_reserve_cols(hs->colsA, hs->cols_cap, &ca))) return rc;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                       hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5]);
+                       hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5], plane_tiles);
+    if (vx) HIPCHK(hipEventRecord(ev[7], ctx->stream));
+    if (vx) hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, hs->offsets.as<uint64_t>(), ca,
+                                d_status, plane_tiles, v_tiles);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -676,8 +705,13 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     if ((rc = hawk_reserve_cols(hs->colsA, std::max<uint64_t>(want, hs->cols_cap), &ca))) return rc;
     hs->cols_cap = ca.cap;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
-    if (nrows) hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                                  hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5]);
+    if (nrows) {
+      hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
+                         hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5], plane_tiles);
+      if (vx) HIPCHK(hipEventRecord(ev[7], ctx->stream));
+      if (vx) hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, hs->offsets.as<uint64_t>(), ca,
+                                  d_status, plane_tiles, v_tiles);
+    }
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_block, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -691,6 +725,10 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     (void)hipEventElapsedTime(&timing->emit_ms, ev[3], ev[4]);
     if (nrows && d_lists) (void)hipEventElapsedTime(&timing->emit_list_ms, ev[3], ev[5]);
     (void)hipEventElapsedTime(&timing->total_ms, ev[0], ev[4]);
+    if (vx) {
+      (void)hipEventElapsedTime(&timing->v_count_ms, ev[6], ev[1]);
+      if (nrows) (void)hipEventElapsedTime(&timing->v_emit_ms, ev[7], ev[4]);
+    }
     uint64_t pos = 0;
     for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
     timing->scanned_positions = pos;
@@ -930,7 +968,7 @@ int hawk_table_collapse_export(hawk_table* t, uint32_t* rep_row, uint32_t* pos, 
 
 // ---------------------------------------------------------------------------- K7 off-targets
 int hawk_genome_finalize(hawk_hapset* rows) {
-  if (!rows) return HAWK_E_INVALID;
+  if (!rows || rows->vplan) return HAWK_E_INVALID;
   HIPCHK(hipSetDevice(rows->ctx->device));
   hawk_launch_ot_onehot(rows->ctx->stream, rows->plane, (uint64_t)rows->n_hap * rows->S);
   HIPCHK(hipGetLastError());
@@ -942,6 +980,7 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
                         uint32_t* out_guide, uint32_t* out_row, uint32_t* out_q, uint8_t* out_strand, uint8_t* out_mm,
                         uint64_t* out_code, uint32_t* out_nmask, uint64_t cap, uint64_t* n_out, hawk_ot_timing* timing) {
   if (!hs || !p || !hs->has_meta || !n_out || (n_guides && !guides2)) return HAWK_E_INVALID;
+  if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
   if (p->guidelen + p->pamlen > 32 || p->guidelen == 0) return HAWK_E_UNSUPPORTED;  // window code = 2 bits x 32
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1116,32 +1155,12 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
 // An expansion plan keeps everything hawk_hapset_expand needs in HBM - the variant table, the carried-variant lists, the
 // per-workgroup variant ranges and (after hawk_xplan_set_meta) the metadata of the rows it produces - so that running
 // it is device work only: the per-tile loop of a whole-contig search re-expands its tiles without touching the host.
-struct hawk_xplan {
-  hawk_ctx* ctx;
-  uint32_t n_var, n_hap, ref_len;
-  uint64_t ncar;
-  std::vector<uint32_t> hap_len;
-  uint32_t* ref_plane[4];  // the REF region's code planes, copied: the plan does not depend on the life of ref_set
-  uint32_t ref_S;
-  DevBuf recs, tiles, codes, off, hlen, hash;  // 32 B per carried variant, 16 B per (row, tile): hawk_expand.hip
-  // metadata of the produced rows (hawk_xplan_set_meta)
-  bool has_meta;
-  std::vector<int32_t> scan_start, scan_stop;
-  DevBuf m_is_ref, m_ss, m_se, m_seg_off, m_seg_rel, m_seg_gen, m_tile;
-  uint32_t nseg, bph, S;
-  int32_t ref_index;
-  int64_t ref_startp, min_gen, max_gen;
-  bool has_partner = false;
-  int32_t partner_start = 0, partner_stop = 0;
-  uint32_t n_ref_rows = 0;
-  std::shared_ptr<uint64_t> groups = std::make_shared<uint64_t>(0);  // groups the last collapse of a set of this plan found
-};
-
 void hawk_xplan_destroy(hawk_xplan* x) {
   if (!x) return;
   (void)hipSetDevice(x->ctx->device);
   (void)hipStreamSynchronize(x->ctx->stream);
   for (auto& p : x->ref_plane) hawk_pool_free(p);
+  for (auto& b : x->ref5) b.release();
   DevBuf* bufs[] = {&x->recs, &x->tiles, &x->codes, &x->off, &x->hlen, &x->hash,
                     &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile};
   for (auto* b : bufs) b->release();
@@ -1210,9 +1229,15 @@ int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0
   if (!rc) rc = x->off.reserve((size_t)(n_hap + 1) * 8);
   if (!rc) rc = x->hlen.reserve((size_t)n_hap * 4);
   if (!rc) rc = x->hash.reserve((size_t)n_hap * 16);
+  for (int p = 0; p < HAWK_PLANES && !rc; ++p) rc = x->ref5[p].reserve((size_t)x->S * 4);
   if (rc) { for (auto* b : temps) b->release(); hawk_xplan_destroy(x); return rc; }
   hipStream_t st = ctx->stream;
   hipError_t e = hipSuccess;
+  for (int p = 0; p < HAWK_PLANES && e == hipSuccess; ++p) {  // REF at the rows' stride (S >= ref_S iff no row is shorter ... either way: copy what fits)
+    e = hipMemsetAsync(x->ref5[p].p, 0, (size_t)x->S * 4, st);
+    if (p < 4 && e == hipSuccess)
+      e = hipMemcpyAsync(x->ref5[p].p, ref_set->plane[p], (size_t)std::min(x->S, x->ref_S) * 4, hipMemcpyDeviceToDevice, st);
+  }
   // every variant's first 32 alt bases as plane bits (A, C, G, T): the build kernel shifts them into place instead of
   // walking the allele text (which only insertions longer than a word still need)
   std::vector<uint32_t> am(nv * 4, 0);
@@ -1338,6 +1363,42 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
     return HAWK_E_HIP;
   }
   if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
+  *out = hs;
+  return HAWK_OK;
+}
+
+int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out) {
+  if (!x || !out || !x->has_meta || x->ref_index != 0) return HAWK_E_INVALID;
+  hawk_ctx* ctx = x->ctx;
+  hawk_hapset* hs = nullptr;
+  int rc = hapset_create_impl(ctx, x->n_hap, x->hap_len.data(), false, &hs, false);
+  if (rc) return rc;
+  if (hs->S != x->S) { hawk_hapset_destroy(hs); return HAWK_E_INVALID; }
+  hs->vplan = x;
+  for (int p = 0; p < HAWK_PLANES; ++p) hs->plane[p] = x->ref5[p].as<uint32_t>();  // row 0 = REF; no other row is ever read
+  const uint32_t n = x->n_hap;
+  rc = hawk_pool_alloc((void**)&hs->d_seg_rel, (size_t)x->nseg * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_gen, (size_t)x->nseg * 8);
+  if (rc) { hawk_hapset_destroy(hs); return rc; }
+  hipStream_t st = ctx->stream;
+  hipError_t e = hipMemcpyAsync(hs->d_is_ref, x->m_is_ref.p, n, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_start, x->m_ss.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_stop, x->m_se.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_off, x->m_seg_off.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_rel, x->m_seg_rel.p, (size_t)x->nseg * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_gen, x->m_seg_gen.p, (size_t)x->nseg * 8, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_tile_meta, x->m_tile.p, (size_t)n * x->bph * sizeof(TileMeta), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "hawk_xplan_view: %s", hipGetErrorString(e));
+    hawk_hapset_destroy(hs);
+    return HAWK_E_HIP;
+  }
+  hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
+  hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
+  hs->ref_index = x->ref_index; hs->has_meta = true; hs->n_ref_rows = x->n_ref_rows;
+  hs->plan_groups = x->groups; hs->last_groups = *x->groups;
+  hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
   *out = hs;
   return HAWK_OK;
 }

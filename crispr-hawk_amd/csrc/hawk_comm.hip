@@ -177,16 +177,25 @@ int hawk_comm_gatherv(hawk_comm* c, const void* send, uint64_t send_bytes, int s
       r_dev = c->scratch2.as<char>();
     }
   }
-  NCCLCHK(g_rccl.GroupStart());
-  if (!root) {
-    if (send_bytes) NCCLCHK(g_rccl.Send(s_dev, send_bytes, kNcclUint8, dst, c->nccl, st));
-  } else {
-    for (int r = 0; r < c->world; ++r) {
-      const uint64_t nb = recv_off[r + 1] - recv_off[r];
-      if (r != dst && nb) NCCLCHK(g_rccl.Recv(r_dev + recv_off[r], nb, kNcclUint8, r, c->nccl, st));
+  // a failure inside the bracket must not leave the group open (later RCCL calls of this thread would queue into it and
+  // never run): the status is carried to behind ncclGroupEnd
+  int r0 = g_rccl.GroupStart();
+  if (r0 == 0) {
+    if (!root) {
+      if (send_bytes) r0 = g_rccl.Send(s_dev, send_bytes, kNcclUint8, dst, c->nccl, st);
+    } else {
+      for (int r = 0; r < c->world && r0 == 0; ++r) {
+        const uint64_t nb = recv_off[r + 1] - recv_off[r];
+        if (r != dst && nb) r0 = g_rccl.Recv(r_dev + recv_off[r], nb, kNcclUint8, r, c->nccl, st);
+      }
     }
+    const int r1 = g_rccl.GroupEnd();
+    if (r0 == 0) r0 = r1;
   }
-  NCCLCHK(g_rccl.GroupEnd());
+  if (r0 != 0) {
+    snprintf(g_comm_err, sizeof(g_comm_err), "hawk_comm_gatherv: %s", g_rccl.GetErrorString(r0));
+    return HAWK_E_COMM;
+  }
   if (root) {
     if (send_bytes) HIPCHK(hipMemcpyAsync(r_dev + recv_off[dst], s_dev, send_bytes, hipMemcpyDeviceToDevice, st));
     if (!recv_on_device && recv_off[c->world])
@@ -194,6 +203,44 @@ int hawk_comm_gatherv(hawk_comm* c, const void* send, uint64_t send_bytes, int s
   }
   HIPCHK(hipStreamSynchronize(st));
   return HAWK_OK;
+}
+
+// The arithmetic of hawk_table_gather without any device or RCCL call (so that it can be driven on a CPU with any
+// transport, tests/test_parallel_gloo.py): from the directory every rank contributed - {rows, haplotype offset, candidates,
+// hits} per rank - the row offset of every rank's slice in the merged table, the totals, and the transfers of this rank:
+// one (column, peer, byte offset in the merged column, bytes) per column and peer for the destination (recv; its own
+// slice is a local copy and is listed with peer == dst), one per column for a sender (offset 0 = start of its own column).
+static const size_t kColWidth[HAWK_GATHER_COLS] = {4, 4, 1, 8, 8, 1, 8, 8, 8, 8, 8, 8};  // hap pos strand start stop flags cfdon win[0..4]
+int hawk_host_gather_plan(int world, int rank, int dst, const uint64_t* dir4, uint64_t* row_off, uint64_t* totals3,
+                          hawk_gather_op* ops, uint32_t cap, uint32_t* n_ops) {
+  if (world < 1 || rank < 0 || rank >= world || dst < 0 || dst >= world || !dir4 || !row_off || !totals3 || !n_ops) return HAWK_E_INVALID;
+  row_off[0] = 0;
+  totals3[1] = totals3[2] = 0;
+  for (int r = 0; r < world; ++r) {
+    row_off[r + 1] = row_off[r] + dir4[4 * r];
+    totals3[1] += dir4[4 * r + 2];
+    totals3[2] += dir4[4 * r + 3];
+  }
+  totals3[0] = row_off[world];
+  uint32_t k_ops = 0;
+  for (int k = 0; k < HAWK_GATHER_COLS; ++k) {
+    if (rank != dst) {
+      const uint64_t n = dir4[4 * rank];
+      if (n) {
+        if (ops && k_ops < cap) ops[k_ops] = hawk_gather_op{(uint32_t)k, (uint32_t)dst, 0, n * kColWidth[k]};
+        ++k_ops;
+      }
+    } else {
+      for (int r = 0; r < world; ++r) {
+        const uint64_t n = dir4[4 * r];
+        if (!n) continue;
+        if (ops && k_ops < cap) ops[k_ops] = hawk_gather_op{(uint32_t)k, (uint32_t)r, row_off[r] * kColWidth[k], n * kColWidth[k]};
+        ++k_ops;
+      }
+    }
+  }
+  *n_ops = k_ops;
+  return (ops && k_ops > cap) ? HAWK_E_CAPACITY : HAWK_OK;
 }
 
 int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst, hawk_table** merged, float* ms) {
@@ -211,61 +258,85 @@ int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst,
   int rc = hawk_comm_allgather_u64(c, mine, 4, all.data());
   if (rc) return rc;
   std::vector<uint64_t> off(W + 1, 0);
-  for (int r = 0; r < W; ++r) off[r + 1] = off[r] + all[4 * r];
-  const uint64_t total = off[W];
+  uint64_t totals[3];
+  std::vector<hawk_gather_op> ops((size_t)HAWK_GATHER_COLS * W);
+  uint32_t n_ops = 0;
+  if ((rc = hawk_host_gather_plan(W, c->rank, dst, all.data(), off.data(), totals, ops.data(), (uint32_t)ops.size(), &n_ops))) return rc;
   hawk_table* m = nullptr;
   GuideCols mc = {};
+  int prep = HAWK_OK;  // what this rank has to say before any send is posted
   if (root) {
     m = new (std::nothrow) hawk_table();
-    if (!m) return HAWK_E_INVALID;
-    m->hs = nullptr; m->ctx = ctx; m->gen = 0;
-    m->n_rows = total; m->n_cand = 0; m->n_hits = 0;
-    for (int r = 0; r < W; ++r) { m->n_cand += all[4 * r + 2]; m->n_hits += all[4 * r + 3]; }
-    m->guidelen = t->guidelen; m->pamlen = t->pamlen; m->right = t->right; m->n_groups = 0; m->collapsed = false;
-    if ((rc = hawk_reserve_cols(m->own, std::max<uint64_t>(total, 1), &mc))) { hawk_table_destroy(m); return rc; }
-    m->cols = mc; m->cap = mc.cap;
+    if (!m) prep = HAWK_E_INVALID;
+    if (m) {
+      m->hs = nullptr; m->ctx = ctx; m->gen = 0;
+      m->n_rows = totals[0]; m->n_cand = totals[1]; m->n_hits = totals[2];
+      m->guidelen = t->guidelen; m->pamlen = t->pamlen; m->right = t->right; m->n_groups = 0; m->collapsed = false;
+      prep = hawk_reserve_cols(m->own, std::max<uint64_t>(totals[0], 1), &mc);
+      m->cols = mc; m->cap = mc.cap;
+    }
+  }
+  // go / no-go: a destination that could not reserve the merged columns must not leave its peers blocked in ncclSend
+  {
+    uint64_t word = (uint64_t)(prep != HAWK_OK);
+    std::vector<uint64_t> words(W);
+    rc = hawk_comm_allgather_u64(c, &word, 1, words.data());
+    bool stop = rc != HAWK_OK;
+    for (int r = 0; r < W && !stop; ++r) stop = words[r] != 0;
+    if (stop) {
+      if (m) hawk_table_destroy(m);
+      if (rc) return rc;
+      if (prep) return prep;
+      snprintf(g_comm_err, sizeof(g_comm_err), "hawk_table_gather: the destination rank could not reserve the merged table");
+      return HAWK_E_COMM;
+    }
   }
   const GuideCols& sc = t->cols;
   const uint64_t n = t->n_rows;
-  // column pointers and widths: hap pos strand start stop flags cfdon win[0..4]
-  const void* sp[12] = {sc.hap, sc.pos, sc.strand, sc.start, sc.stop, sc.flags, sc.cfdon, sc.win, sc.win + sc.cap, sc.win + 2 * sc.cap,
-                        sc.win + 3 * sc.cap, sc.win + 4 * sc.cap};
-  void* rp[12] = {mc.hap, mc.pos, mc.strand, mc.start, mc.stop, mc.flags, mc.cfdon, mc.win, mc.win + mc.cap, mc.win + 2 * mc.cap,
-                  mc.win + 3 * mc.cap, mc.win + 4 * mc.cap};
-  const size_t wd[12] = {4, 4, 1, 8, 8, 1, 8, 8, 8, 8, 8, 8};
-  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  const void* sp[HAWK_GATHER_COLS] = {sc.hap, sc.pos, sc.strand, sc.start, sc.stop, sc.flags, sc.cfdon, sc.win, sc.win + sc.cap, sc.win + 2 * sc.cap,
+                                      sc.win + 3 * sc.cap, sc.win + 4 * sc.cap};
+  void* rp[HAWK_GATHER_COLS] = {mc.hap, mc.pos, mc.strand, mc.start, mc.stop, mc.flags, mc.cfdon, mc.win, mc.win + mc.cap, mc.win + 2 * mc.cap,
+                                mc.win + 3 * mc.cap, mc.win + 4 * mc.cap};
+  // from here on every failure releases the merged table
+  auto fail = [&](int code) { if (m) hawk_table_destroy(m); return code; };
+#define HIPCHK_M(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      snprintf(hawk_hip_err_buf(), 256, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return fail(HAWK_E_HIP);                                                                 \
+    }                                                                                          \
+  } while (0)
+  HIPCHK_M(hipEventRecord(ctx->ev[6], st));
   int r0 = g_rccl.GroupStart();
   if (r0 == 0) {
-    for (int k = 0; k < 12 && r0 == 0; ++k) {
-      if (!root) {
-        if (n) r0 = g_rccl.Send(sp[k], n * wd[k], kNcclUint8, dst, c->nccl, st);
-      } else {
-        for (int r = 0; r < W && r0 == 0; ++r) {
-          const uint64_t nr = all[4 * r];
-          if (r != dst && nr) r0 = g_rccl.Recv((char*)rp[k] + off[r] * wd[k], nr * wd[k], kNcclUint8, r, c->nccl, st);
-        }
-      }
+    for (uint32_t i = 0; i < n_ops && r0 == 0; ++i) {
+      const hawk_gather_op& op = ops[i];
+      if (!root) r0 = g_rccl.Send(sp[op.col], op.bytes, kNcclUint8, dst, c->nccl, st);
+      else if ((int)op.peer != dst) r0 = g_rccl.Recv((char*)rp[op.col] + op.offset, op.bytes, kNcclUint8, (int)op.peer, c->nccl, st);
     }
     const int r1 = g_rccl.GroupEnd();
     if (r0 == 0) r0 = r1;
   }
   if (r0 != 0) {
     snprintf(g_comm_err, sizeof(g_comm_err), "hawk_table_gather: %s", g_rccl.GetErrorString(r0));
-    if (m) hawk_table_destroy(m);
-    return HAWK_E_COMM;
+    return fail(HAWK_E_COMM);
   }
   if (root) {
-    for (int k = 0; k < 12; ++k)
-      if (n) HIPCHK(hipMemcpyAsync((char*)rp[k] + off[dst] * wd[k], sp[k], n * wd[k], hipMemcpyDeviceToDevice, st));
+    for (uint32_t i = 0; i < n_ops; ++i) {  // the destination's own slice: a local copy
+      const hawk_gather_op& op = ops[i];
+      if ((int)op.peer == dst && n) HIPCHK_M(hipMemcpyAsync((char*)rp[op.col] + op.offset, sp[op.col], op.bytes, hipMemcpyDeviceToDevice, st));
+    }
     for (int r = 0; r < W; ++r) {
       const uint64_t nr = all[4 * r];
       const uint32_t ho = (uint32_t)all[4 * r + 1];
       if (nr && ho) hipLaunchKernelGGL(k_hap_shift, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, mc.hap + off[r], nr, ho);
     }
-    HIPCHK(hipGetLastError());
+    HIPCHK_M(hipGetLastError());
   }
-  HIPCHK(hipEventRecord(ctx->ev[7], st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK_M(hipEventRecord(ctx->ev[7], st));
+  HIPCHK_M(hipStreamSynchronize(st));
+#undef HIPCHK_M
   if (ms) (void)hipEventElapsedTime(ms, ctx->ev[6], ctx->ev[7]);
   if (root) *merged = m;
   return HAWK_OK;

@@ -82,6 +82,21 @@ struct RefInfo {
   const uint32_t* bits[2];  // per strand: bit q set <=> REF has a candidate window starting at q (k_ref_bits); n_bits valid bits
   uint32_t n_bits;
 };
+// The search straight from an expansion plan (hawk_vsearch.hip): what it reads beside the rows' metadata.
+struct VcArgs {
+  const uint32_t* ref[4];   // REF planes A, C, G, T (ref_S words each, zero past the last base)
+  uint32_t ref_S;
+  const void* recs_;        // HxVar[]: one record per carried variant of every row (hawk_hx.h)
+  const uint8_t* alt_codes;
+  const uint64_t* hv_off;   // [n_hap + 1] record range of every row
+  const void* tiles_;       // HxTile[n_hap * tiles per row]
+  const uint2* hpF;         // REF PAM hits per strand: {hit bits of word w, hits in the words before}, w <= ref_S
+  const uint2* hpR;
+};
+void hawk_launch_vsearch(hipStream_t st, int pass, const HapSetDev& hs, const VcArgs& va, const ScanParams& p, const struct GuideParams& gp,
+                         const struct RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, uint32_t* counts0, unsigned long long* shards,
+                         const uint64_t* offsets, struct GuideCols out, int* status, uint32_t tile0, uint32_t n_tiles);
+void hawk_launch_ref_hits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, int32_t ref_index, void* hpF, void* hpR);
 void hawk_launch_ref_bits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const RefInfo& ri, uint32_t* bitsF, uint32_t* bitsR);
 
 // K7 records
@@ -129,7 +144,7 @@ void hawk_launch_emit_hits(hipStream_t st, const HapSetDev& hs, uint32_t bph, co
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, uint32_t* big_count,
-                        unsigned long long* big_list, hipEvent_t mid = nullptr);
+                        unsigned long long* big_list, hipEvent_t mid = nullptr, uint32_t n_tiles = 0xffffffffu);
 size_t hawk_collapse_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit);
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
                          int flank_up, int flank_down, int64_t base, unsigned begin_bit, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,

@@ -94,8 +94,38 @@ struct hawk_hapset {
   DevBuf refbits;             // REF's candidate-window bitmaps, one per strand (k_ref_bits)
   bool refbits_valid = false;
   uint64_t refbits_key[6] = {0, 0, 0, 0, 0, 0};
+  // a VIEW of an expansion plan (hawk_xplan_view): rows and metadata of the plan's haplotypes without their planes -
+  // plane[] points at the plan's REF planes (row 0 only) and hawk_search runs from the plan's records (hawk_vsearch.hip)
+  const struct hawk_xplan* vplan = nullptr;
+  DevBuf vcnt0;               // per tile: rows of strand 0 (k_vsearch<0> -> k_vsearch<1>)
+  DevBuf refhp;               // REF's PAM hits + prefix counts per strand (k_ref_hits), keyed like refbits
   DevBuf colsA[8];
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
+};
+
+// An expansion plan keeps everything hawk_hapset_expand needs in HBM - the variant table, the carried-variant lists, the
+// per-workgroup variant ranges and (after hawk_xplan_set_meta) the metadata of the rows it produces - so that running
+// it is device work only: the per-tile loop of a whole-contig search re-expands its tiles without touching the host.
+struct hawk_xplan {
+  hawk_ctx* ctx;
+  uint32_t n_var, n_hap, ref_len;
+  uint64_t ncar;
+  std::vector<uint32_t> hap_len;
+  uint32_t* ref_plane[4];  // the REF region's code planes, copied: the plan does not depend on the life of ref_set
+  uint32_t ref_S;
+  DevBuf ref5[HAWK_PLANES];  // the same planes (+ an all-zero V plane) at the ROWS' stride S: row 0 of a view (hawk_xplan_view)
+  DevBuf recs, tiles, codes, off, hlen, hash;  // 32 B per carried variant, 16 B per (row, tile): hawk_expand.hip
+  // metadata of the produced rows (hawk_xplan_set_meta)
+  bool has_meta;
+  std::vector<int32_t> scan_start, scan_stop;
+  DevBuf m_is_ref, m_ss, m_se, m_seg_off, m_seg_rel, m_seg_gen, m_tile;
+  uint32_t nseg, bph, S;
+  int32_t ref_index;
+  int64_t ref_startp, min_gen, max_gen;
+  bool has_partner = false;
+  int32_t partner_start = 0, partner_stop = 0;
+  uint32_t n_ref_rows = 0;
+  std::shared_ptr<uint64_t> groups = std::make_shared<uint64_t>(0);  // groups the last collapse of a set of this plan found
 };
 
 struct hawk_table {

@@ -18,10 +18,9 @@
 // Reference semantics: search_guides.py:32-46 (match), 87-99 (scan), 395-420 (in range),
 // 468-471 (REF-identical skip), 260-280 (coordinates), 340-369 (redundancy), 134-160 (window);
 // scoring.py:352-387 + cfdscore.py:53-95 after annotation.py:27-51 (CFDon).
-#include "hawk_bits.h"
+#include "hawk_rows.h"
 
 #define CAP 512    // survivors staged per round (2 per thread)
-#define NSEG 64    // position-map segments staged per tile
 #define TILE_WORDS (HAWK_BLOCK * HAWK_WPT)  // 1024 plane words per tile
 #define LDS_OFF 4                            // tile word w lives at s_pl[p][LDS_OFF + w]; word -1 at [3]
 #define LDS_ROW (TILE_WORDS + 8)             // + halo: 1 word before, 2 after (+ pad)
@@ -30,14 +29,6 @@
 #endif
 #define LIST_CAP 512                         // valid survivors a tile may hand from the count pass to the emit pass
 
-__device__ __forceinline__ int seg_find(const uint32_t* s_rel, int n, uint32_t rel) {
-  int lo = 0, hi = n;  // last j in [0,n) with s_rel[j] <= rel (s_rel[0] <= every rel of the tile)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (s_rel[mid] <= rel) lo = mid; else hi = mid;
-  }
-  return lo;
-}
 // 64 bits starting at tile-relative bit position bp (>= -32) of a staged plane slice
 __device__ __forceinline__ W2 ext_lds(const uint32_t* pl, int bp) {
   const uint32_t x = (uint32_t)(bp + 32 * LDS_OFF);
@@ -45,60 +36,6 @@ __device__ __forceinline__ W2 ext_lds(const uint32_t* pl, int bp) {
   const uint32_t a = pl[w], b = pl[w + 1], c = pl[w + 2];
   return W2{fsh(a, b, sh), fsh(b, c, sh)};
 }
-// reverse the low L bits of a slice (bit i <-> bit L-1-i), 32 < L <= 64 or L <= 32
-__device__ __forceinline__ W2 rev_bits(W2 v, int L) {
-  const uint32_t rl = __brev(v.hi), rh = __brev(v.lo);  // 64-bit reversal
-  const uint32_t sh = (uint32_t)(64 - L);               // then shift right by 64 - L (0 <= sh < 64)
-  if (sh == 0) return W2{rl, rh};
-  if (sh < 32) return W2{fsh(rl, rh, sh), rh >> sh};
-  return W2{sh == 32 ? rh : rh >> (sh - 32), 0u};
-}
-
-// K4: CFDon on the 5'->3' guide.  Strand-1 slices are first turned into the 5'->3' guide (reverse the L
-// bits, swap A<->T and C<->G planes = reverse complement), after which both strands read spacer base t at
-// bit t and PAM[-2:] at bits L-2, L-1.  Only positions where REF and this guide differ contribute, visited
-// in ascending t so the fp64 product is formed exactly as cfdscore.py:78-95 forms it.
-__device__ __forceinline__ double cfdon_from_slices(const W2 (&core)[4], const W2 (&rcore)[4], uint32_t s, int L,
-                                                    uint32_t cfdmask, const double* s_cfd, bool& err) {
-  W2 g[4], r[4];
-  if (s) {
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl) { g[pl] = rev_bits(core[3 - pl], L); r[pl] = rev_bits(rcore[3 - pl], L); }
-  } else {
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl) { g[pl] = core[pl]; r[pl] = rcore[pl]; }
-  }
-  // spacer positions 0..min(guidelen,20)-1 all sit in the low word
-  uint32_t diff = ((g[0].lo ^ r[0].lo) | (g[1].lo ^ r[1].lo) | (g[2].lo ^ r[2].lo) | (g[3].lo ^ r[3].lo)) & cfdmask;
-  // a lookup needs both bases to be exactly one of A,C,G,T (else KeyError in the reference)
-  const uint32_t g2 = (g[0].lo & g[1].lo) | ((g[0].lo | g[1].lo) & (g[2].lo | g[3].lo)) | (g[2].lo & g[3].lo);
-  const uint32_t r2 = (r[0].lo & r[1].lo) | ((r[0].lo | r[1].lo) & (r[2].lo | r[3].lo)) | (r[2].lo & r[3].lo);
-  err = (diff & (g2 | r2)) != 0;
-  const uint32_t gb0 = g[1].lo | g[3].lo, gb1 = g[2].lo | g[3].lo;  // base index bits: A0 C1 G2 T3
-  const uint32_t rb0 = r[1].lo | r[3].lo, rb1 = r[2].lo | r[3].lo;
-  double score = 1.0;
-  while (diff && !err) {
-    const uint32_t t = (uint32_t)__builtin_ctz(diff);
-    diff &= diff - 1;
-    const uint32_t a = ((rb0 >> t) & 1u) | (((rb1 >> t) & 1u) << 1);
-    const uint32_t b = ((gb0 >> t) & 1u) | (((gb1 >> t) & 1u) << 1);
-    score *= s_cfd[(t * 4 + a) * 4 + b];
-  }
-  if (!err) {
-    const int o0 = L - 2, o1 = L - 1;  // PAM[-2:] (wave-uniform positions)
-    uint32_t c0 = 0, c1 = 0;
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl) {
-      c0 |= (((o0 < 32 ? g[pl].lo : g[pl].hi) >> (o0 & 31)) & 1u) << pl;
-      c1 |= (((o1 < 32 ? g[pl].lo : g[pl].hi) >> (o1 & 31)) & 1u) << pl;
-    }
-    const int p0 = base_index(c0), p1 = base_index(c1);
-    if (p0 < 0 || p1 < 0) err = true;
-    else score *= s_cfd[320 + 4 * p0 + p1];
-  }
-  return err ? __longlong_as_double(0x7ff8000000000000ll) : score;
-}
-
 template <int PASS>
 __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParams& p_in, const GuideParams& gp, const RefInfo& ri,
                                             const TileMeta* __restrict__ tmeta, uint32_t* __restrict__ counts,
@@ -735,8 +672,9 @@ void hawk_launch_ref_bits(hipStream_t st, const HapSetDev& hs, const ScanParams&
 void hawk_launch_search(hipStream_t st, int pass, const HapSetDev& hs, const ScanParams& p, const GuideParams& gp,
                         const RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, unsigned long long* shards,
                         const uint64_t* offsets, GuideCols out, int* status, uint32_t* lists, uint32_t* big_count,
-                        unsigned long long* big_list, hipEvent_t mid) {
-  const uint32_t ntile = hs.n_hap * p.bph;
+                        unsigned long long* big_list, hipEvent_t mid, uint32_t n_tiles) {
+  const uint32_t ntile = n_tiles == 0xffffffffu ? hs.n_hap * p.bph : n_tiles;  // a plan view: the REF row's tiles only
+  if (!ntile) { if (pass == 1 && mid) (void)hipEventRecord(mid, st); return; }
   const dim3 grid(ntile), block(HAWK_BLOCK);
   if (pass == 0) {
     hipLaunchKernelGGL(k_search_count, grid, block, 0, st, hs, p, gp, ri, tmeta, counts, shards, status, lists, big_count, big_list);

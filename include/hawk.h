@@ -125,6 +125,15 @@ int hawk_xplan_set_meta(hawk_xplan* x, const uint8_t* is_ref, const int32_t* sca
                         const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, int32_t ref_index);
 int hawk_xplan_set_ref_partner_range(hawk_xplan* x, int32_t start, int32_t stop);
 int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms);
+/* A VIEW of the plan's rows: a haplotype set with the plan's metadata (hawk_xplan_set_meta must have been called, REF = row
+ * 0) but WITHOUT planes.  hawk_search on a view computes the same table, totals and row order as on the set hawk_xplan_run
+ * writes - encode (encoder.py:48-57 over every haplotype) and search (search_guides.py:510-548) in one step, straight from
+ * REF + the rows' variant records: windows without a variant base are dropped by the reference (search_guides.py:468-471),
+ * so only the words around a row's variants are assembled (in registers) and matched; the PAM hits of the verbatim REF
+ * stretches in between, which only the totals count, come from prefix counts over REF's own hits.  Everything that reads
+ * planes (hawk_pam_scan, hawk_hapset_download_plane, hawk_offtarget_scan ...) returns HAWK_E_INVALID on a view; tables,
+ * collapse, export and gather work as on any set.  The plan must outlive the view. */
+int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out);
 void hawk_xplan_destroy(hawk_xplan* x);
 
 /* ---- K2: pam_search() (search_guides.py:102-131) ---------------------------------------
@@ -161,6 +170,8 @@ typedef struct {          /* kernel times of the last hawk_search (HIP events on
   float total_ms;   /* first kernel start to last kernel end, including the host round trip for the row count */
   uint64_t scanned_positions; /* sum over haplotypes of (scan_stop - scan_start) */
   float emit_list_ms; /* k_emit_list alone (0 when the hand-over lists are switched off) */
+  float v_count_ms;   /* a plan view (hawk_xplan_view): k_vsearch<0> alone - count_ms also holds the REF row's plane kernel */
+  float v_emit_ms;    /* ... k_vsearch<1> alone */
   float reserved;
 } hawk_timing;
 
@@ -271,6 +282,16 @@ int hawk_comm_allgather_u64(hawk_comm* c, const uint64_t* mine, uint32_t k, uint
 int hawk_comm_gatherv(hawk_comm* c, const void* send, uint64_t send_bytes, int send_on_device, void* recv,
                       const uint64_t* recv_off, int recv_on_device, int dst);
 int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst, hawk_table** merged, float* ms);
+/* The arithmetic of hawk_table_gather as a host function, free of device and RCCL calls (it runs without a GPU): from the
+ * directory all ranks contributed - dir4[4 r .. 4 r + 3] = {rows, haplotype offset, candidates, hits} of rank r - the row
+ * offset of every rank's slice in the merged table (row_off[world + 1]), the totals {rows, candidates, hits} and this
+ * rank's transfers.  Columns are numbered hap pos strand start stop flags cfdon win[0..4] (HAWK_GATHER_COLS).  A sender gets
+ * one op per column {col, dst, 0, bytes}; the destination one per column and rank {col, rank, byte offset into the merged
+ * column, bytes}, its own slice included (a local copy).  ops == NULL only counts. */
+#define HAWK_GATHER_COLS 12
+typedef struct { uint32_t col, peer; uint64_t offset, bytes; } hawk_gather_op;
+int hawk_host_gather_plan(int world, int rank, int dst, const uint64_t* dir4, uint64_t* row_off, uint64_t* totals3,
+                          hawk_gather_op* ops, uint32_t cap, uint32_t* n_ops);
 
 /* ---- f3: VCF sample columns -> allele codes -> carried-variant lists.  Replaces the per-sample Python work of
  * VariantRecord.read_vcf_line -> _genotypes_to_samples (variant.py:286-311, 558-619) and the inversion into

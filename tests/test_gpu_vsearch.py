@@ -1,0 +1,134 @@
+"""hawk_xplan_view: the search straight from an expansion plan (hawk_vsearch.hip) against the search on the planes the
+same plan materialises (hawk_xplan_run + hawk_search, itself held to the reference's fixtures and the oracle by
+test_gpu_parity.py): every column, row for row, and the job totals, on inputs that reach each path of the kernel -
+tiles with no variant, the usual few, more records than LDS stages, more dirty words than one pass holds, long
+insertions and deletions across word / tile edges, rows that end in a tile, PAMs of every shape."""
+import numpy as np
+import pytest
+
+from crisprhawk_hip import _lib, synth
+from crisprhawk_hip.workload import expand_on_device
+from oracle import oracle as ora
+from util import load_golden, synth_region_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("hap", "pos", "strand", "start", "stop", "flags")
+
+
+def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False):
+    bits, bitsrc, _, _ = ora.pam_encode(pam_s)
+    mm, pt = synth.cfd_tables() if cfd else (None, None)
+    ds, _info, _ms, _kept = expand_on_device(reg, len(pam_s), keep_plan=True)
+    a = ds.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
+    if not reg.variants:  # nothing to view
+        return a
+    assert ds.plan is not None
+    view = ds.plan.view()
+    b = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
+    assert (b.n_rows, b.n_candidates, b.n_hits) == (a.n_rows, a.n_candidates, a.n_hits)
+    for c in COLS:
+        assert np.array_equal(getattr(a, c), getattr(b, c)), c
+    assert np.array_equal(a.win, b.win)
+    assert np.array_equal(a.cfdon, b.cfdon, equal_nan=True)
+    # a second search on the view (cached REF bitmaps, reserved columns) and a different geometry after it
+    b2 = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
+    assert b2.n_rows == a.n_rows and np.array_equal(b2.start, a.start) and np.array_equal(b2.win, a.win)
+    with pytest.raises(_lib.HawkStatusError):
+        view.pam_scan(bits, bitsrc, len(pam_s))  # a view holds no planes
+    ds.plan.close()
+    assert b.timing["count_ms"] > 0
+    return a
+
+
+@pytest.mark.parametrize("case", ["phased4", "phased16", "cpf1", "indel_dense", "tiny"])
+def test_view_search_on_reference_fixture_inputs(case):
+    fx = load_golden(f"g3_search_{case}.json.gz")
+    reg = synth_region_from_fixture(fx)
+    a = _same_table(reg, fx["pam"], fx["guidelen"], fx["right"], cfd="cfdon" in fx)
+    assert a.n_rows == len(fx["guides"])
+
+
+@pytest.mark.parametrize("pam_s,guidelen,right", [("NGG", 20, False), ("TTTV", 23, True), ("NNGRRT", 21, False), ("NGN", 20, False),
+                                                  ("TTTV", 23, False), ("NNNRRT", 24, True), ("NGG", 40, False), ("NG", 5, False)])
+def test_view_search_pam_and_guide_shapes(pam_s, guidelen, right):
+    reg = synth.make_region(8101, "chrV", 150_000, 3_000, 140_000)
+    synth.add_phased_variants(reg, 8102, 2500, 6, frac_snv=0.8, frac_del=0.1, max_indel=8, af_min=0.05, af_max=0.6)
+    _same_table(reg, pam_s, guidelen, right, cfd=(pam_s == "NGG" and guidelen == 20))
+
+
+@pytest.mark.parametrize("region_len", [32_568, 32_569, 32_600, 65_336, 65_400, 70_000])
+def test_view_search_rows_ending_around_tile_edges(region_len):
+    reg = synth.make_region(8200 + region_len % 89, "chrB", region_len + 3000, 1200, 1200 + region_len)
+    synth.add_phased_variants(reg, 8201, 90, 3, frac_snv=0.5, frac_del=0.25, af_min=0.3, af_max=0.8)
+    _same_table(reg, "NGG", 20, False)
+    _same_table(reg, "TTTV", 23, True, cfd=False)
+
+
+def test_view_search_dense_tiles():
+    # a variant every ~12 nt carried by most haplotypes: more records per tile than LDS stages (the builder reads the rest
+    # from global memory) and more dirty words than one pass holds (strand 0 over all chunks, then strand 1)
+    reg = synth.make_region(8301, "chrX", 75_000, 2_000, 72_000)
+    synth.add_phased_variants(reg, 8302, 6000, 3, frac_snv=0.8, frac_del=0.1, max_indel=3, af_min=0.6, af_max=0.95)
+    _same_table(reg, "NGG", 20, False)
+    _same_table(reg, "TTTV", 23, True, cfd=False)
+
+
+def test_view_search_crowded_tiles_long_deletions_long_insertion():
+    reg = synth.make_region(8351, "chrK", 170_000, 5_000, 165_000)
+    rng = np.random.default_rng(8352)
+    seq = reg.contig_seq
+    n_samples = 3
+    reg.samples = [f"S{i:04d}" for i in range(n_samples)]
+    sites = []
+
+    def gt(p):
+        g = (rng.random((n_samples, 2)) < p).astype(np.uint8)
+        g[0, 0] = 1
+        return g
+    for pos in range(20_000, 60_000, 25):
+        refb = seq[pos - 1]
+        sites.append(synth.VariantSite(pos, refb, "ACGT"[("ACGT".index(refb) + 1) % 4], 0.7, gt(0.7)))
+    for pos in (70_000, 76_000, 82_000, 88_000):
+        sites.append(synth.VariantSite(pos, seq[pos - 1:pos + 1500], seq[pos - 1], 0.5, gt(0.5)))
+    for pos, k in ((120_000, 400), (120_900, 31), (121_500, 32), (122_000, 33), (37_777, 70), (69_990, 45)):
+        sites.append(synth.VariantSite(pos, seq[pos - 1], seq[pos - 1] + "".join("ACGT"[b] for b in rng.integers(0, 4, k)), 0.5, gt(0.5)))
+    for pos in range(130_000, 160_000, 700):
+        refb = seq[pos - 1]
+        sites.append(synth.VariantSite(pos, refb, "ACGT"[("ACGT".index(refb) + 2) % 4], 0.3, gt(0.3)))
+    sites.sort(key=lambda v: v.pos)
+    reg.variants = sites
+    _same_table(reg, "NGG", 20, False)
+    _same_table(reg, "TTTV", 23, True, cfd=False)
+    _same_table(reg, "NNGRRT", 21, False, cfd=False)
+
+
+def test_view_search_variants_at_the_very_ends():
+    # variants within the first / last bases of the region string: the first word's string has nothing in front of it
+    reg = synth.make_region(8401, "chrE", 3000, 700, 1500)
+    synth.add_phased_variants(reg, 8402, 80, 3, frac_snv=0.2, frac_del=0.4, max_indel=6, af_min=0.2, af_max=0.7, edge_margin=1)
+    _same_table(reg, "NGG", 20, False)
+    _same_table(reg, "NGN", 20, False)
+
+
+def test_view_search_iupac_reference():
+    # ambiguity codes in the REFERENCE sequence (N / R / Y ...): matched as sets by the PAM, NA under a CFD lookup
+    reg = synth.make_region(8501, "chrN", 60_000, 500, 58_000, iupac_frac=0.01)
+    synth.add_phased_variants(reg, 8502, 900, 4, af_min=0.1, af_max=0.6)
+    _same_table(reg, "NNGRRT", 21, False, cfd=False)
+    _same_table(reg, "NGG", 20, False, cfd=True, na_on_ambiguous=True)
+
+
+def test_view_search_random_campaign():
+    rng = np.random.default_rng(8601)
+    shapes = [("NGG", 20, False), ("TTTV", 23, True), ("NNGRRT", 21, False), ("NRG", 20, False), ("TTCN", 20, True), ("NGK", 18, False)]
+    for it in range(24):
+        n = int(rng.integers(2_000, 120_000))
+        reg = synth.make_region(8700 + it, "chrR", n + 2_500, 1_000, 1_000 + n)
+        max_indel = int(rng.choice([2, 8, 40]))
+        sites = min(int(n / rng.choice([15, 40, 120, 400, 2000])), n // (max_indel + 2) - 8)
+        synth.add_phased_variants(reg, 8800 + it, max(sites, 2), int(rng.integers(1, 9)), frac_snv=float(rng.choice([0.3, 0.7, 0.9])),
+                                  frac_del=float(rng.choice([0.05, 0.3])), max_indel=max_indel,
+                                  af_min=0.05, af_max=float(rng.choice([0.3, 0.9])))
+        pam_s, guidelen, right = shapes[it % len(shapes)]
+        _same_table(reg, pam_s, guidelen, right, cfd=(pam_s in ("NGG", "NRG", "NGK") and not right))

@@ -189,3 +189,59 @@ def test_gather_tables_world3_tcp(tmp_path):
             want = np.concatenate([np.where(p["hap"] == 0, 0, p["hap"].astype(np.int64) + o).astype(np.uint32)
                                    for p, o in zip(parts, off)])
         assert np.array_equal(got[k], want), k
+
+
+def test_table_gather_plan_world3_with_a_fake_transport():
+    """hawk_table_gather's directory / offset arithmetic (hawk_host_gather_plan, the function the RCCL path itself runs)
+    for a world of three with one empty rank, driven on the CPU: the transfers every rank is told to post are carried out
+    by a byte-copying stand-in for ncclSend / ncclRecv and must reproduce the concatenated table, haplotype indices moved
+    into the global numbering as k_hap_shift does."""
+    import ctypes as C
+    from crisprhawk_hip import _lib
+    L = _lib.lib()
+
+    class Op(C.Structure):
+        _fields_ = [("col", C.c_uint32), ("peer", C.c_uint32), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+    widths = [4, 4, 1, 8, 8, 1, 8, 8, 8, 8, 8, 8]
+    rng = np.random.default_rng(11)
+    world, dst = 3, 1
+    rows = [5, 0, 7]
+    hap_off = [0, 3, 3]
+    tabs = [[rng.integers(0, 255, size=n * w, dtype=np.uint8) for w in widths] for n in rows]
+    for r in range(world):  # column 0 = haplotype index (u32): make it small numbers, 0 = REF
+        tabs[r][0] = rng.integers(0, 3, size=rows[r]).astype(np.uint32).view(np.uint8)
+    dir4 = np.array([[rows[r], hap_off[r], 100 + r, 200 + r] for r in range(world)], dtype=np.uint64).reshape(-1)
+    plans = []
+    for r in range(world):
+        off = np.zeros(world + 1, dtype=np.uint64)
+        tot = np.zeros(3, dtype=np.uint64)
+        n_ops = C.c_uint32(0)
+        ops = (Op * (12 * world))()
+        rc = L.hawk_host_gather_plan(world, r, dst, dir4.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                     tot.ctypes.data_as(C.c_void_p), C.byref(ops), 12 * world, C.byref(n_ops))
+        assert rc == 0
+        assert off.tolist() == [0, 5, 5, 12] and tot.tolist() == [12, 303, 603]
+        plans.append([(o.col, o.peer, o.offset, o.bytes) for o in ops[:n_ops.value]])
+        # counting only
+        rc = L.hawk_host_gather_plan(world, r, dst, dir4.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                     tot.ctypes.data_as(C.c_void_p), None, 0, C.byref(n_ops))
+        assert rc == 0 and n_ops.value == len(plans[-1])
+    assert plans[1 if dst != 1 else 0] and all(p == dst and o == 0 for _, p, o, _ in plans[0])  # a sender: one op per column, to dst
+    assert len(plans[0]) == 12 and len(plans[2]) == 12 and len(plans[dst]) == 24  # the empty rank posts nothing, two slices arrive
+    merged = [np.zeros(12 * w, dtype=np.uint8) for w in widths]
+    sends = {r: {col: nb for col, _, _, nb in plans[r]} for r in range(world) if r != dst}
+    for col, peer, offset, nb in plans[dst]:
+        src = tabs[peer][col]
+        assert len(src) == nb and (peer == dst or sends[peer][col] == nb)  # every recv meets a send of the same size
+        merged[col][offset:offset + nb] = src
+    want = [np.concatenate([tabs[r][k] for r in range(world)]) for k in range(12)]
+    for k in range(12):
+        assert np.array_equal(merged[k], want[k])
+    hap = merged[0].view(np.uint32).copy()
+    for r in range(world):  # k_hap_shift
+        sl = slice(int(sum(rows[:r])), int(sum(rows[:r + 1])))
+        hap[sl] = np.where(hap[sl] == 0, 0, hap[sl] + hap_off[r])
+    local = np.concatenate([tabs[r][0].view(np.uint32) for r in range(world)])
+    assert np.array_equal(hap == 0, local == 0) and hap.max() <= 2 + 3
+    assert L.hawk_host_gather_plan(3, 3, 0, dir4.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                   tot.ctypes.data_as(C.c_void_p), None, 0, C.byref(n_ops)) == _lib.HAWK_E_INVALID
