@@ -468,9 +468,11 @@ def end_to_end(args, R: Ranks, reg, pam, mm, pt, info, kept, c1):
 def _end_to_end_once(args, R: Ranks, reg, pam, mm, pt, c1, extras):
     from crisprhawk_hip.workload import expand_on_device
     t0 = time.perf_counter()
-    ds, info2, ems, kept2 = expand_on_device(reg, len(pam), device=R.device)
+    ds, info2, ems, kept2 = expand_on_device(reg, len(pam), device=R.device, keep_plan=True)
     t1 = time.perf_counter()
-    tab = ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+    plan2 = getattr(ds, "plan", None)
+    target = plan2.view() if (plan2 is not None and not args.planes) else ds
+    tab = target.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
     R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
     t2 = time.perf_counter()
     tab.collapse(download_perm=False)
@@ -479,12 +481,13 @@ def _end_to_end_once(args, R: Ranks, reg, pam, mm, pt, c1, extras):
     d2h = sum(getattr(g, k).nbytes for k in ("rep_row", "pos", "strand", "start", "stop", "flags", "cfdon", "win", "member_hap")) + \
         g.member_off.nbytes + g.gc_num.nbytes + g.gc_den.nbytes
     res = {"wall_s": t3 - t0, "candidates_per_s": tab.n_candidates / (t3 - t0),
-           "stages_s": {"expand (host index preparation + kernels)": t1 - t0, "search + CFDon": t2 - t1,
+           "stages_s": {"plan (variant table, genotype matrix up, lists / records / segments / scan bounds on the device, one expansion for "
+                        "the content hashes, which rows collapse)": t1 - t0, "search + CFDon (from the plan)": t2 - t1,
                         "collapse + D2H of the report groups": t3 - t2},
            "kernels_ms": {"expand": ems, "search": tab.timing["total_ms"], "collapse": tab.collapse_ms, "export": g.export_ms},
            "rows": tab.n_rows, "groups": g.n_groups, "d2h_bytes": int(d2h),
-           "what": "in-memory variant records + genotype matrix -> hawk_xplan_create/run -> hawk_search -> hawk_table_collapse -> "
-                   "hawk_table_collapse_export; FASTA/VCF text ingest (f3) is timed by --vcf"}
+           "what": "in-memory variant records + genotype matrix -> hawk_gt_lists -> hawk_xplan_create_gt -> hawk_xplan_view + hawk_search -> "
+                   "hawk_table_collapse -> hawk_table_collapse_export; FASTA/VCF text ingest (f3) is timed by --vcf"}
     if extras and args.report and not c1:
         from crisprhawk_hip import reports
         from crisprhawk_hip.workload import hap_labels
@@ -502,6 +505,8 @@ def _end_to_end_once(args, R: Ranks, reg, pam, mm, pt, c1, extras):
     if extras and args.vcf and not c1:
         res["vcf_ingest"] = time_vcf_ingest(reg, ds, len(pam), R.device)
     tab.close()
+    if plan2 is not None:
+        plan2.close()
     ds.close()
     return res
 

@@ -20,6 +20,8 @@ HAWK_E_CFD = -5
 HAWK_E_NODEVICE = -6
 HAWK_E_UNSUPPORTED = -7
 HAWK_E_COMM = -8
+HAWK_E_OVERLAP = -9
+HAWK_E_CLAMP = -10
 
 EXPORTS = [
     "hawk_device_count", "hawk_init", "hawk_destroy", "hawk_strerror", "hawk_last_hip_error", "hawk_stream",
@@ -28,7 +30,8 @@ EXPORTS = [
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
     "hawk_table_collapse", "hawk_table_collapse_download", "hawk_gt_parse", "hawk_gt_destroy", "hawk_gt_codes", "hawk_gt_lists",
-    "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_host_gather_plan",
+    "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_host_gather_plan", "hawk_xplan_create_gt", "hawk_xplan_rows",
+    "hawk_xplan_finish_meta", "hawk_xplan_segments", "hawk_xplan_install_meta", "hawk_host_alloc", "hawk_host_free",
     "hawk_xplan_destroy", "hawk_hapset_set_ref_partner_range", "hawk_xplan_set_ref_partner_range", "hawk_table_collapse_ex", "hawk_table_collapse_export", "hawk_comm_unique_id", "hawk_comm_init",
     "hawk_comm_destroy", "hawk_comm_last_error", "hawk_comm_allgather_u64", "hawk_comm_gatherv", "hawk_table_gather", "hawk_host_ragged_join", "hawk_host_group_join", "hawk_host_group_samples", "hawk_gbt_predict", "hawk_gt_from_codes",
 ]
@@ -147,3 +150,31 @@ def context(device: Optional[int] = None):
         check(lib().hawk_init(device, C.byref(h)), "hawk_init")
         _ctx[device] = h
     return _ctx[device]
+
+
+# ---------------------------------------------------------------------------- page-locked result buffers
+_PINNED_FREE = {}  # bytes -> [address]: blocks given back by arrays that died (hipHostMalloc costs milliseconds per 100 MB)
+_PINNED_MIN = 1 << 20
+
+
+def pinned_empty(n: int, dtype, device: Optional[int] = None):
+    """np.empty(n, dtype) in page-locked host memory when the array is large (a device-to-host copy into it runs at link
+    speed); small arrays are plain numpy.  The block goes back to a free list when the array is collected."""
+    import numpy as np
+    import weakref
+    dt = np.dtype(dtype)
+    nbytes = int(n) * dt.itemsize
+    if nbytes < _PINNED_MIN:
+        return np.empty(n, dtype=dt)
+    size = (nbytes + (1 << 20) - 1) >> 20 << 20
+    pool = _PINNED_FREE.setdefault(size, [])
+    if pool:
+        addr = pool.pop()
+    else:
+        p = C.c_void_p()
+        check(lib().hawk_host_alloc(context(device), C.c_uint64(size), C.byref(p)), "hawk_host_alloc")
+        addr = p.value
+    buf = (C.c_uint8 * size).from_address(addr)
+    arr = np.frombuffer(buf, dtype=dt, count=int(n))
+    weakref.finalize(buf, pool.append, addr)
+    return arr

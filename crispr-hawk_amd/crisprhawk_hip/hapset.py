@@ -297,7 +297,7 @@ class GroupTable:
         self.rep_row = np.empty(ng, np.uint32); self.pos = np.empty(ng, np.uint32); self.strand = np.empty(ng, np.uint8)
         self.start = np.empty(ng, np.int64); self.stop = np.empty(ng, np.int64); self.flags = np.empty(ng, np.uint8)
         self.cfdon = np.empty(ng, np.float64); self.win = np.empty((5, ng), np.uint64)
-        self.member_hap = np.empty(n_rows, np.uint32)
+        self.member_hap = _lib.pinned_empty(n_rows, np.uint32)  # C3: 112 MB, the bulk of the export
         self.member_off = np.zeros(ng + 1, np.int64)
         self.gc_num = np.zeros(ng, np.uint8); self.gc_den = np.zeros(ng, np.uint8)
 

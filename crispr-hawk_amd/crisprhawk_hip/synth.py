@@ -63,6 +63,22 @@ class SynthRegion:
     variants: List[VariantSite] = field(default_factory=list)
     gt_matrix: Optional[np.ndarray] = None  # uint8 [len(variants), 2 * n_samples]: the records' genotypes as one matrix
 
+    def variant_columns(self):
+        """The records as columns - positions, REF / ALT alleles as one byte blob each with offsets - next to the genotype
+        matrix: the in-memory form the device path ingests (built once per variant list, like `gt_matrix`)."""
+        key = (id(self.variants), len(self.variants))
+        c = getattr(self, "_vcols", None)
+        if c is None or c[0] != key:
+            pos = np.array([v.pos for v in self.variants], dtype=np.int64)
+            reflen = np.array([len(v.ref) for v in self.variants], dtype=np.int64)
+            altlen = np.array([len(v.alt) for v in self.variants], dtype=np.int64)
+            ref_blob = np.frombuffer("".join(v.ref for v in self.variants).encode("ascii"), dtype=np.uint8)
+            alt_blob = np.frombuffer("".join(v.alt for v in self.variants).encode("ascii"), dtype=np.uint8)
+            off = lambda ln: np.concatenate(([0], np.cumsum(ln)))
+            c = (key, dict(pos=pos, ref_blob=ref_blob, ref_off=off(reflen), alt_blob=alt_blob, alt_off=off(altlen)))
+            self._vcols = c
+        return c[1]
+
     @property
     def startp(self) -> int:  # padded start (reference Coordinate.start)
         return max(0, self.bed_start - PADDING)
@@ -169,6 +185,7 @@ def add_phased_variants(
         out, ks = [out[i] for i in keep], [ks[i] for i in keep]
     reg.variants = out
     reg.gt_matrix = gt_all[np.asarray(ks, dtype=np.int64)] if ks else None
+    reg.variant_columns()
     return reg
 
 

@@ -18,13 +18,55 @@ from .synth import SynthRegion
 
 
 class HapInfo:
-    """Host-side labels of one device haplotype (what Guide rows inherit from it)."""
+    """Host-side labels of one device haplotype (what Guide rows inherit from it).  `variant_idx` may be given as a callable:
+    the carried-variant lists of a device-built plan stay in HBM until a label is asked for (CarriedLists)."""
 
-    __slots__ = ("samples", "variant_idx")
+    __slots__ = ("samples", "_v")
 
     def __init__(self, samples: List[str], variant_idx):
         self.samples = samples
-        self.variant_idx = variant_idx
+        self._v = variant_idx
+
+    @property
+    def variant_idx(self):
+        if callable(self._v):
+            self._v = self._v()
+        return self._v
+
+
+class CarriedLists:
+    """The carried-variant lists of a genotype inversion (hawk_gt_lists), left on the device: `idx` downloads the variant
+    indices once, when something on the host (a report label) first asks, and releases the device object."""
+
+    def __init__(self, g, n_entries: int):
+        self._g, self._n, self._idx = g, int(n_entries), None
+
+    @property
+    def idx(self) -> np.ndarray:
+        if self._idx is None:
+            import ctypes as C
+            from . import _lib
+            from .hapset import _p
+            out = np.zeros(max(self._n, 1), dtype=np.uint32)
+            _lib.check(_lib.lib().hawk_gt_lists_download(self._g, _p(out), None), "hawk_gt_lists_download")
+            self._idx = out[:self._n]
+            self.close()
+        return self._idx
+
+    def rows(self, a: int, b: int):
+        return lambda: self.idx[a:b]
+
+    def close(self) -> None:
+        if self._g is not None:
+            from . import _lib
+            _lib.lib().hawk_gt_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _digest(arr: np.ndarray) -> bytes:
@@ -122,6 +164,41 @@ def _variant_table(pos: np.ndarray, refs: List[str], alts: List[str], seq: str, 
     return r0, span, chain, altlen, alt_off, alt_codes
 
 
+def _variant_table_columns(cols, seq, startp: int):
+    """_variant_table from records held as columns (SynthRegion.variant_columns): the same arrays and the same checks,
+    without a Python step per record."""
+    from .expand import HaplotypeBuildError
+    n_ref = len(seq)
+    pos = np.asarray(cols["pos"], dtype=np.int64)
+    nv = len(pos)
+    ref_off, alt_off_all = np.asarray(cols["ref_off"], dtype=np.int64), np.asarray(cols["alt_off"], dtype=np.int64)
+    reflen, altlen = np.diff(ref_off), np.diff(alt_off_all)
+    r0 = pos - startp
+    if np.any(np.diff(r0) < 0):
+        raise HaplotypeBuildError("variants must be sorted by position")
+    chain = altlen - reflen
+    span = np.where(chain < 0, -chain + 1, 1)
+    if np.any((chain < 0) & (altlen != 1)) or np.any((chain == 0) & (reflen != 1)):
+        raise HaplotypeBuildError("device expansion handles SNVs, deletions (alt of one base) and insertions")
+    if np.any(r0 < 0) or np.any(r0 + span > n_ref):
+        raise HaplotypeBuildError("variant outside the region")
+    if nv:
+        seq_u8 = np.frombuffer(seq.encode("ascii"), dtype=np.uint8) if isinstance(seq, str) else np.asarray(seq, dtype=np.uint8)
+        ref_blob = np.asarray(cols["ref_blob"], dtype=np.uint8)
+        if np.any(reflen < span):
+            i = int(np.flatnonzero(reflen < span)[0])
+            raise HaplotypeBuildError(f"Mismatching reference alleles at position {int(pos[i])}")
+        # REF allele must match over the replaced span (haplotype.py:203-208), letters compared case-insensitively
+        rec = np.repeat(np.arange(nv), span)
+        k = np.arange(len(rec)) - np.repeat(np.cumsum(span) - span, span)
+        bad = np.flatnonzero(((seq_u8[r0[rec] + k] ^ ref_blob[ref_off[rec] + k]) & 0xDF) != 0)
+        if len(bad):
+            raise HaplotypeBuildError(f"Mismatching reference alleles at position {int(pos[int(rec[int(bad[0])])])}")
+    alt_blob = np.asarray(cols["alt_blob"], dtype=np.uint8)
+    alt_codes = _NIB[alt_blob] if len(alt_blob) else np.zeros(0, np.uint8)
+    return r0, span, chain, altlen, alt_off_all[:-1].copy(), alt_codes
+
+
 class ScanOwnership:
     """Which PAM positions of a haplotype row this set scans, for a row string that is one tile of a larger region
     (tiling.py).  `own_lo` / `own_hi`: genomic positions of the seams (None = the region's own rule at that end,
@@ -170,12 +247,25 @@ class RowMeta:
     hawk_hapset_set_meta takes - with list-like access to per-row `HostHaplotype` views for the few callers that want one
     (labels keep `host_meta[r].seg`).  Replaces 5009 Python objects and as many numpy calls per expansion."""
 
-    def __init__(self, seg_start: np.ndarray, seg_rel: np.ndarray, seg_gen: np.ndarray, hap_len: np.ndarray, alias: np.ndarray, startp: int):
-        self.seg_start, self.seg_rel, self.seg_gen = seg_start, seg_rel, seg_gen
+    def __init__(self, seg_start, seg_rel, seg_gen, hap_len: np.ndarray, alias: np.ndarray, startp: int, fetch=None, rev=None):
+        """`fetch`: a callable returning (seg_start, seg_rel, seg_gen) - the segments of a device-built plan are downloaded
+        only when something on the host reads them; `rev`: {genomic position: posmap_rev of every row}, computed on the
+        device beside the segments."""
+        self._segs = None if fetch is not None else (seg_start, seg_rel, seg_gen)
+        self._fetch, self._rev = fetch, dict(rev or {})
         self.hap_len, self.alias, self.startp = np.asarray(hap_len, dtype=np.int64), alias, startp
         self.n = len(hap_len)
         self.scan_lo = np.zeros(self.n, dtype=np.int64)
         self.scan_hi = np.zeros(self.n, dtype=np.int64)
+
+    def _need(self):
+        if self._segs is None:
+            self._segs = self._fetch()
+        return self._segs
+
+    seg_start = property(lambda self: self._need()[0])
+    seg_rel = property(lambda self: self._need()[1])
+    seg_gen = property(lambda self: self._need()[2])
 
     def __len__(self):
         return self.n
@@ -198,6 +288,8 @@ class RowMeta:
         from . import _lib
         from .hapset import _p
         from .reports import _host_lib
+        if int(g) in self._rev:
+            return self._rev[int(g)]
         ss = np.ascontiguousarray(self.seg_start, dtype=np.uint64)
         sr = np.ascontiguousarray(self.seg_rel, dtype=np.uint32)
         sg = np.ascontiguousarray(self.seg_gen, dtype=np.int64)
@@ -307,6 +399,103 @@ def build_segments_numpy(ind, hv_idx, hv_o, hv_off, r0, chain, startp: int, hap_
     return seg_start, rel_m.astype(np.uint32), gen_m
 
 
+class _RowInfos:
+    """The HapInfo of every row of an expansion (None for rows collapsed onto another), built when first read: the sample
+    labels of 5009 rows are Python strings nobody needs before a report is written."""
+
+    def __init__(self, n_hap, samples, e_s, e_g, e_r, e_owner, rows_of):
+        self._args = (n_hap, samples, e_s, e_g, e_r, e_owner, rows_of)
+        self._info = None
+
+    def _build(self):
+        if self._info is None:
+            n_hap, samples, e_s, e_g, e_r, e_owner, rows_of = self._args
+            gts = ("1|1", "1|0", "0|1")
+            labels_e = [f"{samples[si]}:{gts[g]}" for si, g in zip(e_s.tolist(), e_g.tolist())]
+            info: List[Optional[HapInfo]] = [HapInfo(["REF"], ())] + [None] * (n_hap - 1)
+            for lab, r, o in zip(labels_e, e_r.tolist(), e_owner.tolist()):
+                if o == 0:
+                    continue  # collapses onto REF, which keeps samples == "REF" (haplotypes.py:255-258)
+                if info[o] is None:
+                    info[o] = HapInfo([lab], rows_of(o))
+                else:
+                    info[o].samples.append(lab)
+            self._info = info
+        return self._info
+
+    def __getitem__(self, i):
+        return self._build()[i]
+
+    def __len__(self):
+        return self._args[0]
+
+    def __iter__(self):
+        return iter(self._build())
+
+
+class _KeptInfos:
+    """info of the kept rows, in row order (what the expansion entry points return), as lazily as _RowInfos"""
+
+    def __init__(self, infos: _RowInfos, kept: List[int]):
+        self._infos, self._kept = infos, kept
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self._infos[i] for i in self._kept[j]]
+        return self._infos[self._kept[j]]
+
+    def __len__(self):
+        return len(self._kept)
+
+    def __iter__(self):
+        return (self._infos[i] for i in self._kept)
+
+
+def _collapse_rows(hashes: np.ndarray, samples: List[str], live: np.ndarray, n_hap: int, rows_of):
+    """Labels, homozygous merge and collapse by content of the rows of an expansion (haplotypes.py:232-368), all rows at
+    once on their 16-byte content hashes.  `rows_of(r)` -> the carried-variant indices of row r (or a callable yielding
+    them).  Returns (alias[n_hap], info[n_hap] with None for rows collapsed onto another)."""
+    # entries in the reference's order (haplotypes.py:297-368): samples in panel order, copy 0 then copy 1; a sample
+    # whose two copies hold the same sequence contributes one "1|1" entry; a copy without variants is the REF sequence
+    # the 128-bit content hash folded into one sortable word; rows grouped under one word are then held to their group's
+    # first member on both words, so a fold collision (never seen) only costs the slower exact grouping
+    h64 = hashes[:, 0] * np.uint64(0x9e3779b97f4a7c15) + (hashes[:, 1] ^ (hashes[:, 1] >> np.uint64(29)))
+    _, first_idx, key_id = np.unique(h64, return_index=True, return_inverse=True)
+    key_id = key_id.reshape(-1)
+    if not np.array_equal(hashes, hashes[first_idx[key_id]]):
+        _, key_id = np.unique(hashes, axis=0, return_inverse=True)
+        key_id = key_id.reshape(-1)
+    ns = len(samples)
+    row_of_col = np.zeros(2 * ns, dtype=np.int64)          # 0 = "no row" (the copy carries nothing: it IS REF)
+    row_of_col[np.asarray(live, dtype=np.int64)] = np.arange(1, n_hap)
+    r_a, r_b = row_of_col[0::2], row_of_col[1::2]           # rows of copy 0 / copy 1 per sample (0: none)
+    k_a, k_b = key_id[r_a], key_id[r_b]                     # row 0 is REF, so "none" reads REF's key
+    present = (r_a > 0) | (r_b > 0)
+    homo = present & (k_a == k_b)
+    alias = np.arange(n_hap)
+    alias[(key_id == key_id[0]) & (alias > 0)] = 0          # a copy whose variants reproduce the REF sequence
+    both = homo & (r_a > 0) & (r_b > 0)
+    # entry list: (sample, row, genotype code 0 = 1|1, 1 = 1|0, 2 = 0|1), rows that do not exist dropped
+    e_s = np.concatenate((np.flatnonzero(homo), np.flatnonzero(present & ~homo), np.flatnonzero(present & ~homo)))
+    e_r = np.concatenate((r_a[homo], r_a[present & ~homo], r_b[present & ~homo]))
+    e_g = np.concatenate((np.zeros(int(homo.sum()), np.int64), np.ones(int((present & ~homo).sum()), np.int64),
+                          np.full(int((present & ~homo).sum()), 2, np.int64)))
+    ok = e_r > 0
+    e_s, e_r, e_g = e_s[ok], e_r[ok], e_g[ok]
+    order = np.lexsort((e_g, e_s))                          # sample order, then 1|1 / 1|0 before 0|1
+    e_s, e_r, e_g = e_s[order], e_r[order], e_g[order]
+    # the first row seen with a key owns it (REF owns its own key); later rows with that key alias onto the owner
+    e_k = key_id[e_r]
+    owner_of_key = np.full(int(key_id.max()) + 1, -1, dtype=np.int64)
+    uk, first_pos = np.unique(e_k, return_index=True)
+    owner_of_key[uk] = e_r[first_pos]
+    owner_of_key[key_id[0]] = 0
+    e_owner = owner_of_key[e_k]
+    alias[e_r] = e_owner
+    alias[r_b[both]] = alias[r_a[both]]                     # the second copy of a homozygous sample follows the first
+    return alias, _RowInfos(n_hap, samples, e_s, e_g, e_r, e_owner, rows_of)
+
+
 def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, samples: List[str], tab, live: np.ndarray,
                  counts_live: np.ndarray, hv_idx: np.ndarray, hv_o: np.ndarray, tot_live: np.ndarray, device,
                  own: Optional[ScanOwnership] = None, keep_plan: bool = False, indel_entries: Optional[np.ndarray] = None):
@@ -354,50 +543,8 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     plan.n_records = int(len(hv_idx))
     ds, hashes, ms_val = plan.run(want_hash=True)
     ms = C.c_float(ms_val)
-    # ---- labels, homozygous merge, collapse by content (all on 16-byte hashes), for all rows at once -----------
-    # entries in the reference's order (haplotypes.py:297-368): samples in panel order, copy 0 then copy 1; a sample
-    # whose two copies hold the same sequence contributes one "1|1" entry; a copy without variants is the REF sequence
-    _, key_id = np.unique(hashes, axis=0, return_inverse=True)
-    key_id = key_id.reshape(-1)
-    ns = len(samples)
-    row_of_col = np.zeros(2 * ns, dtype=np.int64)          # 0 = "no row" (the copy carries nothing: it IS REF)
-    row_of_col[np.asarray(live, dtype=np.int64)] = np.arange(1, n_hap)
-    r_a, r_b = row_of_col[0::2], row_of_col[1::2]           # rows of copy 0 / copy 1 per sample (0: none)
-    k_a, k_b = key_id[r_a], key_id[r_b]                     # row 0 is REF, so "none" reads REF's key
-    present = (r_a > 0) | (r_b > 0)
-    homo = present & (k_a == k_b)
-    alias = np.arange(n_hap)
-    alias[(key_id == key_id[0]) & (alias > 0)] = 0          # a copy whose variants reproduce the REF sequence
-    both = homo & (r_a > 0) & (r_b > 0)
-    # entry list: (sample, row, genotype code 0 = 1|1, 1 = 1|0, 2 = 0|1), rows that do not exist dropped
-    e_s = np.concatenate((np.flatnonzero(homo), np.flatnonzero(present & ~homo), np.flatnonzero(present & ~homo)))
-    e_r = np.concatenate((r_a[homo], r_a[present & ~homo], r_b[present & ~homo]))
-    e_g = np.concatenate((np.zeros(int(homo.sum()), np.int64), np.ones(int((present & ~homo).sum()), np.int64),
-                          np.full(int((present & ~homo).sum()), 2, np.int64)))
-    ok = e_r > 0
-    e_s, e_r, e_g = e_s[ok], e_r[ok], e_g[ok]
-    order = np.lexsort((e_g, e_s))                          # sample order, then 1|1 / 1|0 before 0|1
-    e_s, e_r, e_g = e_s[order], e_r[order], e_g[order]
-    # the first row seen with a key owns it (REF owns its own key); later rows with that key alias onto the owner
-    e_k = key_id[e_r]
-    owner_of_key = np.full(int(key_id.max()) + 1, -1, dtype=np.int64)
-    uk, first_pos = np.unique(e_k, return_index=True)
-    owner_of_key[uk] = e_r[first_pos]
-    owner_of_key[key_id[0]] = 0
-    e_owner = owner_of_key[e_k]
-    alias[e_r] = e_owner
-    alias[r_b[both]] = alias[r_a[both]]                     # the second copy of a homozygous sample follows the first
-    gts = ("1|1", "1|0", "0|1")
-    labels_e = [f"{samples[si]}:{gts[g]}" for si, g in zip(e_s.tolist(), e_g.tolist())]
-    info: List[Optional[HapInfo]] = [HapInfo(["REF"], ())] + [None] * (n_hap - 1)
     hv_off_i = hv_off.astype(np.int64)
-    for lab, r, o in zip(labels_e, e_r.tolist(), e_owner.tolist()):
-        if o == 0:
-            continue  # collapses onto REF, which keeps samples == "REF" (haplotypes.py:255-258)
-        if info[o] is None:
-            info[o] = HapInfo([lab], hv_idx[hv_off_i[o]:hv_off_i[o + 1]])
-        else:
-            info[o].samples.append(lab)
+    alias, info = _collapse_rows(hashes, samples, live, n_hap, lambda o: hv_idx[hv_off_i[o]:hv_off_i[o + 1]])
     # ---- position-map segments + scan bounds per row ------------------------------------------
     seg_start, seg_rel_all, seg_gen_all = build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp, hap_len, alias)
     haps = RowMeta(seg_start, seg_rel_all.astype(np.uint32), seg_gen_all, hap_len, alias, startp)
@@ -416,7 +563,70 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     else:
         plan.close()
     kept = np.flatnonzero(alias == np.arange(n_hap)).tolist()
-    return ds, [info[i] for i in kept], float(ms.value), kept
+    return ds, _KeptInfos(info, kept), float(ms.value), kept
+
+
+def _expand_rows_gt(ref_set, seq, startp: int, stopp: int, pamlen: int, samples: List[str], tab, g, col_off: np.ndarray, device,
+                    keep_plan: bool = False):
+    """_expand_rows for lists that are still on the device (`g`: a hawk_gt after hawk_gt_lists): the plan is created from
+    them in place (hawk_xplan_create_gt) - checks, position-map segments and the scan bounds' reverse look-ups are kernels
+    over the lists; the host sees a few words per ROW (lengths, content hashes, two look-ups) and decides which rows
+    collapse.  Labels read the lists / segments lazily (CarriedLists, RowMeta's fetch).  Takes ownership of `g`."""
+    import ctypes as C
+    from . import _lib
+    from .expand import HaplotypeBuildError
+    from .hapset import ExpansionPlan, _p
+    r0, span, chain, altlen, alt_off, alt_codes = tab
+    L = _lib.lib()
+    counts = np.diff(col_off.astype(np.int64))
+    live = np.flatnonzero(counts)
+    lists = CarriedLists(g, int(col_off[-1]))
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
+    arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(chain, dtype=np.int32), np.ascontiguousarray(alt_codes)]
+    xh, n_hap_c = C.c_void_p(), C.c_uint32(0)
+    lo_g, hi_g = startp + 100, stopp - 100
+    rc = L.hawk_xplan_create_gt(ref_set._h, g, len(r0), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), _p(arrs[5]),
+                                len(alt_codes), C.c_int64(startp), 1, C.c_int64(lo_g), C.c_int64(hi_g), C.byref(n_hap_c), C.byref(xh))
+    if rc == _lib.HAWK_E_OVERLAP:
+        raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
+    if rc == _lib.HAWK_E_CLAMP:
+        raise HaplotypeBuildError("variant beyond the original region length (haplotype.py:199-201 clamp)")
+    _lib.check(rc, "hawk_xplan_create_gt")
+    n_hap = n_hap_c.value
+    hap_len = np.zeros(n_hap, dtype=np.uint32)
+    rev0, rev1 = np.zeros(n_hap, dtype=np.int64), np.zeros(n_hap, dtype=np.int64)
+    _lib.check(L.hawk_xplan_rows(xh, _p(hap_len), _p(rev0), _p(rev1)), "hawk_xplan_rows")
+    plan = ExpansionPlan(xh, hap_len, device)
+    plan.n_records = int(col_off[-1])
+    ds, hashes, ms_val = plan.run(want_hash=True)
+    row_end = np.concatenate(([0, 0], col_off.astype(np.int64)[live + 1]))  # row r's list: [row_end[r], row_end[r + 1])
+    alias, info = _collapse_rows(hashes, samples, live, n_hap, lambda o: lists.rows(int(row_end[o]), int(row_end[o + 1])))
+
+    def fetch():
+        nseg = C.c_uint64(0)
+        _lib.check(L.hawk_xplan_segments(plan._x, None, None, None, C.c_uint64(0), C.byref(nseg)), "hawk_xplan_segments")
+        so = np.zeros(n_hap + 1, dtype=np.uint32)
+        sr, sg = np.zeros(nseg.value, dtype=np.uint32), np.zeros(nseg.value, dtype=np.int64)
+        _lib.check(L.hawk_xplan_segments(plan._x, _p(so), _p(sr), _p(sg), C.c_uint64(nseg.value), None), "hawk_xplan_segments")
+        return so.astype(np.int64), sr, sg
+    haps = RowMeta(None, None, None, hap_len, alias, startp, fetch=fetch, rev={lo_g: rev0, hi_g: rev1})
+    haps.compute_scans(startp, stopp, pamlen, None)
+    _lib.check(L.hawk_xplan_finish_meta(plan._x, _p(haps.scan_lo.astype(np.int32)), _p(haps.scan_hi.astype(np.int32))), "hawk_xplan_finish_meta")
+    is_ref = np.zeros(n_hap, dtype=np.uint8)
+    is_ref[0] = 1
+    plan.ref_index, plan.is_ref = 0, is_ref
+    _lib.check(L.hawk_xplan_install_meta(plan._x, ds._h), "hawk_xplan_install_meta")
+    ds.ref_index, ds.is_ref = 0, is_ref
+    ds.alias = alias
+    ds.host_meta = haps
+    plan.alias, plan.host_meta = alias, haps
+    plan._lists = lists  # the labels' lists die with the plan at the latest
+    if keep_plan:
+        ds.plan = plan
+    else:
+        ds._plan_keepalive = plan  # the lazy segment download reads the plan
+    kept = np.flatnonzero(alias == np.arange(n_hap)).tolist()
+    return ds, _KeptInfos(info, kept), float(ms_val), kept
 
 
 def _ref_only_set(seq, startp: int, stopp: int, pamlen: int, device, own: Optional[ScanOwnership] = None):
@@ -431,6 +641,30 @@ def _ref_only_set(seq, startp: int, stopp: int, pamlen: int, device, own: Option
                    "hawk_hapset_set_ref_partner_range")
     ds.host_meta = [meta]
     return ds
+
+
+def invert_on_device(ctx, G: np.ndarray, r0: np.ndarray, chain: np.ndarray):
+    """A 0/1 genotype matrix G[variant, chromosome copy] -> (hawk_gt handle whose carried-variant lists are in HBM,
+    col_off[n_cols + 1]).  The caller owns the handle (hawk_gt_destroy, or hand it to _expand_rows_gt)."""
+    import ctypes as C
+    from . import _lib
+    from .hapset import _p
+    G = np.ascontiguousarray(G, dtype=np.uint8)
+    nv, n_cols = G.shape
+    if n_cols % 2:
+        raise ValueError("genotype matrix needs two columns per sample")
+    L = _lib.lib()
+    g = C.c_void_p()
+    _lib.check(L.hawk_gt_from_codes(ctx, _p(G), C.c_uint64(nv), n_cols // 2, C.byref(g)), "hawk_gt_from_codes")
+    try:
+        col_off = np.zeros(n_cols + 1, dtype=np.uint64)
+        _lib.check(L.hawk_gt_lists(g, _p(np.arange(nv, dtype=np.uint32)), _p(np.ones(nv, dtype=np.uint8)),
+                                   _p(np.ascontiguousarray(r0, dtype=np.int32)), _p(np.ascontiguousarray(chain, dtype=np.int32)), nv,
+                                   _p(col_off), None, None), "hawk_gt_lists")
+    except Exception:
+        L.hawk_gt_destroy(g)
+        raise
+    return g, col_off
 
 
 def carried_lists_on_device(ctx, G: np.ndarray, r0: np.ndarray, chain: np.ndarray, want_indels: bool = False):
@@ -485,7 +719,10 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
     if not reg.variants or shi <= slo:
         ref_set.alias = np.zeros(1, dtype=np.int64)
         return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
-    tab = _variant_table(np.array([v.pos for v in reg.variants]), [v.ref for v in reg.variants], [v.alt for v in reg.variants], seq, startp)
+    if hasattr(reg, "variant_columns"):
+        tab = _variant_table_columns(reg.variant_columns(), seq, startp)
+    else:
+        tab = _variant_table(np.array([v.pos for v in reg.variants]), [v.ref for v in reg.variants], [v.alt for v in reg.variants], seq, startp)
     r0, span, chain = tab[0], tab[1], tab[2]
     # which variants each chromosome copy carries: the in-memory genotype matrix goes to the device as allele codes and
     # is inverted there (hawk_gt_lists, the kernels of the VCF path) - a host-side nonzero scan of the 155 MB matrix
@@ -497,15 +734,13 @@ def expand_on_device(reg: SynthRegion, pamlen: int, device: Optional[int] = None
         G = gm if (slo, shi) == (0, len(reg.samples)) else gm[:, 2 * slo:2 * shi]  # the panel already is one matrix
     else:
         G = np.stack([v.gt[slo:shi].reshape(-1) for v in reg.variants])  # [site, 2*sample]
-    col_off, col_delta, hv_idx, hv_o, indel = carried_lists_on_device(ref_set._ctx, G, r0, chain, want_indels=True)
-    counts = np.diff(col_off.astype(np.int64))
-    live = np.flatnonzero(counts)
-    tot = col_delta[live]
-    if len(live) == 0:
+    g, col_off = invert_on_device(ref_set._ctx, G, r0, chain)
+    if int(col_off[-1]) == 0:
+        from . import _lib
+        _lib.lib().hawk_gt_destroy(g)
         ref_set.alias = np.zeros(1, dtype=np.int64)
         return ref_set, [HapInfo(["REF"], ())], 0.0, [0]
-    return _expand_rows(ref_set, seq, startp, stopp, pamlen, reg.samples[slo:shi], tab, live, counts[live], hv_idx, hv_o, tot, device,
-                        keep_plan=keep_plan, indel_entries=indel)
+    return _expand_rows_gt(ref_set, seq, startp, stopp, pamlen, reg.samples[slo:shi], tab, g, col_off, device, keep_plan=keep_plan)
 
 
 class VcfVariants:
@@ -597,22 +832,15 @@ def expand_from_vcf(region_seq: str, startp: int, stopp: int, block, samples: Li
         _lib.check(L.hawk_gt_lists(g, _p(vt.line), _p(vt.allele), _p(np.ascontiguousarray(r0, dtype=np.int32)),
                                    _p(np.ascontiguousarray(chain, dtype=np.int32)), len(vt), _p(col_off), _p(col_delta),
                                    C.byref(ms_lists)), "hawk_gt_lists")
-        ne = int(col_off[-1])
-        hv_idx = np.zeros(max(ne, 1), dtype=np.uint32)
-        hv_o = np.zeros(max(ne, 1), dtype=np.int32)
-        _lib.check(L.hawk_gt_lists_download(g, _p(hv_idx), _p(hv_o)), "hawk_gt_lists_download")
-        hv_idx, hv_o = hv_idx[:ne], hv_o[:ne]
-        ni = C.c_uint64(0)  # the carried indels (position-map segments are built from them)
-        _lib.check(L.hawk_gt_lists_indels(g, None, C.c_uint64(0), C.byref(ni)), "hawk_gt_lists_indels")
-        indel = np.zeros(max(ni.value, 1), dtype=np.uint32)
-        _lib.check(L.hawk_gt_lists_indels(g, _p(indel), C.c_uint64(ni.value), C.byref(ni)), "hawk_gt_lists_indels")
-        indel = indel[:ni.value]
+        handed = False
+        if int(col_off[-1]) == 0:  # no chromosome copy carries anything: REF alone
+            ref_set.alias = np.zeros(1, dtype=np.int64)
+            return ref_set, [HapInfo(["REF"], ())], {"parse": float(ms_parse.value), "lists": float(ms_lists.value), "expand": 0.0}, [0], vt
+        handed = True
+        ds, info, ms_expand, kept = _expand_rows_gt(ref_set, region_seq, startp, stopp, pamlen, samples, tab, g, col_off, device)
     finally:
-        L.hawk_gt_destroy(g)
-    counts = np.diff(col_off.astype(np.int64))
-    live = np.flatnonzero(counts)
-    ds, info, ms_expand, kept = _expand_rows(ref_set, region_seq, startp, stopp, pamlen, samples, tab, live, counts[live], hv_idx,
-                                             hv_o, col_delta[live], device, indel_entries=indel)
+        if not locals().get("handed", False):
+            L.hawk_gt_destroy(g)
     return ds, info, {"parse": float(ms_parse.value), "lists": float(ms_lists.value), "expand": ms_expand}, kept, vt
 
 

@@ -109,6 +109,8 @@ const char* hawk_strerror(int s) {
     case HAWK_E_NODEVICE: return "no GPU device visible";
     case HAWK_E_UNSUPPORTED: return "parameter outside supported range";
     case HAWK_E_COMM: return "RCCL failure";
+    case HAWK_E_OVERLAP: return "a chromosome copy carries overlapping variants";
+    case HAWK_E_CLAMP: return "variant beyond the original region length";
     default: return "unknown status";
   }
 }
@@ -148,6 +150,16 @@ void hawk_destroy(hawk_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
 }
+
+// page-locked host memory for result buffers: a device-to-host copy into it runs at link speed instead of through the
+// driver's bounce buffers (the 131 MB of a C3 group export: 2.5 instead of 6.5 ms)
+int hawk_host_alloc(hawk_ctx* ctx, uint64_t bytes, void** out) {
+  if (!ctx || !out) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipHostMalloc(out, std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+  return HAWK_OK;
+}
+void hawk_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 void* hawk_stream(hawk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int hawk_sync(hawk_ctx* ctx) {
@@ -1167,38 +1179,16 @@ void hawk_xplan_destroy(hawk_xplan* x) {
   delete x;
 }
 
-int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
-                      const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
-                      uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
-                      const uint32_t* hap_len, hawk_xplan** out) {
-  if (!ref_set || !out || !n_hap || !hv_off || !hap_len || (n_var && (!v_r0 || !v_span || !v_alt_off || !v_alt_len || !alt_codes)))
-    return HAWK_E_INVALID;
+// The device half of plan creation: copies of REF's planes, the variant table, one record per carried variant, the tile
+// index.  The carried-variant lists come from the host (hv_idx / hv_o, uploaded into temporaries) or are already in HBM
+// (d_idx / d_o: the genotype inversion left them there, hawk_xplan_create_gt).
+static int xplan_build(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span, const uint32_t* v_alt_off,
+                       const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len, uint32_t n_hap, const uint64_t* hv_off,
+                       const uint32_t* hv_idx, const int32_t* hv_o, const uint32_t* d_idx, const int32_t* d_o, const uint32_t* hap_len,
+                       uint32_t maxlen, hawk_xplan** out) {
   hawk_ctx* ctx = ref_set->ctx;
   const uint32_t ref_len = ref_set->hap_len[0];
   const uint64_t ncar = hv_off[n_hap];
-  if (ncar && (!hv_idx || !hv_o)) return HAWK_E_INVALID;
-  // validate everything the kernel will index with, on the host
-  for (uint32_t i = 0; i < n_var; ++i) {
-    if ((uint64_t)v_r0[i] + v_span[i] > ref_len || v_span[i] == 0 || v_alt_len[i] == 0) return HAWK_E_INVALID;
-    if ((uint64_t)v_alt_off[i] + v_alt_len[i] > alt_codes_len) return HAWK_E_INVALID;
-    if (i && v_r0[i] < v_r0[i - 1]) return HAWK_E_INVALID;  // sorted by position (alleles of one site may share it)
-  }
-  uint32_t maxlen = 0;
-  for (uint32_t h = 0; h < n_hap; ++h) {
-    if (hv_off[h + 1] < hv_off[h]) return HAWK_E_INVALID;
-    int64_t off = 0;
-    uint32_t prev = 0;
-    for (uint64_t k = hv_off[h]; k < hv_off[h + 1]; ++k) {
-      const uint32_t vi = hv_idx[k];
-      if (vi >= n_var || (k > hv_off[h] && (vi <= prev || v_r0[vi] < v_r0[prev] + v_span[prev]))) return HAWK_E_INVALID;  // ascending, non-overlapping within a row
-      if ((int64_t)hv_o[k] != (int64_t)v_r0[vi] + off) return HAWK_E_INVALID;  // exclusive prefix of the length changes
-      off += (int64_t)v_alt_len[vi] - (int64_t)v_span[vi];
-      prev = vi;
-    }
-    if ((int64_t)hap_len[h] != (int64_t)ref_len + off) return HAWK_E_INVALID;
-    if (hap_len[h] >= (1u << 31) - 256) return HAWK_E_UNSUPPORTED;
-    maxlen = std::max(maxlen, hap_len[h]);
-  }
   HIPCHK(hipSetDevice(ctx->device));
   hawk_xplan* x = new (std::nothrow) hawk_xplan();
   if (!x) return HAWK_E_INVALID;
@@ -1221,8 +1211,8 @@ int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0
   if (!rc) rc = t_ao.reserve(nv * 4);
   if (!rc) rc = t_al.reserve(nv * 4);
   if (!rc) rc = t_am.reserve(nv * 16);
-  if (!rc) rc = t_idx.reserve(nc * 4);
-  if (!rc) rc = t_o.reserve(nc * 4);
+  if (!rc && !d_idx) rc = t_idx.reserve(nc * 4);
+  if (!rc && !d_idx) rc = t_o.reserve(nc * 4);
   if (!rc) rc = x->recs.reserve(nc * hawk_hx_record_bytes());
   if (!rc) rc = x->tiles.reserve(nwg * hawk_hx_tile_bytes());
   if (!rc) rc = x->codes.reserve(std::max<size_t>(alt_codes_len, 1));
@@ -1257,13 +1247,13 @@ int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0
     if (e == hipSuccess) e = hipMemcpyAsync(t_am.p, am.data(), (size_t)n_var * 16, hipMemcpyHostToDevice, st);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(x->off.p, hv_off, (size_t)(n_hap + 1) * 8, hipMemcpyHostToDevice, st);
-  if (ncar && e == hipSuccess) {
+  if (ncar && e == hipSuccess && !d_idx) {
     e = hipMemcpyAsync(t_idx.p, hv_idx, ncar * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(t_o.p, hv_o, ncar * 4, hipMemcpyHostToDevice, st);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(x->hlen.p, hap_len, (size_t)n_hap * 4, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
-    hawk_launch_hx_prepare(st, x->off.as<uint64_t>(), t_idx.as<uint32_t>(), t_o.as<int32_t>(), ncar, t_r0.as<uint32_t>(),
+    hawk_launch_hx_prepare(st, x->off.as<uint64_t>(), d_idx ? d_idx : t_idx.as<uint32_t>(), d_o ? d_o : t_o.as<int32_t>(), ncar, t_r0.as<uint32_t>(),
                            t_span.as<uint32_t>(), t_ao.as<uint32_t>(), t_al.as<uint32_t>(), t_am.p, x->hlen.as<uint32_t>(), n_hap, x->S,
                            x->recs.p, x->tiles.p);
     e = hipGetLastError();
@@ -1277,6 +1267,41 @@ int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0
   }
   *out = x;
   return HAWK_OK;
+}
+
+int hawk_xplan_create(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                      const uint32_t* v_alt_off, const uint32_t* v_alt_len, const uint8_t* alt_codes, uint32_t alt_codes_len,
+                      uint32_t n_hap, const uint64_t* hv_off, const uint32_t* hv_idx, const int32_t* hv_o,
+                      const uint32_t* hap_len, hawk_xplan** out) {
+  if (!ref_set || !out || !n_hap || !hv_off || !hap_len || (n_var && (!v_r0 || !v_span || !v_alt_off || !v_alt_len || !alt_codes)))
+    return HAWK_E_INVALID;
+  const uint32_t ref_len = ref_set->hap_len[0];
+  const uint64_t ncar = hv_off[n_hap];
+  if (ncar && (!hv_idx || !hv_o)) return HAWK_E_INVALID;
+  // validate everything the kernel will index with, on the host
+  for (uint32_t i = 0; i < n_var; ++i) {
+    if ((uint64_t)v_r0[i] + v_span[i] > ref_len || v_span[i] == 0 || v_alt_len[i] == 0) return HAWK_E_INVALID;
+    if ((uint64_t)v_alt_off[i] + v_alt_len[i] > alt_codes_len) return HAWK_E_INVALID;
+    if (i && v_r0[i] < v_r0[i - 1]) return HAWK_E_INVALID;  // sorted by position (alleles of one site may share it)
+  }
+  uint32_t maxlen = 0;
+  for (uint32_t h = 0; h < n_hap; ++h) {
+    if (hv_off[h + 1] < hv_off[h]) return HAWK_E_INVALID;
+    int64_t off = 0;
+    uint32_t prev = 0;
+    for (uint64_t k = hv_off[h]; k < hv_off[h + 1]; ++k) {
+      const uint32_t vi = hv_idx[k];
+      if (vi >= n_var || (k > hv_off[h] && (vi <= prev || v_r0[vi] < v_r0[prev] + v_span[prev]))) return HAWK_E_INVALID;  // ascending, non-overlapping within a row
+      if ((int64_t)hv_o[k] != (int64_t)v_r0[vi] + off) return HAWK_E_INVALID;  // exclusive prefix of the length changes
+      off += (int64_t)v_alt_len[vi] - (int64_t)v_span[vi];
+      prev = vi;
+    }
+    if ((int64_t)hap_len[h] != (int64_t)ref_len + off) return HAWK_E_INVALID;
+    if (hap_len[h] >= (1u << 31) - 256) return HAWK_E_UNSUPPORTED;
+    maxlen = std::max(maxlen, hap_len[h]);
+  }
+  return xplan_build(ref_set, n_var, v_r0, v_span, v_alt_off, v_alt_len, alt_codes, alt_codes_len, n_hap, hv_off, hv_idx, hv_o, nullptr, nullptr,
+                     hap_len, maxlen, out);
 }
 
 int hawk_xplan_set_meta(hawk_xplan* x, const uint8_t* is_ref, const int32_t* scan_start, const int32_t* scan_stop,
@@ -1320,6 +1345,33 @@ int hawk_xplan_set_ref_partner_range(hawk_xplan* x, int32_t start, int32_t stop)
   return HAWK_OK;
 }
 
+// the rows' metadata of a plan into a set of its rows (hawk_xplan_run's, or a view), device to device
+static int xplan_install(const hawk_xplan* x, hawk_hapset* hs) {
+  if (!x->has_meta || hs->n_hap != x->n_hap || hs->S != x->S) return HAWK_E_INVALID;
+  hipStream_t st = x->ctx->stream;
+  const uint32_t n = x->n_hap;
+  hawk_pool_free(hs->d_seg_rel); hs->d_seg_rel = nullptr;
+  hawk_pool_free(hs->d_seg_gen); hs->d_seg_gen = nullptr;
+  int rc = hawk_pool_alloc((void**)&hs->d_seg_rel, (size_t)x->nseg * 4);
+  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_gen, (size_t)x->nseg * 8);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(hs->d_is_ref, x->m_is_ref.p, n, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(hs->d_scan_start, x->m_ss.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(hs->d_scan_stop, x->m_se.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_off, x->m_seg_off.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_rel, x->m_seg_rel.p, (size_t)x->nseg * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(hs->d_seg_gen, x->m_seg_gen.p, (size_t)x->nseg * 8, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(hs->d_tile_meta, x->m_tile.p, (size_t)n * x->bph * sizeof(TileMeta), hipMemcpyDeviceToDevice, st));
+  hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
+  hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
+  hs->ref_index = x->ref_index; hs->has_meta = true; hs->n_ref_rows = x->n_ref_rows;
+  hs->plan_groups = x->groups; hs->last_groups = *x->groups;
+  hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
+  hs->refbits_valid = false;
+  ++hs->cols_gen;
+  return HAWK_OK;
+}
+
 int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* kernel_ms) {
   if (!x || !out) return HAWK_E_INVALID;
   hawk_ctx* ctx = x->ctx;
@@ -1339,22 +1391,8 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess && hash_out) e = hipMemcpyAsync(hash_out, x->hash.p, (size_t)x->n_hap * 16, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess && x->has_meta) {  // install the rows' metadata, device to device
-    const uint32_t n = x->n_hap;
-    rc = hawk_pool_alloc((void**)&hs->d_seg_rel, (size_t)x->nseg * 4);
-    if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_gen, (size_t)x->nseg * 8);
+    rc = xplan_install(x, hs);
     if (rc) { hawk_hapset_destroy(hs); return rc; }
-    e = hipMemcpyAsync(hs->d_is_ref, x->m_is_ref.p, n, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_start, x->m_ss.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_stop, x->m_se.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_off, x->m_seg_off.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_rel, x->m_seg_rel.p, (size_t)x->nseg * 4, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_gen, x->m_seg_gen.p, (size_t)x->nseg * 8, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs->d_tile_meta, x->m_tile.p, (size_t)n * x->bph * sizeof(TileMeta), hipMemcpyDeviceToDevice, st);
-    hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
-    hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
-    hs->ref_index = x->ref_index; hs->has_meta = true; hs->n_ref_rows = x->n_ref_rows;
-    hs->plan_groups = x->groups; hs->last_groups = *x->groups;
-    hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
   }
   if (e == hipSuccess && (hash_out || kernel_ms)) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
@@ -1376,30 +1414,158 @@ int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out) {
   if (hs->S != x->S) { hawk_hapset_destroy(hs); return HAWK_E_INVALID; }
   hs->vplan = x;
   for (int p = 0; p < HAWK_PLANES; ++p) hs->plane[p] = x->ref5[p].as<uint32_t>();  // row 0 = REF; no other row is ever read
-  const uint32_t n = x->n_hap;
-  rc = hawk_pool_alloc((void**)&hs->d_seg_rel, (size_t)x->nseg * 4);
-  if (!rc) rc = hawk_pool_alloc((void**)&hs->d_seg_gen, (size_t)x->nseg * 8);
-  if (rc) { hawk_hapset_destroy(hs); return rc; }
-  hipStream_t st = ctx->stream;
-  hipError_t e = hipMemcpyAsync(hs->d_is_ref, x->m_is_ref.p, n, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_start, x->m_ss.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_scan_stop, x->m_se.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_off, x->m_seg_off.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_rel, x->m_seg_rel.p, (size_t)x->nseg * 4, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_seg_gen, x->m_seg_gen.p, (size_t)x->nseg * 8, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(hs->d_tile_meta, x->m_tile.p, (size_t)n * x->bph * sizeof(TileMeta), hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) {
-    snprintf(g_hip_err, sizeof(g_hip_err), "hawk_xplan_view: %s", hipGetErrorString(e));
-    hawk_hapset_destroy(hs);
-    return HAWK_E_HIP;
-  }
-  hs->ref_startp = x->ref_startp; hs->min_gen = x->min_gen; hs->max_gen = x->max_gen;
-  hs->scan_start = x->scan_start; hs->scan_stop = x->scan_stop;
-  hs->ref_index = x->ref_index; hs->has_meta = true; hs->n_ref_rows = x->n_ref_rows;
-  hs->plan_groups = x->groups; hs->last_groups = *x->groups;
-  hs->has_partner = x->has_partner; hs->partner_start = x->partner_start; hs->partner_stop = x->partner_stop;
+  rc = xplan_install(x, hs);
+  if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HAWK_E_HIP;
+  if (rc) { hs->vplan = nullptr; for (int p = 0; p < HAWK_PLANES; ++p) hs->plane[p] = nullptr; hawk_hapset_destroy(hs); return rc; }
   *out = hs;
+  return HAWK_OK;
+}
+
+int hawk_xplan_install_meta(hawk_xplan* x, hawk_hapset* hs) {
+  if (!x || !hs || hs->vplan) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(x->ctx->device));
+  int rc = xplan_install(x, hs);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(x->ctx->stream));
+  return HAWK_OK;
+}
+
+int hawk_xplan_create_gt(hawk_hapset* ref_set, hawk_gt* g, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                         const uint32_t* v_alt_off, const uint32_t* v_alt_len, const int32_t* v_chain, const uint8_t* alt_codes,
+                         uint32_t alt_codes_len, int64_t startp, int check_clamp, int64_t rev_g0, int64_t rev_g1, uint32_t* n_hap_out,
+                         hawk_xplan** out) {
+  if (!ref_set || !g || !out || !n_hap_out || !g->d_col_off || g->n_var != n_var || !n_var || !v_r0 || !v_span || !v_alt_off || !v_alt_len ||
+      !v_chain || !alt_codes)
+    return HAWK_E_INVALID;
+  hawk_ctx* ctx = ref_set->ctx;
+  if (g->ctx != ctx) return HAWK_E_INVALID;
+  const uint32_t ref_len = ref_set->hap_len[0];
+  for (uint32_t i = 0; i < n_var; ++i) {  // the variant table: everything the kernels index with (as hawk_xplan_create)
+    if ((uint64_t)v_r0[i] + v_span[i] > ref_len || v_span[i] == 0 || v_alt_len[i] == 0) return HAWK_E_INVALID;
+    if ((uint64_t)v_alt_off[i] + v_alt_len[i] > alt_codes_len) return HAWK_E_INVALID;
+    if (i && v_r0[i] < v_r0[i - 1]) return HAWK_E_INVALID;
+    if ((int64_t)v_chain[i] != (int64_t)v_alt_len[i] - (int64_t)v_span[i]) return HAWK_E_INVALID;
+  }
+  // rows: REF, then every chromosome copy (column) that carries something, in column order.  Columns without a variant
+  // contribute no entry, so the rows' lists are the inversion's list array as it stands.
+  const uint32_t n_cols = 2 * g->n_samples;
+  std::vector<uint64_t> hv_off(2, 0), ioff(2, 0);
+  std::vector<uint32_t> hap_len(1, ref_len);
+  uint32_t maxlen = ref_len;
+  for (uint32_t c = 0; c < n_cols; ++c) {
+    if (g->h_off[c + 1] == g->h_off[c]) continue;
+    const int64_t len = (int64_t)ref_len + g->h_delta[c];
+    if (len <= 0 || len >= (int64_t)((1u << 31) - 256)) return HAWK_E_UNSUPPORTED;
+    hv_off.push_back(g->h_off[c + 1]);
+    ioff.push_back(g->h_ioff[c + 1]);
+    hap_len.push_back((uint32_t)len);
+    maxlen = std::max(maxlen, (uint32_t)len);
+  }
+  const uint32_t n_hap = (uint32_t)hap_len.size();
+  *n_hap_out = n_hap;
+  hawk_xplan* x = nullptr;
+  int rc = xplan_build(ref_set, n_var, v_r0, v_span, v_alt_off, v_alt_len, alt_codes, alt_codes_len, n_hap, hv_off.data(), nullptr, nullptr,
+                       g->d_idx, g->d_o, hap_len.data(), maxlen, &x);
+  if (rc) return rc;
+  // ---- checks over every list entry, position-map segments, the two reverse look-ups: device work over the lists in place
+  hipStream_t st = ctx->stream;
+  DevBuf t_r0, t_span, t_ch, t_ioff, t_cnt, t_status, t_rev;
+  DevBuf* temps[] = {&t_r0, &t_span, &t_ch, &t_ioff, &t_cnt, &t_status, &t_rev};
+  auto done = [&](int code) { for (auto* b : temps) b->release(); if (code) hawk_xplan_destroy(x); return code; };
+  if ((rc = t_r0.reserve((size_t)n_var * 4)) || (rc = t_span.reserve((size_t)n_var * 4)) || (rc = t_ch.reserve((size_t)n_var * 4)) ||
+      (rc = t_ioff.reserve((size_t)(n_hap + 1) * 8)) || (rc = t_cnt.reserve((size_t)n_hap * 4)) || (rc = t_status.reserve(16)) ||
+      (rc = t_rev.reserve((size_t)n_hap * 16)) || (rc = x->m_seg_off.reserve((size_t)(n_hap + 1) * 4)))
+    return done(rc);
+#define HIPCHK_X(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return done(HAWK_E_HIP);                                                                 \
+    }                                                                                          \
+  } while (0)
+  HIPCHK_X(hipMemcpyAsync(t_r0.p, v_r0, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+  HIPCHK_X(hipMemcpyAsync(t_span.p, v_span, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+  HIPCHK_X(hipMemcpyAsync(t_ch.p, v_chain, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
+  HIPCHK_X(hipMemcpyAsync(t_ioff.p, ioff.data(), (size_t)(n_hap + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK_X(hipMemsetAsync(t_status.p, 0, 16, st));
+  hawk_launch_list_check(st, x->off.as<uint64_t>(), n_hap, g->d_idx, g->d_o, t_r0.as<int32_t>(), t_span.as<int32_t>(), t_ch.as<int32_t>(), n_var,
+                         ref_len, check_clamp, t_status.as<uint32_t>());
+  hawk_launch_segments(st, t_ioff.as<uint64_t>(), g->d_indel, g->d_idx, g->d_o, t_r0.as<int32_t>(), t_ch.as<int32_t>(), x->hlen.as<uint32_t>(), n_hap,
+                       startp, t_cnt.as<uint32_t>(), x->m_seg_off.as<uint32_t>(), nullptr, nullptr);
+  HIPCHK_X(hipGetLastError());
+  uint32_t status = 0, nseg = 0;
+  HIPCHK_X(hipMemcpyAsync(&status, t_status.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK_X(hipMemcpyAsync(&nseg, x->m_seg_off.as<uint32_t>() + n_hap, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK_X(hipStreamSynchronize(st));
+  if (status & 4u) return done(HAWK_E_INVALID);      // a list out of order: not what the inversion writes
+  if (status & 1u) return done(HAWK_E_OVERLAP);      // a chromosome copy carries overlapping variants (haplotype.py:214-252 raises)
+  if (status & 2u) return done(HAWK_E_CLAMP);        // an indel beyond the region's original length (haplotype.py:199-201)
+  if ((rc = x->m_seg_rel.reserve((size_t)nseg * 4)) || (rc = x->m_seg_gen.reserve((size_t)nseg * 8))) return done(rc);
+  hawk_launch_segments(st, t_ioff.as<uint64_t>(), g->d_indel, g->d_idx, g->d_o, t_r0.as<int32_t>(), t_ch.as<int32_t>(), x->hlen.as<uint32_t>(), n_hap,
+                       startp, t_cnt.as<uint32_t>(), x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), x->m_seg_gen.as<int64_t>());
+  hawk_launch_rev_lookup(st, x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), x->m_seg_gen.as<int64_t>(), x->hlen.as<uint32_t>(), n_hap,
+                         rev_g0, rev_g1, t_rev.as<int64_t>(), t_rev.as<int64_t>() + n_hap);
+  HIPCHK_X(hipGetLastError());
+  x->rev0.resize(n_hap); x->rev1.resize(n_hap);
+  HIPCHK_X(hipMemcpyAsync(x->rev0.data(), t_rev.p, (size_t)n_hap * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK_X(hipMemcpyAsync(x->rev1.data(), t_rev.as<int64_t>() + n_hap, (size_t)n_hap * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK_X(hipStreamSynchronize(st));
+#undef HIPCHK_X
+  x->nseg = nseg; x->ref_startp = startp;
+  x->min_gen = startp; x->max_gen = startp + (int64_t)ref_len;  // every row's positions map into REF's range
+  (void)done(HAWK_OK);
+  *out = x;
+  return HAWK_OK;
+}
+
+int hawk_xplan_rows(hawk_xplan* x, uint32_t* hap_len, int64_t* rev0, int64_t* rev1) {
+  if (!x) return HAWK_E_INVALID;
+  if (hap_len) memcpy(hap_len, x->hap_len.data(), (size_t)x->n_hap * 4);
+  if ((rev0 || rev1) && x->rev0.size() != x->n_hap) return HAWK_E_INVALID;
+  if (rev0) memcpy(rev0, x->rev0.data(), (size_t)x->n_hap * 8);
+  if (rev1) memcpy(rev1, x->rev1.data(), (size_t)x->n_hap * 8);
+  return HAWK_OK;
+}
+
+int hawk_xplan_finish_meta(hawk_xplan* x, const int32_t* scan_start, const int32_t* scan_stop) {
+  if (!x || !scan_start || !scan_stop || !x->nseg) return HAWK_E_INVALID;
+  hawk_ctx* ctx = x->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t n = x->n_hap;
+  for (uint32_t h = 0; h < n; ++h)
+    if (scan_start[h] < 0 || scan_stop[h] > (int32_t)x->hap_len[h]) return HAWK_E_INVALID;
+  int rc;
+  if ((rc = x->m_is_ref.reserve(n)) || (rc = x->m_ss.reserve((size_t)n * 4)) || (rc = x->m_se.reserve((size_t)n * 4)) ||
+      (rc = x->m_tile.reserve((size_t)n * x->bph * sizeof(TileMeta))))
+    return rc;
+  hipStream_t st = ctx->stream;
+  std::vector<uint8_t> is_ref(n, 0);
+  is_ref[0] = 1;
+  HIPCHK(hipMemcpyAsync(x->m_is_ref.p, is_ref.data(), n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_ss.p, scan_start, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(x->m_se.p, scan_stop, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  hawk_launch_tile_meta(st, x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), x->hlen.as<uint32_t>(), x->m_is_ref.as<uint8_t>(),
+                        x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, x->bph, x->m_tile.as<TileMeta>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  x->scan_start.assign(scan_start, scan_start + n);
+  x->scan_stop.assign(scan_stop, scan_stop + n);
+  x->ref_index = 0; x->n_ref_rows = 1; x->has_meta = true;
+  return HAWK_OK;
+}
+
+int hawk_xplan_segments(hawk_xplan* x, uint32_t* seg_off, uint32_t* seg_rel, int64_t* seg_gen, uint64_t cap, uint64_t* n_seg) {
+  if (!x || !x->nseg) return HAWK_E_INVALID;
+  if (n_seg) *n_seg = x->nseg;
+  if (!seg_off && !seg_rel && !seg_gen) return HAWK_OK;
+  if (cap < x->nseg) return HAWK_E_CAPACITY;
+  hawk_ctx* ctx = x->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (seg_off) HIPCHK(hipMemcpyAsync(seg_off, x->m_seg_off.p, (size_t)(x->n_hap + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (seg_rel) HIPCHK(hipMemcpyAsync(seg_rel, x->m_seg_rel.p, (size_t)x->nseg * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (seg_gen) HIPCHK(hipMemcpyAsync(seg_gen, x->m_seg_gen.p, (size_t)x->nseg * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return HAWK_OK;
 }
 
@@ -1419,17 +1585,6 @@ int hawk_hapset_expand(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
 }
 
 // ---------------------------------------------------------------------------- f3: VCF genotypes
-struct hawk_gt {
-  hawk_ctx* ctx;
-  uint64_t n_lines;
-  uint32_t n_samples, n_var;
-  uint8_t* d_codes;   // [n_lines][2 * n_samples]
-  uint8_t* d_flags;   // [n_lines]
-  uint64_t n_entries; // carried-variant entries over all columns (valid after hawk_gt_lists)
-  uint64_t* d_col_off; uint32_t* d_idx; int32_t* d_o; int64_t* d_delta;
-  uint64_t n_indel = 0;          // entries whose variant changes the length (var_chain != 0)
-  uint32_t* d_indel = nullptr;   // their entry indices, ascending
-};
 
 int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const uint64_t* line_off, const uint64_t* gt_off,
                   uint64_t n_lines, uint32_t n_samples, hawk_gt** out, float* kernel_ms) {
@@ -1493,6 +1648,7 @@ void hawk_gt_destroy(hawk_gt* g) {
   if (g->d_o) hawk_pool_free(g->d_o);
   if (g->d_delta) hawk_pool_free(g->d_delta);
   if (g->d_indel) hawk_pool_free(g->d_indel);
+  if (g->d_ioff) hawk_pool_free(g->d_ioff);
   delete g;
 }
 
@@ -1519,6 +1675,8 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   if (g->d_o) { hawk_pool_free(g->d_o); g->d_o = nullptr; }
   if (g->d_delta) { hawk_pool_free(g->d_delta); g->d_delta = nullptr; }
   if (g->d_indel) { hawk_pool_free(g->d_indel); g->d_indel = nullptr; }
+  if (g->d_ioff) { hawk_pool_free(g->d_ioff); g->d_ioff = nullptr; }
+  g->h_off.assign(n_cols + 1, 0); g->h_ioff.assign(n_cols + 1, 0); g->h_delta.assign(n_cols, 0);
   g->n_var = n_var; g->n_entries = 0; g->n_indel = 0;
   if (kernel_ms) *kernel_ms = 0.f;
   std::vector<uint64_t> off(n_cols + 1, 0);
@@ -1531,8 +1689,8 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   unsigned long long* d_bal = nullptr;
   POOLCHK(&d_vl, (size_t)n_var * 4); POOLCHK(&d_va, n_var); POOLCHK(&d_r0, (size_t)n_var * 4);
   POOLCHK(&d_ch, (size_t)n_var * 4); POOLCHK(&d_cnt, (size_t)n_cols * 2 * 4);
-  uint64_t* d_ioff = nullptr;
-  POOLCHK(&d_ioff, (size_t)(n_cols + 1) * 8);
+  POOLCHK(&g->d_ioff, (size_t)(n_cols + 1) * 8);
+  uint64_t* d_ioff = g->d_ioff;
   POOLCHK(&d_bal, (size_t)n_cols * n_chunk * 8);
   POOLCHK(&g->d_col_off, (size_t)(n_cols + 1) * 8); POOLCHK(&g->d_delta, (size_t)n_cols * 8);
   HIPCHK(hipMemcpyAsync(d_vl, var_line, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
@@ -1559,8 +1717,10 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   hawk_launch_gt_fill(st, n_cols, d_r0, d_ch, n_var, d_bal, g->d_col_off, g->d_idx, g->d_o, g->d_delta, d_ioff, g->d_indel);
   HIPCHK(hipEventRecord(ctx->ev[3], st));
   HIPCHK(hipGetLastError());
-  if (col_delta) HIPCHK(hipMemcpyAsync(col_delta, g->d_delta, (size_t)n_cols * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(g->h_delta.data(), g->d_delta, (size_t)n_cols * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (col_delta) memcpy(col_delta, g->h_delta.data(), (size_t)n_cols * 8);
+  g->h_off = off; g->h_ioff = ioff;
   if (kernel_ms) {
     float a = 0.f, b = 0.f;
     (void)hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]); (void)hipEventElapsedTime(&b, ctx->ev[2], ctx->ev[3]);
@@ -1570,7 +1730,6 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   g->n_entries = ne;
   g->n_indel = ni;
   hawk_pool_free(d_vl); hawk_pool_free(d_va); hawk_pool_free(d_r0); hawk_pool_free(d_ch); hawk_pool_free(d_cnt); hawk_pool_free(d_bal);
-  hawk_pool_free(d_ioff);
   return HAWK_OK;
 }
 

@@ -97,6 +97,17 @@ void hawk_launch_vsearch(hipStream_t st, int pass, const HapSetDev& hs, const Vc
                          const struct RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, uint32_t* counts0, unsigned long long* shards,
                          const uint64_t* offsets, struct GuideCols out, int* status, uint32_t tile0, uint32_t n_tiles);
 void hawk_launch_ref_hits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, int32_t ref_index, void* hpF, void* hpR);
+// hawk_meta.hip: the rows' metadata of an expansion plan, built on the device
+void hawk_launch_list_check(hipStream_t st, const uint64_t* row_off, uint32_t n_rows, const uint32_t* hv_idx, const int32_t* hv_o,
+                            const int32_t* v_r0, const int32_t* v_span, const int32_t* v_chain, uint32_t n_var, uint32_t ref_len,
+                            int check_clamp, uint32_t* status);
+void hawk_launch_segments(hipStream_t st, const uint64_t* ioff, const uint32_t* indel, const uint32_t* hv_idx, const int32_t* hv_o,
+                          const int32_t* v_r0, const int32_t* v_chain, const uint32_t* hap_len, uint32_t n_rows, int64_t startp,
+                          uint32_t* seg_cnt, uint32_t* seg_off, uint32_t* seg_rel /* null: count + offsets only */, int64_t* seg_gen);
+void hawk_launch_rev_lookup(hipStream_t st, const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, const uint32_t* hap_len,
+                            uint32_t n_rows, int64_t g0, int64_t g1, int64_t* out0, int64_t* out1);
+void hawk_launch_tile_meta(hipStream_t st, const uint32_t* seg_off, const uint32_t* seg_rel, const uint32_t* hap_len, const uint8_t* is_ref,
+                           const int32_t* scan_start, const int32_t* scan_stop, uint32_t n_rows, uint32_t bph, TileMeta* tm);
 void hawk_launch_ref_bits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const RefInfo& ri, uint32_t* bitsF, uint32_t* bitsR);
 
 // K7 records

@@ -125,7 +125,24 @@ struct hawk_xplan {
   bool has_partner = false;
   int32_t partner_start = 0, partner_stop = 0;
   uint32_t n_ref_rows = 0;
+  std::vector<int64_t> rev0, rev1;  // hawk_xplan_create_gt: posmap_rev of every row at the two positions asked for
   std::shared_ptr<uint64_t> groups = std::make_shared<uint64_t>(0);  // groups the last collapse of a set of this plan found
+};
+
+// genotypes of a VCF block in HBM and, after hawk_gt_lists, the carried-variant lists of every chromosome copy
+struct hawk_gt {
+  hawk_ctx* ctx;
+  uint64_t n_lines;
+  uint32_t n_samples, n_var;
+  uint8_t* d_codes;   // [n_lines][2 * n_samples]
+  uint8_t* d_flags;   // [n_lines]
+  uint64_t n_entries; // carried-variant entries over all columns (valid after hawk_gt_lists)
+  uint64_t* d_col_off; uint32_t* d_idx; int32_t* d_o; int64_t* d_delta;
+  uint64_t n_indel = 0;          // entries whose variant changes the length (var_chain != 0)
+  uint32_t* d_indel = nullptr;   // their entry indices, ascending
+  uint64_t* d_ioff = nullptr;    // [2 * n_samples + 1] where each column's carried indels start in d_indel
+  std::vector<uint64_t> h_off, h_ioff;  // host copies of d_col_off / d_ioff (after hawk_gt_lists)
+  std::vector<int64_t> h_delta;         // per column: sum of the length changes of its carried variants
 };
 
 struct hawk_table {

@@ -36,7 +36,9 @@ typedef enum {
   HAWK_E_CFD = -5,        /* non-ACGT base under a CFD lookup: CrisprHawkCfdScoreError (cfdscore.py:93-94) */
   HAWK_E_NODEVICE = -6,   /* no gfx950 device visible */
   HAWK_E_UNSUPPORTED = -7, /* parameter outside the kernel's range (e.g. guidelen+pamlen > 44) */
-  HAWK_E_COMM = -8         /* RCCL failure or librccl.so missing (hawk_comm_last_error() has the text) */
+  HAWK_E_COMM = -8,        /* RCCL failure or librccl.so missing (hawk_comm_last_error() has the text) */
+  HAWK_E_OVERLAP = -9,     /* a chromosome copy carries overlapping variants (haplotype.py:214-252 raises on them) */
+  HAWK_E_CLAMP = -10       /* an indel reaches past the region's original length (the reference's clamp, haplotype.py:199-201) */
 } hawk_status;
 
 typedef struct hawk_ctx hawk_ctx;
@@ -58,6 +60,10 @@ int hawk_sync(hawk_ctx* ctx);
 /* Device memory is served by a caching allocator (freed planes / columns / workspaces are reused by the next
  * haplotype set of the same shape, e.g. the next tile of a whole-contig search); this returns the cache to HIP. */
 int hawk_release_cached_memory(hawk_ctx* ctx);
+/* Page-locked host memory for buffers a download writes into (hawk_table_download, hawk_table_collapse_export ...): the copy
+ * then runs at link speed.  Plain host memory is accepted everywhere; this is an optimisation for large results. */
+int hawk_host_alloc(hawk_ctx* ctx, uint64_t bytes, void** out);
+void hawk_host_free(void* p);
 
 /* ---- haplotype set: replaces encode() per haplotype (crisprhawk.py:64-81, encoder.py:48-57)
  * plus the Haplotype fields the search reads (haplotype.py:395-491) ---------------------- */
@@ -134,6 +140,25 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
  * planes (hawk_pam_scan, hawk_hapset_download_plane, hawk_offtarget_scan ...) returns HAWK_E_INVALID on a view; tables,
  * collapse, export and gather work as on any set.  The plan must outlive the view. */
 int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out);
+/* Plan creation straight from the genotype inversion: `g` is a hawk_gt after hawk_gt_lists, whose carried-variant lists
+ * are still in HBM - they are used in place (rows = REF + every chromosome copy with a non-empty list, in column order),
+ * nothing is downloaded, and what the host used to do over every list entry runs as kernels: the ascending /
+ * non-overlapping check (HAWK_E_OVERLAP), the reference's end-of-region clamp for indels when check_clamp != 0
+ * (HAWK_E_CLAMP), the position-map segments of every row (haplotype.py:90-159) and posmap_rev at the two genomic positions
+ * rev_g0 / rev_g1 the scan bounds start from (search_guides.py:49-84).  v_chain[i] = alt_len - span.  hawk_xplan_rows
+ * returns the rows' lengths and the two look-ups (-1: the position is deleted from that row); the caller turns them into
+ * scan ranges (rows collapsed onto another get an empty one) and hawk_xplan_finish_meta builds the per-tile records.
+ * hawk_xplan_segments downloads the segments (for labels / reports); hawk_xplan_install_meta gives a set hawk_xplan_run
+ * wrote BEFORE the metadata existed (the run whose hashes decide which rows collapse) the finished metadata. */
+typedef struct hawk_gt hawk_gt;
+int hawk_xplan_create_gt(hawk_hapset* ref_set, hawk_gt* g, uint32_t n_var, const uint32_t* v_r0, const uint32_t* v_span,
+                         const uint32_t* v_alt_off, const uint32_t* v_alt_len, const int32_t* v_chain, const uint8_t* alt_codes,
+                         uint32_t alt_codes_len, int64_t startp, int check_clamp, int64_t rev_g0, int64_t rev_g1, uint32_t* n_hap_out,
+                         hawk_xplan** out);
+int hawk_xplan_rows(hawk_xplan* x, uint32_t* hap_len, int64_t* rev0, int64_t* rev1);
+int hawk_xplan_finish_meta(hawk_xplan* x, const int32_t* scan_start, const int32_t* scan_stop);
+int hawk_xplan_segments(hawk_xplan* x, uint32_t* seg_off, uint32_t* seg_rel, int64_t* seg_gen, uint64_t cap, uint64_t* n_seg);
+int hawk_xplan_install_meta(hawk_xplan* x, hawk_hapset* hs);
 void hawk_xplan_destroy(hawk_xplan* x);
 
 /* ---- K2: pam_search() (search_guides.py:102-131) ---------------------------------------
@@ -308,7 +333,6 @@ int hawk_host_gather_plan(int world, int rank, int dst, const uint64_t* dir4, ui
  *   hawk_gt_lists_download copies hv_idx and hv_o = var_r0 + exclusive running sum of var_chain within the
  *   column (host or device destinations) - the inputs of hawk_hapset_expand for the rows "columns with a
  *   non-empty list, in column order". */
-typedef struct hawk_gt hawk_gt;
 int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const uint64_t* line_off, const uint64_t* gt_off,
                   uint64_t n_lines, uint32_t n_samples, hawk_gt** out, float* kernel_ms);
 /* The same object from an allele-code matrix the caller already holds (codes[n_lines][2*n_samples], host): genotypes that
