@@ -451,18 +451,49 @@ class _KeptInfos:
         return (self._infos[i] for i in self._kept)
 
 
-def _collapse_rows(hashes: np.ndarray, samples: List[str], live: np.ndarray, n_hap: int, rows_of):
+def _exact_keys(ds, hashes: np.ndarray) -> np.ndarray:
+    """Rows grouped by content, exactly: rows sharing a 128-bit content hash are compared base for base on the device
+    (hawk_hapset_rows_equal) against the first row of their hash group; a row that differs (a hash collision - never seen)
+    opens a group of its own with the rows that equal IT.  Returns one key per row."""
+    import ctypes as C
+    from . import _lib
+    from .hapset import _p
+    h64 = hashes[:, 0] * np.uint64(0x9e3779b97f4a7c15) + (hashes[:, 1] ^ (hashes[:, 1] >> np.uint64(29)))
+    _, first_idx, key_id = np.unique(h64, return_index=True, return_inverse=True)
+    key_id = key_id.reshape(-1).astype(np.int64)
+    n = len(key_id)
+    head = first_idx[key_id]
+    todo = np.flatnonzero(head != np.arange(n))  # rows that would be merged with an earlier row
+    next_key = int(key_id.max()) + 1 if n else 0
+    while len(todo):
+        a = np.ascontiguousarray(todo, dtype=np.uint32)
+        b = np.ascontiguousarray(head[todo], dtype=np.uint32)
+        eq = np.zeros(len(todo), dtype=np.uint8)
+        _lib.check(_lib.lib().hawk_hapset_rows_equal(ds._h, len(todo), _p(a), _p(b), _p(eq)), "hawk_hapset_rows_equal")
+        bad = todo[eq == 0]
+        if len(bad) == 0:
+            break
+        # per old group: its first mismatching row heads a new group, the other mismatching rows are tried against it
+        for k in np.unique(key_id[bad]).tolist():
+            rows = bad[key_id[bad] == k]
+            key_id[rows] = next_key
+            head[rows] = rows[0]
+            next_key += 1
+        todo = bad[head[bad] != bad]
+    return key_id
+
+
+def _collapse_rows(hashes: np.ndarray, samples: List[str], live: np.ndarray, n_hap: int, rows_of, ds=None):
     """Labels, homozygous merge and collapse by content of the rows of an expansion (haplotypes.py:232-368), all rows at
     once on their 16-byte content hashes.  `rows_of(r)` -> the carried-variant indices of row r (or a callable yielding
     them).  Returns (alias[n_hap], info[n_hap] with None for rows collapsed onto another)."""
     # entries in the reference's order (haplotypes.py:297-368): samples in panel order, copy 0 then copy 1; a sample
     # whose two copies hold the same sequence contributes one "1|1" entry; a copy without variants is the REF sequence
-    # the 128-bit content hash folded into one sortable word; rows grouped under one word are then held to their group's
-    # first member on both words, so a fold collision (never seen) only costs the slower exact grouping
-    h64 = hashes[:, 0] * np.uint64(0x9e3779b97f4a7c15) + (hashes[:, 1] ^ (hashes[:, 1] >> np.uint64(29)))
-    _, first_idx, key_id = np.unique(h64, return_index=True, return_inverse=True)
-    key_id = key_id.reshape(-1)
-    if not np.array_equal(hashes, hashes[first_idx[key_id]]):
+    # rows that hold the same bases: grouped on the 128-bit content hash and then compared on the device, base for base
+    # (the reference compares the strings, haplotypes.py:274-294); without a set to compare on, the hash alone
+    if ds is not None:
+        key_id = _exact_keys(ds, hashes)
+    else:
         _, key_id = np.unique(hashes, axis=0, return_inverse=True)
         key_id = key_id.reshape(-1)
     ns = len(samples)
@@ -544,7 +575,7 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
     ds, hashes, ms_val = plan.run(want_hash=True)
     ms = C.c_float(ms_val)
     hv_off_i = hv_off.astype(np.int64)
-    alias, info = _collapse_rows(hashes, samples, live, n_hap, lambda o: hv_idx[hv_off_i[o]:hv_off_i[o + 1]])
+    alias, info = _collapse_rows(hashes, samples, live, n_hap, lambda o: hv_idx[hv_off_i[o]:hv_off_i[o + 1]], ds)
     # ---- position-map segments + scan bounds per row ------------------------------------------
     seg_start, seg_rel_all, seg_gen_all = build_segments(ind, hv_idx, hv_o, hv_off, r0, chain, startp, hap_len, alias)
     haps = RowMeta(seg_start, seg_rel_all.astype(np.uint32), seg_gen_all, hap_len, alias, startp)
@@ -600,7 +631,7 @@ def _expand_rows_gt(ref_set, seq, startp: int, stopp: int, pamlen: int, samples:
     plan.n_records = int(col_off[-1])
     ds, hashes, ms_val = plan.run(want_hash=True)
     row_end = np.concatenate(([0, 0], col_off.astype(np.int64)[live + 1]))  # row r's list: [row_end[r], row_end[r + 1])
-    alias, info = _collapse_rows(hashes, samples, live, n_hap, lambda o: lists.rows(int(row_end[o]), int(row_end[o + 1])))
+    alias, info = _collapse_rows(hashes, samples, live, n_hap, lambda o: lists.rows(int(row_end[o]), int(row_end[o + 1])), ds)
 
     def fetch():
         nseg = C.c_uint64(0)

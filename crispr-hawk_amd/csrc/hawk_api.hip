@@ -371,6 +371,27 @@ int hawk_hapset_set_ref_partner_range(hawk_hapset* hs, int32_t start, int32_t st
   return HAWK_OK;
 }
 
+static HapSetDev make_dev(const hawk_hapset* hs);
+int hawk_hapset_rows_equal(hawk_hapset* hs, uint32_t n_pairs, const uint32_t* rows_a, const uint32_t* rows_b, uint8_t* equal) {
+  if (!hs || hs->vplan || (n_pairs && (!rows_a || !rows_b || !equal))) return HAWK_E_INVALID;
+  if (!n_pairs) return HAWK_OK;
+  for (uint32_t i = 0; i < n_pairs; ++i)
+    if (rows_a[i] >= hs->n_hap || rows_b[i] >= hs->n_hap) return HAWK_E_INVALID;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  uint32_t *d_a = nullptr, *d_b = nullptr;
+  uint8_t* d_e = nullptr;
+  POOLCHK(&d_a, (size_t)n_pairs * 4); POOLCHK(&d_b, (size_t)n_pairs * 4); POOLCHK(&d_e, n_pairs);
+  HIPCHK(hipMemcpyAsync(d_a, rows_a, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_b, rows_b, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+  hawk_launch_rows_equal(ctx->stream, make_dev(hs), n_pairs, d_a, d_b, d_e);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(equal, d_e, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hawk_pool_free(d_a); hawk_pool_free(d_b); hawk_pool_free(d_e);
+  return HAWK_OK;
+}
+
 int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words) {
   if (!hs || plane < 0 || plane >= HAWK_PLANES || !out_words) return HAWK_E_INVALID;
   if (hs->vplan) return HAWK_E_INVALID;  // a plan view holds no planes
@@ -834,15 +855,23 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   int rc;
   if ((rc = hs->ckeys.reserve(2 * n * 8)) || (rc = hs->cvals.reserve(2 * n * 4)) || (rc = hs->cflags.reserve(n * 4)) ||
       (rc = hs->cgidx.reserve(n * 4)) || (rc = hs->ctemp.reserve(temp_bytes + 16)) || (rc = hs->cgoff.reserve((n + 1) * 8)) ||
-      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(16)))
+      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ccnt.reserve(32)))
     return rc;
-  // identity of a row beyond (start, strand): 63 hash bits, or - HAWK_COLLAPSE_EXACT=1 - the full key (hawk_collapse.hip)
+  // Rows are grouped on (start, strand, 63 hash bits of the rest) and the grouping is then VERIFIED: every member against
+  // its group's first member on the full key (k_collapse_verify).  A mismatch - two different rows under one hash, never
+  // seen - sends the call through the exact path (full 64-byte keys compared neighbour by neighbour), which
+  // HAWK_COLLAPSE_EXACT=1 forces from the start; HAWK_COLLAPSE_VERIFY=0 switches the check off (A/B timing only).
   const char* ex = getenv("HAWK_COLLAPSE_EXACT");
-  const bool exact = ex && ex[0] == '1';
+  const char* vf = getenv("HAWK_COLLAPSE_VERIFY");
+  const char* wk = getenv("HAWK_COLLAPSE_WEAK_HASH");  // test knob: every row hashes alike, so the verify pass HAS to catch it
+  const bool verify = !(vf && vf[0] == '0'), weak = wk && wk[0] == '1';
+  bool exact = ex && ex[0] == '1';
+  for (int round = 0; round < 2; ++round, exact = true) {
   if (exact && (rc = hs->cfull.reserve(hawk_collapse_full_bytes(n)))) return rc;
   // ---- grouping through a hash table (hawk_collapse.hip) when groups are expected to be far fewer than rows: the sort
   // below then only orders (group number, row).  HAWK_COLLAPSE_MODE=sort / hash overrides the choice; a table that turns
   // out too small, or an unlucky seed twice, falls through to the sort.
+  bool verified_bad = false;
   {
     const char* md = getenv("HAWK_COLLAPSE_MODE");
     const bool force_hash = md && md[0] == 'h', force_sort = md && md[0] == 's';
@@ -850,7 +879,7 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
     uint64_t C = 1024;
     while (C < 2 * g_est) C <<= 1;  // at most half full (with the 25 % head room of g_est)
     const bool fits = C <= (1ull << 26) && hs->max_gen - hs->min_gen < 0xffffffffll;
-    const bool want = !exact && !force_sort && fits && (force_hash || (n >= (1u << 20) && (hs->last_groups == 0 || hs->last_groups * 8 <= n)));
+    const bool want = !exact && !weak && !force_sort && fits && (force_hash || (n >= (1u << 20) && (hs->last_groups == 0 || hs->last_groups * 8 <= n)));
     if (want) {
       const size_t tb = hawk_collapse_hash_temp_bytes(n, (uint32_t)C);
       if ((rc = hs->ctable.reserve(C * 16)) || (rc = hs->cocc.reserve(C * 4)) || (rc = hs->cdense.reserve(C * 4)) ||
@@ -858,7 +887,7 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
           (rc = hs->ccnt.reserve(32)))
         return rc;
       for (int attempt = 0; attempt < 2; ++attempt) {
-        unsigned long long hc[3] = {0, 0, 0};
+        unsigned long long hc[4] = {0, 0, 0, 0};
         HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 32, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
         if (hawk_launch_collapse_hash1(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)flank_up, (int)flank_down,
@@ -877,11 +906,17 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
                                        hs->cflags.as<uint32_t>(), hs->ckeys.as<uint32_t>(), hs->cvals.as<uint32_t>(), hs->cgoff.as<uint64_t>(),
                                        hs->cgc.as<uint8_t>(), hs->cgc.as<uint8_t>() + n))
           return HAWK_E_HIP;
+        if (verify)
+          hawk_launch_collapse_verify(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)flank_up, (int)flank_down,
+                                      hs->cvals.as<uint32_t>() + n, hs->ckeys.as<uint32_t>() + n, nullptr, hs->cgoff.as<uint64_t>(),
+                                      hs->ccnt.as<unsigned long long>() + 3);
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&hc[3], hs->ccnt.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (kernel_ms) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); *kernel_ms += ms; }
+        if (hc[3]) { verified_bad = true; break; }  // two different rows under one group: the exact path decides
         hs->last_groups = ng;
         if (hs->plan_groups) *hs->plan_groups = ng;
         t->n_groups = ng; t->collapsed = true;
@@ -890,24 +925,30 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
       }
     }
   }
-  unsigned long long cnt[2] = {0, 0};
+  if (verified_bad) continue;
+  unsigned long long cnt[3] = {0, 0, 0};
   for (int attempt = 0; attempt < 4; ++attempt) {  // a new seed whenever two different rows collide in the hash bits
-    HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(hs->ccnt.p, 0, 32, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (hawk_launch_collapse(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)t->right, (int)flank_up,
                              (int)flank_down, hs->min_gen, begin_bit, end_bit, 0x9e3779b97f4a7c15ull * (uint64_t)(attempt + 1), hs->ctemp.p,
                              temp_bytes, hs->ckeys.as<uint64_t>(), hs->cvals.as<uint32_t>(), hs->cflags.as<uint32_t>(),
                              hs->cgidx.as<uint32_t>(), hs->ccnt.as<unsigned long long>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(),
-                             hs->cgc.as<uint8_t>() + n, hs->cgidx.as<uint32_t>(), exact ? hs->cfull.p : nullptr))
+                             hs->cgc.as<uint8_t>() + n, hs->cgidx.as<uint32_t>(), exact ? hs->cfull.p : nullptr, weak && !exact))
       return HAWK_E_HIP;
+    if (verify && !exact)  // group of sorted position j: exclusive scan of the head flags + its own flag - 1
+      hawk_launch_collapse_verify(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)flank_up, (int)flank_down,
+                                  hs->cvals.as<uint32_t>() + n, hs->cgidx.as<uint32_t>(), hs->cflags.as<uint32_t>(), hs->cgoff.as<uint64_t>(),
+                                  hs->ccnt.as<unsigned long long>() + 2);
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(cnt, hs->ccnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cnt, hs->ccnt.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (kernel_ms) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); *kernel_ms += ms; }
     if (cnt[0] == cnt[1]) break;
   }
-  if (cnt[0] != cnt[1]) return HAWK_E_UNSUPPORTED;
+  if (cnt[0] != cnt[1]) { if (!exact) continue; return HAWK_E_UNSUPPORTED; }
+  if (cnt[2]) continue;  // the verify pass found a group holding two different rows: once more, exactly
   const uint64_t ng = cnt[1];
   HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -916,6 +957,8 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   t->n_groups = ng; t->collapsed = true;
   *n_groups = ng;
   return HAWK_OK;
+  }
+  return HAWK_E_UNSUPPORTED;
 }
 
 int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {

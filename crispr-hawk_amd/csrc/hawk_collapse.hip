@@ -63,8 +63,8 @@ __device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
 }
 
 __global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
-                                                       int64_t base, uint64_t seed, uint32_t hash_mask, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ id2,
+                                                       int64_t base, uint64_t seed, uint32_t hash_mask, uint32_t id_mask,
+                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ id2,
                                                        ulonglong4* __restrict__ full /* exact mode, else null */) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_collapse_keys(GuideCols c, const uint8_
   h = mix64(h ^ (uint64_t)k.stop ^ ((uint64_t)(k.sr >> 1) << 63));
   keys[i] = ((uint64_t)(k.start - base) << 32) | ((uint64_t)(k.sr & 1u) << 31) | ((h >> 33) & hash_mask);
   vals[i] = (uint32_t)i;
-  id2[i] = (uint32_t)h;
+  id2[i] = (uint32_t)h & id_mask;  // id_mask / hash_mask = 0: the test that forces hash collisions (HAWK_COLLAPSE_WEAK_HASH)
 }
 
 __device__ __forceinline__ bool same4(const ulonglong4& a, const ulonglong4& b) {
@@ -137,6 +137,52 @@ __global__ __launch_bounds__(256) void k_collapse_groups(GuideCols c, uint64_t n
   gc_den[g] = (uint8_t)__popcll(gc | at);
 }
 
+// Every member of a group against the group's first member on the FULL key (start, stop, strand, origin, the five core
+// slices): grouping by hash - 63 bits in either path above - is thereby checked, not trusted; one mismatch sends the call
+// to the exact path.  `grp_a[j] + (grp_b ? grp_b[j] - 1 : 0)` = the group of sorted position j (sort path: exclusive scan of
+// the head flags + the flag - 1; hash path: the sorted group numbers).  The head's key is shared by the group's members
+// (L2), the member's own key is the one scattered read per row.
+__global__ __launch_bounds__(256) void k_collapse_verify(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
+                                                         const uint32_t* __restrict__ perm, const uint32_t* __restrict__ grp_a,
+                                                         const uint32_t* __restrict__ grp_b, const uint64_t* __restrict__ group_off,
+                                                         unsigned long long* __restrict__ mismatches) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (j < n) {
+    const uint32_t g = grp_b ? grp_a[j] + grp_b[j] - 1u : grp_a[j];
+    const uint64_t hj = group_off[g];
+    if (hj != j) bad = !same_row(row_key(c, is_ref, perm[j], L, up, down), row_key(c, is_ref, perm[hj], L, up, down));
+  }
+  const unsigned long long b = __ballot(bad);
+  if (b && (threadIdx.x & 63) == 0) atomicAdd(mismatches, (unsigned long long)__popcll(b));
+}
+void hawk_launch_collapse_verify(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
+                                 int flank_down, const uint32_t* perm, const uint32_t* grp_a, const uint32_t* grp_b, const uint64_t* group_off,
+                                 unsigned long long* mismatches) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_collapse_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, is_ref, n, guidelen + pamlen, flank_up,
+                     flank_down, perm, grp_a, grp_b, group_off, mismatches);
+}
+
+// whole rows of a set against each other, all five planes: the check behind collapsing haplotypes on their content hash
+__global__ __launch_bounds__(256) void k_rows_equal(HapSetDev hs, const uint32_t* __restrict__ ra, const uint32_t* __restrict__ rb,
+                                                    uint8_t* __restrict__ equal) {
+  __shared__ uint32_t s_diff;
+  if (threadIdx.x == 0) s_diff = 0;
+  __syncthreads();
+  const size_t a = (size_t)ra[blockIdx.x] * hs.S, b = (size_t)rb[blockIdx.x] * hs.S;
+  uint32_t d = 0;
+  for (uint32_t w = threadIdx.x; w < hs.S; w += 256)
+#pragma unroll
+    for (int pl = 0; pl < HAWK_PLANES; ++pl) d |= hs.plane[pl][a + w] ^ hs.plane[pl][b + w];
+  if (d) atomicOr(&s_diff, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) equal[blockIdx.x] = s_diff ? 0 : 1;
+}
+void hawk_launch_rows_equal(hipStream_t st, const HapSetDev& hs, uint32_t n_pairs, const uint32_t* ra, const uint32_t* rb, uint8_t* equal) {
+  if (n_pairs) hipLaunchKernelGGL(k_rows_equal, dim3(n_pairs), dim3(256), 0, st, hs, ra, rb, equal);
+}
+
 // bytes of the full-key records (64 per row)
 size_t hawk_collapse_full_bytes(uint64_t n) { return (size_t)n * 64; }
 
@@ -153,10 +199,11 @@ size_t hawk_collapse_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
                          int flank_up, int flank_down, int64_t base, unsigned begin_bit, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
-                         uint8_t* gc_den, uint32_t* id2, void* full) {
+                         uint8_t* gc_den, uint32_t* id2, void* full, int weak_hash) {
   const int L = guidelen + pamlen;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, L, flank_up, flank_down, base, seed, ~((1u << begin_bit) - 1u) & 0x7fffffffu, keys, vals, id2, (ulonglong4*)full);
+  hipLaunchKernelGGL(k_collapse_keys, grid, block, 0, st, c, is_ref, n, L, flank_up, flank_down, base, seed,
+                     weak_hash ? 0u : (~((1u << begin_bit) - 1u) & 0x7fffffffu), weak_hash ? 0u : 0xffffffffu, keys, vals, id2, (ulonglong4*)full);
   size_t tb = temp_bytes;
   if (rocprim::radix_sort_pairs(temp, tb, keys, keys + n, vals, vals + n, n, begin_bit, end_bit, st) != hipSuccess) return -2;
   hipLaunchKernelGGL(k_collapse_heads, grid, block, 0, st, (const ulonglong4*)full, id2, n, keys + n, vals + n, flags, counters);

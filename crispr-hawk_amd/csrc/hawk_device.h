@@ -160,7 +160,11 @@ size_t hawk_collapse_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit
 int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int right,
                          int flank_up, int flank_down, int64_t base, unsigned begin_bit, unsigned end_bit, uint64_t seed, void* temp, size_t temp_bytes, uint64_t* keys, uint32_t* vals,
                          uint32_t* flags, uint32_t* gidx, unsigned long long* counters, uint64_t* group_off, uint8_t* gc_num,
-                         uint8_t* gc_den, uint32_t* id2 /* may alias gidx */, void* full /* null: identity by hash */);
+                         uint8_t* gc_den, uint32_t* id2 /* may alias gidx */, void* full /* null: identity by hash */, int weak_hash = 0);
+void hawk_launch_collapse_verify(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
+                                 int flank_down, const uint32_t* perm, const uint32_t* grp_a, const uint32_t* grp_b, const uint64_t* group_off,
+                                 unsigned long long* mismatches);
+void hawk_launch_rows_equal(hipStream_t st, const HapSetDev& hs, uint32_t n_pairs, const uint32_t* ra, const uint32_t* rb, uint8_t* equal);
 size_t hawk_collapse_full_bytes(uint64_t n);
 size_t hawk_collapse_hash_temp_bytes(uint64_t n, uint32_t C);
 int hawk_launch_collapse_hash1(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,

@@ -98,6 +98,10 @@ int hawk_hapset_set_ref_partner_range(hawk_hapset* hs, int32_t start, int32_t st
  * (n_hap * stride words) — for tests and for decoding windows on the host. */
 int hawk_hapset_stride(const hawk_hapset* hs, uint32_t* stride_words);
 int hawk_hapset_download_plane(hawk_hapset* hs, int plane, uint32_t* out_words);
+/* equal[i] = 1 iff rows rows_a[i] and rows_b[i] hold the same bases, case included (all five planes compared): what makes
+ * collapsing haplotypes on their 128-bit content hash (hawk_xplan_run's hash_out; haplotypes.py:274-294 compares the
+ * strings) exact - the caller checks every row it is about to alias onto another. */
+int hawk_hapset_rows_equal(hawk_hapset* hs, uint32_t n_pairs, const uint32_t* rows_a, const uint32_t* rows_b, uint8_t* equal);
 /* Upload planes computed elsewhere (5 * n_hap * stride words, plane-major). */
 int hawk_hapset_upload_planes(hawk_hapset* hs, const uint32_t* planes);
 

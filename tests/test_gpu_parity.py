@@ -396,6 +396,63 @@ def test_collapse_groups_against_oracle(pam, guidelen, right, exact, mode, monke
     _check_collapse(hs, tab, guidelen, len(pam), right)
 
 
+def test_collapse_verify_pass_catches_hash_collisions(monkeypatch):
+    """The grouping is verified against the full keys by default (k_collapse_verify).  With HAWK_COLLAPSE_WEAK_HASH=1 every
+    row of one (start, strand) hashes alike - the worst collision there can be: unverified, the groups come out merged
+    (fewer than the oracle's); verified, the call notices and reruns exactly, and the groups are the oracle's."""
+    reg = synth.make_region(7501, "chrC", 40_000, 1_000, 38_000)
+    synth.add_phased_variants(reg, 7502, 300, 6, af_min=0.3, af_max=0.8)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, 3) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    bits, bitsrc, _, _ = ora.pam_encode("NGG")
+    ds = device_set(hs)
+    monkeypatch.delenv("HAWK_COLLAPSE_EXACT", raising=False)
+    monkeypatch.delenv("HAWK_COLLAPSE_MODE", raising=False)
+    good = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
+    monkeypatch.setenv("HAWK_COLLAPSE_WEAK_HASH", "1")
+    monkeypatch.setenv("HAWK_COLLAPSE_VERIFY", "0")
+    merged = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
+    assert merged.n_groups < good.n_groups  # the collisions are real: without the check different rows share a group
+    monkeypatch.setenv("HAWK_COLLAPSE_VERIFY", "1")
+    tab = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
+    assert tab.n_groups == good.n_groups
+    assert np.array_equal(tab.group_perm, good.group_perm) and np.array_equal(tab.group_off, good.group_off)
+    _check_collapse(hs, tab, 20, 3, False)
+
+
+def test_haplotype_collapse_compares_rows_not_only_hashes():
+    """Rows are aliased onto another row of equal CONTENT: the 128-bit hashes only propose the pairs, the device compares
+    them base for base (hawk_hapset_rows_equal).  Forged hashes - every row the same - must give the grouping of the
+    true contents, and rows_equal itself must tell a one-base difference."""
+    import ctypes as C
+    from crisprhawk_hip import _lib
+    from crisprhawk_hip.hapset import _p
+    from crisprhawk_hip.workload import _exact_keys, expand_on_device
+    reg = synth.make_region(7521, "chrD", 30_000, 1_000, 28_000)
+    synth.add_phased_variants(reg, 7522, 5, 30, af_min=0.3, af_max=0.7)  # few sites, many samples: many equal copies
+    ds, info, _ms, kept = expand_on_device(reg, 3)
+    assert len(kept) < ds.n_hap  # some rows did collapse
+    planes = ds.planes()
+    content = {}
+    want = np.array([content.setdefault(planes[:, r, :].tobytes(), len(content)) for r in range(ds.n_hap)])
+    forged = np.zeros((ds.n_hap, 2), dtype=np.uint64)
+    got = _exact_keys(ds, forged)
+    # same partition of the rows
+    assert len(set(zip(want.tolist(), got.tolist()))) == len(set(want.tolist())) == len(set(got.tolist()))
+    # and the production keys (real hashes) give it too
+    assert np.array_equal(ds.alias == np.arange(ds.n_hap), np.array([want[r] not in want[:r] for r in range(ds.n_hap)]))
+    a = np.array([1, 1, 2], dtype=np.uint32)
+    twin = int(np.flatnonzero(want == want[1])[-1])
+    other = int(np.flatnonzero(want != want[1])[0])
+    b = np.array([twin, other, 2], dtype=np.uint32)
+    eq = np.zeros(3, dtype=np.uint8)
+    _lib.check(_lib.lib().hawk_hapset_rows_equal(ds._h, 3, _p(a), _p(b), _p(eq)), "hawk_hapset_rows_equal")
+    assert eq.tolist() == [1, 0, 1]
+
+
 def test_collapse_with_scorer_flanks_splits_groups_and_both_paths_agree(monkeypatch):
     # with the model scorers' 4 + 3 flanking bases in the key (hawk_table_collapse_ex; reports.py:978-1003) rows whose
     # spacer+PAM agree but whose flanks differ stay apart: never fewer groups than without, and the same arrays from the
