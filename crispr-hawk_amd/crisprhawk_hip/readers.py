@@ -294,7 +294,6 @@ class VCF:
             self._index_lines(buf, carry_off, np.zeros(1, np.int64), np.array([len(buf) - 1]), starts_l, ends_l, pos_l, contigs)
             if buf[0] == ord("#"):
                 header_last = bytes(buf[:-1]).decode()
-            self._tail_fix = total  # reads past the file end are clipped; the missing newline is re-added on fetch
         if header_last is None or not header_last.startswith("#CHROM"):
             exception_handler(ValueError, f"Input VCF {fname} has no #CHROM header line", os.EX_DATAERR, debug)
         self._samples = header_last.strip().split()[9:]  # variant.py:657
@@ -322,7 +321,8 @@ class VCF:
         W = 64
         idx = np.minimum(st[:, None] + np.arange(W)[None, :], len(buf) - 1)
         head = buf[idx]
-        istab = head == 9
+        # only the line's own bytes count: a short line must not borrow the tabs of the line behind it
+        istab = (head == 9) & (np.arange(W)[None, :] < (en - st)[:, None])
         t1 = istab.argmax(axis=1)
         rest = istab.copy()
         rest[np.arange(len(st)), t1] = False

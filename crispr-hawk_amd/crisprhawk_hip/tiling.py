@@ -176,6 +176,19 @@ class TiledRegionSearch:
         v_hi = int(np.searchsorted(p.pos, tile.seq_hi, side="right"))
         while v_hi > v_lo and p.pos[v_hi - 1] + p.ref_len[v_hi - 1] - 1 > tile.seq_hi:
             v_hi -= 1
+        # A record that only partly lies in the tile string is left out: harmless while it stays clear of everything the
+        # tile owns (its neighbour carries it whole).  One that reaches to within flank + guard of the owned range - an
+        # indel or SV longer than the flank - would map the seam differently on its two sides: refuse, the tiles need a
+        # larger flank (TiledRegionSearch(flank=...)).
+        reach = self.guard
+        k = v_lo - 1  # the last record starting before the tile string: does its REF span reach in?  (interior seams only:
+        #               at the region's own ends a straddling record is outside the region, as for the one-piece search)
+        if tile.own_lo is not None and k >= 0 and p.pos[k] + p.ref_len[k] - 1 >= tile.seq_lo and p.pos[k] + p.ref_len[k] - 1 >= tile.own_lo - reach:
+            raise ValueError(f"variant at {int(p.pos[k])} (REF span {int(p.ref_len[k])}) crosses the start of tile {t}'s string into what the "
+                             "tile scans: the flank is too small for this record")
+        if tile.own_hi is not None and v_hi < len(p.pos) and p.pos[v_hi] <= tile.seq_hi and p.pos[v_hi] <= tile.own_hi + reach:
+            raise ValueError(f"variant at {int(p.pos[v_hi])} (REF span {int(p.ref_len[v_hi])}) crosses the end of tile {t}'s string inside what "
+                             "the tile scans: the flank is too small for this record")
         if v_hi <= v_lo:
             return self._keep(t, PreparedTile(tile, ref_set, None, [ref_label], 1))
         tab = _variant_table(p.pos[v_lo:v_hi], p.ref[v_lo:v_hi], p.alt[v_lo:v_hi], seq, tile.seq_lo)

@@ -124,12 +124,23 @@ int hawk_device_count(int* n) {
   return HAWK_OK;
 }
 
+// One context - one stream - per device and process: the caching allocator's reuse of a freed block is safe because
+// everything that touches the block is ordered on that one stream (hawk_host.h).  A second hawk_init for a device hands out
+// the SAME context and counts the reference; the last hawk_destroy releases it.
+namespace {
+hawk_ctx* g_ctx_of[HAWK_MAX_DEVICES] = {};
+int g_ctx_refs[HAWK_MAX_DEVICES] = {};
+std::mutex g_ctx_mu;
+}  // namespace
+
 int hawk_init(int device, hawk_ctx** out) {
   if (!out) return HAWK_E_INVALID;
   int c = 0;
   hawk_device_count(&c);
   if (c <= 0) return HAWK_E_NODEVICE;
-  if (device < 0 || device >= c) return HAWK_E_INVALID;
+  if (device < 0 || device >= c || device >= HAWK_MAX_DEVICES) return HAWK_E_INVALID;
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  if (g_ctx_of[device]) { ++g_ctx_refs[device]; *out = g_ctx_of[device]; return HAWK_OK; }
   HIPCHK(hipSetDevice(device));
   hawk_ctx* ctx = new (std::nothrow) hawk_ctx();
   if (!ctx) return HAWK_E_INVALID;
@@ -137,12 +148,21 @@ int hawk_init(int device, hawk_ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipHostMalloc(&ctx->pinned, 256, hipHostMallocDefault));
+  g_ctx_of[device] = ctx; g_ctx_refs[device] = 1;
   *out = ctx;
   return HAWK_OK;
 }
 
 void hawk_destroy(hawk_ctx* ctx) {
   if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    const int d = ctx->device;
+    if (d >= 0 && d < HAWK_MAX_DEVICES && g_ctx_of[d] == ctx) {
+      if (--g_ctx_refs[d] > 0) return;
+      g_ctx_of[d] = nullptr;
+    }
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& e : ctx->ev) (void)hipEventDestroy(e);
@@ -256,8 +276,9 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
     if (seq_off[h + 1] - seq_off[h] != hs->hap_len[h]) return HAWK_E_INVALID;
   uint64_t* d_off = nullptr;
   unsigned long long* d_bad = nullptr;
-  POOLCHK(&d_off, (hs->n_hap + 1) * 8);
-  POOLCHK(&d_bad, 8);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_off, (hs->n_hap + 1) * 8);
+  TEMPCHK(tmp, &d_bad, 8);
   HIPCHK(hipMemcpyAsync(d_off, seq_off, (hs->n_hap + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
   // stage the ASCII in batches of whole haplotypes (<= 256 MiB of HBM staging)
@@ -266,7 +287,7 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
   for (auto l : hs->hap_len) maxlen = std::max<uint64_t>(maxlen, l);
   const uint64_t stage_bytes = std::max(kStage, maxlen);
   uint8_t* d_stage = nullptr;
-  POOLCHK(&d_stage, std::min<uint64_t>(stage_bytes, std::max<uint64_t>(hs->total_len, 1)));
+  TEMPCHK(tmp, &d_stage, std::min<uint64_t>(stage_bytes, std::max<uint64_t>(hs->total_len, 1)));
   uint32_t h0 = 0;
   while (h0 < hs->n_hap) {
     uint32_t h1 = h0;
@@ -280,7 +301,6 @@ int hawk_hapset_pack_ascii(hawk_hapset* hs, const char* seqs, const uint64_t* se
   }
   unsigned long long bad = ~0ull;
   HIPCHK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
-  hawk_pool_free(d_stage); hawk_pool_free(d_off); hawk_pool_free(d_bad);
   if (bad != ~0ull) {
     if (bad_index) *bad_index = bad;
     return HAWK_E_IUPAC;
@@ -381,14 +401,14 @@ int hawk_hapset_rows_equal(hawk_hapset* hs, uint32_t n_pairs, const uint32_t* ro
   HIPCHK(hipSetDevice(ctx->device));
   uint32_t *d_a = nullptr, *d_b = nullptr;
   uint8_t* d_e = nullptr;
-  POOLCHK(&d_a, (size_t)n_pairs * 4); POOLCHK(&d_b, (size_t)n_pairs * 4); POOLCHK(&d_e, n_pairs);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_a, (size_t)n_pairs * 4); TEMPCHK(tmp, &d_b, (size_t)n_pairs * 4); TEMPCHK(tmp, &d_e, n_pairs);
   HIPCHK(hipMemcpyAsync(d_a, rows_a, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_b, rows_b, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
   hawk_launch_rows_equal(ctx->stream, make_dev(hs), n_pairs, d_a, d_b, d_e);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(equal, d_e, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hawk_pool_free(d_a); hawk_pool_free(d_b); hawk_pool_free(d_e);
   return HAWK_OK;
 }
 
@@ -484,15 +504,15 @@ int hawk_pam_scan(hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t 
   }
   if (nf > cap_fwd || nr > cap_rev || !hits_fwd || !hits_rev) return (nf || nr) ? HAWK_E_CAPACITY : HAWK_OK;
   uint32_t *d_f = nullptr, *d_r = nullptr;
-  POOLCHK(&d_f, std::max<uint64_t>(nf, 1) * 4);
-  POOLCHK(&d_r, std::max<uint64_t>(nr, 1) * 4);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_f, std::max<uint64_t>(nf, 1) * 4);
+  TEMPCHK(tmp, &d_r, std::max<uint64_t>(nr, 1) * 4);
   hawk_launch_emit_hits(ctx->stream, d, sp.bph, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
                         hs->offsets.as<uint64_t>(), nf, d_f, d_r);
   HIPCHK(hipGetLastError());
   if (nf) HIPCHK(hipMemcpyAsync(hits_fwd, d_f, nf * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (nr) HIPCHK(hipMemcpyAsync(hits_rev, d_r, nr * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hawk_pool_free(d_f); hawk_pool_free(d_r);
   return HAWK_OK;
 }
 
@@ -548,8 +568,9 @@ int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_
   const size_t nn = m->n_nodes, nt = m->n_trees;
   double *d_x = nullptr, *d_th = nullptr, *d_v = nullptr, *d_o = nullptr;
   int32_t *d_off = nullptr, *d_f = nullptr, *d_l = nullptr, *d_r = nullptr;
-  POOLCHK(&d_x, n * n_features * 8); POOLCHK(&d_off, (nt + 1) * 4); POOLCHK(&d_f, nn * 4); POOLCHK(&d_l, nn * 4); POOLCHK(&d_r, nn * 4);
-  POOLCHK(&d_th, nn * 8); POOLCHK(&d_v, nn * 8); POOLCHK(&d_o, n * 8);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_x, n * n_features * 8); TEMPCHK(tmp, &d_off, (nt + 1) * 4); TEMPCHK(tmp, &d_f, nn * 4); TEMPCHK(tmp, &d_l, nn * 4); TEMPCHK(tmp, &d_r, nn * 4);
+  TEMPCHK(tmp, &d_th, nn * 8); TEMPCHK(tmp, &d_v, nn * 8); TEMPCHK(tmp, &d_o, n * 8);
   hipStream_t st = ctx->stream;
   HIPCHK(hipMemcpyAsync(d_x, feats, n * n_features * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_off, m->tree_off, (nt + 1) * 4, hipMemcpyHostToDevice, st));
@@ -562,8 +583,6 @@ int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d_o, n * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  hawk_pool_free(d_x); hawk_pool_free(d_off); hawk_pool_free(d_f); hawk_pool_free(d_l); hawk_pool_free(d_r); hawk_pool_free(d_th);
-  hawk_pool_free(d_v); hawk_pool_free(d_o);
   return HAWK_OK;
 }
 
@@ -1188,8 +1207,9 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
   char *d_wt = nullptr, *d_sg = nullptr, *d_p = nullptr;
   double *d_tab = nullptr, *d_out = nullptr;
   int* d_status = nullptr;
-  POOLCHK(&d_wt, n * len); POOLCHK(&d_sg, n * len); POOLCHK(&d_p, n * 2);
-  POOLCHK(&d_tab, 336 * 8); POOLCHK(&d_out, n * 8); POOLCHK(&d_status, 4);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_wt, n * len); TEMPCHK(tmp, &d_sg, n * len); TEMPCHK(tmp, &d_p, n * 2);
+  TEMPCHK(tmp, &d_tab, 336 * 8); TEMPCHK(tmp, &d_out, n * 8); TEMPCHK(tmp, &d_status, 4);
   HIPCHK(hipMemcpyAsync(d_wt, wt, n * len, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_sg, sg, n * len, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_p, pam2, n * 2, hipMemcpyHostToDevice, ctx->stream));
@@ -1202,7 +1222,6 @@ int hawk_cfd(hawk_ctx* ctx, const char* wt, const char* sg, uint32_t len, const 
   HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hawk_pool_free(d_wt); hawk_pool_free(d_sg); hawk_pool_free(d_p); hawk_pool_free(d_tab); hawk_pool_free(d_out); hawk_pool_free(d_status);
   return status;
 }
 
@@ -1646,7 +1665,8 @@ int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const u
   POOLCHK(&g->d_codes, ncode); POOLCHK(&g->d_flags, std::max<size_t>(n_lines, 1));
   if (n_lines) {
     uint8_t* d_text = nullptr; uint64_t *d_lo = nullptr, *d_go = nullptr;
-    POOLCHK(&d_text, text_len); POOLCHK(&d_lo, (n_lines + 1) * 8); POOLCHK(&d_go, n_lines * 8);
+    PoolScope tmp;
+    TEMPCHK(tmp, &d_text, text_len); TEMPCHK(tmp, &d_lo, (n_lines + 1) * 8); TEMPCHK(tmp, &d_go, n_lines * 8);
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemcpyAsync(d_text, text, text_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_lo, line_off, (n_lines + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1658,7 +1678,6 @@ int hawk_gt_parse(hawk_ctx* ctx, const uint8_t* text, uint64_t text_len, const u
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]);
-    hawk_pool_free(d_text); hawk_pool_free(d_lo); hawk_pool_free(d_go);
   }
   *out = g;
   return HAWK_OK;
@@ -1730,11 +1749,12 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   }
   uint32_t *d_vl = nullptr, *d_cnt = nullptr; uint8_t* d_va = nullptr; int32_t *d_r0 = nullptr, *d_ch = nullptr;
   unsigned long long* d_bal = nullptr;
-  POOLCHK(&d_vl, (size_t)n_var * 4); POOLCHK(&d_va, n_var); POOLCHK(&d_r0, (size_t)n_var * 4);
-  POOLCHK(&d_ch, (size_t)n_var * 4); POOLCHK(&d_cnt, (size_t)n_cols * 2 * 4);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_vl, (size_t)n_var * 4); TEMPCHK(tmp, &d_va, n_var); TEMPCHK(tmp, &d_r0, (size_t)n_var * 4);
+  TEMPCHK(tmp, &d_ch, (size_t)n_var * 4); TEMPCHK(tmp, &d_cnt, (size_t)n_cols * 2 * 4);
   POOLCHK(&g->d_ioff, (size_t)(n_cols + 1) * 8);
   uint64_t* d_ioff = g->d_ioff;
-  POOLCHK(&d_bal, (size_t)n_cols * n_chunk * 8);
+  TEMPCHK(tmp, &d_bal, (size_t)n_cols * n_chunk * 8);
   POOLCHK(&g->d_col_off, (size_t)(n_cols + 1) * 8); POOLCHK(&g->d_delta, (size_t)n_cols * 8);
   HIPCHK(hipMemcpyAsync(d_vl, var_line, (size_t)n_var * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_va, var_allele, n_var, hipMemcpyHostToDevice, st));
@@ -1772,7 +1792,6 @@ int hawk_gt_lists(hawk_gt* g, const uint32_t* var_line, const uint8_t* var_allel
   memcpy(col_off, off.data(), (size_t)(n_cols + 1) * 8);
   g->n_entries = ne;
   g->n_indel = ni;
-  hawk_pool_free(d_vl); hawk_pool_free(d_va); hawk_pool_free(d_r0); hawk_pool_free(d_ch); hawk_pool_free(d_cnt); hawk_pool_free(d_bal);
   return HAWK_OK;
 }
 
@@ -1805,7 +1824,8 @@ int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* we
   HIPCHK(hipSetDevice(ctx->device));
   const size_t nw = HAWK_DEEPCPF1_NPARAMS;
   char* d_s = nullptr; float *d_w = nullptr, *d_o = nullptr; int* d_status = nullptr;
-  POOLCHK(&d_s, n * 34); POOLCHK(&d_w, nw * 4); POOLCHK(&d_o, n * 4); POOLCHK(&d_status, 4);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_s, n * 34); TEMPCHK(tmp, &d_w, nw * 4); TEMPCHK(tmp, &d_o, n * 4); TEMPCHK(tmp, &d_status, 4);
   HIPCHK(hipMemcpyAsync(d_s, seqs34, n * 34, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_w, weights, nw * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream));
@@ -1815,7 +1835,6 @@ int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* we
   HIPCHK(hipMemcpyAsync(out, d_o, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hawk_pool_free(d_s); hawk_pool_free(d_w); hawk_pool_free(d_o); hawk_pool_free(d_status);
   return status;
 }
 
@@ -1839,10 +1858,11 @@ int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_m
   const size_t nn = m->n_nodes, nt = m->n_trees;
   char* d_s = nullptr; int32_t *d_off = nullptr, *d_f = nullptr, *d_l = nullptr, *d_r = nullptr;
   double *d_th = nullptr, *d_v = nullptr, *d_o = nullptr, *d_fo = nullptr; int* d_status = nullptr;
-  POOLCHK(&d_s, n * 30); POOLCHK(&d_off, (nt + 1) * 4); POOLCHK(&d_f, nn * 4);
-  POOLCHK(&d_l, nn * 4); POOLCHK(&d_r, nn * 4); POOLCHK(&d_th, nn * 8); POOLCHK(&d_v, nn * 8);
-  POOLCHK(&d_o, n * 8); POOLCHK(&d_status, 4);
-  if (feats_out) POOLCHK(&d_fo, n * 627 * 8);
+  PoolScope tmp;
+  TEMPCHK(tmp, &d_s, n * 30); TEMPCHK(tmp, &d_off, (nt + 1) * 4); TEMPCHK(tmp, &d_f, nn * 4);
+  TEMPCHK(tmp, &d_l, nn * 4); TEMPCHK(tmp, &d_r, nn * 4); TEMPCHK(tmp, &d_th, nn * 8); TEMPCHK(tmp, &d_v, nn * 8);
+  TEMPCHK(tmp, &d_o, n * 8); TEMPCHK(tmp, &d_status, 4);
+  if (feats_out) TEMPCHK(tmp, &d_fo, n * 627 * 8);
   hipStream_t st = ctx->stream;
   HIPCHK(hipMemcpyAsync(d_s, seqs30, n * 30, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_off, m->tree_off, (nt + 1) * 4, hipMemcpyHostToDevice, st));
@@ -1859,8 +1879,6 @@ int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_m
   if (feats_out) HIPCHK(hipMemcpyAsync(feats_out, d_fo, n * 627 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  hawk_pool_free(d_s); hawk_pool_free(d_off); hawk_pool_free(d_f); hawk_pool_free(d_l); hawk_pool_free(d_r); hawk_pool_free(d_th);
-  hawk_pool_free(d_v); hawk_pool_free(d_o); hawk_pool_free(d_status); if (d_fo) hawk_pool_free(d_fo);
   return status;
 }
 

@@ -41,6 +41,24 @@ void hawk_pool_trim();                          // hipFree every cached block of
     if (rc_) return rc_;                                                         \
   } while (0)
 
+// Temporaries of one C-ABI call: whatever TEMPCHK allocated goes back to the pool when the call returns, on the error paths
+// too (the frees used to sit at the end of the success path only).  Blocks return to the pool, not to hipFree: work still
+// queued on the context's stream keeps them valid, and the next user is on the same stream.
+struct PoolScope {
+  std::vector<void*> held;
+  ~PoolScope() { for (void* q : held) hawk_pool_free(q); }
+  int alloc(void** out, size_t bytes) {
+    int rc = hawk_pool_alloc(out, bytes);
+    if (!rc) held.push_back(*out);
+    return rc;
+  }
+};
+#define TEMPCHK(scope, ptr, bytes)                                               \
+  do {                                                                           \
+    int rc_ = (scope).alloc(reinterpret_cast<void**>(ptr), (bytes));             \
+    if (rc_) return rc_;                                                         \
+  } while (0)
+
 // grow-only device buffer
 struct DevBuf {
   void* p = nullptr;

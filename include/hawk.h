@@ -48,7 +48,10 @@ typedef struct hawk_table hawk_table;
 #define HAWK_GUIDESEQPAD 10 /* guide.py:21 */
 #define HAWK_MAX_CORE 44    /* guidelen + pamlen limit: the 20-nt padded window must fit 64 bits */
 
-/* ---- context ----------------------------------------------------------------------- */
+/* ---- context -----------------------------------------------------------------------
+ * One context = one HIP stream per device and process.  hawk_init for a device that already has a context returns that
+ * same context (reference-counted; the last hawk_destroy releases it): the library serves device memory from a caching
+ * allocator whose reuse of freed blocks is ordered by that single stream. */
 int hawk_device_count(int* n);
 int hawk_init(int device, hawk_ctx** out);
 void hawk_destroy(hawk_ctx* ctx);

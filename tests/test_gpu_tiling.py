@@ -215,3 +215,42 @@ def test_soft_masked_reference_is_upper_cased_like_the_reference_does():
         out.append(_tiled_groups(mg))
     assert len(out[0]) > 500 and out[0].keys() == out[1].keys()
     assert all(out[0][k][0] == out[1][k][0] and _same(out[0][k][1], out[1][k][1]) for k in out[0])
+
+
+def test_record_longer_than_the_flank_at_a_seam_is_refused():
+    """a record that only partly lies in a tile string is left to the neighbour that holds it whole - fine while
+    it stays clear of what the tile scans.  A deletion longer than the flank that straddles the edge of a tile STRING and
+    reaches into the tile's own range would map the seam differently on its two sides: prepare_tile refuses it."""
+    reg = synth.make_region(9901, "chrL", 24_000, 1_000, 22_000)
+    seq = reg.contig_seq
+    reg.samples = ["S0000", "S0001"]
+    gt = np.array([[1, 0], [0, 1]], dtype=np.uint8)
+    pam = PAM("NGG", False, True)
+    pam.encode(0)
+    trs0 = TiledRegionSearch(lambda lo, hi: seq[lo - 1:hi], reg.contig, reg.startp, reg.stopp, VariantPanel.from_region(reg), pam, 20, False,
+                             tile_nt=4000, flank=200)
+    t1 = trs0.tiles[1]
+    # a 300-nt deletion starting before tile 1's string and ending inside its flank, 40 nt short of its own range: refused
+    pos = t1.seq_lo - 100
+    span = t1.own_lo - 40 - pos
+    assert span > trs0.flank
+    reg.variants = [synth.VariantSite(pos, seq[pos - 1:pos - 1 + span + 1], seq[pos - 1], 0.5, gt)]
+    trs = TiledRegionSearch(lambda lo, hi: seq[lo - 1:hi], reg.contig, reg.startp, reg.stopp, VariantPanel.from_region(reg), pam, 20, False,
+                            tile_nt=4000, flank=200)
+    with pytest.raises(ValueError, match="flank is too small"):
+        trs.prepare_tile(1)
+    # the same deletion with a flank that holds it: every tile prepares, and the tiled groups are the one-piece groups
+    trs = TiledRegionSearch(lambda lo, hi: seq[lo - 1:hi], reg.contig, reg.startp, reg.stopp, VariantPanel.from_region(reg), pam, 20, False,
+                            tile_nt=4000, flank=1024)
+    mg = trs.run()
+    want, _res = _oracle_groups(reg, "NGG", 20, False)
+    got = _tiled_groups(mg)
+    assert set(got) == set(want)
+    # a short record cut by the far edge of a tile string (inside the flank, far from the own range) is simply left out
+    pos = trs0.tiles[0].seq_hi - 2
+    reg.variants = [synth.VariantSite(pos, seq[pos - 1:pos + 5], seq[pos - 1], 0.5, gt)]
+    trs = TiledRegionSearch(lambda lo, hi: seq[lo - 1:hi], reg.contig, reg.startp, reg.stopp, VariantPanel.from_region(reg), pam, 20, False,
+                            tile_nt=4000, flank=200)
+    mg = trs.run()
+    want, _res = _oracle_groups(reg, "NGG", 20, False)
+    assert set(_tiled_groups(mg)) == set(want)

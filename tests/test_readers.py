@@ -319,3 +319,32 @@ def test_vcf_index_streams_and_reads_only_what_it_returns(tmp_path, monkeypatch)
             assert len(blk) == len(want) and (len(want) == 0 or bytes(blk.text[-1:]) == b"\n")
         if hi - lo < 10_000:
             assert 0 < len(set(inflated)) < 0.2 * (len(vb._src._c_off) - 1)
+
+
+def test_vcf_index_rejects_truncated_and_one_tab_lines(tmp_path):
+    """CHROM / POS come from the first 64 bytes of a line - a short body line must not borrow the tabs of the
+    line behind it (it is malformed, variant.py would fail on it too), and a header line longer than an index chunk is
+    carried across chunks."""
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+    good = "chrZ\t100\t.\tA\tG\t.\tPASS\tAF=0.5\tGT\t0|1\n"
+    for bad_line in ("chrZ\t200\n", "chrZ\n", "chrZ\t\tx\tA\tG\t.\tPASS\t.\tGT\t0|1\n"):
+        f = tmp_path / "bad.vcf"
+        f.write_text(head + good + bad_line + good.replace("100", "300"))
+        with pytest.raises(ValueError, match="Malformed VCF record"):
+            readers.VCF(str(f), 0, True)
+    f = tmp_path / "trunc.vcf"
+    f.write_text(head + good + "chrZ\t200")  # truncated final record, no newline
+    with pytest.raises(ValueError, match="Malformed VCF record"):
+        readers.VCF(str(f), 0, True)
+    # a #CHROM line longer than the index chunk (thousands of samples): read through the carry path
+    names = [f"S{i:05d}" for i in range(3000)]
+    long_head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"
+    f = tmp_path / "wide.vcf"
+    f.write_text(long_head + "chrZ\t100\t.\tA\tG\t.\tPASS\tAF=0.5\tGT\t" + "\t".join(["0|1"] * 3000) + "\n")
+    old = readers._TextSource.CHUNK
+    readers._TextSource.CHUNK = 4096
+    try:
+        v = readers.VCF(str(f), 0, True)
+    finally:
+        readers._TextSource.CHUNK = old
+    assert v.samples == names and v.phased and list(v._pos) == [100]
