@@ -52,6 +52,7 @@ LIST_BYTES = 4  # one u32 hand-over entry per guide row (count pass writes it, k
 REC_BYTES = 32  # one record per carried variant of a chromosome copy (hawk_hx.h HxVar): what the fused step reads instead of planes
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
 PROFILE_TRAFFIC_R3 = os.path.join(ROOT, "profiles", "r03_traffic.json")
+PROFILE_C5_PMC = os.path.join(ROOT, "profiles", "r03_c5_pmc.json")  # per-wave SQ counters of the off-target kernels at the full C5 size
 REFERENCE_TIMING = os.path.join(ROOT, "profiles", "r02_reference_python_timing.json")  # tools/time_reference.py, build container
 
 
@@ -588,6 +589,27 @@ def cpu_baseline(reg, pam, args, mm, pt):
                       f"({cand} candidates, {dt:.1f} s, 1 thread of {usable_cores()} usable)"}
 
 
+def cpu_baseline_c4(seq, panel, n_block, pam, args, mm, pt):
+    """The oracle on a bounded sample of the C4 workload: a 1 Mb window of the contig behind the N block, the panel's own
+    variants and genotypes there, REF + the first --cpu-haps chromosome copies; one host thread."""
+    from crisprhawk_hip import synth
+    lo = n_block + 500_000
+    hi = min(lo + 1_000_000, len(seq) - 1_000)
+    startp = lo - 100
+    sub = bytes(seq[startp - 1:hi + 100]).decode()
+    v_lo, v_hi = int(np.searchsorted(panel.pos, startp + 1)), int(np.searchsorted(panel.pos, hi + 100 - 12))
+    n_s = min(len(panel.samples), max(1, args.cpu_haps // 2))
+    G = panel.genotypes.dense(v_lo, v_hi, 0, 2 * n_s)
+    reg = synth.SynthRegion("chr22w", sub, 101, 101 + (hi - lo))
+    reg.samples = list(panel.samples[:n_s])
+    shift = startp - 1  # window position 1 = contig position startp
+    reg.variants = [synth.VariantSite(int(panel.pos[v_lo + k]) - shift, panel.ref[v_lo + k], panel.alt[v_lo + k], float(panel.af[v_lo + k]),
+                                      G[k].reshape(n_s, 2).astype(np.uint8)) for k in range(v_hi - v_lo)]
+    out = cpu_baseline(reg, pam, args, mm, pt)
+    out["sample"] = f"a {hi - lo}-nt window of the contig behind the N block, the panel's calls of its first {n_s} samples: " + out["sample"]
+    return out
+
+
 def _cpu_worker(wid, n_workers, batches, argv, barrier, q):
     """One oracle worker (own process, spawn context - the parent has initialised HIP): prepare its batches untimed,
     meet the others at the barrier, then search + CFDon back to back; report start / end stamps and candidates."""
@@ -707,14 +729,25 @@ def run_c4(args, R: Ranks):
                                      f"region-tiled (BASELINE.json configs[3])", "pam": args.pam, "guidelen": args.guidelen,
                          "right": args.right, "tiles": len(trs.tiles), "tile_nt": args.tile_nt, "variant_sites": len(panel.pos),
                          "partition": "sample blocks of one panel, REF on every rank" if not args.weak else "own columns per rank",
-                         "step": "per tile: hawk_xplan_run -> hawk_search (+CFDon, NA on N) -> hawk_table_collapse",
+                         "step": "per tile: search (+CFDon, NA on N) straight from the tile's expansion plan (hawk_xplan_view: no plane "
+                                 "written) -> hawk_table_collapse; tiles without variants search their REF planes",
                          "candidates_per_step": cand_all, "guide_rows_rank0": rows, "report_groups_rank0": groups,
                          "scanned_positions_per_step": pos_all})
-        step_bytes = READ_BYTES_PER_POS * positions + ROW_BYTES * rows
-        out["roofline"] = {"bound": "hbm", "kernel": "hawk_search (k_search_count + k_emit_list, summed over tiles)",
-                           "achieved": step_bytes / (search_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": step_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "launch_ms": search_ms,
-                           "algorithmic_bytes_per_launch": step_bytes}
+        records = sum(s.get("records", 0) for s in st)
+        emit_ms = sum(s.get("v_emit_ms", 0.0) for s in st)
+        step_bytes = ROW_BYTES * rows + 2 * REC_BYTES * records
+        emit_bytes = ROW_BYTES * rows + REC_BYTES * records
+        out["roofline"] = {"bound": "hbm", "kernel": "k_vsearch<1> (summed over tiles)",
+                           "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9 if emit_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": emit_bytes / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if emit_ms else 0.0, "traffic": None, "launch_ms": emit_ms,
+                           "algorithmic_bytes_per_launch": emit_bytes, "records": records,
+                           "step_level": {"algorithmic_bytes": step_bytes, "ms": search_ms,
+                                          "frac": step_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if search_ms else None,
+                                          "what": "records read by both passes (32 B each) + rows written once (74 B), all tiles"},
+                           "survey_priced": {"bytes": 0.75 * positions + ROW_BYTES * rows,
+                                             "effective_GBps": (0.75 * positions + ROW_BYTES * rows) / (search_ms * 1e-3) / 1e9 if search_ms else None}}
+        if R.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_c4(seq, panel, n_block, pam, args, *(cfd if cfd else (None, None)))
         out["kernels_ms"] = {"search_all_tiles": search_ms, "collapse_all_tiles": collapse_ms,
                              "wall_per_step": elapsed / args.steps * 1e3}
         out["per_tile"] = [{k: s[k] for k in ("tile", "n_hap", "rows", "groups", "search_ms", "collapse_ms")} for s in st]
@@ -773,15 +806,32 @@ def run_c5(args, R: Ranks):
         out["metric"] = "PAM-site x guide comparisons/sec (off-target enumeration)"
         out["unit"] = "site-guide pairs/s"
         pairs = tm["n_sites"] * len(guides)
-        ach = pairs * 10 / (avg("match_ms") * 1e-3) if avg("match_ms") else 0.0  # ~10 integer lane-ops per all-pairs compare
-        out["roofline"] = {"bound": "valu", "kernel": "k_ot_match_seeded_lds (pigeonhole-seeded match)", "achieved": ach / 1e12,
-                           "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-ops/s (all-pairs equivalent: 10 integer ops per site-guide pair)",
-                           "frac": ach / VALU_PEAK_LANE_OPS, "traffic": None, "launch_ms": avg("match_ms"),
-                           "note": "the seeded kernel visits ~ (mm+1)/4^4 of the pairs; 'achieved' prices the pairs it RESOLVES at the "
-                                   "all-pairs cost, so frac > 1 is possible and means the filter beats brute force at the VALU peak",
-                           "scan_kernel": {"kernel": "k_scan_raw", "launch_ms": avg("scan_ms"),
-                                           "achieved_GBps": 0.75 * tm["scanned_positions"] / (avg("scan_ms") * 1e-3) / 1e9 if avg("scan_ms") else None,
-                                           "frac_of_hbm": 0.75 * tm["scanned_positions"] / (avg("scan_ms") * 1e-3) / 1e9 / HBM_PEAK_GBS if avg("scan_ms") else None}}
+        # What bounds the seeded match is vector-instruction issue (it moves almost nothing through HBM): `achieved` = the
+        # wave64 VALU instructions the kernel EXECUTES per second x 64 lanes - counted by rocprofv3 (SQ_INSTS_VALU x SQ_WAVES
+        # of the committed profile, profiles/r03_c5_pmc.json, scaled by the pairs of this run) over the launch time measured
+        # here - against the chip's integer lane-op peak.  Skipped pairs are not priced: that is the filter's gain and shows
+        # in `value`, not in the fraction.
+        pmc = json.load(open(PROFILE_C5_PMC)) if os.path.exists(PROFILE_C5_PMC) else None
+        roof = {"bound": "valu", "kernel": "k_ot_match_seeded_lds (pigeonhole-seeded match)", "achieved": None,
+                "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-ops/s (executed wave64 VALU instructions x 64)", "frac": None,
+                "traffic": None, "launch_ms": avg("match_ms")}
+        if pmc and avg("match_ms"):
+            k = pmc["k_ot_match_seeded_lds"]
+            c = pmc["_config"]
+            ref_pairs = None
+            insts = k["waves"] * k["per_wave"]["SQ_INSTS_VALU"]
+            same = (c["genome_nt"], c["guides"], c["pam"], c["guidelen"], c["mm"]) == (args.genome_nt, args.guides, pam_s, guidelen, args.mm)
+            roof["profile"] = {"valu_insts_per_launch": insts, "waves": k["waves"], "valu_insts_per_wave": k["per_wave"]["SQ_INSTS_VALU"],
+                               "lds_insts_per_wave": k["per_wave"]["SQ_INSTS_LDS"], "lds_bank_conflict_cycles_per_wave": k["per_wave"]["SQ_LDS_BANK_CONFLICT"],
+                               "same_config_as_this_run": same}
+            if same:
+                ach = insts * 64 / (avg("match_ms") * 1e-3)
+                roof["achieved"], roof["frac"] = ach / 1e12, ach / VALU_PEAK_LANE_OPS
+                roof["lane_ops_per_resolved_pair"] = insts * 64 / pairs
+        roof["scan_kernel"] = {"kernel": "k_scan_raw", "launch_ms": avg("scan_ms"),
+                               "achieved_GBps": 0.75 * tm["scanned_positions"] / (avg("scan_ms") * 1e-3) / 1e9 if avg("scan_ms") else None,
+                               "frac_of_hbm": 0.75 * tm["scanned_positions"] / (avg("scan_ms") * 1e-3) / 1e9 / HBM_PEAK_GBS if avg("scan_ms") else None}
+        out["roofline"] = roof
         out["kernels_ms"] = {k: avg(k) for k in ("scan_ms", "sites_ms", "match_ms", "total_ms")}
         out["index_build_s"] = t_idx
     if R.world > 1:

@@ -25,9 +25,9 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import parallel
+from . import _lib, parallel
 from .hapset import GroupTable
-from .workload import HapInfo, RowLabel, ScanOwnership, _expand_rows, _ref_only_set, _variant_table, carried_lists_on_device
+from .workload import HapInfo, RowLabel, ScanOwnership, _expand_rows_gt, _ref_only_set, _variant_table, invert_on_device
 
 PADDING = 100  # region_constructor.py:21
 
@@ -138,6 +138,7 @@ class TiledRegionSearch:
                  sample_range: Optional[Tuple[int, int]] = None):
         self.fetch, self.contig, self.startp, self.stopp, self.panel = fetch, contig, startp, stopp, panel
         self.pam, self.guidelen, self.right, self.device = pam, guidelen, bool(right), device
+        self.fused = True  # False: materialise every tile's planes (hawk_xplan_run) and search those - round 2's step, for A/B
         self.L = guidelen + len(pam)
         self.guard = self.L + 2 * 10 + 8
         self.flank = flank if flank is not None else max(1024, 8 * self.guard)
@@ -194,14 +195,13 @@ class TiledRegionSearch:
         tab = _variant_table(p.pos[v_lo:v_hi], p.ref[v_lo:v_hi], p.alt[v_lo:v_hi], seq, tile.seq_lo)
         r0, chain = tab[0], tab[2]
         # the tile's genotype rectangle is inverted into per-copy carried lists on the device (hawk_gt_lists)
-        col_off, col_delta, hv_idx, hv_o = carried_lists_on_device(ref_set._ctx, p.genotypes.dense(v_lo, v_hi, 2 * slo, 2 * shi), r0, chain)
-        counts = np.diff(col_off.astype(np.int64))
-        live = np.flatnonzero(counts)
-        if len(live) == 0:
+        # ... and stays there: plan, checks, segments and the seams' reverse look-ups are built from the lists in place
+        g, col_off = invert_on_device(ref_set._ctx, p.genotypes.dense(v_lo, v_hi, 2 * slo, 2 * shi), r0, chain)
+        if int(col_off[-1]) == 0:
+            _lib.lib().hawk_gt_destroy(g)
             return self._keep(t, PreparedTile(tile, ref_set, None, [ref_label], 1))
-        tot = col_delta[live]
-        ds, info, _ms, kept = _expand_rows(ref_set, seq, tile.seq_lo, tile.seq_hi, pamlen, p.samples[slo:shi], tab, live, counts[live],
-                                           hv_idx, hv_o, tot, self.device, own=own, keep_plan=keep_plan)
+        ds, info, _ms, kept = _expand_rows_gt(ref_set, seq, tile.seq_lo, tile.seq_hi, pamlen, p.samples[slo:shi], tab, g, col_off,
+                                              self.device, keep_plan=keep_plan, own=own)
         ref_set.close()
         labels: List[Optional[RowLabel]] = [None] * ds.n_hap
         vid, af, ref, alt = p.vid, p.af, p.ref, p.alt
@@ -224,15 +224,22 @@ class TiledRegionSearch:
 
     # ---- the per-tile device step -----------------------------------------------------------------
     def run_tile(self, t: int, cfd=None, flank_key: Tuple[int, int] = (0, 0), cfd_na_on_ambiguous: bool = True, export: bool = True):
-        """expand -> search (+ CFDon) -> collapse (-> group export) of tile t.  Returns (GroupTable or None, stats)."""
+        """search (+ CFDon) straight from the tile's plan -> collapse (-> group export) of tile t: no haplotype plane is
+        written (hawk_xplan_view); a tile without variants searches its REF set.  Returns (GroupTable or None, stats)."""
         pt = self.prepared[t] or self.prepare_tile(t)
-        ds = pt.expand()
+        fused = pt.plan is not None and self.fused
+        if fused and pt._first is not None:  # the preparation run's planes (content hashes) are not needed again
+            pt._first.close()
+            pt._first = None
+        ds = pt.plan.view() if fused else pt.expand()
         try:
             mm, ptab = cfd if cfd is not None else (None, None)
             tab = ds.search(self.pam.bits, self.pam.bitsrc, len(self.pam), self.guidelen, self.right, mm, ptab, download=False,
                             cfd_na_on_ambiguous=cfd_na_on_ambiguous)
             stats = {"tile": t, "rows": tab.n_rows, "candidates": tab.n_candidates, "hits": tab.n_hits, "n_hap": ds.n_hap,
-                     "search_ms": tab.timing["total_ms"], "scanned_positions": tab.timing["scanned_positions"]}
+                     "search_ms": tab.timing["total_ms"], "scanned_positions": tab.timing["scanned_positions"],
+                     "v_count_ms": tab.timing.get("v_count_ms", 0.0), "v_emit_ms": tab.timing.get("v_emit_ms", 0.0),
+                     "records": int(getattr(pt.plan, "n_records", 0)) if pt.plan is not None else 0}
             tab.collapse(flank_key, download_perm=False)
             stats["collapse_ms"], stats["groups"] = tab.collapse_ms, tab.n_groups
             g = None
@@ -244,8 +251,8 @@ class TiledRegionSearch:
         finally:
             if pt.plan is None:
                 pt._first = ds  # REF-only tile: the prepared set is the only copy
-            else:
-                ds.close()
+            elif not fused:
+                ds.close()      # (a view lives and dies with its plan)
 
     # ---- the whole region ---------------------------------------------------------------------------
     def run(self, cfd=None, flank_key: Tuple[int, int] = (0, 0), cfd_na_on_ambiguous: bool = True, keep_plans: bool = False):

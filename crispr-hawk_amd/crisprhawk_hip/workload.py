@@ -598,7 +598,7 @@ def _expand_rows(ref_set, seq: str, startp: int, stopp: int, pamlen: int, sample
 
 
 def _expand_rows_gt(ref_set, seq, startp: int, stopp: int, pamlen: int, samples: List[str], tab, g, col_off: np.ndarray, device,
-                    keep_plan: bool = False):
+                    keep_plan: bool = False, own: Optional[ScanOwnership] = None):
     """_expand_rows for lists that are still on the device (`g`: a hawk_gt after hawk_gt_lists): the plan is created from
     them in place (hawk_xplan_create_gt) - checks, position-map segments and the scan bounds' reverse look-ups are kernels
     over the lists; the host sees a few words per ROW (lengths, content hashes, two look-ups) and decides which rows
@@ -615,9 +615,13 @@ def _expand_rows_gt(ref_set, seq, startp: int, stopp: int, pamlen: int, samples:
     u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
     arrs = [u32(r0), u32(span), u32(alt_off), u32(altlen), np.ascontiguousarray(chain, dtype=np.int32), np.ascontiguousarray(alt_codes)]
     xh, n_hap_c = C.c_void_p(), C.c_uint32(0)
-    lo_g, hi_g = startp + 100, stopp - 100
+    # where the scan bounds start from: the region's own rule (search_guides.py:49-84) or, for a tile of a larger region, its
+    # seams; the end-of-region clamp is the region's and cannot be reproduced by a tile (divergences)
+    lo_g = startp + 100 if (own is None or own.own_lo is None) else own.own_lo
+    hi_g = stopp - 100 if (own is None or own.own_hi is None) else own.own_hi
     rc = L.hawk_xplan_create_gt(ref_set._h, g, len(r0), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), _p(arrs[5]),
-                                len(alt_codes), C.c_int64(startp), 1, C.c_int64(lo_g), C.c_int64(hi_g), C.byref(n_hap_c), C.byref(xh))
+                                len(alt_codes), C.c_int64(startp), 1 if own is None else 0, C.c_int64(lo_g), C.c_int64(hi_g),
+                                C.byref(n_hap_c), C.byref(xh))
     if rc == _lib.HAWK_E_OVERLAP:
         raise HaplotypeBuildError("a chromosome copy carries overlapping variants")
     if rc == _lib.HAWK_E_CLAMP:
@@ -641,8 +645,10 @@ def _expand_rows_gt(ref_set, seq, startp: int, stopp: int, pamlen: int, samples:
         _lib.check(L.hawk_xplan_segments(plan._x, _p(so), _p(sr), _p(sg), C.c_uint64(nseg.value), None), "hawk_xplan_segments")
         return so.astype(np.int64), sr, sg
     haps = RowMeta(None, None, None, hap_len, alias, startp, fetch=fetch, rev={lo_g: rev0, hi_g: rev1})
-    haps.compute_scans(startp, stopp, pamlen, None)
+    haps.compute_scans(startp, stopp, pamlen, own)
     _lib.check(L.hawk_xplan_finish_meta(plan._x, _p(haps.scan_lo.astype(np.int32)), _p(haps.scan_hi.astype(np.int32))), "hawk_xplan_finish_meta")
+    if own is not None and own.partner is not None:
+        _lib.check(L.hawk_xplan_set_ref_partner_range(plan._x, int(own.partner[0]), int(own.partner[1])), "hawk_xplan_set_ref_partner_range")
     is_ref = np.zeros(n_hap, dtype=np.uint8)
     is_ref[0] = 1
     plan.ref_index, plan.is_ref = 0, is_ref

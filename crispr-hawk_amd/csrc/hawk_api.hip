@@ -925,10 +925,12 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
                                        hs->cflags.as<uint32_t>(), hs->ckeys.as<uint32_t>(), hs->cvals.as<uint32_t>(), hs->cgoff.as<uint64_t>(),
                                        hs->cgc.as<uint8_t>(), hs->cgc.as<uint8_t>() + n))
           return HAWK_E_HIP;
-        if (verify)  // slot_of_row = cflags, slot -> group number = cocc (hawk_launch_collapse_hash2's arguments above)
-          hawk_launch_collapse_verify_rows(ctx->stream, t->cols, hs->d_is_ref, n, (int)t->guidelen, (int)t->pamlen, (int)flank_up, (int)flank_down,
-                                           hs->cvals.as<uint32_t>() + n, hs->cflags.as<uint32_t>(), hs->cocc.as<uint32_t>(), hs->cgoff.as<uint64_t>(),
-                                           hs->ccnt.as<unsigned long long>() + 3);
+        if (verify) {  // slot_of_row = cflags, slot -> group number = cocc (hawk_launch_collapse_hash2's arguments above)
+          if ((rc = hs->cfull.reserve(ng * 64 + 64))) return rc;
+          hawk_launch_collapse_verify_rows(ctx->stream, t->cols, hs->d_is_ref, n, (uint32_t)ng, (int)t->guidelen, (int)t->pamlen, (int)flank_up,
+                                           (int)flank_down, hs->cvals.as<uint32_t>() + n, hs->cflags.as<uint32_t>(), hs->cocc.as<uint32_t>(),
+                                           hs->cgoff.as<uint64_t>(), hs->cfull.p, hs->ccnt.as<unsigned long long>() + 3);
+        }
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + ng, &n, 8, hipMemcpyHostToDevice, ctx->stream));

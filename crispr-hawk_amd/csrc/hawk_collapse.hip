@@ -156,28 +156,42 @@ __global__ __launch_bounds__(256) void k_collapse_verify(GuideCols c, const uint
   const unsigned long long b = __ballot(bad);
   if (b && (threadIdx.x & 63) == 0) atomicAdd(mismatches, (unsigned long long)__popcll(b));
 }
-// The same check in TABLE order, for the hash-table path, which knows every row's group (slot -> group number): a row reads
-// its own key where it lies (coalesced) and only the group's first member elsewhere - a few 10^5 rows that stay in L2 -
-// instead of two scattered keys per row (C3: 0.6 instead of 3.3 ms).
+// The same check in TABLE order, for the hash-table path, which knows every row's group (slot -> group number): first the
+// full key of every group's first member as one 64-byte record per group (k_collapse_head_keys: a few 10^5 records that
+// stay in L2), then every row reads its own key where it lies (coalesced) and its group's record - three gathers per row
+// instead of two scattered keys of nine columns each.
+__global__ __launch_bounds__(256) void k_collapse_head_keys(GuideCols c, const uint8_t* __restrict__ is_ref, uint32_t G, int L, int up, int down,
+                                                            const uint32_t* __restrict__ perm, const uint64_t* __restrict__ group_off,
+                                                            ulonglong4* __restrict__ full) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  const RowKey k = row_key(c, is_ref, perm[group_off[g]], L, up, down);
+  full[2 * (size_t)g] = make_ulonglong4((unsigned long long)k.start, (unsigned long long)k.stop, (unsigned long long)k.sr, k.core[0]);
+  full[2 * (size_t)g + 1] = make_ulonglong4(k.core[1], k.core[2], k.core[3], k.core[4]);
+}
 __global__ __launch_bounds__(256) void k_collapse_verify_rows(GuideCols c, const uint8_t* __restrict__ is_ref, uint64_t n, int L, int up, int down,
-                                                              const uint32_t* __restrict__ perm, const uint32_t* __restrict__ slot_of_row,
-                                                              const uint32_t* __restrict__ slot2rank, const uint64_t* __restrict__ group_off,
-                                                              unsigned long long* __restrict__ mismatches) {
+                                                              const uint32_t* __restrict__ slot_of_row, const uint32_t* __restrict__ slot2rank,
+                                                              const ulonglong4* __restrict__ full, unsigned long long* __restrict__ mismatches) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool bad = false;
   if (i < n) {
-    const uint64_t head = perm[group_off[slot2rank[slot_of_row[i]]]];
-    if (head != i) bad = !same_row(row_key(c, is_ref, i, L, up, down), row_key(c, is_ref, head, L, up, down));
+    const RowKey k = row_key(c, is_ref, i, L, up, down);
+    const size_t g = slot2rank[slot_of_row[i]];
+    const ulonglong4 a = full[2 * g], b = full[2 * g + 1];
+    bad = !(a.x == (unsigned long long)k.start && a.y == (unsigned long long)k.stop && a.z == (unsigned long long)k.sr && a.w == k.core[0] &&
+            b.x == k.core[1] && b.y == k.core[2] && b.z == k.core[3] && b.w == k.core[4]);
   }
-  const unsigned long long b = __ballot(bad);
-  if (b && (threadIdx.x & 63) == 0) atomicAdd(mismatches, (unsigned long long)__popcll(b));
+  const unsigned long long bl = __ballot(bad);
+  if (bl && (threadIdx.x & 63) == 0) atomicAdd(mismatches, (unsigned long long)__popcll(bl));
 }
-void hawk_launch_collapse_verify_rows(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
-                                      int flank_down, const uint32_t* perm, const uint32_t* slot_of_row, const uint32_t* slot2rank,
-                                      const uint64_t* group_off, unsigned long long* mismatches) {
-  if (!n) return;
+void hawk_launch_collapse_verify_rows(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, uint32_t G, int guidelen, int pamlen,
+                                      int flank_up, int flank_down, const uint32_t* perm, const uint32_t* slot_of_row, const uint32_t* slot2rank,
+                                      const uint64_t* group_off, void* full /* 64 B per group */, unsigned long long* mismatches) {
+  if (!n || !G) return;
+  hipLaunchKernelGGL(k_collapse_head_keys, dim3((G + 255) / 256), dim3(256), 0, st, c, is_ref, G, guidelen + pamlen, flank_up, flank_down, perm,
+                     group_off, (ulonglong4*)full);
   hipLaunchKernelGGL(k_collapse_verify_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, is_ref, n, guidelen + pamlen, flank_up,
-                     flank_down, perm, slot_of_row, slot2rank, group_off, mismatches);
+                     flank_down, slot_of_row, slot2rank, (const ulonglong4*)full, mismatches);
 }
 void hawk_launch_collapse_verify(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
                                  int flank_down, const uint32_t* perm, const uint32_t* grp_a, const uint32_t* grp_b, const uint64_t* group_off,

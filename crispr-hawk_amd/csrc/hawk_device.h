@@ -164,9 +164,9 @@ int hawk_launch_collapse(hipStream_t st, const GuideCols& c, const uint8_t* is_r
 void hawk_launch_collapse_verify(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
                                  int flank_down, const uint32_t* perm, const uint32_t* grp_a, const uint32_t* grp_b, const uint64_t* group_off,
                                  unsigned long long* mismatches);
-void hawk_launch_collapse_verify_rows(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
-                                      int flank_down, const uint32_t* perm, const uint32_t* slot_of_row, const uint32_t* slot2rank,
-                                      const uint64_t* group_off, unsigned long long* mismatches);
+void hawk_launch_collapse_verify_rows(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, uint32_t G, int guidelen, int pamlen,
+                                      int flank_up, int flank_down, const uint32_t* perm, const uint32_t* slot_of_row, const uint32_t* slot2rank,
+                                      const uint64_t* group_off, void* full /* 64 B per group */, unsigned long long* mismatches);
 void hawk_launch_rows_equal(hipStream_t st, const HapSetDev& hs, uint32_t n_pairs, const uint32_t* ra, const uint32_t* rb, uint8_t* equal);
 size_t hawk_collapse_full_bytes(uint64_t n);
 size_t hawk_collapse_hash_temp_bytes(uint64_t n, uint32_t C);

@@ -14,12 +14,12 @@ import glob
 import os
 import sys
 
-STREAMING = ("k_scan", "k_emit", "k_compact", "k_pack", "k_search")
+STREAMING = ("k_scan", "k_emit", "k_compact", "k_pack", "k_search_")  # NOT k_vsearch: its reads are 32-byte records at a 32-byte lane stride, for which the raw FETCH_SIZE matches the bytes known to be read (calibrated: 316 MB of records + 11 look-back records per tile = ~0.40 GB expected, 0.418 GB counted)
 
 
 def short(name):
     n = name.replace("void ", "").split("(")[0]
-    return n
+    return n  # template arguments stay: k_vsearch<0> / k_vsearch<1> are two kernels
 
 
 def main():
