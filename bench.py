@@ -190,33 +190,40 @@ def plan_carried(ds) -> int:
     return int(getattr(ds.plan, "n_records", 0))
 
 
-def vsearch_roofline(rows, records, positions, count_ms, emit_ms, traffic_key=None):
-    """The fused step's two kernels (hawk_vsearch.hip).  What they have to move through HBM: every carried-variant record in
-    (32 B, both passes) and every guide row out (74 B, the emit pass) - the haplotype positions themselves are never
-    materialised, so pricing the launch at SURVEY §8(d)'s 0.75 B per scanned position would describe a different
-    algorithm; that figure is reported as `survey_priced` (effective GB/s at the survey's price), not as the fraction."""
-    emit_bytes = ROW_BYTES * rows + REC_BYTES * records
-    count_bytes = REC_BYTES * records
-    cands = [("k_vsearch<1>", emit_ms, emit_bytes), ("k_vsearch<0>", count_ms, count_bytes)]
+def vsearch_roofline(rows, records, positions, hits, L, scored, count_ms, emit_ms, traffic_key=None):
+    """The fused step's two kernels (hawk_vsearch.hip).  `achieved` prices a launch as SURVEY 8(d) prices the work it does
+    - K2: 0.75 B per scanned haplotype position; K3: L/8 B of variant plane per PAM hit + (L + 20)/2 B of code read and a
+    32 B record written per kept row; K4: 2 x ceil(L/2) B read + 8 B written per scored row - over its HIP-event duration.
+    What the kernels really move through HBM is far less (the point of the design: positions are never materialised): every
+    carried-variant record in (32 B) and, in the emit pass, every row out (74 B) - reported as `moved` next to the PMC
+    `traffic`.  Neither kernel is HBM-bound: per-wave counters (profiles/r03_pmc_vsearch_final.txt) show vector-instruction
+    issue and s_waitcnt latency."""
+    k2 = 0.75 * positions
+    k3_read, k3_write = hits * L / 8.0 + rows * (L + 20) / 2.0, rows * 32.0
+    k4 = rows * (2 * ((L + 1) // 2) + 8.0) if scored else 0.0
+    emit_alg, count_alg = k2 + k3_read + k3_write + k4, k2 + k3_read
+    emit_moved, count_moved = ROW_BYTES * rows + REC_BYTES * records, REC_BYTES * records
+    cands = [("k_vsearch<1>", emit_ms, emit_alg, emit_moved), ("k_vsearch<0>", count_ms, count_alg, count_moved)]
     cands.sort(key=lambda c: -c[1])
-    (dom, dom_ms, dom_bytes), (oth, oth_ms, oth_bytes) = cands
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+    (dom, dom_ms, dom_alg, dom_moved), (oth, oth_ms, oth_alg, oth_moved) = cands
+    gbps = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms else 0.0
     traffic = None
     if traffic_key and os.path.exists(PROFILE_TRAFFIC_R3):
         tk = json.load(open(PROFILE_TRAFFIC_R3)).get(traffic_key, {}).get(dom)
         traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]
-    step_bytes = ROW_BYTES * rows + 2 * REC_BYTES * records
-    survey = 0.75 * positions + ROW_BYTES * rows
     tot_ms = count_ms + emit_ms
-    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes, "row_bytes": ROW_BYTES,
-            "record_bytes": REC_BYTES, "records": records,
-            "other_kernel": {"kernel": oth, "launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_bytes,
-                             "frac": (oth_bytes / (oth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if oth_ms else None,
-                             "note": "no table output: bound by instruction issue and LDS / L2 latency, not by HBM"},
-            "survey_priced": {"bytes": survey, "what": "0.75 B per scanned haplotype position (SURVEY 8d, K2) + 74 B per guide row",
-                              "effective_GBps_both_kernels": survey / (tot_ms * 1e-3) / 1e9 if tot_ms else None},
-            "step_level": {"algorithmic_bytes": step_bytes, "what": "records read by both passes (32 B each) + rows written once (74 B)"}}
+    step_alg = k2 + k3_read + k3_write + k4  # every unit priced once for the step
+    return {"bound": "hbm", "kernel": dom, "achieved": gbps(dom_alg, dom_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbps(dom_alg, dom_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_alg,
+            "pricing": "SURVEY 8(d): K2 0.75 B/position + K3 (L/8 B/hit, (L+20)/2 + 32 B/row) + K4 (2*ceil(L/2) + 8 B/scored row)",
+            "moved": {"bytes": dom_moved, "GBps": gbps(dom_moved, dom_ms), "frac_of_hbm_peak": gbps(dom_moved, dom_ms) / HBM_PEAK_GBS,
+                      "what": "what this launch has to move given the plan representation: 32 B per carried-variant record in"
+                              + (" + 74 B per guide row out" if dom.endswith("<1>") else "")},
+            "records": records, "row_bytes": ROW_BYTES, "record_bytes": REC_BYTES,
+            "other_kernel": {"kernel": oth, "launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_alg, "frac": gbps(oth_alg, oth_ms) / HBM_PEAK_GBS,
+                             "moved_bytes": oth_moved},
+            "step_level": {"algorithmic_bytes": step_alg, "what": "SURVEY 8(d) K2 + K3 + K4, every unit priced once",
+                           "moved_bytes": ROW_BYTES * rows + 2 * REC_BYTES * records}}
 
 
 def pam_scan_kernel(ds, pam):
@@ -319,7 +326,8 @@ def run_region(args, R: Ranks):
         out["config"]["step"] = ("encode + search + CFDon from the expansion plan (REF planes + variant records resident; no haplotype plane written)"
                                  if fused else "hawk_search over haplotype planes resident in HBM")
         if fused:
-            out["roofline"] = vsearch_roofline(rows, int(plan_carried(ds)), positions, avg("v_count_ms"), avg("v_emit_ms"), tkey)
+            out["roofline"] = vsearch_roofline(rows, int(plan_carried(ds)), positions, tab.n_hits, args.guidelen + len(pam), score,
+                                               avg("v_count_ms"), avg("v_emit_ms"), tkey)
         else:
             out["roofline"] = search_roofline(pam, positions, rows, avg("count_ms"), avg("emit_list_ms"), avg("emit_ms"), tkey)
         sl = out["roofline"]["step_level"]

@@ -2,9 +2,10 @@
 
 TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg; the product package (crisprhawk_hip) must never import this module.
-Parity status: pinned against reference-generated vectors (tests/test_oracle_golden.py),
-except the off-target enumeration which has no reference implementation to pin to
-("parity unpinned", see hawk_oracle.c).
+Parity status: pinned against reference-generated vectors G1-G10 (tests/test_oracle_golden.py),
+except the off-target enumeration (CRISPRitz, absent: its targets file in G10 is a brute force of
+the call's semantics) and Biopython's Tm_NN behind four Azimuth features ("parity unpinned", see
+hawk_oracle.c).
 """
 
 import ctypes as C
