@@ -258,6 +258,16 @@ class ExpansionPlan:
             self._view = v
         return v
 
+    def cluster_stats(self) -> dict:
+        """hawk_xplan_cluster_stats: the cluster dictionary the first view() built - how many cluster instances the rows hold,
+        how many distinct clusters those are, and whether searches of the view run per distinct cluster."""
+        u, ni, nd, st = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        slots, ms = C.c_uint64(), C.c_float()
+        _lib.check(self._L.hawk_xplan_cluster_stats(self._x, C.byref(u), C.byref(ni), C.byref(nd), C.byref(slots), C.byref(ms), C.byref(st)),
+                   "hawk_xplan_cluster_stats")
+        return {"usable": bool(u.value), "instances": ni.value, "distinct": nd.value, "template_slots": slots.value, "build_ms": ms.value,
+                "status": st.value}
+
     def close(self) -> None:
         v = getattr(self, "_view", None)
         if v is not None:

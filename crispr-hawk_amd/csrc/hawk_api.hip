@@ -253,7 +253,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
                     &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->ctable, &hs->cocc, &hs->cdense, &hs->cgkey, &hs->cgslot, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
-                    &hs->big, &hs->refhp, &hs->vcnt0};
+                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_trows};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   for (auto& b : hs->crep) b.release();
@@ -610,9 +610,14 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   const HapSetDev d = make_dev(hs);
   ++hs->cols_gen;  // the columns are about to be rewritten: earlier tables of this set become stale
   const uint64_t ntile = (uint64_t)hs->n_hap * sp.bph;
-  if ((rc = hs->counts.reserve(ntile * 4)) || (rc = hs->offsets.reserve((ntile + 1) * 8)) ||
+  // A view of a plan whose cluster dictionary is usable is searched per distinct cluster (hawk_csearch.hip): the scan then runs
+  // over REF's tiles + one count per cluster instance.  HAWK_VIEW_SEARCH=words keeps the per-word search (hawk_vsearch.hip).
+  bool by_cluster = hs->vplan && hs->vplan->cl.built && hs->vplan->cl.usable && hs->ref_index == 0;
+  if (by_cluster) { const char* e = getenv("HAWK_VIEW_SEARCH"); if (e && e[0] == 'w') by_cluster = false; }
+  const uint64_t nscan = by_cluster ? (uint64_t)sp.bph + hs->vplan->cl.n_inst : ntile;
+  if ((rc = hs->counts.reserve(nscan * 4)) || (rc = hs->offsets.reserve((nscan + 1) * 8)) ||
       (rc = hs->misc.reserve(512 * 8 + 64)) ||
-      (rc = hs->cfd.reserve(336 * 8)) || (rc = hs->partial.reserve((ntile / 1024 + 2) * 8)))
+      (rc = hs->cfd.reserve(336 * 8)) || (rc = hs->partial.reserve((nscan / 1024 + 2) * 8)))
     return rc;
   // hand-over lists (2 KB per tile): the count pass leaves each small tile's valid survivors for the emit pass.
   // HAWK_LIST_EMIT=0 keeps the recompute-everything emit pass (A/B measurements).
@@ -681,7 +686,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     ri.bits[0] = hs->refbits.as<uint32_t>();
     ri.bits[1] = hs->refbits.as<uint32_t>() + hs->S;
     ri.n_bits = hs->S * 32u;
-    if (vx && ((rc = hs->refhp.reserve(((size_t)hs->S + 1) * 8 * 2)) || (rc = hs->vcnt0.reserve(ntile * 4)))) return rc;
+    if (vx && ((rc = hs->refhp.reserve(((size_t)hs->S + 1) * 8 * 2)) || (rc = hs->vcnt0.reserve(by_cluster ? 16 : ntile * 4)))) return rc;
     if (!hs->refbits_valid || memcmp(hs->refbits_key, key, sizeof(key)) != 0) {
       hawk_launch_ref_bits(ctx->stream, d, sp, ri, hs->refbits.as<uint32_t>(), hs->refbits.as<uint32_t>() + hs->S);
       // REF's PAM hits + prefix counts: what the clean stretches of a plan's rows are counted from
@@ -700,15 +705,44 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     va.hpF = hs->refhp.as<uint2>(); va.hpR = hs->refhp.as<uint2>() + hs->S + 1;
   }
   const uint32_t v_tiles = vx ? (uint32_t)ntile - plane_tiles : 0u;
+  ClDict cd;
+  memset(&cd, 0, sizeof(cd));
+  if (by_cluster) {
+    const auto& cl = vx->cl;
+    cd.n_inst = cl.n_inst; cd.n_uniq = cl.n_uniq;
+    cd.inst_uid = cl.inst_uid.as<uint32_t>(); cd.inst_o = cl.inst_o.as<int32_t>(); cd.inst_row = cl.inst_row.as<uint32_t>();
+    cd.inst_pa = cl.inst_pa.as<int32_t>(); cd.inst_rb = cl.inst_rb.as<int32_t>();
+    cd.u_rec = cl.u_rec.as<uint32_t>(); cd.u_n = cl.u_n.as<uint32_t>(); cd.u_row = cl.u_row.as<uint32_t>(); cd.u_o = cl.u_o.as<int32_t>();
+    cd.u_half = cl.u_half.as<uint32_t>(); cd.u_slot = cl.u_slot.as<uint64_t>();
+    if ((rc = hs->cs_res.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 16)) || (rc = hs->cs_trows.reserve((size_t)std::max<uint64_t>(cl.slots, 1) * hawk_cs_row_bytes())))
+      return rc;
+  }
+  // the view's share of the two passes: per dirty word of every row, or per distinct cluster + a copy per instance
+  uint32_t* const d_counts_v = hs->counts.as<uint32_t>() + plane_tiles;
+  auto view_count = [&]() {
+    if (by_cluster) {
+      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_trows.p, d_status);
+      (void)hipEventRecord(ctx->ev[8], ctx->stream);
+      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, d_counts_v, d_shards);
+    } else {
+      hawk_launch_vsearch(ctx->stream, 0, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, nullptr,
+                          GuideCols{}, d_status, plane_tiles, v_tiles);
+    }
+  };
+  auto view_emit = [&](const GuideCols& cols) {
+    if (by_cluster) hawk_launch_cs_emit(ctx->stream, cd, hs->cs_res.p, hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles, cols, d_status);
+    else hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards,
+                             hs->offsets.as<uint64_t>(), cols, d_status, plane_tiles, v_tiles);
+  };
   GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
   hawk_launch_search(ctx->stream, 0, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards, nullptr, none, d_status, d_lists, d_big_count, d_big,
                      nullptr, plane_tiles);
   if (vx) HIPCHK(hipEventRecord(ev[6], ctx->stream));
-  if (vx) hawk_launch_vsearch(ctx->stream, 0, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, nullptr, none, d_status, plane_tiles, v_tiles);
+  if (vx) view_count();
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
-  hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), ntile, hs->partial.as<unsigned long long>(), d_shards,
+  hawk_launch_mscan(ctx->stream, hs->counts.as<uint32_t>(), nscan, hs->partial.as<unsigned long long>(), d_shards,
                     hs->offsets.as<uint64_t>(), d_totals);
   HIPCHK(hipEventRecord(ev[2], ctx->stream));
   HIPCHK(hipGetLastError());
@@ -731,8 +765,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
                        hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5], plane_tiles);
     if (vx) HIPCHK(hipEventRecord(ev[7], ctx->stream));
-    if (vx) hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, hs->offsets.as<uint64_t>(), ca,
-                                d_status, plane_tiles, v_tiles);
+    if (vx) view_emit(ca);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -761,8 +794,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
       hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
                          hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5], plane_tiles);
       if (vx) HIPCHK(hipEventRecord(ev[7], ctx->stream));
-      if (vx) hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, hs->offsets.as<uint64_t>(), ca,
-                                  d_status, plane_tiles, v_tiles);
+      if (vx) view_emit(ca);
     }
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
@@ -780,6 +812,8 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     if (vx) {
       (void)hipEventElapsedTime(&timing->v_count_ms, ev[6], ev[1]);
       if (nrows) (void)hipEventElapsedTime(&timing->v_emit_ms, ev[7], ev[4]);
+      timing->v_path = by_cluster ? 2u : 1u;
+      if (by_cluster) (void)hipEventElapsedTime(&timing->v_templates_ms, ev[6], ev[8]);
     }
     uint64_t pos = 0;
     for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
@@ -1238,7 +1272,9 @@ void hawk_xplan_destroy(hawk_xplan* x) {
   for (auto& p : x->ref_plane) hawk_pool_free(p);
   for (auto& b : x->ref5) b.release();
   DevBuf* bufs[] = {&x->recs, &x->tiles, &x->codes, &x->off, &x->hlen, &x->hash,
-                    &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile};
+                    &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile,
+                    &x->cl.inst_uid, &x->cl.inst_o, &x->cl.inst_row, &x->cl.inst_pa, &x->cl.inst_rb, &x->cl.u_rec, &x->cl.u_n, &x->cl.u_row,
+                    &x->cl.u_o, &x->cl.u_half, &x->cl.u_slot};
   for (auto* b : bufs) b->release();
   delete x;
 }
@@ -1398,7 +1434,7 @@ int hawk_xplan_set_meta(hawk_xplan* x, const uint8_t* is_ref, const int32_t* sca
   x->scan_stop.assign(scan_stop, scan_stop + n);
   x->n_ref_rows = 0;
   for (uint32_t h = 0; h < n; ++h) x->n_ref_rows += is_ref[h] ? 1u : 0u;
-  x->has_meta = true;
+  x->has_meta = true; x->cl.built = false; x->cl.usable = false;
   return HAWK_OK;
 }
 
@@ -1469,6 +1505,117 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
   return HAWK_OK;
 }
 
+// The cluster dictionary of a plan (hawk_csearch.hip): which rows carry which distinct variant cluster.  Built once per plan,
+// from the records and the rows' scan bounds; a search of a view then does the per-window work once per distinct cluster.
+// Not usable (the per-word search of hawk_vsearch.hip takes the plan instead) when a chain of variants is longer than the
+// builder accepts, when two different clusters share a hash, or when sharing is too thin to pay for the template rows.
+static int xplan_build_dict(hawk_xplan* x) {
+  auto& cl = x->cl;
+  if (cl.built) return HAWK_OK;
+  cl.built = true; cl.usable = false; cl.status = 0; cl.n_inst = cl.n_uniq = 0; cl.slots = 0; cl.build_ms = 0.f;
+  hawk_ctx* ctx = x->ctx;
+  hipStream_t st = ctx->stream;
+  const uint32_t n = x->n_hap;
+  if (x->ncar == 0 || x->ncar >= (1ull << 32) - 2 || n < 2) { cl.status = 4; return HAWK_OK; }
+  PoolScope tmp;
+  uint32_t *d_cnt, *d_off, *d_status;
+  TEMPCHK(tmp, &d_cnt, (size_t)n * 4);
+  TEMPCHK(tmp, &d_off, (size_t)(n + 1) * 4);
+  TEMPCHK(tmp, &d_status, 64);
+  HIPCHK(hipMemsetAsync(d_status, 0, 64, st));
+  HIPCHK(hipEventRecord(ctx->ev[8], st));
+  hawk_launch_cl_count(st, x->recs.p, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_cnt);
+  hawk_launch_scan_u32(st, d_cnt, n, d_off);
+  uint32_t n_inst = 0;
+  HIPCHK(hipMemcpyAsync(&n_inst, d_off + n, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
+  int rc;
+  if ((rc = cl.inst_uid.reserve((size_t)n_inst * 4)) || (rc = cl.inst_o.reserve((size_t)n_inst * 4)) || (rc = cl.inst_row.reserve((size_t)n_inst * 4)) ||
+      (rc = cl.inst_pa.reserve((size_t)n_inst * 4)) || (rc = cl.inst_rb.reserve((size_t)n_inst * 4)))
+    return rc;
+  uint32_t *d_rec, *d_n, *d_slot, *d_flag, *d_trep, *d_slot_uid;
+  uint64_t *d_key, *d_rank;
+  uint8_t* d_cls;
+  unsigned long long *d_tkey, *d_partial, *d_shards;
+  ScanTotals* d_tot;
+  uint32_t tsize = 1024;
+  while (tsize < 2u * n_inst && tsize < (1u << 31)) tsize <<= 1;
+  TEMPCHK(tmp, &d_rec, (size_t)n_inst * 4);
+  TEMPCHK(tmp, &d_n, (size_t)n_inst * 4);
+  TEMPCHK(tmp, &d_slot, (size_t)n_inst * 4);
+  TEMPCHK(tmp, &d_flag, (size_t)n_inst * 4);
+  TEMPCHK(tmp, &d_key, (size_t)n_inst * 8);
+  TEMPCHK(tmp, &d_rank, ((size_t)n_inst + 1) * 8);
+  TEMPCHK(tmp, &d_cls, (size_t)n_inst);
+  TEMPCHK(tmp, &d_tkey, (size_t)tsize * 8);
+  TEMPCHK(tmp, &d_trep, (size_t)tsize * 4);
+  TEMPCHK(tmp, &d_slot_uid, (size_t)tsize * 4);
+  TEMPCHK(tmp, &d_partial, ((size_t)n_inst / 1024 + 2) * 8);
+  TEMPCHK(tmp, &d_shards, 512 * 8);
+  TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
+  HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsize * 8, st));
+  HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsize * 4, st));
+  HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
+  hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
+                      cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(), cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>(), d_rec, d_n, d_key, d_cls,
+                      d_status);
+  hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_flag);
+  hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
+  ScanTotals tot;
+  HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  const uint32_t n_uniq = (uint32_t)tot.n_keep;
+  cl.n_inst = n_inst; cl.n_uniq = n_uniq;
+  if (n_uniq) {
+    uint32_t* d_span2;
+    TEMPCHK(tmp, &d_span2, (size_t)n_uniq * 4);
+    if ((rc = cl.u_rec.reserve((size_t)n_uniq * 4)) || (rc = cl.u_n.reserve((size_t)n_uniq * 4)) || (rc = cl.u_row.reserve((size_t)n_uniq * 4)) ||
+        (rc = cl.u_o.reserve((size_t)n_uniq * 4)) || (rc = cl.u_half.reserve((size_t)n_uniq * 4)) || (rc = cl.u_slot.reserve(((size_t)n_uniq + 1) * 8)))
+      return rc;
+    hawk_launch_cl_assign(st, n_inst, d_flag, d_rank, d_slot, d_trep, x->recs.p, cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(),
+                          cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>(), d_rec, d_n, d_key, d_cls, d_slot_uid, cl.u_rec.as<uint32_t>(),
+                          cl.u_n.as<uint32_t>(), cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_half.as<uint32_t>(), d_span2,
+                          cl.inst_uid.as<uint32_t>(), d_status);
+    hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, cl.u_slot.as<uint64_t>(), d_tot + 1);
+    HIPCHK(hipMemcpyAsync(&tot, d_tot + 1, sizeof(tot), hipMemcpyDeviceToHost, st));
+  } else {
+    HIPCHK(hipMemsetAsync(cl.inst_uid.p, 0xff, (size_t)n_inst * 4, st));
+    tot.n_keep = 0;
+  }
+  uint32_t status = 0;
+  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(ctx->ev[9], st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  (void)hipEventElapsedTime(&cl.build_ms, ctx->ev[8], ctx->ev[9]);
+  cl.slots = tot.n_keep;
+  cl.status = status;
+  // worth it when clusters are shared (the template rows are extra traffic otherwise) and the templates fit a sane budget
+  // (HAWK_CLUSTER_MAX_SLOTS template rows, default 2^27 = 10 GB; HAWK_CLUSTER_MIN_SHARE instances per distinct cluster, default 3:
+  // read per call so that tests can send small panels down this path)
+  const char* e1 = getenv("HAWK_CLUSTER_MAX_SLOTS");
+  const char* e2 = getenv("HAWK_CLUSTER_MIN_SHARE");
+  const uint64_t max_slots = e1 ? strtoull(e1, nullptr, 10) : (1ull << 27);
+  const double min_share = e2 ? atof(e2) : 3.0;
+  if (!status && (cl.slots > max_slots || (double)n_inst < min_share * (double)std::max<uint32_t>(n_uniq, 1))) cl.status = 4;
+  cl.usable = cl.status == 0;
+  return HAWK_OK;
+}
+
+int hawk_xplan_cluster_stats(const hawk_xplan* x, uint32_t* usable, uint32_t* n_instances, uint32_t* n_distinct, uint64_t* template_slots,
+                             float* build_ms, uint32_t* status) {
+  if (!x) return HAWK_E_INVALID;
+  if (usable) *usable = x->cl.built && x->cl.usable ? 1u : 0u;
+  if (n_instances) *n_instances = x->cl.n_inst;
+  if (n_distinct) *n_distinct = x->cl.n_uniq;
+  if (template_slots) *template_slots = x->cl.slots;
+  if (build_ms) *build_ms = x->cl.build_ms;
+  if (status) *status = x->cl.built ? x->cl.status : 0xffffffffu;
+  return HAWK_OK;
+}
+
 int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out) {
   if (!x || !out || !x->has_meta || x->ref_index != 0) return HAWK_E_INVALID;
   hawk_ctx* ctx = x->ctx;
@@ -1480,6 +1627,7 @@ int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out) {
   for (int p = 0; p < HAWK_PLANES; ++p) hs->plane[p] = x->ref5[p].as<uint32_t>();  // row 0 = REF; no other row is ever read
   rc = xplan_install(x, hs);
   if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HAWK_E_HIP;
+  if (!rc) rc = xplan_build_dict(x);
   if (rc) { hs->vplan = nullptr; for (int p = 0; p < HAWK_PLANES; ++p) hs->plane[p] = nullptr; hawk_hapset_destroy(hs); return rc; }
   *out = hs;
   return HAWK_OK;
@@ -1615,7 +1763,7 @@ int hawk_xplan_finish_meta(hawk_xplan* x, const int32_t* scan_start, const int32
   HIPCHK(hipStreamSynchronize(st));
   x->scan_start.assign(scan_start, scan_start + n);
   x->scan_stop.assign(scan_stop, scan_stop + n);
-  x->ref_index = 0; x->n_ref_rows = 1; x->has_meta = true;
+  x->ref_index = 0; x->n_ref_rows = 1; x->has_meta = true; x->cl.built = false; x->cl.usable = false;
   return HAWK_OK;
 }
 

@@ -1,0 +1,519 @@
+// hawk_csearch.hip — the guide search from an expansion plan, once per DISTINCT variant cluster instead of once per row.
+//
+// A non-REF haplotype row contributes guide rows only where a window touches an alt allele (search_guides.py:468-471), and
+// what those rows look like - PAM hits, coordinates, the REF partner, the padded window, CFDon - depends on nothing but
+// the carried variants within reach of the window: two variants interact only if fewer than CL_LINK = 64 positions
+// separate their alleles (a window's padded slice spans guidelen + pamlen + 2 x 10 <= 64 positions).  So a row's records
+// fall into CLUSTERS (maximal runs with gaps <= CL_LINK), and a cluster carried by many chromosome copies - a common SNV
+// with no neighbour - yields the same rows in every one of them, shifted by the copies' upstream indels.  On the C3 panel
+// 8.8 x 10^6 cluster instances are 7.3 x 10^4 distinct clusters.
+//
+//   dictionary (once per plan; hawk_xplan_view):  k_cl_count / k_cl_fill cut every row into cluster instances and hash
+//       their variant identities, k_cl_insert / k_cl_assign / k_cl_uid number the distinct ones (exactly: every instance is
+//       compared with its representative, record by record).  An instance whose windows could meet a row-specific bound
+//       (scan range, row ends) is a cluster of its own; one wholly outside the scan range carries no cluster at all.
+//   per search:  k_cs_templates builds each distinct cluster's rows ONCE, on its representative row, with the string
+//       builder, PAM match, filters and classification of hawk_vsearch.hip (80-byte template rows, strand 0 / strand 1
+//       regions in position order); k_cs_count gives every instance its row count and adds up the job's totals
+//       (candidates, hits: the cluster's own + REF's hits under the shift of the clean stretch in front of it);
+//       after the offset scan k_cs_emit copies template rows into the guide table, a wave per 64 consecutive instances,
+//       patching haplotype row and position.
+// The table holds the same rows as hawk_search on the materialised planes; their order within a haplotype is (cluster,
+// strand, position) instead of (tile, strand, position) - GuideTable.emission_order() sorts either into the reference's.
+// The REF row goes through the plane kernels as before.
+#include "hawk_vc.h"
+
+#define CL_LINK 64
+#define CL_NONE 0xffffffffu
+#define CL_FAR (1 << 29)     // "position" of a row's closing instance: the clean run in front of it reaches the row's end
+#define CL_MAXWALK 4096      // records per cluster the dictionary accepts (longer chains: the per-word search takes the plan)
+#define CS_G 8               // lanes per distinct cluster in k_cs_templates: one 32-window word each per round
+
+struct __attribute__((aligned(16))) CsRow {  // a template row: GuideCols' fields, position relative to the cluster's first allele
+  int32_t pos;
+  uint8_t strand, flags;
+  uint16_t pad;
+  int64_t start, stop;
+  double cfdon;
+  uint64_t win[5];
+  uint64_t pad2;
+};
+static_assert(sizeof(CsRow) == 80, "template row layout");
+size_t hawk_cs_row_bytes() { return sizeof(CsRow); }
+
+__device__ __forceinline__ uint64_t cl_mix(uint64_t h, uint64_t v) {
+  h = (h ^ v) * 0x9E3779B97F4A7C15ull;
+  return h ^ (h >> 29);
+}
+__device__ __forceinline__ bool cl_starts(const HxVar* __restrict__ recs, uint64_t j, uint64_t lo) {
+  if (j == lo) return true;
+  const int32_t prev_end = recs[j - 1].o + (int32_t)recs[j - 1].alt_len;
+  return recs[j].o - prev_end > CL_LINK;
+}
+
+// ---- dictionary -----------------------------------------------------------------------------------
+// instances per row: its clusters + one closing instance (the clean run behind the last cluster); REF and rows that scan
+// nothing (collapsed onto another row) have none
+__global__ __launch_bounds__(256) void k_cl_count(const HxVar* __restrict__ recs, const uint64_t* __restrict__ hv_off,
+                                                  const uint8_t* __restrict__ is_ref, const int32_t* __restrict__ ss,
+                                                  const int32_t* __restrict__ se, uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t s_w[256 / WAVE];
+  const uint32_t row = blockIdx.x;
+  const uint64_t lo = hv_off[row], hi = hv_off[row + 1];
+  const bool dead = is_ref[row] || se[row] <= ss[row];
+  uint32_t c = 0;
+  if (!dead)
+    for (uint64_t j = lo + threadIdx.x; j < hi; j += 256) c += cl_starts(recs, j, lo) ? 1u : 0u;
+  uint32_t tot;
+  (void)block_excl_scan<256 / WAVE>(c, s_w, &tot);
+  if (threadIdx.x == 0) cnt[row] = dead ? 0u : tot + 1u;
+}
+
+struct ClInst {  // per instance (k_cl_fill)
+  int32_t* o;      // row position of the cluster's first allele (closing instance: CL_FAR)
+  uint32_t* row;
+  int32_t* pa;     // where the clean run in front of the instance starts: end of the previous record's allele, 0 at the row's start
+  int32_t* rb;     // REF shift of that run
+  uint32_t* rec;   // first record of the cluster (index over all rows)
+  uint32_t* n;     // its records
+  uint64_t* key;   // hash of the variant identities (+ the row, for a cluster that must stay the row's own)
+  uint8_t* cls;    // 0: no cluster (closing instance, or cluster wholly outside the scan range), 1: shareable, 2: the row's own
+};
+
+__global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs, const uint64_t* __restrict__ hv_off,
+                                                 const uint32_t* __restrict__ hap_len, const int32_t* __restrict__ ss_,
+                                                 const int32_t* __restrict__ se_, const uint32_t* __restrict__ inst_off, ClInst ci,
+                                                 uint32_t* __restrict__ status) {
+  __shared__ uint32_t s_w[256 / WAVE];
+  const uint32_t row = blockIdx.x;
+  const uint32_t i0 = inst_off[row], i1 = inst_off[row + 1];
+  if (i0 == i1) return;  // workgroup-uniform
+  const uint64_t lo = hv_off[row], hi = hv_off[row + 1];
+  const int32_t ss = ss_[row], se = se_[row], hl = (int32_t)hap_len[row];
+  uint32_t at = i0;
+  for (uint64_t b0 = lo; b0 < hi; b0 += 256) {  // workgroup-uniform trip count
+    const uint64_t j = b0 + threadIdx.x;
+    const bool st = j < hi && cl_starts(recs, j, lo);
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<256 / WAVE>(st ? 1u : 0u, s_w, &tot);
+    if (st) {
+      const uint32_t i = at + ex;
+      uint64_t e = j, h = 0x243F6A8885A308D3ull;
+      uint32_t n = 0;
+      do {
+        h = cl_mix(h, recs[e].alt_off);
+        ++n; ++e;
+      } while (e < hi && !cl_starts(recs, e, lo) && n < CL_MAXWALK);
+      if (e < hi && !cl_starts(recs, e, lo)) atomicOr(status, 1u);  // a chain too long for this path
+      const int32_t o_first = recs[j].o, o_end = recs[e - 1].o + (int32_t)recs[e - 1].alt_len;
+      int32_t pa = 0, rb = 0;
+      if (j > lo) { pa = recs[j - 1].o + (int32_t)recs[j - 1].alt_len; rb = (int32_t)recs[j - 1].rs - pa; }
+      // window starts the cluster can touch: [o_first - (L - 1), o_end), L <= 44; the ranges they are tested against
+      // (search_guides.py:49-84, 395-420) are [ss - po, se - po) and [PAD, len - L - PAD], po in {0, guidelen}
+      const bool outside = o_end <= ss - 44 || o_first - 43 >= se;
+      const bool interior = o_first - 43 >= (ss > HAWK_PAD ? ss : HAWK_PAD) && o_first >= 64 && o_end <= se - 44 &&
+                            o_end <= hl - 44 - HAWK_PAD + 1 && o_end + 128 <= hl;
+      uint64_t key = h;
+      uint8_t cls = 1;
+      if (outside) { cls = 0; key = 0; }
+      else if (!interior) { cls = 2; key = cl_mix(h ^ 0xA4093822299F31D0ull, (uint64_t)row + 1u); }
+      if (cls && key == 0) key = 1;
+      ci.o[i] = o_first; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb;
+      ci.rec[i] = (uint32_t)j; ci.n[i] = n; ci.key[i] = key; ci.cls[i] = cls;
+    }
+    at += tot;
+  }
+  if (threadIdx.x == 0) {  // the closing instance
+    const uint32_t i = i1 - 1;
+    int32_t pa = 0, rb = 0;
+    if (hi > lo) { pa = recs[hi - 1].o + (int32_t)recs[hi - 1].alt_len; rb = (int32_t)recs[hi - 1].rs - pa; }
+    ci.o[i] = CL_FAR; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb; ci.rec[i] = 0; ci.n[i] = 0; ci.key[i] = 0; ci.cls[i] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
+                                                   unsigned long long* __restrict__ tkey, uint32_t* __restrict__ trep, uint32_t mask,
+                                                   uint32_t* __restrict__ inst_slot) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_inst) return;
+  if (!cls[i]) { inst_slot[i] = CL_NONE; return; }
+  const unsigned long long k = key[i];
+  uint32_t s = (uint32_t)(k >> 17) & mask;
+  for (;;) {  // the table has >= 2 slots per instance: a free slot is always met
+    const unsigned long long cur = atomicCAS(&tkey[s], 0ull, k);
+    if (cur == 0ull || cur == k) break;
+    s = (s + 1u) & mask;
+  }
+  inst_slot[i] = s;
+  atomicMin(&trep[s], i);
+}
+__global__ __launch_bounds__(256) void k_cl_flag(uint32_t n_inst, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ inst_slot,
+                                                 const uint32_t* __restrict__ trep, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_inst) flag[i] = (cls[i] && trep[inst_slot[i]] == i) ? 1u : 0u;
+}
+struct ClUniq {  // per distinct cluster
+  uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* half; uint32_t* span2;
+};
+// the representatives (lowest instance of every distinct cluster) number the clusters in instance order
+__global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
+                                                   const uint32_t* __restrict__ inst_slot, ClInst ci, const HxVar* __restrict__ recs,
+                                                   uint32_t* __restrict__ slot_uid, ClUniq cu) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_inst || !flag[i]) return;
+  const uint32_t u = (uint32_t)rank[i];
+  slot_uid[inst_slot[i]] = u;
+  const uint32_t r = ci.rec[i], n = ci.n[i];
+  const int32_t o_first = recs[r].o, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
+  cu.rec[u] = r; cu.n[u] = n; cu.row[u] = ci.row[i]; cu.o[u] = o_first;
+  const uint32_t half = (uint32_t)(o_end - o_first) + CL_LINK;  // window starts per strand: <= o_end - o_first + L - 1
+  cu.half[u] = half; cu.span2[u] = 2u * half;
+}
+__global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint32_t* __restrict__ trep,
+                                                const uint32_t* __restrict__ slot_uid, ClInst ci, const HxVar* __restrict__ recs,
+                                                uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_inst) return;
+  const uint8_t c = ci.cls[i];
+  if (!c) { inst_uid[i] = CL_NONE; return; }
+  const uint32_t s = inst_slot[i], r = trep[s];
+  inst_uid[i] = slot_uid[s];
+  if (r == i) return;
+  // exactness: same hash is not same cluster until the variant identities have been compared
+  bool bad = c != 1 || ci.cls[r] != 1 || ci.n[r] != ci.n[i];
+  if (!bad) {
+    const HxVar* a = recs + ci.rec[i];
+    const HxVar* b = recs + ci.rec[r];
+    for (uint32_t k = 0; k < ci.n[i]; ++k) bad = bad || a[k].alt_off != b[k].alt_off;
+  }
+  if (bad) atomicOr(status, 2u);
+}
+
+void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint8_t* is_ref, const int32_t* ss, const int32_t* se,
+                          uint32_t n_rows, uint32_t* cnt) {
+  hipLaunchKernelGGL(k_cl_count, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, is_ref, ss, se, cnt);
+}
+void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
+                         uint32_t n_rows, const uint32_t* inst_off, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
+                         uint64_t* key, uint8_t* cls, uint32_t* status) {
+  ClInst ci{o, row, pa, rb, rec, n, key, cls};
+  hipLaunchKernelGGL(k_cl_fill, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, hap_len, ss, se, inst_off, ci, status);
+}
+void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep, uint32_t mask,
+                           uint32_t* inst_slot, uint32_t* flag) {
+  const uint32_t nb = (n_inst + 255) / 256;
+  hipLaunchKernelGGL(k_cl_insert, dim3(nb), dim3(256), 0, st, n_inst, key, cls, static_cast<unsigned long long*>(tkey), trep, mask, inst_slot);
+  hipLaunchKernelGGL(k_cl_flag, dim3(nb), dim3(256), 0, st, n_inst, cls, inst_slot, trep, flag);
+}
+void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
+                           const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
+                           uint64_t* key, uint8_t* cls, uint32_t* slot_uid, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o,
+                           uint32_t* u_half, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
+  const uint32_t nb = (n_inst + 255) / 256;
+  ClInst ci{o, row, pa, rb, rec, n, key, cls};
+  ClUniq cu{u_rec, u_n, u_row, u_o, u_half, u_span2};
+  hipLaunchKernelGGL(k_cl_assign, dim3(nb), dim3(256), 0, st, n_inst, flag, rank, inst_slot, ci, static_cast<const HxVar*>(recs), slot_uid, cu);
+  hipLaunchKernelGGL(k_cl_uid, dim3(nb), dim3(256), 0, st, n_inst, inst_slot, trep, slot_uid, ci, static_cast<const HxVar*>(recs), inst_uid, status);
+}
+
+// ---- per search ------------------------------------------------------------------------------------
+__device__ __forceinline__ VcRanges cs_ranges(const HapSetDev& hs, const ScanParams& p, uint32_t h) {
+  VcRanges rg;
+  const int ss = hs.scan_start[h], se = hs.scan_stop[h], haplen = (int)hs.hap_len[h];
+  const int poF = p.right ? 0 : p.guidelen, poR = p.right ? p.guidelen : 0;
+  const int qmin = HAWK_PAD, qmax = haplen - p.L - HAWK_PAD + 1;
+  rg.slo[0] = ss - poF; rg.shi[0] = se - poF; rg.slo[1] = ss - poR; rg.shi[1] = se - poR;
+  rg.lo[0] = rg.slo[0] > qmin ? rg.slo[0] : qmin; rg.hi[0] = rg.shi[0] < qmax ? rg.shi[0] : qmax;
+  rg.lo[1] = rg.slo[1] > qmin ? rg.slo[1] : qmin; rg.hi[1] = rg.shi[1] < qmax ? rg.shi[1] : qmax;
+  return rg;
+}
+// inclusive sum over the CS_G lanes of a group
+__device__ __forceinline__ uint32_t group_incl_scan(uint32_t v, uint32_t gl) {
+#pragma unroll
+  for (int d = 1; d < CS_G; d <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)v, d, CS_G);
+    if (gl >= (uint32_t)d) v += t;
+  }
+  return v;
+}
+
+// Every distinct cluster's rows, once: a group of CS_G lanes per cluster, each lane one word of 32 window starts per round.
+// res[u] = {rows of strand 0, rows of strand 1, PAM hits, candidates} of the cluster's own window starts.
+__global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, GuideParams gp, RefInfo ri,
+                                                      uint4* __restrict__ res, CsRow* __restrict__ trows, int* status) {
+  __shared__ double s_cfd[336];
+  const uint32_t tid = threadIdx.x;
+  if (gp.score_cfdon) for (uint32_t i = tid; i < 336; i += 256) s_cfd[i] = gp.cfd_mm[i];
+  __syncthreads();
+  const uint32_t gl = tid & (CS_G - 1);
+  uint32_t u = (blockIdx.x * 256 + tid) / CS_G;
+  const bool live = u < cd.n_uniq;
+  if (!live) u = cd.n_uniq - 1;  // lanes of a surplus group redo the last cluster and write nothing
+  const HxVar* __restrict__ recs = static_cast<const HxVar*>(va.recs_);
+  const uint32_t h = cd.u_row[u], r0 = cd.u_rec[u], nc = cd.u_n[u];
+  const uint32_t back = (uint64_t)r0 > va.hv_off[h] ? 1u : 0u;  // the record in front of the cluster sets the REF shift it starts from
+  const HxVar* __restrict__ sv = recs + r0 - back;
+  const int nrec = (int)(nc + back);
+  const int L = p.L;
+  const int32_t haplen = (int32_t)hs.hap_len[h];
+  const int32_t o_first = recs[r0].o;
+  const int32_t o_end = recs[r0 + nc - 1].o + (int32_t)recs[r0 + nc - 1].alt_len;
+  const int32_t qa = o_first - (L - 1) > 0 ? o_first - (L - 1) : 0;
+  const int32_t qb = o_end < haplen ? o_end : haplen;
+  const int nwords = qb > qa ? (qb - qa + 31) / 32 : 0;
+  const VcRanges rg = cs_ranges(hs, p, h);
+  const int poF = p.right ? 0 : p.guidelen, poR = p.right ? p.guidelen : 0;
+  const uint32_t mlo = L >= 32 ? 0xffffffffu : ((1u << L) - 1u), mhi = L <= 32 ? 0u : ((1u << (L - 32)) - 1u);
+  const int W = L + 2 * HAWK_PAD;
+  const uint32_t whi = W >= 64 ? 0xffffffffu : ((1u << (W - 32)) - 1u);
+  const int ncfd = gp.guidelen < 20 ? gp.guidelen : 20;
+  const uint32_t cfdmask = (1u << ncfd) - 1u;
+  auto ref32 = [&](int pl, uint32_t r) -> uint32_t {
+    const uint32_t w = (r >> 5) < va.ref_S - 2 ? (r >> 5) : va.ref_S - 2;
+    return ext32_glb(va.ref[pl], (w << 5) | (r & 31u));
+  };
+  const uint64_t slot0 = cd.u_slot[u];
+  const uint32_t half = cd.u_half[u];
+  uint32_t base0 = 0, base1 = 0, hits = 0, cand = 0;
+#pragma unroll 1
+  for (int w0 = 0; w0 < nwords; w0 += CS_G) {  // uniform within a group
+    const int w = w0 + (int)gl;
+    const bool active = w < nwords;
+    const int32_t q0 = qa + 32 * w;
+    uint32_t X[5][3];
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) X[pl][0] = X[pl][1] = X[pl][2] = 0;
+    uint32_t kF = 0, kR = 0;
+    if (active) {
+      const int32_t p0 = q0 - HAWK_PAD;
+      const int32_t p0c = p0 < 0 ? 0 : p0;
+      int32_t shift_run = 0;
+      if (!vc_string_fast(va, sv, nrec, p0c, haplen, q0 + 32, X, shift_run))
+        hx_words_t<false, 3>(va.alt_codes, sv, sv, nrec, nrec, false, p0c, haplen, ref32, X[0], X[1], X[2], X[3], X[4]);
+      if (p0 < 0) {  // the string starts at the row's first base: bit i is position q0 - PAD + i all the same
+        const uint32_t sh = (uint32_t)(-p0);
+#pragma unroll
+        for (int pl = 0; pl < 5; ++pl) {
+          X[pl][2] = fsh(X[pl][1], X[pl][2], 32u - sh);
+          X[pl][1] = fsh(X[pl][0], X[pl][1], 32u - sh);
+          X[pl][0] = X[pl][0] << sh;
+        }
+      }
+      uint32_t v0 = X[4][0], v1 = X[4][1], v2 = X[4][2];  // E: window starts whose spacer + PAM holds a variant base
+      int r = 1;
+      while (2 * r <= L && r < 32) {
+        v0 |= fsh(v0, v1, (uint32_t)r); v1 |= fsh(v1, v2, (uint32_t)r); v2 |= v2 >> r;
+        r *= 2;
+      }
+      const int rem = L - r;
+      if (rem > 0) {
+        if (rem < 32) { v0 |= fsh(v0, v1, (uint32_t)rem); v1 |= fsh(v1, v2, (uint32_t)rem); v2 |= v2 >> rem; }
+        else { v0 |= v1; v1 |= v2; }
+      }
+      const uint32_t E = fsh(v0, v1, HAWK_PAD);
+      const uint32_t own = range_mask(q0, qa, qb);
+      uint32_t f = pam_match96(X, p.pam_fwd, p.pamlen, HAWK_PAD + poF) & own;
+      uint32_t rv = pam_match96(X, p.pam_rev, p.pamlen, HAWK_PAD + poR) & own;
+      f &= range_mask(q0, rg.slo[0], rg.shi[0]);
+      rv &= range_mask(q0, rg.slo[1], rg.shi[1]);
+      hits += __popc(f) + __popc(rv);
+      f &= range_mask(q0, rg.lo[0], rg.hi[0]);
+      rv &= range_mask(q0, rg.lo[1], rg.hi[1]);
+      cand += __popc(f) + __popc(rv);
+      kF = f & E;
+      kR = rv & E;
+    }
+    // which survivors are rows: not the REF guide at the same (start, strand) again (remove_redundant_guides)
+    uint32_t vF = 0, vR = 0;
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      uint32_t m = s ? kR : kF;
+      while (m) {
+        const uint32_t bpos = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        const uint32_t q = (uint32_t)q0 + bpos;
+        const int64_t start = posmap_global(hs, h, q);
+        const int64_t qr64 = start - ri.startp;
+        const bool inr = qr64 >= 0 && qr64 < (int64_t)ri.n_bits;
+        const uint32_t qr = inr ? (uint32_t)qr64 : 0u;
+        const bool has_ref = inr && (((s ? ri.bits[1] : ri.bits[0])[qr >> 5] >> (qr & 31u)) & 1u);
+        bool same = has_ref;
+        if (has_ref) {
+#pragma unroll
+          for (int pl = 0; pl < 4; ++pl) {
+            W2 wn = ext96(X[pl][0], X[pl][1], X[pl][2], bpos);
+            wn.hi &= whi;
+            const uint32_t clo = fsh(wn.lo, wn.hi, HAWK_PAD) & mlo, chi = (wn.hi >> HAWK_PAD) & mhi;
+            const W2 rc = ext_glb(va.ref[pl], qr);
+            same = same && (rc.lo & mlo) == clo && (rc.hi & mhi) == chi;
+          }
+        }
+        if (!same) { if (s) vR |= 1u << bpos; else vF |= 1u << bpos; }
+      }
+    }
+    const uint32_t cF = (uint32_t)__popc(vF), cR = (uint32_t)__popc(vR);
+    const uint32_t inc = group_incl_scan(cF | (cR << 16), gl);
+    const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
+    const uint32_t ex = inc - (cF | (cR << 16));
+    uint32_t at0 = base0 + (ex & 0xffffu), at1 = base1 + (ex >> 16);
+    base0 += tot & 0xffffu; base1 += tot >> 16;
+    if (!live) continue;
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      uint32_t m = s ? vR : vF;
+      while (m) {
+        const uint32_t bpos = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        const uint32_t q = (uint32_t)q0 + bpos;
+        const uint32_t k = s ? at1++ : at0++;
+        if (k >= half) { atomicExch(status, -3 /* HAWK_E_CAPACITY: more rows than window starts */); continue; }
+        W2 win[5], core[4], rcore[4];
+#pragma unroll
+        for (int pl = 0; pl < 5; ++pl) {
+          win[pl] = ext96(X[pl][0], X[pl][1], X[pl][2], bpos);
+          win[pl].hi &= whi;
+          if (pl < 4) {
+            core[pl].lo = fsh(win[pl].lo, win[pl].hi, HAWK_PAD) & mlo;
+            core[pl].hi = (win[pl].hi >> HAWK_PAD) & mhi;
+          }
+        }
+        const int64_t start = posmap_global(hs, h, q), stop = posmap_global(hs, h, q + (uint32_t)L);
+        const int64_t qr64 = start - ri.startp;
+        const bool inr = qr64 >= 0 && qr64 < (int64_t)ri.n_bits;
+        const uint32_t qr = inr ? (uint32_t)qr64 : 0u;
+        const bool has_ref = inr && (((s ? ri.bits[1] : ri.bits[0])[qr >> 5] >> (qr & 31u)) & 1u);
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+          rcore[pl] = ext_glb(va.ref[pl], qr);
+          rcore[pl].lo &= mlo; rcore[pl].hi &= mhi;
+          if (!has_ref) rcore[pl] = core[pl];
+        }
+        double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
+        if (gp.score_cfdon && has_ref) {
+          bool err;
+          score = cfdon_from_slices(core, rcore, (uint32_t)s, L, cfdmask, s_cfd, err);
+          if (err && gp.score_cfdon == 1) atomicExch(status, -5 /* HAWK_E_CFD */);
+        }
+        const bool pamfirst = (p.right != 0) != (s != 0);
+        CsRow tr;
+        tr.pos = (int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first;
+        tr.strand = (uint8_t)s; tr.flags = has_ref ? 1 : 0; tr.pad = 0;
+        tr.start = start; tr.stop = stop; tr.cfdon = score;
+#pragma unroll
+        for (int pl = 0; pl < HAWK_PLANES; ++pl) tr.win[pl] = (uint64_t)win[pl].lo | ((uint64_t)win[pl].hi << 32);
+        tr.pad2 = 0;
+        trows[slot0 + (s ? half : 0u) + k] = tr;
+      }
+    }
+  }
+  // the group's totals
+  const uint32_t h2 = group_incl_scan(hits, gl), c2 = group_incl_scan(cand, gl);
+  if (live && gl == CS_G - 1) res[u] = make_uint4(base0, base1, h2, c2);
+}
+
+// every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it
+__global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, const uint4* __restrict__ res,
+                                                  uint32_t* __restrict__ counts, unsigned long long* __restrict__ shards) {
+  __shared__ uint32_t s_red[256 / WAVE][2];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t cand = 0, hits = 0;
+  if (i < cd.n_inst) {
+    const uint32_t h = cd.inst_row[i], u = cd.inst_uid[i];
+    const VcRanges rg = cs_ranges(hs, p, h);
+    const int32_t pa = cd.inst_pa[i], o = cd.inst_o[i];
+    const int32_t pb = o - (p.L - 1);
+    if (pb > pa) vc_count_run(va, rg, pa, pb, cd.inst_rb[i], cand, hits);
+    uint32_t c = 0;
+    if (u != CL_NONE) {
+      const uint4 r = res[u];
+      c = r.x + r.y; hits += r.z; cand += r.w;
+    }
+    counts[i] = c;
+  }
+  const uint32_t a = wave_sum(cand), b = wave_sum(hits);
+  if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+    for (int wv = 0; wv < 256 / WAVE; ++wv) { t0 += s_red[wv][0]; t1 += s_red[wv][1]; }
+    if (t0 | t1) {
+      atomicAdd(&shards[(blockIdx.x & 255u) * 2 + 0], (unsigned long long)t0);
+      atomicAdd(&shards[(blockIdx.x & 255u) * 2 + 1], (unsigned long long)t1);
+    }
+  }
+}
+
+// the guide table: a wave per 64 consecutive instances copies their clusters' template rows (their offsets are consecutive,
+// so the wave's stores are), patching haplotype row and position
+__global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restrict__ res, const CsRow* __restrict__ trows,
+                                                 const uint64_t* __restrict__ offsets, GuideCols out, int* status) {
+  __shared__ uint32_t s_ex[4][WAVE + 1];
+  __shared__ uint32_t s_n0[4][WAVE], s_half[4][WAVE], s_h[4][WAVE];
+  __shared__ int32_t s_dq[4][WAVE];
+  __shared__ uint64_t s_slot[4][WAVE], s_off[4][WAVE];
+  const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t cnt = 0, n0 = 0, half = 0, h = 0;
+  int32_t dq = 0;
+  uint64_t slot = 0, off = 0;
+  if (i < cd.n_inst) {
+    const uint32_t u = cd.inst_uid[i];
+    if (u != CL_NONE) {
+      const uint4 r = res[u];
+      n0 = r.x; cnt = r.x + r.y;
+      if (cnt) {
+        slot = cd.u_slot[u]; half = cd.u_half[u]; h = cd.inst_row[i];
+        dq = cd.inst_o[i];  // template positions are relative to the cluster's first allele
+        off = offsets[i];
+      }
+    }
+  }
+  const uint32_t inc = wave_incl_scan(cnt);
+  const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+  s_ex[wv][lane] = inc - cnt;
+  s_n0[wv][lane] = n0; s_half[wv][lane] = half; s_h[wv][lane] = h; s_dq[wv][lane] = dq; s_slot[wv][lane] = slot; s_off[wv][lane] = off;
+  __syncthreads();
+  for (uint32_t t = lane; t < Wt; t += WAVE) {
+    uint32_t l = 0;
+#pragma unroll
+    for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;  // l + step <= 63
+    const uint32_t k = t - s_ex[wv][l];
+    const uint32_t kn0 = s_n0[wv][l];
+    const uint64_t src = s_slot[wv][l] + (k < kn0 ? k : s_half[wv][l] + (k - kn0));
+    const uint64_t o = s_off[wv][l] + k;
+    if (o >= out.cap) { atomicExch(status, -3 /* HAWK_E_CAPACITY */); continue; }
+    const uint4* __restrict__ tp = reinterpret_cast<const uint4*>(trows + src);
+    const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3], e = tp[4];
+    // CsRow: pos, strand|flags, start, stop | cfdon, win0 | win1, win2 | win3, win4 | pad
+    out.hap[o] = s_h[wv][l];
+    out.pos[o] = (uint32_t)((int32_t)a.x + s_dq[wv][l]);
+    out.strand[o] = (uint8_t)(a.y & 0xffu);
+    out.flags[o] = (uint8_t)((a.y >> 8) & 0xffu);
+    out.start[o] = (int64_t)((uint64_t)a.z | ((uint64_t)a.w << 32));
+    out.stop[o] = (int64_t)((uint64_t)b.x | ((uint64_t)b.y << 32));
+    out.cfdon[o] = __longlong_as_double((long long)((uint64_t)b.z | ((uint64_t)b.w << 32)));
+    out.win[0 * out.cap + o] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+    out.win[1 * out.cap + o] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+    out.win[2 * out.cap + o] = (uint64_t)d.x | ((uint64_t)d.y << 32);
+    out.win[3 * out.cap + o] = (uint64_t)d.z | ((uint64_t)d.w << 32);
+    out.win[4 * out.cap + o] = (uint64_t)e.x | ((uint64_t)e.y << 32);
+  }
+}
+
+void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const GuideParams& gp,
+                              const RefInfo& ri, void* res, void* trows, int* status) {
+  if (!cd.n_uniq) return;
+  const uint32_t nb = (uint32_t)(((uint64_t)cd.n_uniq * CS_G + 255) / 256);
+  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), static_cast<CsRow*>(trows), status);
+}
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
+                          uint32_t* counts, unsigned long long* shards) {
+  if (!cd.n_inst) return;
+  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), counts, shards);
+}
+void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const void* trows, const uint64_t* offsets, GuideCols out, int* status) {
+  if (!cd.n_inst) return;
+  hipLaunchKernelGGL(k_cs_emit, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), static_cast<const CsRow*>(trows),
+                     offsets, out, status);
+}

@@ -25,7 +25,7 @@ char* hawk_hip_err_buf();  // thread-local text of the last HIP failure (hawk_la
 struct hawk_ctx {
   int device;
   hipStream_t stream;
-  hipEvent_t ev[8];
+  hipEvent_t ev[10];
   void* pinned = nullptr;  // 256 B of page-locked host memory: the per-search totals + status come back in one copy
 };
 
@@ -117,6 +117,7 @@ struct hawk_hapset {
   const struct hawk_xplan* vplan = nullptr;
   DevBuf vcnt0;               // per tile: rows of strand 0 (k_vsearch<0> -> k_vsearch<1>)
   DevBuf refhp;               // REF's PAM hits + prefix counts per strand (k_ref_hits), keyed like refbits
+  DevBuf cs_res, cs_trows;    // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}; template rows
   DevBuf colsA[8];
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
 };
@@ -145,6 +146,15 @@ struct hawk_xplan {
   uint32_t n_ref_rows = 0;
   std::vector<int64_t> rev0, rev1;  // hawk_xplan_create_gt: posmap_rev of every row at the two positions asked for
   std::shared_ptr<uint64_t> groups = std::make_shared<uint64_t>(0);  // groups the last collapse of a set of this plan found
+  // the cluster dictionary (hawk_csearch.hip), built by the first hawk_xplan_view after the metadata is set
+  struct {
+    bool built = false, usable = false;
+    uint32_t n_inst = 0, n_uniq = 0;
+    uint64_t slots = 0;     // template rows reserved over all distinct clusters
+    uint32_t status = 0;    // why it is not usable: 1 a chain of > 4096 records, 2 hash collision, 4 too large / too little sharing
+    float build_ms = 0.f;
+    DevBuf inst_uid, inst_o, inst_row, inst_pa, inst_rb, u_rec, u_n, u_row, u_o, u_half, u_slot;
+  } cl;
 };
 
 // genotypes of a VCF block in HBM and, after hawk_gt_lists, the carried-variant lists of every chromosome copy

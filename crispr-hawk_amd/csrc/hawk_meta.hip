@@ -176,6 +176,9 @@ void hawk_launch_segments(hipStream_t st, const uint64_t* ioff, const uint32_t* 
     hipLaunchKernelGGL(k_seg_fill, dim3(n_rows), dim3(256), 0, st, ioff, indel, hv_idx, hv_o, v_r0, v_chain, hap_len, startp, seg_off, seg_rel, seg_gen);
   }
 }
+void hawk_launch_scan_u32(hipStream_t st, const uint32_t* cnt, uint32_t n, uint32_t* off) {
+  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, cnt, n, off);
+}
 void hawk_launch_rev_lookup(hipStream_t st, const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen, const uint32_t* hap_len,
                             uint32_t n_rows, int64_t g0, int64_t g1, int64_t* out0, int64_t* out1) {
   hipLaunchKernelGGL(k_rev_lookup, dim3((n_rows + 3) / 4), dim3(256), 0, st, seg_off, seg_rel, seg_gen, hap_len, n_rows, g0, g1, out0, out1);

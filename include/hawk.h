@@ -147,6 +147,15 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
  * planes (hawk_pam_scan, hawk_hapset_download_plane, hawk_offtarget_scan ...) returns HAWK_E_INVALID on a view; tables,
  * collapse, export and gather work as on any set.  The plan must outlive the view. */
 int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out);
+/* The cluster dictionary hawk_xplan_view builds for a plan (crispr-hawk_amd/csrc/hawk_csearch.hip): a row's carried variants
+ * fall into clusters (alleles within 64 positions of each other - the reach of one padded guide window); a cluster carried by
+ * many chromosome copies is searched ONCE per hawk_search and its rows copied to every carrier.  usable = 0: the plan is
+ * searched per row instead (status 1: a chain of more than 4096 variants, 2: two different clusters with one hash, 4: too
+ * little sharing - fewer than HAWK_CLUSTER_MIN_SHARE (3) instances per distinct cluster - or more than
+ * HAWK_CLUSTER_MAX_SLOTS (2^27) template rows).  Same table either way, up to the order of a haplotype's rows.
+ * No reference counterpart: the reference searches every haplotype string on its own (search_guides.py:510-548). */
+int hawk_xplan_cluster_stats(const hawk_xplan* x, uint32_t* usable, uint32_t* n_instances, uint32_t* n_distinct, uint64_t* template_slots,
+                             float* build_ms, uint32_t* status);
 /* Plan creation straight from the genotype inversion: `g` is a hawk_gt after hawk_gt_lists, whose carried-variant lists
  * are still in HBM - they are used in place (rows = REF + every chromosome copy with a non-empty list, in column order),
  * nothing is downloaded, and what the host used to do over every list entry runs as kernels: the ascending /
@@ -204,7 +213,9 @@ typedef struct {          /* kernel times of the last hawk_search (HIP events on
   float emit_list_ms; /* k_emit_list alone (0 when the hand-over lists are switched off) */
   float v_count_ms;   /* a plan view (hawk_xplan_view): k_vsearch<0> alone - count_ms also holds the REF row's plane kernel */
   float v_emit_ms;    /* ... k_vsearch<1> alone */
-  float reserved;
+  float v_templates_ms; /* the cluster path of a view: k_cs_templates alone (v_count_ms: templates + k_cs_count; v_emit_ms: k_cs_emit) */
+  uint32_t v_path;    /* 0: planes, 1: a view searched per dirty word (k_vsearch), 2: a view searched per distinct cluster (hawk_csearch.hip) */
+  float reserved[2];
 } hawk_timing;
 
 /* Runs the whole device pipeline; the guide table stays in HBM. `timing` may be NULL. */

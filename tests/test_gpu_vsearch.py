@@ -1,8 +1,11 @@
-"""hawk_xplan_view: the search straight from an expansion plan (hawk_vsearch.hip) against the search on the planes the
+"""hawk_xplan_view: the search straight from an expansion plan - per dirty word of every row (hawk_vsearch.hip) and per
+distinct variant cluster (hawk_csearch.hip) - against the search on the planes the
 same plan materialises (hawk_xplan_run + hawk_search, itself held to the reference's fixtures and the oracle by
 test_gpu_parity.py): every column, row for row, and the job totals, on inputs that reach each path of the kernel -
 tiles with no variant, the usual few, more records than LDS stages, more dirty words than one pass holds, long
 insertions and deletions across word / tile edges, rows that end in a tile, PAMs of every shape."""
+import os
+
 import numpy as np
 import pytest
 
@@ -16,6 +19,20 @@ pytestmark = pytest.mark.gpu
 COLS = ("hap", "pos", "strand", "start", "stop", "flags")
 
 
+@pytest.fixture(autouse=True)
+def _small_panels_take_the_cluster_path_too(monkeypatch):
+    # the dictionary is only used when clusters are shared (>= 3 instances per distinct cluster): these panels have 3-6 samples
+    monkeypatch.setenv("HAWK_CLUSTER_MIN_SHARE", "0")
+    monkeypatch.delenv("HAWK_VIEW_SEARCH", raising=False)
+
+
+def _canonical(t):
+    """rows in the reference's emission order (haplotype, strand, position): the cluster path orders a haplotype's rows by
+    cluster, the plane path by tile"""
+    o = np.lexsort((t.pos, t.strand, t.hap))
+    return {c: getattr(t, c)[o] for c in COLS} | {"win": t.win[:, o], "cfdon": t.cfdon[o]}
+
+
 def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False):
     bits, bitsrc, _, _ = ora.pam_encode(pam_s)
     mm, pt = synth.cfd_tables() if cfd else (None, None)
@@ -25,15 +42,31 @@ def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False):
         return a
     assert ds.plan is not None
     view = ds.plan.view()
-    b = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
+    os.environ["HAWK_VIEW_SEARCH"] = "words"
+    try:
+        b = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
+    finally:
+        del os.environ["HAWK_VIEW_SEARCH"]
+    assert b.timing["v_path"] == 1
     assert (b.n_rows, b.n_candidates, b.n_hits) == (a.n_rows, a.n_candidates, a.n_hits)
     for c in COLS:
         assert np.array_equal(getattr(a, c), getattr(b, c)), c
     assert np.array_equal(a.win, b.win)
     assert np.array_equal(a.cfdon, b.cfdon, equal_nan=True)
+    # per distinct cluster: the same rows, a haplotype's in cluster order
+    st = ds.plan.cluster_stats()
+    assert st["usable"], st
+    c = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
+    assert c.timing["v_path"] == 2
+    assert (c.n_rows, c.n_candidates, c.n_hits) == (a.n_rows, a.n_candidates, a.n_hits)
+    ca, cc = _canonical(a), _canonical(c)
+    for k in COLS:
+        assert np.array_equal(ca[k], cc[k]), k
+    assert np.array_equal(ca["win"], cc["win"])
+    assert np.array_equal(ca["cfdon"], cc["cfdon"], equal_nan=True)
     # a second search on the view (cached REF bitmaps, reserved columns) and a different geometry after it
     b2 = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
-    assert b2.n_rows == a.n_rows and np.array_equal(b2.start, a.start) and np.array_equal(b2.win, a.win)
+    assert b2.n_rows == a.n_rows and np.array_equal(b2.start, c.start) and np.array_equal(b2.win, c.win)
     with pytest.raises(_lib.HawkStatusError):
         view.pam_scan(bits, bitsrc, len(pam_s))  # a view holds no planes
     ds.plan.close()
