@@ -334,7 +334,9 @@ def run_region(args, R: Ranks):
         sl["ms"] = avg("total_ms")
         sl["frac"] = sl["algorithmic_bytes"] / (sl["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sl["ms"] else None
         out["kernels_ms"] = {"count": avg("count_ms"), "offsets": avg("offsets_ms"), "emit": avg("emit_ms"), "emit_list": avg("emit_list_ms"),
-                             "vsearch_count": avg("v_count_ms"), "vsearch_emit": avg("v_emit_ms"), "device_total": avg("total_ms")}
+                             "vsearch_count": avg("v_count_ms"), "vsearch_emit": avg("v_emit_ms"), "view_templates": avg("v_templates_ms"),
+                             "view_path": {0: "planes", 1: "per dirty word (hawk_vsearch.hip)", 2: "per distinct cluster (hawk_csearch.hip)"}[int(tm[-1]["v_path"])],
+                             "device_total": avg("total_ms")}
         out["pam_scan_kernel"] = pam_scan_kernel(ds, pam)
         out["haplotype_expansion"] = {"kernels_ms": expand_ms, "rows": ds.n_hap,
                                       "where": "device (hawk_xplan_run); not part of the fused step, which writes no planes" if fused

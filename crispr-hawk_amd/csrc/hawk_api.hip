@@ -253,7 +253,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
                     &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->ctable, &hs->cocc, &hs->cdense, &hs->cgkey, &hs->cgslot, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
-                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_trows};
+                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_tbase, &hs->cs_trows};
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   for (auto& b : hs->crep) b.release();
@@ -651,6 +651,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   unsigned long long* d_shards = hs->misc.as<unsigned long long>();          // [256][2] candidate / hit partial sums
   int* d_status = reinterpret_cast<int*>(hs->misc.as<char>() + 512 * 8);
   uint32_t* d_big_count = reinterpret_cast<uint32_t*>(hs->misc.as<char>() + 512 * 8 + 16);  // zeroed with misc
+  unsigned long long* d_tcount = reinterpret_cast<unsigned long long*>(hs->misc.as<char>() + 512 * 8 + 8);  // template rows handed out (hawk_csearch.hip)
   // status (4 B) | work-list count | totals share one 64-byte block: a single copy into page-locked memory per search
   static_assert(sizeof(ScanTotals) == 32, "status block layout");
   ScanTotals* d_totals = reinterpret_cast<ScanTotals*>(hs->misc.as<char>() + 512 * 8 + 32);
@@ -690,7 +691,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     if (!hs->refbits_valid || memcmp(hs->refbits_key, key, sizeof(key)) != 0) {
       hawk_launch_ref_bits(ctx->stream, d, sp, ri, hs->refbits.as<uint32_t>(), hs->refbits.as<uint32_t>() + hs->S);
       // REF's PAM hits + prefix counts: what the clean stretches of a plan's rows are counted from
-      if (vx) hawk_launch_ref_hits(ctx->stream, d, sp, hs->ref_index, hs->refhp.p, hs->refhp.as<uint2>() + hs->S + 1);
+      if (vx) hawk_launch_ref_hits(ctx->stream, d, sp, hs->ref_index, hs->refhp.p);
       HIPCHK(hipGetLastError());
       memcpy(hs->refbits_key, key, sizeof(key));
       hs->refbits_valid = true;
@@ -702,7 +703,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     for (int pl = 0; pl < 4; ++pl) va.ref[pl] = vx->ref5[pl].as<uint32_t>();
     va.ref_S = hs->S;
     va.recs_ = vx->recs.p; va.alt_codes = vx->codes.as<uint8_t>(); va.hv_off = vx->off.as<uint64_t>(); va.tiles_ = vx->tiles.p;
-    va.hpF = hs->refhp.as<uint2>(); va.hpR = hs->refhp.as<uint2>() + hs->S + 1;
+    va.hp = hs->refhp.as<uint4>();
   }
   const uint32_t v_tiles = vx ? (uint32_t)ntile - plane_tiles : 0u;
   ClDict cd;
@@ -713,15 +714,19 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     cd.inst_uid = cl.inst_uid.as<uint32_t>(); cd.inst_o = cl.inst_o.as<int32_t>(); cd.inst_row = cl.inst_row.as<uint32_t>();
     cd.inst_pa = cl.inst_pa.as<int32_t>(); cd.inst_rb = cl.inst_rb.as<int32_t>();
     cd.u_rec = cl.u_rec.as<uint32_t>(); cd.u_n = cl.u_n.as<uint32_t>(); cd.u_row = cl.u_row.as<uint32_t>(); cd.u_o = cl.u_o.as<int32_t>();
-    cd.u_half = cl.u_half.as<uint32_t>(); cd.u_slot = cl.u_slot.as<uint64_t>();
-    if ((rc = hs->cs_res.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 16)) || (rc = hs->cs_trows.reserve((size_t)std::max<uint64_t>(cl.slots, 1) * hawk_cs_row_bytes())))
+    cd.u_seg = cl.u_seg.as<uint32_t>();
+    // template rows: packed as the search produces them; their number is bounded by the window starts of the distinct clusters,
+    // and a search that needs more than the rows reserved so far says so and is rerun (as the guide columns are)
+    if ((rc = hs->cs_res.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 16)) || (rc = hs->cs_tbase.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 4)) ||
+        (rc = hs->cs_trows.reserve((size_t)std::max<uint64_t>(cl.slots, 1) * hawk_cs_row_bytes())))
       return rc;
   }
   // the view's share of the two passes: per dirty word of every row, or per distinct cluster + a copy per instance
   uint32_t* const d_counts_v = hs->counts.as<uint32_t>() + plane_tiles;
   auto view_count = [&]() {
     if (by_cluster) {
-      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_trows.p, d_status);
+      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, d_tcount,
+                               std::max<uint64_t>(vx->cl.slots, 1), d_status);
       (void)hipEventRecord(ctx->ev[8], ctx->stream);
       hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, d_counts_v, d_shards);
     } else {
@@ -730,7 +735,8 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     }
   };
   auto view_emit = [&](const GuideCols& cols) {
-    if (by_cluster) hawk_launch_cs_emit(ctx->stream, cd, hs->cs_res.p, hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles, cols, d_status);
+    if (by_cluster) hawk_launch_cs_emit(ctx->stream, cd, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
+                                        ri.startp, cols, d_status);
     else hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards,
                              hs->offsets.as<uint64_t>(), cols, d_status, plane_tiles, v_tiles);
   };
@@ -1274,7 +1280,7 @@ void hawk_xplan_destroy(hawk_xplan* x) {
   DevBuf* bufs[] = {&x->recs, &x->tiles, &x->codes, &x->off, &x->hlen, &x->hash,
                     &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile,
                     &x->cl.inst_uid, &x->cl.inst_o, &x->cl.inst_row, &x->cl.inst_pa, &x->cl.inst_rb, &x->cl.u_rec, &x->cl.u_n, &x->cl.u_row,
-                    &x->cl.u_o, &x->cl.u_half, &x->cl.u_slot};
+                    &x->cl.u_o, &x->cl.u_seg};
   for (auto* b : bufs) b->release();
   delete x;
 }
@@ -1534,6 +1540,17 @@ static int xplan_build_dict(hawk_xplan* x) {
   if ((rc = cl.inst_uid.reserve((size_t)n_inst * 4)) || (rc = cl.inst_o.reserve((size_t)n_inst * 4)) || (rc = cl.inst_row.reserve((size_t)n_inst * 4)) ||
       (rc = cl.inst_pa.reserve((size_t)n_inst * 4)) || (rc = cl.inst_rb.reserve((size_t)n_inst * 4)))
     return rc;
+  // built in (row, position) order, then laid out stretch by stretch of REF (k_cl_permute)
+  uint32_t bshift = 15;
+  while (((x->ref_len >> bshift) + 1) > 1024) ++bshift;
+  const uint32_t n_bkt = (x->ref_len >> bshift) + 1;
+  uint32_t *t_uid, *t_row, *d_cnt_br, *d_first_rb;
+  int32_t *t_o, *t_pa, *t_rb;
+  uint16_t* d_bkt;
+  uint64_t* d_base_br;
+  TEMPCHK(tmp, &t_uid, (size_t)n_inst * 4); TEMPCHK(tmp, &t_row, (size_t)n_inst * 4); TEMPCHK(tmp, &t_o, (size_t)n_inst * 4);
+  TEMPCHK(tmp, &t_pa, (size_t)n_inst * 4); TEMPCHK(tmp, &t_rb, (size_t)n_inst * 4); TEMPCHK(tmp, &d_bkt, (size_t)n_inst * 2);
+  TEMPCHK(tmp, &d_cnt_br, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_first_rb, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_base_br, ((size_t)n * n_bkt + 1) * 8);
   uint32_t *d_rec, *d_n, *d_slot, *d_flag, *d_trep, *d_slot_uid;
   uint64_t *d_key, *d_rank;
   uint8_t* d_cls;
@@ -1551,15 +1568,14 @@ static int xplan_build_dict(hawk_xplan* x) {
   TEMPCHK(tmp, &d_tkey, (size_t)tsize * 8);
   TEMPCHK(tmp, &d_trep, (size_t)tsize * 4);
   TEMPCHK(tmp, &d_slot_uid, (size_t)tsize * 4);
-  TEMPCHK(tmp, &d_partial, ((size_t)n_inst / 1024 + 2) * 8);
+  TEMPCHK(tmp, &d_partial, ((size_t)std::max<uint64_t>(n_inst, (uint64_t)n * n_bkt) / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
   HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsize * 8, st));
   HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsize * 4, st));
   HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
   hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
-                      cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(), cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>(), d_rec, d_n, d_key, d_cls,
-                      d_status);
+                      t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls, d_bkt, bshift, n_bkt, d_cnt_br, d_first_rb, d_status);
   hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_flag);
   hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
   ScanTotals tot;
@@ -1572,18 +1588,22 @@ static int xplan_build_dict(hawk_xplan* x) {
     uint32_t* d_span2;
     TEMPCHK(tmp, &d_span2, (size_t)n_uniq * 4);
     if ((rc = cl.u_rec.reserve((size_t)n_uniq * 4)) || (rc = cl.u_n.reserve((size_t)n_uniq * 4)) || (rc = cl.u_row.reserve((size_t)n_uniq * 4)) ||
-        (rc = cl.u_o.reserve((size_t)n_uniq * 4)) || (rc = cl.u_half.reserve((size_t)n_uniq * 4)) || (rc = cl.u_slot.reserve(((size_t)n_uniq + 1) * 8)))
+        (rc = cl.u_o.reserve((size_t)n_uniq * 4)) || (rc = cl.u_seg.reserve((size_t)n_uniq * 4)))
       return rc;
-    hawk_launch_cl_assign(st, n_inst, d_flag, d_rank, d_slot, d_trep, x->recs.p, cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(),
-                          cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>(), d_rec, d_n, d_key, d_cls, d_slot_uid, cl.u_rec.as<uint32_t>(),
-                          cl.u_n.as<uint32_t>(), cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_half.as<uint32_t>(), d_span2,
-                          cl.inst_uid.as<uint32_t>(), d_status);
-    hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, cl.u_slot.as<uint64_t>(), d_tot + 1);
+    uint64_t* d_slot64;
+    TEMPCHK(tmp, &d_slot64, ((size_t)n_uniq + 1) * 8);
+    hawk_launch_cl_assign(st, n_inst, d_flag, d_rank, d_slot, d_trep, x->recs.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls,
+                          x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), d_slot_uid, cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
+                          cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, t_uid, d_status);
+    hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, d_slot64, d_tot + 1);
     HIPCHK(hipMemcpyAsync(&tot, d_tot + 1, sizeof(tot), hipMemcpyDeviceToHost, st));
   } else {
-    HIPCHK(hipMemsetAsync(cl.inst_uid.p, 0xff, (size_t)n_inst * 4, st));
+    HIPCHK(hipMemsetAsync(t_uid, 0xff, (size_t)n_inst * 4, st));
     tot.n_keep = 0;
   }
+  hawk_launch_mscan(st, d_cnt_br, (uint64_t)n * n_bkt, d_partial, d_shards, d_base_br, d_tot);
+  hawk_launch_cl_permute(st, n_inst, n, n_bkt, d_bkt, d_base_br, d_first_rb, t_uid, t_o, t_row, t_pa, t_rb, cl.inst_uid.as<uint32_t>(),
+                         cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(), cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>());
   uint32_t status = 0;
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[9], st));

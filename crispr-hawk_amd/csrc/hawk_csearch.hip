@@ -28,17 +28,14 @@
 #define CL_FAR (1 << 29)     // "position" of a row's closing instance: the clean run in front of it reaches the row's end
 #define CL_MAXWALK 4096      // records per cluster the dictionary accepts (longer chains: the per-word search takes the plan)
 #define CS_G 8               // lanes per distinct cluster in k_cs_templates: one 32-window word each per round
+#ifndef CS_ABL
+#define CS_ABL 0             // ablation builds only (tools/ab_cs.sh)
+#endif
 
-struct __attribute__((aligned(16))) CsRow {  // a template row: GuideCols' fields, position relative to the cluster's first allele
-  int32_t pos;
-  uint8_t strand, flags;
-  uint16_t pad;
-  int64_t start, stop;
-  double cfdon;
-  uint64_t win[5];
-  uint64_t pad2;
-};
-static_assert(sizeof(CsRow) == 80, "template row layout");
+// a template row, 64 bytes = one L2 sector pair: {position relative to the cluster's first allele, strand | flags << 8,
+// start - REF's first position, stop - start} {cfdon, win0} {win1, win2} {win3, win4}
+struct __attribute__((aligned(16))) CsRow { uint4 a, b, c, d; };
+static_assert(sizeof(CsRow) == 64, "template row layout");
 size_t hawk_cs_row_bytes() { return sizeof(CsRow); }
 
 __device__ __forceinline__ uint64_t cl_mix(uint64_t h, uint64_t v) {
@@ -78,12 +75,13 @@ struct ClInst {  // per instance (k_cl_fill)
   uint32_t* n;     // its records
   uint64_t* key;   // hash of the variant identities (+ the row, for a cluster that must stay the row's own)
   uint8_t* cls;    // 0: no cluster (closing instance, or cluster wholly outside the scan range), 1: shareable, 2: the row's own
+  uint16_t* bkt;   // which stretch of REF the instance lies in (REF position >> bshift): the order the searches walk the instances in
 };
 
 __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs, const uint64_t* __restrict__ hv_off,
                                                  const uint32_t* __restrict__ hap_len, const int32_t* __restrict__ ss_,
                                                  const int32_t* __restrict__ se_, const uint32_t* __restrict__ inst_off, ClInst ci,
-                                                 uint32_t* __restrict__ status) {
+                                                 uint32_t bshift, uint32_t n_bkt, uint32_t* __restrict__ status) {
   __shared__ uint32_t s_w[256 / WAVE];
   const uint32_t row = blockIdx.x;
   const uint32_t i0 = inst_off[row], i1 = inst_off[row + 1];
@@ -120,6 +118,8 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
       if (cls && key == 0) key = 1;
       ci.o[i] = o_first; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb;
       ci.rec[i] = (uint32_t)j; ci.n[i] = n; ci.key[i] = key; ci.cls[i] = cls;
+      const uint32_t b = (uint32_t)(o_first + rb > 0 ? o_first + rb : 0) >> bshift;  // REF position of the first allele
+      ci.bkt[i] = (uint16_t)(b < n_bkt ? b : n_bkt - 1);
     }
     at += tot;
   }
@@ -128,7 +128,43 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
     int32_t pa = 0, rb = 0;
     if (hi > lo) { pa = recs[hi - 1].o + (int32_t)recs[hi - 1].alt_len; rb = (int32_t)recs[hi - 1].rs - pa; }
     ci.o[i] = CL_FAR; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb; ci.rec[i] = 0; ci.n[i] = 0; ci.key[i] = 0; ci.cls[i] = 0;
+    const uint32_t b = (uint32_t)(pa + rb > 0 ? pa + rb : 0) >> bshift;
+    ci.bkt[i] = (uint16_t)(b < n_bkt ? b : n_bkt - 1);
   }
+}
+
+// The searches walk the instances stretch by stretch of REF (bucket-major: all rows' instances of the first 32 kb, then of the
+// next ...) rather than row by row: the workgroups in flight at any time then copy the template rows of ONE stretch's clusters,
+// a few hundred KB that stay in every XCD's L2, instead of gathering from all of them.  Within a stretch the order is (row,
+// position), so a wave's 64 instances still write one contiguous piece of the table.
+#define CL_MAXBKT 1024
+__global__ __launch_bounds__(256) void k_cl_bucket(const uint32_t* __restrict__ inst_off, const uint16_t* __restrict__ bkt, uint32_t n_rows,
+                                                   uint32_t n_bkt, uint32_t* __restrict__ cnt_br, uint32_t* __restrict__ first_rb) {
+  __shared__ uint32_t s_cnt[CL_MAXBKT], s_first[CL_MAXBKT];
+  const uint32_t row = blockIdx.x;
+  for (uint32_t b = threadIdx.x; b < n_bkt; b += 256) { s_cnt[b] = 0; s_first[b] = 0xffffffffu; }
+  __syncthreads();
+  const uint32_t i0 = inst_off[row], i1 = inst_off[row + 1];
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const uint32_t b = bkt[i];
+    atomicAdd(&s_cnt[b], 1u);
+    atomicMin(&s_first[b], i);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_bkt; b += 256) {
+    cnt_br[(size_t)b * n_rows + row] = s_cnt[b];
+    first_rb[(size_t)row * n_bkt + b] = s_first[b];
+  }
+}
+struct ClPerm { const uint32_t* uid; const int32_t* o; const uint32_t* row; const int32_t* pa; const int32_t* rb;
+                uint32_t* uid2; int32_t* o2; uint32_t* row2; int32_t* pa2; int32_t* rb2; };
+__global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* __restrict__ bkt,
+                                                    const uint64_t* __restrict__ base_br, const uint32_t* __restrict__ first_rb, ClPerm pm) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_inst) return;
+  const uint32_t b = bkt[i], row = pm.row[i];
+  const uint64_t d = base_br[(size_t)b * n_rows + row] + (i - first_rb[(size_t)row * n_bkt + b]);
+  pm.uid2[d] = pm.uid[i]; pm.o2[d] = pm.o[i]; pm.row2[d] = row; pm.pa2[d] = pm.pa[i]; pm.rb2[d] = pm.rb[i];
 }
 
 __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
@@ -153,11 +189,12 @@ __global__ __launch_bounds__(256) void k_cl_flag(uint32_t n_inst, const uint8_t*
   if (i < n_inst) flag[i] = (cls[i] && trep[inst_slot[i]] == i) ? 1u : 0u;
 }
 struct ClUniq {  // per distinct cluster
-  uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* half; uint32_t* span2;
+  uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* seg; uint32_t* span2;
 };
 // the representatives (lowest instance of every distinct cluster) number the clusters in instance order
 __global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
                                                    const uint32_t* __restrict__ inst_slot, ClInst ci, const HxVar* __restrict__ recs,
+                                                   const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
                                                    uint32_t* __restrict__ slot_uid, ClUniq cu) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_inst || !flag[i]) return;
@@ -165,9 +202,17 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32
   slot_uid[inst_slot[i]] = u;
   const uint32_t r = ci.rec[i], n = ci.n[i];
   const int32_t o_first = recs[r].o, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
-  cu.rec[u] = r; cu.n[u] = n; cu.row[u] = ci.row[i]; cu.o[u] = o_first;
-  const uint32_t half = (uint32_t)(o_end - o_first) + CL_LINK;  // window starts per strand: <= o_end - o_first + L - 1
-  cu.half[u] = half; cu.span2[u] = 2u * half;
+  const uint32_t row = ci.row[i];
+  cu.rec[u] = r; cu.n[u] = n; cu.row[u] = row; cu.o[u] = o_first;
+  cu.span2[u] = 2u * ((uint32_t)(o_end - o_first) + CL_LINK);  // rows the cluster can have: window starts [o_first - L + 1, o_end) x 2 strands
+  // the position-map segment in force CL_LINK + PAD positions in front of the cluster: every position a search asks for lies behind it
+  const uint32_t rel = o_first > CL_LINK + HAWK_PAD ? (uint32_t)(o_first - CL_LINK - HAWK_PAD) : 0u;
+  uint32_t lo = seg_off[row], hi = seg_off[row + 1];
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_rel[mid] <= rel) lo = mid; else hi = mid;
+  }
+  cu.seg[u] = lo;
 }
 __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint32_t* __restrict__ trep,
                                                 const uint32_t* __restrict__ slot_uid, ClInst ci, const HxVar* __restrict__ recs,
@@ -195,9 +240,18 @@ void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_o
 }
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
                          uint32_t n_rows, const uint32_t* inst_off, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                         uint64_t* key, uint8_t* cls, uint32_t* status) {
-  ClInst ci{o, row, pa, rb, rec, n, key, cls};
-  hipLaunchKernelGGL(k_cl_fill, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, hap_len, ss, se, inst_off, ci, status);
+                         uint64_t* key, uint8_t* cls, uint16_t* bkt, uint32_t bshift, uint32_t n_bkt, uint32_t* cnt_br, uint32_t* first_rb,
+                         uint32_t* status) {
+  ClInst ci{o, row, pa, rb, rec, n, key, cls, bkt};
+  hipLaunchKernelGGL(k_cl_fill, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, hap_len, ss, se, inst_off, ci, bshift, n_bkt,
+                     status);
+  hipLaunchKernelGGL(k_cl_bucket, dim3(n_rows), dim3(256), 0, st, inst_off, bkt, n_rows, n_bkt, cnt_br, first_rb);
+}
+void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* bkt, const uint64_t* base_br,
+                            const uint32_t* first_rb, const uint32_t* uid, const int32_t* o, const uint32_t* row, const int32_t* pa, const int32_t* rb,
+                            uint32_t* uid2, int32_t* o2, uint32_t* row2, int32_t* pa2, int32_t* rb2) {
+  ClPerm pm{uid, o, row, pa, rb, uid2, o2, row2, pa2, rb2};
+  hipLaunchKernelGGL(k_cl_permute, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, n_rows, n_bkt, bkt, base_br, first_rb, pm);
 }
 void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep, uint32_t mask,
                            uint32_t* inst_slot, uint32_t* flag) {
@@ -207,12 +261,13 @@ void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key,
 }
 void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
                            const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                           uint64_t* key, uint8_t* cls, uint32_t* slot_uid, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o,
-                           uint32_t* u_half, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
+                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* slot_uid, uint32_t* u_rec,
+                           uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
   const uint32_t nb = (n_inst + 255) / 256;
-  ClInst ci{o, row, pa, rb, rec, n, key, cls};
-  ClUniq cu{u_rec, u_n, u_row, u_o, u_half, u_span2};
-  hipLaunchKernelGGL(k_cl_assign, dim3(nb), dim3(256), 0, st, n_inst, flag, rank, inst_slot, ci, static_cast<const HxVar*>(recs), slot_uid, cu);
+  ClInst ci{o, row, pa, rb, rec, n, key, cls, nullptr};
+  ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
+  hipLaunchKernelGGL(k_cl_assign, dim3(nb), dim3(256), 0, st, n_inst, flag, rank, inst_slot, ci, static_cast<const HxVar*>(recs), seg_off, seg_rel,
+                     slot_uid, cu);
   hipLaunchKernelGGL(k_cl_uid, dim3(nb), dim3(256), 0, st, n_inst, inst_slot, trep, slot_uid, ci, static_cast<const HxVar*>(recs), inst_uid, status);
 }
 
@@ -237,11 +292,23 @@ __device__ __forceinline__ uint32_t group_incl_scan(uint32_t v, uint32_t gl) {
   return v;
 }
 
+// position map (haplotype.py:90-159) from a hint: k0 = a segment of row h starting at or before every position the cluster asks for
+__device__ __forceinline__ int64_t posmap_hint(const HapSetDev& hs, uint32_t k0, uint32_t kend, uint32_t rel) {
+  uint32_t k = k0;
+  while (k + 1 < kend && hs.seg_rel[k + 1] <= rel) ++k;
+  return hs.seg_gen[k] + (int64_t)(rel - hs.seg_rel[k]);
+}
+
 // Every distinct cluster's rows, once: a group of CS_G lanes per cluster, each lane one word of 32 window starts per round.
-// res[u] = {rows of strand 0, rows of strand 1, PAM hits, candidates} of the cluster's own window starts.
+// res[u] = {rows of strand 0, rows of strand 1, PAM hits, candidates} of the cluster's own window starts; its template rows sit
+// at tbase[u] (strand 0 in position order, then strand 1), packed: a workgroup adds up its clusters' rows and takes its
+// stretch of the template array with one atomic.
 __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, GuideParams gp, RefInfo ri,
-                                                      uint4* __restrict__ res, CsRow* __restrict__ trows, int* status) {
+                                                      uint4* __restrict__ res, uint32_t* __restrict__ tbase, CsRow* __restrict__ trows,
+                                                      unsigned long long* __restrict__ t_count, uint64_t t_cap, int* status) {
   __shared__ double s_cfd[336];
+  __shared__ uint32_t s_w[256 / WAVE];
+  __shared__ unsigned long long s_base;
   const uint32_t tid = threadIdx.x;
   if (gp.score_cfdon) for (uint32_t i = tid; i < 336; i += 256) s_cfd[i] = gp.cfd_mm[i];
   __syncthreads();
@@ -251,12 +318,13 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   if (!live) u = cd.n_uniq - 1;  // lanes of a surplus group redo the last cluster and write nothing
   const HxVar* __restrict__ recs = static_cast<const HxVar*>(va.recs_);
   const uint32_t h = cd.u_row[u], r0 = cd.u_rec[u], nc = cd.u_n[u];
+  const uint32_t seg0 = cd.u_seg[u], seg_end = hs.seg_off[h + 1];
   const uint32_t back = (uint64_t)r0 > va.hv_off[h] ? 1u : 0u;  // the record in front of the cluster sets the REF shift it starts from
   const HxVar* __restrict__ sv = recs + r0 - back;
   const int nrec = (int)(nc + back);
   const int L = p.L;
   const int32_t haplen = (int32_t)hs.hap_len[h];
-  const int32_t o_first = recs[r0].o;
+  const int32_t o_first = cd.u_o[u];
   const int32_t o_end = recs[r0 + nc - 1].o + (int32_t)recs[r0 + nc - 1].alt_len;
   const int32_t qa = o_first - (L - 1) > 0 ? o_first - (L - 1) : 0;
   const int32_t qb = o_end < haplen ? o_end : haplen;
@@ -272,67 +340,56 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
     const uint32_t w = (r >> 5) < va.ref_S - 2 ? (r >> 5) : va.ref_S - 2;
     return ext32_glb(va.ref[pl], (w << 5) | (r & 31u));
   };
-  const uint64_t slot0 = cd.u_slot[u];
-  const uint32_t half = cd.u_half[u];
-  uint32_t base0 = 0, base1 = 0, hits = 0, cand = 0;
-#pragma unroll 1
-  for (int w0 = 0; w0 < nwords; w0 += CS_G) {  // uniform within a group
-    const int w = w0 + (int)gl;
-    const bool active = w < nwords;
-    const int32_t q0 = qa + 32 * w;
-    uint32_t X[5][3];
+  // one word: the five 96-bit strings around window starts [q0, q0 + 32), PAM hits, candidates, the starts kept by the filters
+  auto word = [&](int32_t q0, uint32_t (&X)[5][3], uint32_t& kF, uint32_t& kR, uint32_t& hits, uint32_t& cand) {
+    const int32_t p0 = q0 - HAWK_PAD;
+    const int32_t p0c = p0 < 0 ? 0 : p0;
+    int32_t shift_run = 0;
+    if (!vc_string_fast(va, sv, nrec, p0c, haplen, q0 + 32, X, shift_run))
+      hx_words_t<false, 3>(va.alt_codes, sv, sv, nrec, nrec, false, p0c, haplen, ref32, X[0], X[1], X[2], X[3], X[4]);
+    if (p0 < 0) {  // the string starts at the row's first base: bit i is position q0 - PAD + i all the same
+      const uint32_t sh = (uint32_t)(-p0);
 #pragma unroll
-    for (int pl = 0; pl < 5; ++pl) X[pl][0] = X[pl][1] = X[pl][2] = 0;
-    uint32_t kF = 0, kR = 0;
-    if (active) {
-      const int32_t p0 = q0 - HAWK_PAD;
-      const int32_t p0c = p0 < 0 ? 0 : p0;
-      int32_t shift_run = 0;
-      if (!vc_string_fast(va, sv, nrec, p0c, haplen, q0 + 32, X, shift_run))
-        hx_words_t<false, 3>(va.alt_codes, sv, sv, nrec, nrec, false, p0c, haplen, ref32, X[0], X[1], X[2], X[3], X[4]);
-      if (p0 < 0) {  // the string starts at the row's first base: bit i is position q0 - PAD + i all the same
-        const uint32_t sh = (uint32_t)(-p0);
-#pragma unroll
-        for (int pl = 0; pl < 5; ++pl) {
-          X[pl][2] = fsh(X[pl][1], X[pl][2], 32u - sh);
-          X[pl][1] = fsh(X[pl][0], X[pl][1], 32u - sh);
-          X[pl][0] = X[pl][0] << sh;
-        }
+      for (int pl = 0; pl < 5; ++pl) {
+        X[pl][2] = fsh(X[pl][1], X[pl][2], 32u - sh);
+        X[pl][1] = fsh(X[pl][0], X[pl][1], 32u - sh);
+        X[pl][0] = X[pl][0] << sh;
       }
-      uint32_t v0 = X[4][0], v1 = X[4][1], v2 = X[4][2];  // E: window starts whose spacer + PAM holds a variant base
-      int r = 1;
-      while (2 * r <= L && r < 32) {
-        v0 |= fsh(v0, v1, (uint32_t)r); v1 |= fsh(v1, v2, (uint32_t)r); v2 |= v2 >> r;
-        r *= 2;
-      }
-      const int rem = L - r;
-      if (rem > 0) {
-        if (rem < 32) { v0 |= fsh(v0, v1, (uint32_t)rem); v1 |= fsh(v1, v2, (uint32_t)rem); v2 |= v2 >> rem; }
-        else { v0 |= v1; v1 |= v2; }
-      }
-      const uint32_t E = fsh(v0, v1, HAWK_PAD);
-      const uint32_t own = range_mask(q0, qa, qb);
-      uint32_t f = pam_match96(X, p.pam_fwd, p.pamlen, HAWK_PAD + poF) & own;
-      uint32_t rv = pam_match96(X, p.pam_rev, p.pamlen, HAWK_PAD + poR) & own;
-      f &= range_mask(q0, rg.slo[0], rg.shi[0]);
-      rv &= range_mask(q0, rg.slo[1], rg.shi[1]);
-      hits += __popc(f) + __popc(rv);
-      f &= range_mask(q0, rg.lo[0], rg.hi[0]);
-      rv &= range_mask(q0, rg.lo[1], rg.hi[1]);
-      cand += __popc(f) + __popc(rv);
-      kF = f & E;
-      kR = rv & E;
     }
-    // which survivors are rows: not the REF guide at the same (start, strand) again (remove_redundant_guides)
-    uint32_t vF = 0, vR = 0;
+    uint32_t v0 = X[4][0], v1 = X[4][1], v2 = X[4][2];  // E: window starts whose spacer + PAM holds a variant base
+    int r = 1;
+    while (2 * r <= L && r < 32) {
+      v0 |= fsh(v0, v1, (uint32_t)r); v1 |= fsh(v1, v2, (uint32_t)r); v2 |= v2 >> r;
+      r *= 2;
+    }
+    const int rem = L - r;
+    if (rem > 0) {
+      if (rem < 32) { v0 |= fsh(v0, v1, (uint32_t)rem); v1 |= fsh(v1, v2, (uint32_t)rem); v2 |= v2 >> rem; }
+      else { v0 |= v1; v1 |= v2; }
+    }
+    const uint32_t E = fsh(v0, v1, HAWK_PAD);
+    const uint32_t own = range_mask(q0, qa, qb);
+    uint32_t f = pam_match96(X, p.pam_fwd, p.pamlen, HAWK_PAD + poF) & own;
+    uint32_t rv = pam_match96(X, p.pam_rev, p.pamlen, HAWK_PAD + poR) & own;
+    f &= range_mask(q0, rg.slo[0], rg.shi[0]);
+    rv &= range_mask(q0, rg.slo[1], rg.shi[1]);
+    hits += __popc(f) + __popc(rv);
+    f &= range_mask(q0, rg.lo[0], rg.hi[0]);
+    rv &= range_mask(q0, rg.lo[1], rg.hi[1]);
+    cand += __popc(f) + __popc(rv);
+    kF = f & E;
+    kR = rv & E;
+  };
+  // which kept starts are rows: not the REF guide at the same (start, strand) again (remove_redundant_guides)
+  auto classify = [&](int32_t q0, const uint32_t (&X)[5][3], uint32_t kF, uint32_t kR, uint32_t& vF, uint32_t& vR) {
+    vF = 0; vR = 0;
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
       uint32_t m = s ? kR : kF;
       while (m) {
         const uint32_t bpos = (uint32_t)__builtin_ctz(m);
         m &= m - 1u;
-        const uint32_t q = (uint32_t)q0 + bpos;
-        const int64_t start = posmap_global(hs, h, q);
+        const int64_t start = posmap_hint(hs, seg0, seg_end, (uint32_t)q0 + bpos);
         const int64_t qr64 = start - ri.startp;
         const bool inr = qr64 >= 0 && qr64 < (int64_t)ri.n_bits;
         const uint32_t qr = inr ? (uint32_t)qr64 : 0u;
@@ -351,13 +408,8 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
         if (!same) { if (s) vR |= 1u << bpos; else vF |= 1u << bpos; }
       }
     }
-    const uint32_t cF = (uint32_t)__popc(vF), cR = (uint32_t)__popc(vR);
-    const uint32_t inc = group_incl_scan(cF | (cR << 16), gl);
-    const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
-    const uint32_t ex = inc - (cF | (cR << 16));
-    uint32_t at0 = base0 + (ex & 0xffffu), at1 = base1 + (ex >> 16);
-    base0 += tot & 0xffffu; base1 += tot >> 16;
-    if (!live) continue;
+  };
+  auto write = [&](int32_t q0, const uint32_t (&X)[5][3], uint32_t vF, uint32_t vR, uint64_t at0, uint64_t at1) {
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
       uint32_t m = s ? vR : vF;
@@ -365,8 +417,8 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
         const uint32_t bpos = (uint32_t)__builtin_ctz(m);
         m &= m - 1u;
         const uint32_t q = (uint32_t)q0 + bpos;
-        const uint32_t k = s ? at1++ : at0++;
-        if (k >= half) { atomicExch(status, -3 /* HAWK_E_CAPACITY: more rows than window starts */); continue; }
+        const uint64_t k = s ? at1++ : at0++;
+        if (k >= t_cap) { atomicExch(status, -3 /* HAWK_E_CAPACITY: more rows than window starts */); continue; }
         W2 win[5], core[4], rcore[4];
 #pragma unroll
         for (int pl = 0; pl < 5; ++pl) {
@@ -377,7 +429,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
             core[pl].hi = (win[pl].hi >> HAWK_PAD) & mhi;
           }
         }
-        const int64_t start = posmap_global(hs, h, q), stop = posmap_global(hs, h, q + (uint32_t)L);
+        const int64_t start = posmap_hint(hs, seg0, seg_end, q), stop = posmap_hint(hs, seg0, seg_end, q + (uint32_t)L);
         const int64_t qr64 = start - ri.startp;
         const bool inr = qr64 >= 0 && qr64 < (int64_t)ri.n_bits;
         const uint32_t qr = inr ? (uint32_t)qr64 : 0u;
@@ -395,20 +447,74 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
           if (err && gp.score_cfdon == 1) atomicExch(status, -5 /* HAWK_E_CFD */);
         }
         const bool pamfirst = (p.right != 0) != (s != 0);
-        CsRow tr;
-        tr.pos = (int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first;
-        tr.strand = (uint8_t)s; tr.flags = has_ref ? 1 : 0; tr.pad = 0;
-        tr.start = start; tr.stop = stop; tr.cfdon = score;
-#pragma unroll
-        for (int pl = 0; pl < HAWK_PLANES; ++pl) tr.win[pl] = (uint64_t)win[pl].lo | ((uint64_t)win[pl].hi << 32);
-        tr.pad2 = 0;
-        trows[slot0 + (s ? half : 0u) + k] = tr;
+        const int64_t ds = start - ri.startp, de = stop - start;
+        if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED */);
+        const uint64_t sc = (uint64_t)__double_as_longlong(score);
+        uint4* __restrict__ tp = reinterpret_cast<uint4*>(trows + k);
+        tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)s | (has_ref ? 0x100u : 0u),
+                           (uint32_t)(int32_t)ds, (uint32_t)(int32_t)de);
+        tp[1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), win[0].lo, win[0].hi);
+        tp[2] = make_uint4(win[1].lo, win[1].hi, win[2].lo, win[2].hi);
+        tp[3] = make_uint4(win[3].lo, win[3].hi, win[4].lo, win[4].hi);
       }
     }
+  };
+
+  // ---- pass 1: counts.  A cluster of up to CS_G words (nearly all) keeps its strings and verdicts in registers for pass 2.
+  const bool one_round = nwords <= CS_G;  // uniform within a group
+  uint32_t X[5][3];
+#pragma unroll
+  for (int pl = 0; pl < 5; ++pl) X[pl][0] = X[pl][1] = X[pl][2] = 0;
+  uint32_t vF = 0, vR = 0, ex1 = 0, n0 = 0, n1 = 0, hits = 0, cand = 0;
+#pragma unroll 1
+  for (int w0 = 0; w0 < nwords; w0 += CS_G) {
+    const int w = w0 + (int)gl;
+    uint32_t kF = 0, kR = 0;
+    vF = 0; vR = 0;
+    if (w < nwords) {
+      word(qa + 32 * w, X, kF, kR, hits, cand);
+      classify(qa + 32 * w, X, kF, kR, vF, vR);
+    }
+    const uint32_t c = (uint32_t)__popc(vF) | ((uint32_t)__popc(vR) << 16);
+    const uint32_t inc = group_incl_scan(c, gl);
+    const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
+    ex1 = inc - c;
+    n0 += tot & 0xffffu; n1 += tot >> 16;
   }
-  // the group's totals
-  const uint32_t h2 = group_incl_scan(hits, gl), c2 = group_incl_scan(cand, gl);
-  if (live && gl == CS_G - 1) res[u] = make_uint4(base0, base1, h2, c2);
+  hits = group_incl_scan(hits, gl); cand = group_incl_scan(cand, gl);  // the group's totals in its last lane
+  // ---- the workgroup's stretch of the template array
+  const bool leader = live && gl == CS_G - 1;
+  uint32_t btot;
+  const uint32_t bex = block_excl_scan<256 / WAVE>(leader ? n0 + n1 : 0u, s_w, &btot);
+  if (tid == 0) s_base = btot ? atomicAdd(t_count, (unsigned long long)btot) : 0ull;
+  __syncthreads();
+  const uint32_t gex = (uint32_t)__shfl((int)bex, CS_G - 1, CS_G);  // the leader's exclusive offset = rows of the groups before
+  const uint64_t tb = s_base + gex;
+  if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
+  if (tb + n0 + n1 > 0xffffffffull) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
+  if (!live || n0 + n1 == 0) return;  // no barrier below
+  // ---- pass 2: rows
+  if (one_round) {
+    write(qa + 32 * (int32_t)gl, X, vF, vR, tb + (ex1 & 0xffffu), tb + n0 + (ex1 >> 16));
+    return;
+  }
+  uint32_t b0 = 0, b1 = 0, h2 = 0, c2 = 0;
+#pragma unroll 1
+  for (int w0 = 0; w0 < nwords; w0 += CS_G) {
+    const int w = w0 + (int)gl;
+    uint32_t kF = 0, kR = 0;
+    vF = 0; vR = 0;
+    if (w < nwords) {
+      word(qa + 32 * w, X, kF, kR, h2, c2);
+      classify(qa + 32 * w, X, kF, kR, vF, vR);
+    }
+    const uint32_t c = (uint32_t)__popc(vF) | ((uint32_t)__popc(vR) << 16);
+    const uint32_t inc = group_incl_scan(c, gl);
+    const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
+    const uint32_t ex = inc - c;
+    if (w < nwords) write(qa + 32 * w, X, vF, vR, tb + b0 + (ex & 0xffffu), tb + n0 + b1 + (ex >> 16));
+    b0 += tot & 0xffffu; b1 += tot >> 16;
+  }
 }
 
 // every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it
@@ -444,76 +550,136 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
   }
 }
 
-// the guide table: a wave per 64 consecutive instances copies their clusters' template rows (their offsets are consecutive,
-// so the wave's stores are), patching haplotype row and position
-__global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restrict__ res, const CsRow* __restrict__ trows,
-                                                 const uint64_t* __restrict__ offsets, GuideCols out, int* status) {
+// the guide table: a wave per 64 consecutive instances copies their clusters' template rows, patching haplotype row and
+// position.  The instances' offsets are consecutive, so a wave's rows are ONE contiguous piece of every column: the rows go
+// through LDS 128 at a time and leave as 16-byte stores per lane (two rows of an 8-byte column, four of a 4-byte one) - the
+// kernel is bound by store instructions, not bytes: a lane storing one 8-byte field per row took 0.58 ms for the 2.08 GB,
+// twice what a fill of that size takes (profiles/r03_csearch_ablation.txt).
+#define CE_CH 128
+// 16 bytes to a 4-byte-aligned address, past the caches' allocation (`nt`): the table is written once and read by a later kernel;
+// with plain stores the 2 GB of rows went through L2 at 4.1 TB/s, streaming at 4.8 (profiles/r03_csearch_ablation.txt).
+// The four dword stores to consecutive addresses are merged into one global_store_dwordx4 ... nt by the compiler.
+__device__ __forceinline__ void nt_store4(uint32_t* q, const uint4& v) {
+  __builtin_nontemporal_store(v.x, q); __builtin_nontemporal_store(v.y, q + 1);
+  __builtin_nontemporal_store(v.z, q + 2); __builtin_nontemporal_store(v.w, q + 3);
+}
+__global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restrict__ res, const uint32_t* __restrict__ tbase,
+                                                 const CsRow* __restrict__ trows, const uint64_t* __restrict__ offsets, int64_t startp,
+                                                 GuideCols out, int* status) {
   __shared__ uint32_t s_ex[4][WAVE + 1];
-  __shared__ uint32_t s_n0[4][WAVE], s_half[4][WAVE], s_h[4][WAVE];
+  __shared__ uint32_t s_tb[4][WAVE], s_h[4][WAVE];
   __shared__ int32_t s_dq[4][WAVE];
-  __shared__ uint64_t s_slot[4][WAVE], s_off[4][WAVE];
+  __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH];  // start, stop, cfdon, win0..4
+  __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];  // hap, pos
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  uint32_t cnt = 0, n0 = 0, half = 0, h = 0;
+  uint32_t cnt = 0, tb = 0, h = 0;
   int32_t dq = 0;
-  uint64_t slot = 0, off = 0;
+  uint64_t off = 0;
   if (i < cd.n_inst) {
     const uint32_t u = cd.inst_uid[i];
+    h = cd.inst_row[i];
+    dq = cd.inst_o[i];  // template positions are relative to the cluster's first allele
+    off = offsets[i];
     if (u != CL_NONE) {
       const uint4 r = res[u];
-      n0 = r.x; cnt = r.x + r.y;
-      if (cnt) {
-        slot = cd.u_slot[u]; half = cd.u_half[u]; h = cd.inst_row[i];
-        dq = cd.inst_o[i];  // template positions are relative to the cluster's first allele
-        off = offsets[i];
-      }
+      cnt = r.x + r.y;
+      tb = tbase[u];
     }
   }
   const uint32_t inc = wave_incl_scan(cnt);
   const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+  // the wave's first row: the offset of its first instance (offsets are cumulative over ALL instances, with or without rows)
+  const uint64_t o0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off) |
+                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32);
   s_ex[wv][lane] = inc - cnt;
-  s_n0[wv][lane] = n0; s_half[wv][lane] = half; s_h[wv][lane] = h; s_dq[wv][lane] = dq; s_slot[wv][lane] = slot; s_off[wv][lane] = off;
+  s_tb[wv][lane] = tb; s_h[wv][lane] = h; s_dq[wv][lane] = dq;
   __syncthreads();
-  for (uint32_t t = lane; t < Wt; t += WAVE) {
-    uint32_t l = 0;
+  if (Wt == 0) return;  // wave-uniform; no workgroup barrier below
+  if (o0 + Wt > out.cap) { if (lane == 0) atomicExch(status, -3 /* HAWK_E_CAPACITY */); return; }
+  uint64_t* const col8[8] = {reinterpret_cast<uint64_t*>(out.start), reinterpret_cast<uint64_t*>(out.stop), reinterpret_cast<uint64_t*>(out.cfdon),
+                             out.win, out.win + out.cap, out.win + 2 * out.cap, out.win + 3 * out.cap, out.win + 4 * out.cap};
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < Wt; c0 += CE_CH) {
 #pragma unroll
-    for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;  // l + step <= 63
-    const uint32_t k = t - s_ex[wv][l];
-    const uint32_t kn0 = s_n0[wv][l];
-    const uint64_t src = s_slot[wv][l] + (k < kn0 ? k : s_half[wv][l] + (k - kn0));
-    const uint64_t o = s_off[wv][l] + k;
-    if (o >= out.cap) { atomicExch(status, -3 /* HAWK_E_CAPACITY */); continue; }
-    const uint4* __restrict__ tp = reinterpret_cast<const uint4*>(trows + src);
-    const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3], e = tp[4];
-    // CsRow: pos, strand|flags, start, stop | cfdon, win0 | win1, win2 | win3, win4 | pad
-    out.hap[o] = s_h[wv][l];
-    out.pos[o] = (uint32_t)((int32_t)a.x + s_dq[wv][l]);
-    out.strand[o] = (uint8_t)(a.y & 0xffu);
-    out.flags[o] = (uint8_t)((a.y >> 8) & 0xffu);
-    out.start[o] = (int64_t)((uint64_t)a.z | ((uint64_t)a.w << 32));
-    out.stop[o] = (int64_t)((uint64_t)b.x | ((uint64_t)b.y << 32));
-    out.cfdon[o] = __longlong_as_double((long long)((uint64_t)b.z | ((uint64_t)b.w << 32)));
-    out.win[0 * out.cap + o] = (uint64_t)c.x | ((uint64_t)c.y << 32);
-    out.win[1 * out.cap + o] = (uint64_t)c.z | ((uint64_t)c.w << 32);
-    out.win[2 * out.cap + o] = (uint64_t)d.x | ((uint64_t)d.y << 32);
-    out.win[3 * out.cap + o] = (uint64_t)d.z | ((uint64_t)d.w << 32);
-    out.win[4 * out.cap + o] = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {
+      const uint32_t r = sub * WAVE + lane, t = c0 + r;
+      if (t < Wt) {
+        uint32_t l = 0;
+#pragma unroll
+        for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;  // l + step <= 63
+        const uint32_t k = t - s_ex[wv][l];
+        const uint4* __restrict__ tp = reinterpret_cast<const uint4*>(trows + (s_tb[wv][l] + k));
+        uint4 a, b, c, d;
+        if (CS_ABL & 1) { a = make_uint4(t, k, l, t); b = a; c = a; d = a; }
+        else { a = tp[0]; b = tp[1]; c = tp[2]; d = tp[3]; }
+        const int64_t start = startp + (int64_t)(int32_t)a.z;
+        const uint64_t o = o0 + t;
+        if (!(CS_ABL & 8)) {
+        __builtin_nontemporal_store((uint8_t)(a.y & 0xffu), out.strand + o);
+        __builtin_nontemporal_store((uint8_t)((a.y >> 8) & 0xffu), out.flags + o);
+        }
+        s_c4[wv][0][r] = s_h[wv][l];
+        s_c4[wv][1][r] = (uint32_t)((int32_t)a.x + s_dq[wv][l]);
+        s_c8[wv][0][r] = (uint64_t)start;
+        s_c8[wv][1][r] = (uint64_t)(start + (int64_t)(int32_t)a.w);
+        s_c8[wv][2][r] = (uint64_t)b.x | ((uint64_t)b.y << 32);
+        s_c8[wv][3][r] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+        s_c8[wv][4][r] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+        s_c8[wv][5][r] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+        s_c8[wv][6][r] = (uint64_t)d.x | ((uint64_t)d.y << 32);
+        s_c8[wv][7][r] = (uint64_t)d.z | ((uint64_t)d.w << 32);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nc = (CS_ABL & 2) ? (s_c8[wv][0][5] == 0x123456789ull ? 1u : 0u) : (Wt - c0 < CE_CH ? Wt - c0 : CE_CH);
+    const uint64_t ob = o0 + c0;
+    {  // 8-byte columns: rows 2 lane, 2 lane + 1
+      const uint32_t r = 2 * lane;
+#pragma unroll
+      for (int cl = 0; cl < 8; ++cl) {
+        if (r + 1 < nc) {
+          const uint4 v = *reinterpret_cast<const uint4*>(&s_c8[wv][cl][r]);
+          nt_store4(reinterpret_cast<uint32_t*>(col8[cl] + ob + r), v);
+        } else if (r < nc) {
+          __builtin_nontemporal_store(s_c8[wv][cl][r], col8[cl] + ob + r);
+        }
+      }
+    }
+    {  // 4-byte columns: rows 4 lane .. 4 lane + 3
+      const uint32_t r = 4 * lane;
+      uint32_t* const col4[2] = {out.hap, out.pos};
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        if (r + 3 < nc) {
+          const uint4 v = *reinterpret_cast<const uint4*>(&s_c4[wv][cl][r]);
+          nt_store4(col4[cl] + ob + r, v);
+        } else {
+          for (uint32_t q = r; q < nc && q < r + 4; ++q) __builtin_nontemporal_store(s_c4[wv][cl][q], col4[cl] + ob + q);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const GuideParams& gp,
-                              const RefInfo& ri, void* res, void* trows, int* status) {
+                              const RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status) {
   if (!cd.n_uniq) return;
   const uint32_t nb = (uint32_t)(((uint64_t)cd.n_uniq * CS_G + 255) / 256);
-  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), static_cast<CsRow*>(trows), status);
+  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), tbase, static_cast<CsRow*>(trows),
+                     t_count, t_cap, status);
 }
 void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
                           uint32_t* counts, unsigned long long* shards) {
   if (!cd.n_inst) return;
   hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), counts, shards);
 }
-void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const void* trows, const uint64_t* offsets, GuideCols out, int* status) {
+void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
+                         int64_t startp, GuideCols out, int* status) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_emit, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), static_cast<const CsRow*>(trows),
-                     offsets, out, status);
+  hipLaunchKernelGGL(k_cs_emit, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), tbase,
+                     static_cast<const CsRow*>(trows), offsets, startp, out, status);
 }

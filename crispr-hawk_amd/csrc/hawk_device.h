@@ -90,13 +90,12 @@ struct VcArgs {
   const uint8_t* alt_codes;
   const uint64_t* hv_off;   // [n_hap + 1] record range of every row
   const void* tiles_;       // HxTile[n_hap * tiles per row]
-  const uint2* hpF;         // REF PAM hits per strand: {hit bits of word w, hits in the words before}, w <= ref_S
-  const uint2* hpR;
+  const uint4* hp;          // REF's PAM hits: {hit bits of word w on strand 0, hits in the words before, the same for strand 1}, w <= ref_S
 };
 void hawk_launch_vsearch(hipStream_t st, int pass, const HapSetDev& hs, const VcArgs& va, const ScanParams& p, const struct GuideParams& gp,
                          const struct RefInfo& ri, const TileMeta* tmeta, uint32_t* counts, uint32_t* counts0, unsigned long long* shards,
                          const uint64_t* offsets, struct GuideCols out, int* status, uint32_t tile0, uint32_t n_tiles);
-void hawk_launch_ref_hits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, int32_t ref_index, void* hpF, void* hpR);
+void hawk_launch_ref_hits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, int32_t ref_index, void* hp);
 // The cluster dictionary of an expansion plan (hawk_csearch.hip): every row's records cut into clusters (variants whose
 // alleles lie within 64 positions of each other), identical clusters of different rows numbered once.
 struct ClDict {
@@ -110,8 +109,7 @@ struct ClDict {
   const uint32_t* u_n;       // the row position of its first allele
   const uint32_t* u_row;
   const int32_t* u_o;
-  const uint32_t* u_half;    // template rows reserved per strand; strand 0 at u_slot, strand 1 at u_slot + u_half
-  const uint64_t* u_slot;
+  const uint32_t* u_seg;     // a position-map segment of that row in force in front of every position a search of the cluster maps
 };
 size_t hawk_cs_row_bytes();
 void hawk_launch_scan_u32(hipStream_t st, const uint32_t* cnt, uint32_t n, uint32_t* off);  // exclusive scan into n + 1 offsets, one workgroup
@@ -119,18 +117,23 @@ void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_o
                           uint32_t n_rows, uint32_t* cnt);
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
                          uint32_t n_rows, const uint32_t* inst_off, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                         uint64_t* key, uint8_t* cls, uint32_t* status);
+                         uint64_t* key, uint8_t* cls, uint16_t* bkt, uint32_t bshift, uint32_t n_bkt, uint32_t* cnt_br, uint32_t* first_rb,
+                         uint32_t* status);
+void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* bkt, const uint64_t* base_br,
+                            const uint32_t* first_rb, const uint32_t* uid, const int32_t* o, const uint32_t* row, const int32_t* pa, const int32_t* rb,
+                            uint32_t* uid2, int32_t* o2, uint32_t* row2, int32_t* pa2, int32_t* rb2);
 void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep, uint32_t mask,
                            uint32_t* inst_slot, uint32_t* flag);
 void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
                            const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                           uint64_t* key, uint8_t* cls, uint32_t* slot_uid, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o,
-                           uint32_t* u_half, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status);
+                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* slot_uid, uint32_t* u_rec,
+                           uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
-                              const struct RefInfo& ri, void* res, void* trows, int* status);
+                              const struct RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status);
 void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
                           uint32_t* counts, unsigned long long* shards);
-void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const void* trows, const uint64_t* offsets, struct GuideCols out, int* status);
+void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
+                         int64_t startp, struct GuideCols out, int* status);
 // hawk_meta.hip: the rows' metadata of an expansion plan, built on the device
 void hawk_launch_list_check(hipStream_t st, const uint64_t* row_off, uint32_t n_rows, const uint32_t* hv_idx, const int32_t* hv_o,
                             const int32_t* v_r0, const int32_t* v_span, const int32_t* v_chain, uint32_t n_var, uint32_t ref_len,

@@ -117,7 +117,7 @@ struct hawk_hapset {
   const struct hawk_xplan* vplan = nullptr;
   DevBuf vcnt0;               // per tile: rows of strand 0 (k_vsearch<0> -> k_vsearch<1>)
   DevBuf refhp;               // REF's PAM hits + prefix counts per strand (k_ref_hits), keyed like refbits
-  DevBuf cs_res, cs_trows;    // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}; template rows
+  DevBuf cs_res, cs_tbase, cs_trows;  // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}, first template row; template rows
   DevBuf colsA[8];
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
 };
@@ -150,10 +150,10 @@ struct hawk_xplan {
   struct {
     bool built = false, usable = false;
     uint32_t n_inst = 0, n_uniq = 0;
-    uint64_t slots = 0;     // template rows reserved over all distinct clusters
+    uint64_t slots = 0;     // bound on the template rows of a search: window starts x 2 strands over all distinct clusters
     uint32_t status = 0;    // why it is not usable: 1 a chain of > 4096 records, 2 hash collision, 4 too large / too little sharing
     float build_ms = 0.f;
-    DevBuf inst_uid, inst_o, inst_row, inst_pa, inst_rb, u_rec, u_n, u_row, u_o, u_half, u_slot;
+    DevBuf inst_uid, inst_o, inst_row, inst_pa, inst_rb, u_rec, u_n, u_row, u_o, u_seg;
   } cl;
 };
 

@@ -829,6 +829,80 @@ __global__ __launch_bounds__(1024) void k_mscan_one(const uint32_t* __restrict__
   }
 }
 
+// The same two launches with 16 entries per thread (4096 per workgroup) for scans of millions of counts - the cluster
+// instances of a plan view (hawk_csearch.hip): the single-workgroup scan of k_mscan2 in between would cost more than both.
+#define MSW_IPT 16
+#define MSW_TILE (HAWK_BLOCK * MSW_IPT)
+__global__ __launch_bounds__(HAWK_BLOCK) void k_mscan1w(const uint32_t* __restrict__ counts, uint64_t n, unsigned long long* __restrict__ partial) {
+  __shared__ unsigned long long s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const uint64_t i0 = (uint64_t)blockIdx.x * MSW_TILE + threadIdx.x * MSW_IPT;
+  unsigned long long s = 0;
+  if (i0 + MSW_IPT <= n) {
+#pragma unroll
+    for (int k = 0; k < MSW_IPT / 4; ++k) { const uint4 v = *reinterpret_cast<const uint4*>(counts + i0 + 4 * k); s += (unsigned long long)v.x + v.y + v.z + v.w; }
+  } else {
+    for (int k = 0; k < MSW_IPT; ++k) if (i0 + k < n) s += counts[i0 + k];
+  }
+  s = (unsigned long long)wave_sum((uint32_t)s) + ((unsigned long long)wave_sum((uint32_t)(s >> 32)) << 32);
+  if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&s_sum, s);
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_sum;
+}
+__global__ __launch_bounds__(HAWK_BLOCK) void k_mscan23w(const uint32_t* __restrict__ counts, uint64_t n, const unsigned long long* __restrict__ partial,
+                                                          uint32_t nb, const unsigned long long* __restrict__ shards, uint64_t* __restrict__ offsets,
+                                                          ScanTotals* __restrict__ totals) {
+  __shared__ uint32_t s_w[HAWK_BLOCK / WAVE];
+  __shared__ unsigned long long s_sum[3];
+  if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long pre = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += HAWK_BLOCK) pre += partial[j];
+  pre = (unsigned long long)wave_sum((uint32_t)pre) + ((unsigned long long)wave_sum((uint32_t)(pre >> 32)) << 32);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && pre) atomicAdd(&s_sum[0], pre);
+  if (blockIdx.x == 0 && shards) {
+    atomicAdd(&s_sum[1], shards[2 * threadIdx.x]);
+    atomicAdd(&s_sum[2], shards[2 * threadIdx.x + 1]);
+  }
+  const uint64_t i0 = (uint64_t)blockIdx.x * MSW_TILE + threadIdx.x * MSW_IPT;
+  uint32_t c[MSW_IPT];
+  uint32_t sum = 0;
+  if (i0 + MSW_IPT <= n) {
+#pragma unroll
+    for (int k = 0; k < MSW_IPT / 4; ++k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(counts + i0 + 4 * k);
+      c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < MSW_IPT; ++k) c[k] = i0 + k < n ? counts[i0 + k] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < MSW_IPT; ++k) sum += c[k];
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan<HAWK_BLOCK / WAVE>(sum, s_w, &tot);  // has the barrier s_sum needs
+  uint64_t run = s_sum[0] + ex;
+  if (i0 + MSW_IPT <= n) {
+#pragma unroll
+    for (int k = 0; k < MSW_IPT; k += 2) {
+      const uint64_t a = run, b = run + c[k];
+      *reinterpret_cast<ulonglong2*>(offsets + i0 + k) = make_ulonglong2(a, b);
+      run = b + c[k + 1];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < MSW_IPT; ++k) {
+      if (i0 + k < n) offsets[i0 + k] = run;
+      run += c[k];
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == nb - 1) { totals->n_keep = s_sum[0] + tot; totals->n_keep_fwd = 0; }
+    if (blockIdx.x == 0) { totals->n_cand = s_sum[1]; totals->n_hits = s_sum[2]; }
+  }
+}
+
 void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* partial,
                        const unsigned long long* shards, uint64_t* offsets, ScanTotals* totals) {
   if (n <= 2048 && shards) {
@@ -837,6 +911,12 @@ void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsig
     return;
   }
   const uint32_t nb = (uint32_t)((n + MS_TILE - 1) / MS_TILE);
+  const uint32_t nbw = (uint32_t)((n + MSW_TILE - 1) / MSW_TILE);
+  if (nb > 4096 && nbw <= 4096 && shards && (reinterpret_cast<uintptr_t>(counts) & 15) == 0 && (reinterpret_cast<uintptr_t>(offsets) & 15) == 0) {
+    hipLaunchKernelGGL(k_mscan1w, dim3(nbw), dim3(HAWK_BLOCK), 0, st, counts, n, partial);
+    hipLaunchKernelGGL(k_mscan23w, dim3(nbw), dim3(HAWK_BLOCK), 0, st, counts, n, partial, nbw, shards, offsets, totals);
+    return;
+  }
   hipLaunchKernelGGL(k_mscan1, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial);
   if (nb <= 4096 && shards) {
     hipLaunchKernelGGL(k_mscan23, dim3(nb), dim3(HAWK_BLOCK), 0, st, counts, n, partial, nb, shards, offsets, totals);

@@ -49,11 +49,13 @@ __device__ __forceinline__ uint32_t pam_match96(const uint32_t (&X)[5][3], uint6
   return m;
 }
 
-// REF PAM hits with window starts in [ra, rb): hp[w] = {hit bits of word w, hits in the words before}
-__device__ __forceinline__ uint32_t ref_hits_between(const uint2* __restrict__ hp, uint32_t ra, uint32_t rb) {
-  const uint2 ea = hp[ra >> 5], eb = hp[rb >> 5];
+// REF PAM hits with window starts in [ra, rb), per strand: hp[w] = {hit bits of word w on strand 0, hits in the words before,
+// the same for strand 1} - one 16-byte entry serves both strands
+__device__ __forceinline__ uint32_t ref_hits_between(const uint4* __restrict__ hp, int s, uint32_t ra, uint32_t rb) {
+  const uint4 ea = hp[ra >> 5], eb = hp[rb >> 5];
   const uint32_t ma = (1u << (ra & 31u)) - 1u, mb = (1u << (rb & 31u)) - 1u;
-  return (eb.y + (uint32_t)__popc(eb.x & mb)) - (ea.y + (uint32_t)__popc(ea.x & ma));
+  return s ? (eb.w + (uint32_t)__popc(eb.z & mb)) - (ea.w + (uint32_t)__popc(ea.z & ma))
+           : (eb.y + (uint32_t)__popc(eb.x & mb)) - (ea.y + (uint32_t)__popc(ea.x & ma));
 }
 
 struct VcRanges {  // per strand, on the window start q: scan range (hits) and scan range x is_pamhit_in_range (candidates)
@@ -62,16 +64,25 @@ struct VcRanges {  // per strand, on the window start q: scan range (hits) and s
 // candidates / hits of the clean window starts [pa, pb) of the row: REF's hits under the stretch's shift
 __device__ __forceinline__ void vc_count_run(const VcArgs& va, const VcRanges& rg, int32_t pa, int32_t pb, int32_t r_base, uint32_t& cand,
                                              uint32_t& hits) {
+  const int lomax = rg.lo[0] > rg.lo[1] ? rg.lo[0] : rg.lo[1], himin = rg.hi[0] < rg.hi[1] ? rg.hi[0] : rg.hi[1];
+  if (pa >= lomax && pb <= himin) {  // inside every range of both strands (all but a row's first and last runs): two entries
+    const uint32_t ra = (uint32_t)(pa + r_base), rb = (uint32_t)(pb + r_base);
+    const uint4 ea = va.hp[ra >> 5], eb = va.hp[rb >> 5];
+    const uint32_t ma = (1u << (ra & 31u)) - 1u, mb = (1u << (rb & 31u)) - 1u;
+    const uint32_t hc = (eb.y + (uint32_t)__popc(eb.x & mb)) - (ea.y + (uint32_t)__popc(ea.x & ma)) +
+                        (eb.w + (uint32_t)__popc(eb.z & mb)) - (ea.w + (uint32_t)__popc(ea.z & ma));
+    hits += hc; cand += hc;
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const uint2* hp = s ? va.hpR : va.hpF;
     const int a = pa > rg.slo[s] ? pa : rg.slo[s], b = pb < rg.shi[s] ? pb : rg.shi[s];
     const int a2 = pa > rg.lo[s] ? pa : rg.lo[s], b2 = pb < rg.hi[s] ? pb : rg.hi[s];
     uint32_t hcount = 0;
-    if (a < b) hcount = ref_hits_between(hp, (uint32_t)(a + r_base), (uint32_t)(b + r_base));
+    if (a < b) hcount = ref_hits_between(va.hp, s, (uint32_t)(a + r_base), (uint32_t)(b + r_base));
     hits += hcount;
-    if (a2 == a && b2 == b) cand += hcount;  // the run lies inside the candidate range too (all but a row's first and last runs)
-    else if (a2 < b2) cand += ref_hits_between(hp, (uint32_t)(a2 + r_base), (uint32_t)(b2 + r_base));
+    if (a2 == a && b2 == b) cand += hcount;
+    else if (a2 < b2) cand += ref_hits_between(va.hp, s, (uint32_t)(a2 + r_base), (uint32_t)(b2 + r_base));
   }
 }
 

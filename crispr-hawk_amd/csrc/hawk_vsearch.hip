@@ -436,9 +436,9 @@ void hawk_launch_vsearch(hipStream_t st, int pass, const HapSetDev& hs, const Vc
 
 // ---------------------------------------------------------------------------------------
 // REF's PAM hits per strand, indexed by window start and NOT cut to any range (clean stretches of the haplotypes read them
-// under their own ranges): hp[w] = {hit bits of word w, hits in the words before}, w <= S.
+// under their own ranges): hp[w] = {hit bits of word w on strand 0, hits in the words before, the same for strand 1}, w <= S.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HAWK_BLOCK) void k_ref_hits(HapSetDev hs, ScanParams p, int32_t ref_index, uint2* __restrict__ hpF, uint2* __restrict__ hpR) {
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ref_hits(HapSetDev hs, ScanParams p, int32_t ref_index, uint4* __restrict__ hp) {
   const uint32_t u = blockIdx.x * HAWK_BLOCK + threadIdx.x;
   const bool active = u < hs.S / 4;
   const size_t rowbase = (size_t)ref_index * hs.S;
@@ -453,25 +453,25 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_ref_hits(HapSetDev hs, ScanParam
   pam_match(A, C, G, Tp, p.pam_rev, p.pamlen, poR, mR);
   if (!active) return;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { hpF[4 * (size_t)u + k].x = mF[k]; hpR[4 * (size_t)u + k].x = mR[k]; }
+  for (int k = 0; k < 4; ++k) hp[4 * (size_t)u + k] = make_uint4(mF[k], 0u, mR[k], 0u);
 }
 // single workgroup: the prefix counts behind the hit words (S is a few 10^4 words: one pass of 1024-entry scans)
-__global__ __launch_bounds__(1024) void k_ref_hits_prefix(uint32_t S, uint2* __restrict__ hpF, uint2* __restrict__ hpR) {
+__global__ __launch_bounds__(1024) void k_ref_hits_prefix(uint32_t S, uint4* __restrict__ hp) {
   __shared__ uint32_t s_w[1024 / WAVE];
   uint32_t carryF = 0, carryR = 0;
   for (uint32_t b0 = 0; b0 <= S; b0 += 1024) {  // entry S closes the table: hit word 0, count = all hits
     const uint32_t w = b0 + threadIdx.x;
     uint32_t xF = 0, xR = 0;
-    if (w < S) { xF = hpF[w].x; xR = hpR[w].x; }
+    if (w < S) { const uint4 e = hp[w]; xF = e.x; xR = e.z; }
     const uint32_t c = (uint32_t)__popc(xF) | ((uint32_t)__popc(xR) << 16);  // <= 32 each, 1024 entries: sums < 2^16
     uint32_t tot;
     const uint32_t ex = block_excl_scan<1024 / WAVE>(c, s_w, &tot);
-    if (w <= S) { hpF[w] = make_uint2(xF, carryF + (ex & 0xffffu)); hpR[w] = make_uint2(xR, carryR + (ex >> 16)); }
+    if (w <= S) hp[w] = make_uint4(xF, carryF + (ex & 0xffffu), xR, carryR + (ex >> 16));
     carryF += tot & 0xffffu; carryR += tot >> 16;
   }
 }
-void hawk_launch_ref_hits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, int32_t ref_index, void* hpF, void* hpR) {
+void hawk_launch_ref_hits(hipStream_t st, const HapSetDev& hs, const ScanParams& p, int32_t ref_index, void* hp) {
   const uint32_t nb = (hs.S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;
-  hipLaunchKernelGGL(k_ref_hits, dim3(nb), dim3(HAWK_BLOCK), 0, st, hs, p, ref_index, (uint2*)hpF, (uint2*)hpR);
-  hipLaunchKernelGGL(k_ref_hits_prefix, dim3(1), dim3(1024), 0, st, hs.S, (uint2*)hpF, (uint2*)hpR);
+  hipLaunchKernelGGL(k_ref_hits, dim3(nb), dim3(HAWK_BLOCK), 0, st, hs, p, ref_index, (uint4*)hp);
+  hipLaunchKernelGGL(k_ref_hits_prefix, dim3(1), dim3(1024), 0, st, hs.S, (uint4*)hp);
 }
