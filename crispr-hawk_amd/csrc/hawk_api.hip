@@ -598,7 +598,14 @@ int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
 }
 extern "C" {
 
+#define HAWK_RETRY_TEMPLATES (-100)  // private to this file: the template rows of a cluster search outgrew their reservation
+static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, hawk_timing* timing);
 int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, hawk_timing* timing) {
+  int rc = hawk_search_once(hs, p, out, timing);
+  if (rc == HAWK_RETRY_TEMPLATES) rc = hawk_search_once(hs, p, out, timing);  // now reserved for the bound: cannot recur
+  return rc == HAWK_RETRY_TEMPLATES ? HAWK_E_CAPACITY : rc;
+}
+static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, hawk_timing* timing) {
   if (!hs || !p || !out || !hs->has_meta) return HAWK_E_INVALID;
   if (p->score_cfdon > 2) return HAWK_E_INVALID;
   if (p->score_cfdon && (p->right || !p->cfd_mm || !p->cfd_pam || p->pamlen < 2)) return HAWK_E_INVALID;
@@ -708,6 +715,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   const uint32_t v_tiles = vx ? (uint32_t)ntile - plane_tiles : 0u;
   ClDict cd;
   memset(&cd, 0, sizeof(cd));
+  uint64_t tcap = 0;
   if (by_cluster) {
     const auto& cl = vx->cl;
     cd.n_inst = cl.n_inst; cd.n_uniq = cl.n_uniq;
@@ -715,20 +723,23 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     cd.inst_pa = cl.inst_pa.as<int32_t>(); cd.inst_rb = cl.inst_rb.as<int32_t>();
     cd.u_rec = cl.u_rec.as<uint32_t>(); cd.u_n = cl.u_n.as<uint32_t>(); cd.u_row = cl.u_row.as<uint32_t>(); cd.u_o = cl.u_o.as<int32_t>();
     cd.u_seg = cl.u_seg.as<uint32_t>();
-    // template rows: packed as the search produces them; their number is bounded by the window starts of the distinct clusters,
-    // and a search that needs more than the rows reserved so far says so and is rerun (as the guide columns are)
+    // template rows: packed as the search produces them.  Their number is bounded by the window starts of the distinct clusters
+    // (cl.slots: 2 strands x every start), but a PAM keeps a few per cent of those: reserve 16 rows per distinct cluster, and
+    // if a search needs more it produces no table (k_cs_count sees the counter), says so and is rerun with the bound reserved
+    const char* e0 = getenv("HAWK_CLUSTER_ROWS0");  // tests: a first reservation small enough to overflow
+    const uint64_t first = e0 ? strtoull(e0, nullptr, 10) : 16ull * cl.n_uniq + 65536;
+    tcap = std::max<uint64_t>(std::min<uint64_t>(cl.slots, std::max<uint64_t>(hs->cs_tcap, first)), 1);
     if ((rc = hs->cs_res.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 16)) || (rc = hs->cs_tbase.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 4)) ||
-        (rc = hs->cs_trows.reserve((size_t)std::max<uint64_t>(cl.slots, 1) * hawk_cs_row_bytes())))
+        (rc = hs->cs_trows.reserve((size_t)tcap * hawk_cs_row_bytes())))
       return rc;
   }
   // the view's share of the two passes: per dirty word of every row, or per distinct cluster + a copy per instance
   uint32_t* const d_counts_v = hs->counts.as<uint32_t>() + plane_tiles;
   auto view_count = [&]() {
     if (by_cluster) {
-      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, d_tcount,
-                               std::max<uint64_t>(vx->cl.slots, 1), d_status);
+      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, d_tcount, tcap, d_status);
       (void)hipEventRecord(ctx->ev[8], ctx->stream);
-      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, d_counts_v, d_shards);
+      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, d_tcount, tcap, d_counts_v, d_shards);
     } else {
       hawk_launch_vsearch(ctx->stream, 0, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, nullptr,
                           GuideCols{}, d_status, plane_tiles, v_tiles);
@@ -736,7 +747,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
   };
   auto view_emit = [&](const GuideCols& cols) {
     if (by_cluster) hawk_launch_cs_emit(ctx->stream, cd, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
-                                        ri.startp, cols, d_status);
+                                        ri.startp, d_tcount, tcap, cols, d_status);
     else hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards,
                              hs->offsets.as<uint64_t>(), cols, d_status, plane_tiles, v_tiles);
   };
@@ -778,6 +789,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(&tot, h_block + 32, sizeof(tot));
     memcpy(&status, h_block, 4);
+    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } }
     nrows = tot.n_keep;
     emitted = nrows <= hs->cols_cap;
     if (!emitted) { status = 0; HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream)); }
@@ -785,6 +797,7 @@ int hawk_search(hawk_hapset* hs, const hawk_search_params* p, hawk_table** out, 
     HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(&tot, h_block + 32, sizeof(tot));
+    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } }
     nrows = tot.n_keep;
   }
   if (count_only) {  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
@@ -1541,8 +1554,10 @@ static int xplan_build_dict(hawk_xplan* x) {
       (rc = cl.inst_pa.reserve((size_t)n_inst * 4)) || (rc = cl.inst_rb.reserve((size_t)n_inst * 4)))
     return rc;
   // built in (row, position) order, then laid out stretch by stretch of REF (k_cl_permute)
-  uint32_t bshift = 15;
-  while (((x->ref_len >> bshift) + 1) > 1024) ++bshift;
+  // HAWK_CLUSTER_ORDER=stretch lays the instances out stretch by stretch of REF (32 kb each: the template rows a search copies
+  // then stay in L2) at the price of a table that is no longer haplotype-major; the default keeps (row, position) order
+  uint32_t bshift = 31;
+  { const char* eo = getenv("HAWK_CLUSTER_ORDER"); if (eo && eo[0] == 's') { bshift = 15; while (((x->ref_len >> bshift) + 1) > 1024) ++bshift; } }
   const uint32_t n_bkt = (x->ref_len >> bshift) + 1;
   uint32_t *t_uid, *t_row, *d_cnt_br, *d_first_rb;
   int32_t *t_o, *t_pa, *t_rb;

@@ -133,10 +133,11 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
   }
 }
 
-// The searches walk the instances stretch by stretch of REF (bucket-major: all rows' instances of the first 32 kb, then of the
-// next ...) rather than row by row: the workgroups in flight at any time then copy the template rows of ONE stretch's clusters,
-// a few hundred KB that stay in every XCD's L2, instead of gathering from all of them.  Within a stretch the order is (row,
-// position), so a wave's 64 instances still write one contiguous piece of the table.
+// Optionally (HAWK_CLUSTER_ORDER=stretch) the instances are laid out stretch by stretch of REF (bucket-major: all rows'
+// instances of the first 32 kb, then of the next ...) rather than row by row: the workgroups in flight at any time then copy the
+// template rows of ONE stretch's clusters, a few hundred KB that stay in every XCD's L2 (the emit pass fetches 0.18 instead of
+// 1.45 GB from HBM).  Within a stretch the order is (row, position), so a wave's 64 instances still write one contiguous
+// piece of the table - but the table is then not haplotype-major, so the default is one stretch: the order they were built in.
 #define CL_MAXBKT 1024
 __global__ __launch_bounds__(256) void k_cl_bucket(const uint32_t* __restrict__ inst_off, const uint16_t* __restrict__ bkt, uint32_t n_rows,
                                                    uint32_t n_bkt, uint32_t* __restrict__ cnt_br, uint32_t* __restrict__ first_rb) {
@@ -309,6 +310,9 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   __shared__ double s_cfd[336];
   __shared__ uint32_t s_w[256 / WAVE];
   __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_X[15][256];  // a short cluster's strings, one column per lane: [plane * 3 + word][lane]
+  __shared__ uint32_t s_k[2][256];   // ... the window starts its filters keep, per strand
+  __shared__ uint32_t s_e[256];      // ... and how many the group's lanes before it keep (strand 0 | strand 1 << 16)
   const uint32_t tid = threadIdx.x;
   if (gp.score_cfdon) for (uint32_t i = tid; i < 336; i += 256) s_cfd[i] = gp.cfd_mm[i];
   __syncthreads();
@@ -460,68 +464,156 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
     }
   };
 
-  // ---- pass 1: counts.  A cluster of up to CS_G words (nearly all) keeps its strings and verdicts in registers for pass 2.
+  // ---- pass 1.  A cluster of up to CS_G words (nearly all of them) leaves its strings and kept starts in LDS: its survivors
+  // are then dealt to the group's lanes one each per round, so that the position-map and REF look-ups of a cluster run side by
+  // side instead of one after the other in the lane that owns the word (the kernel is a chain of dependent loads: with one
+  // lane walking its word's survivors a wave lived 40 us).  Longer clusters count, then write, word by word.
   const bool one_round = nwords <= CS_G;  // uniform within a group
+  const uint32_t g0 = tid & ~(uint32_t)(CS_G - 1);
   uint32_t X[5][3];
 #pragma unroll
   for (int pl = 0; pl < 5; ++pl) X[pl][0] = X[pl][1] = X[pl][2] = 0;
-  uint32_t vF = 0, vR = 0, ex1 = 0, n0 = 0, n1 = 0, hits = 0, cand = 0;
-#pragma unroll 1
-  for (int w0 = 0; w0 < nwords; w0 += CS_G) {
-    const int w = w0 + (int)gl;
+  uint32_t vF = 0, vR = 0, n0 = 0, n1 = 0, hits = 0, cand = 0, TF = 0, TR = 0;
+  if (one_round) {
     uint32_t kF = 0, kR = 0;
-    vF = 0; vR = 0;
-    if (w < nwords) {
-      word(qa + 32 * w, X, kF, kR, hits, cand);
-      classify(qa + 32 * w, X, kF, kR, vF, vR);
-    }
-    const uint32_t c = (uint32_t)__popc(vF) | ((uint32_t)__popc(vR) << 16);
+    if ((int)gl < nwords) word(qa + 32 * (int32_t)gl, X, kF, kR, hits, cand);
+    const uint32_t c = (uint32_t)__popc(kF) | ((uint32_t)__popc(kR) << 16);
     const uint32_t inc = group_incl_scan(c, gl);
     const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
-    ex1 = inc - c;
-    n0 += tot & 0xffffu; n1 += tot >> 16;
+    TF = tot & 0xffffu; TR = tot >> 16;
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) { s_X[pl * 3 + 0][tid] = X[pl][0]; s_X[pl * 3 + 1][tid] = X[pl][1]; s_X[pl * 3 + 2][tid] = X[pl][2]; }
+    s_k[0][tid] = kF; s_k[1][tid] = kR; s_e[tid] = inc - c;
+  } else {
+#pragma unroll 1
+    for (int w0 = 0; w0 < nwords; w0 += CS_G) {
+      const int w = w0 + (int)gl;
+      uint32_t kF = 0, kR = 0;
+      vF = 0; vR = 0;
+      if (w < nwords) {
+        word(qa + 32 * w, X, kF, kR, hits, cand);
+        classify(qa + 32 * w, X, kF, kR, vF, vR);
+      }
+      const uint32_t c = (uint32_t)__popc(vF) | ((uint32_t)__popc(vR) << 16);
+      const uint32_t tot = (uint32_t)__shfl((int)group_incl_scan(c, gl), CS_G - 1, CS_G);
+      n0 += tot & 0xffffu; n1 += tot >> 16;
+    }
   }
   hits = group_incl_scan(hits, gl); cand = group_incl_scan(cand, gl);  // the group's totals in its last lane
-  // ---- the workgroup's stretch of the template array
+  // ---- the workgroup's stretch of the template array: rows of the long clusters, kept starts (>= rows) of the others
   const bool leader = live && gl == CS_G - 1;
+  const uint32_t want = one_round ? TF + TR : n0 + n1;
   uint32_t btot;
-  const uint32_t bex = block_excl_scan<256 / WAVE>(leader ? n0 + n1 : 0u, s_w, &btot);
+  const uint32_t bex = block_excl_scan<256 / WAVE>(leader ? want : 0u, s_w, &btot);  // its barriers publish the groups' LDS entries
   if (tid == 0) s_base = btot ? atomicAdd(t_count, (unsigned long long)btot) : 0ull;
   __syncthreads();
   const uint32_t gex = (uint32_t)__shfl((int)bex, CS_G - 1, CS_G);  // the leader's exclusive offset = rows of the groups before
   const uint64_t tb = s_base + gex;
-  if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
-  if (tb + n0 + n1 > 0xffffffffull) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
-  if (!live || n0 + n1 == 0) return;  // no barrier below
-  // ---- pass 2: rows
-  if (one_round) {
-    write(qa + 32 * (int32_t)gl, X, vF, vR, tb + (ex1 & 0xffffu), tb + n0 + (ex1 >> 16));
+  if (tb + want > 0xffffffffull) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
+  if (!one_round) {
+    if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
+    if (!live || n0 + n1 == 0) return;  // no barrier below
+    uint32_t b0 = 0, b1 = 0, h2 = 0, c2 = 0;
+#pragma unroll 1
+    for (int w0 = 0; w0 < nwords; w0 += CS_G) {
+      const int w = w0 + (int)gl;
+      uint32_t kF = 0, kR = 0;
+      vF = 0; vR = 0;
+      if (w < nwords) {
+        word(qa + 32 * w, X, kF, kR, h2, c2);
+        classify(qa + 32 * w, X, kF, kR, vF, vR);
+      }
+      const uint32_t c = (uint32_t)__popc(vF) | ((uint32_t)__popc(vR) << 16);
+      const uint32_t inc = group_incl_scan(c, gl);
+      const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
+      const uint32_t ex = inc - c;
+      if (w < nwords) write(qa + 32 * w, X, vF, vR, tb + b0 + (ex & 0xffffu), tb + n0 + b1 + (ex >> 16));
+      b0 += tot & 0xffffu; b1 += tot >> 16;
+    }
     return;
   }
-  uint32_t b0 = 0, b1 = 0, h2 = 0, c2 = 0;
+  // ---- pass 2 of a short cluster: survivor j of a strand -> lane j mod CS_G
+  uint32_t done = 0;  // rows written so far (strand 0 first)
 #pragma unroll 1
-  for (int w0 = 0; w0 < nwords; w0 += CS_G) {
-    const int w = w0 + (int)gl;
-    uint32_t kF = 0, kR = 0;
-    vF = 0; vR = 0;
-    if (w < nwords) {
-      word(qa + 32 * w, X, kF, kR, h2, c2);
-      classify(qa + 32 * w, X, kF, kR, vF, vR);
+  for (int sd = 0; sd < 2; ++sd) {
+    const uint32_t T = sd ? TR : TF, sh16 = sd ? 16u : 0u;
+    uint32_t ns = 0;
+#pragma unroll 1
+    for (uint32_t j0 = 0; j0 < T; j0 += CS_G) {  // uniform within a group
+      const uint32_t j = j0 + gl;
+      const bool act = j < T;
+      const uint32_t jj = act ? j : 0u;
+      uint32_t l = 0;
+#pragma unroll
+      for (uint32_t step = CS_G / 2; step; step >>= 1) l += (((s_e[g0 + l + step] >> sh16) & 0xffffu) <= jj) ? step : 0u;
+      const uint32_t src = g0 + l;
+      const uint32_t bpos = select_bit(s_k[sd][src], jj - ((s_e[src] >> sh16) & 0xffffu));
+      const uint32_t q = (uint32_t)(qa + 32 * (int32_t)l) + bpos;
+      W2 win[5], core[4], rcore[4];
+#pragma unroll
+      for (int pl = 0; pl < 5; ++pl) {
+        win[pl] = ext96(s_X[pl * 3 + 0][src], s_X[pl * 3 + 1][src], s_X[pl * 3 + 2][src], bpos);
+        win[pl].hi &= whi;
+        if (pl < 4) {
+          core[pl].lo = fsh(win[pl].lo, win[pl].hi, HAWK_PAD) & mlo;
+          core[pl].hi = (win[pl].hi >> HAWK_PAD) & mhi;
+        }
+      }
+      const int64_t start = posmap_hint(hs, seg0, seg_end, q), stop = posmap_hint(hs, seg0, seg_end, q + (uint32_t)L);
+      const int64_t qr64 = start - ri.startp;
+      const bool inr = qr64 >= 0 && qr64 < (int64_t)ri.n_bits;
+      const uint32_t qr = inr ? (uint32_t)qr64 : 0u;
+      const uint32_t rw = (sd ? ri.bits[1] : ri.bits[0])[qr >> 5];
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) rcore[pl] = ext_glb(va.ref[pl], qr);  // fetched whether or not REF has a guide there: one round trip
+      const bool has_ref = inr && ((rw >> (qr & 31u)) & 1u);
+      bool same = has_ref;
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) {
+        rcore[pl].lo &= mlo; rcore[pl].hi &= mhi;
+        same = same && rcore[pl].lo == core[pl].lo && rcore[pl].hi == core[pl].hi;
+        if (!has_ref) rcore[pl] = core[pl];
+      }
+      const bool valid = act && !same;
+      const uint32_t vinc = group_incl_scan(valid ? 1u : 0u, gl);
+      const uint32_t vtot = (uint32_t)__shfl((int)vinc, CS_G - 1, CS_G);
+      if (valid && live) {
+        const uint64_t k = tb + done + ns + (vinc - 1u);
+        if (k >= t_cap) atomicExch(status, -3 /* HAWK_E_CAPACITY */);
+        else {
+          double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
+          if (gp.score_cfdon && has_ref) {
+            bool err;
+            score = cfdon_from_slices(core, rcore, (uint32_t)sd, L, cfdmask, s_cfd, err);
+            if (err && gp.score_cfdon == 1) atomicExch(status, -5 /* HAWK_E_CFD */);
+          }
+          const bool pamfirst = (p.right != 0) != (sd != 0);
+          const int64_t ds = start - ri.startp, de = stop - start;
+          if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED */);
+          const uint64_t sc = (uint64_t)__double_as_longlong(score);
+          uint4* __restrict__ tp = reinterpret_cast<uint4*>(trows + k);
+          tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)sd | (has_ref ? 0x100u : 0u),
+                             (uint32_t)(int32_t)ds, (uint32_t)(int32_t)de);
+          tp[1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), win[0].lo, win[0].hi);
+          tp[2] = make_uint4(win[1].lo, win[1].hi, win[2].lo, win[2].hi);
+          tp[3] = make_uint4(win[3].lo, win[3].hi, win[4].lo, win[4].hi);
+        }
+      }
+      ns += vtot;
     }
-    const uint32_t c = (uint32_t)__popc(vF) | ((uint32_t)__popc(vR) << 16);
-    const uint32_t inc = group_incl_scan(c, gl);
-    const uint32_t tot = (uint32_t)__shfl((int)inc, CS_G - 1, CS_G);
-    const uint32_t ex = inc - c;
-    if (w < nwords) write(qa + 32 * w, X, vF, vR, tb + b0 + (ex & 0xffffu), tb + n0 + b1 + (ex >> 16));
-    b0 += tot & 0xffffu; b1 += tot >> 16;
+    if (sd == 0) n0 = ns; else n1 = ns;
+    done += ns;
   }
+  if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
 }
 
 // every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it
 __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, const uint4* __restrict__ res,
+                                                  const unsigned long long* __restrict__ t_count, uint64_t t_cap,
                                                   uint32_t* __restrict__ counts, unsigned long long* __restrict__ shards) {
   __shared__ uint32_t s_red[256 / WAVE][2];
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool ovf = *t_count > t_cap;  // the template rows outgrew their reservation: no table (the host reruns the search)
   uint32_t cand = 0, hits = 0;
   if (i < cd.n_inst) {
     const uint32_t h = cd.inst_row[i], u = cd.inst_uid[i];
@@ -534,7 +626,7 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
       const uint4 r = res[u];
       c = r.x + r.y; hits += r.z; cand += r.w;
     }
-    counts[i] = c;
+    counts[i] = ovf ? 0u : c;
   }
   const uint32_t a = wave_sum(cand), b = wave_sum(hits);
   if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
@@ -565,11 +657,12 @@ __device__ __forceinline__ void nt_store4(uint32_t* q, const uint4& v) {
 }
 __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restrict__ res, const uint32_t* __restrict__ tbase,
                                                  const CsRow* __restrict__ trows, const uint64_t* __restrict__ offsets, int64_t startp,
-                                                 GuideCols out, int* status) {
+                                                 const unsigned long long* __restrict__ t_count, uint64_t t_cap, GuideCols out, int* status) {
   __shared__ uint32_t s_ex[4][WAVE + 1];
   __shared__ uint32_t s_tb[4][WAVE], s_h[4][WAVE];
   __shared__ int32_t s_dq[4][WAVE];
   __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH];  // start, stop, cfdon, win0..4
+  if (*t_count > t_cap) return;  // the template rows outgrew their reservation (k_cs_count left no counts): the host reruns the search
   __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];  // hap, pos
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -673,13 +766,14 @@ void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs&
                      t_count, t_cap, status);
 }
 void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
-                          uint32_t* counts, unsigned long long* shards) {
+                          const unsigned long long* t_count, uint64_t t_cap, uint32_t* counts, unsigned long long* shards) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), counts, shards);
+  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), t_count, t_cap, counts,
+                     shards);
 }
 void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
-                         int64_t startp, GuideCols out, int* status) {
+                         int64_t startp, const unsigned long long* t_count, uint64_t t_cap, GuideCols out, int* status) {
   if (!cd.n_inst) return;
   hipLaunchKernelGGL(k_cs_emit, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), tbase,
-                     static_cast<const CsRow*>(trows), offsets, startp, out, status);
+                     static_cast<const CsRow*>(trows), offsets, startp, t_count, t_cap, out, status);
 }

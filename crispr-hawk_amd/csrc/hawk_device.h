@@ -131,9 +131,9 @@ void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
                               const struct RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status);
 void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
-                          uint32_t* counts, unsigned long long* shards);
+                          const unsigned long long* t_count, uint64_t t_cap, uint32_t* counts, unsigned long long* shards);
 void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
-                         int64_t startp, struct GuideCols out, int* status);
+                         int64_t startp, const unsigned long long* t_count, uint64_t t_cap, struct GuideCols out, int* status);
 // hawk_meta.hip: the rows' metadata of an expansion plan, built on the device
 void hawk_launch_list_check(hipStream_t st, const uint64_t* row_off, uint32_t n_rows, const uint32_t* hv_idx, const int32_t* hv_o,
                             const int32_t* v_r0, const int32_t* v_span, const int32_t* v_chain, uint32_t n_var, uint32_t ref_len,

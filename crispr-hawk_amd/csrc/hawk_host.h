@@ -117,6 +117,7 @@ struct hawk_hapset {
   const struct hawk_xplan* vplan = nullptr;
   DevBuf vcnt0;               // per tile: rows of strand 0 (k_vsearch<0> -> k_vsearch<1>)
   DevBuf refhp;               // REF's PAM hits + prefix counts per strand (k_ref_hits), keyed like refbits
+  uint64_t cs_tcap = 0;       // template rows a search of this view may need (raised to the plan's bound after an overflow)
   DevBuf cs_res, cs_tbase, cs_trows;  // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}, first template row; template rows
   DevBuf colsA[8];
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group

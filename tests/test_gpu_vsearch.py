@@ -165,3 +165,13 @@ def test_view_search_random_campaign():
                                   af_min=0.05, af_max=float(rng.choice([0.3, 0.9])))
         pam_s, guidelen, right = shapes[it % len(shapes)]
         _same_table(reg, pam_s, guidelen, right, cfd=(pam_s in ("NGG", "NRG", "NGK") and not right))
+
+
+def test_cluster_search_reruns_when_the_template_rows_outgrow_their_reservation(monkeypatch):
+    # the first reservation is a guess (16 rows per distinct cluster); a dense PAM on a variant-rich panel needs more, the
+    # search then produces no table, raises the reservation to the plan's bound and runs again
+    reg = synth.make_region(8601, "chrT", 40_000, 1_000, 38_000)
+    synth.add_phased_variants(reg, 8602, 900, 4, af_min=0.2, af_max=0.7)
+    monkeypatch.setenv("HAWK_CLUSTER_ROWS0", "64")
+    a = _same_table(reg, "NGN", 20, False)
+    assert a.n_rows > 64
