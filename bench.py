@@ -191,13 +191,12 @@ def plan_carried(ds) -> int:
 
 
 def vsearch_roofline(rows, records, positions, hits, L, scored, count_ms, emit_ms, traffic_key=None):
-    """The fused step's two kernels (hawk_vsearch.hip).  `achieved` prices a launch as SURVEY 8(d) prices the work it does
-    - K2: 0.75 B per scanned haplotype position; K3: L/8 B of variant plane per PAM hit + (L + 20)/2 B of code read and a
-    32 B record written per kept row; K4: 2 x ceil(L/2) B read + 8 B written per scored row - over its HIP-event duration.
-    What the kernels really move through HBM is far less (the point of the design: positions are never materialised): every
-    carried-variant record in (32 B) and, in the emit pass, every row out (74 B) - reported as `moved` next to the PMC
-    `traffic`.  Neither kernel is HBM-bound: per-wave counters (profiles/r03_pmc_vsearch_final.txt) show vector-instruction
-    issue and s_waitcnt latency."""
+    """The per-word search of a plan view (hawk_vsearch.hip; what runs when a plan's cluster dictionary is not usable, or under
+    HAWK_VIEW_SEARCH=words).  `achieved` = the bytes a launch has to move through HBM - every carried-variant record in (32 B)
+    and, in the emit pass, every row out (74 B) - over its HIP-event duration; `survey_priced` is what SURVEY 8(d)'s per-unit
+    figures (K2: 0.75 B per scanned haplotype position ...) would charge for the same work, which the kernels do not move:
+    positions are never materialised.  Neither kernel is HBM-bound: per-wave counters
+    (profiles/r03_pmc_vsearch_final.txt) show vector-instruction issue and s_waitcnt latency."""
     k2 = 0.75 * positions
     k3_read, k3_write = hits * L / 8.0 + rows * (L + 20) / 2.0, rows * 32.0
     k4 = rows * (2 * ((L + 1) // 2) + 8.0) if scored else 0.0
@@ -213,17 +212,59 @@ def vsearch_roofline(rows, records, positions, hits, L, scored, count_ms, emit_m
         traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]
     tot_ms = count_ms + emit_ms
     step_alg = k2 + k3_read + k3_write + k4  # every unit priced once for the step
-    return {"bound": "hbm", "kernel": dom, "achieved": gbps(dom_alg, dom_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbps(dom_alg, dom_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_alg,
-            "pricing": "SURVEY 8(d): K2 0.75 B/position + K3 (L/8 B/hit, (L+20)/2 + 32 B/row) + K4 (2*ceil(L/2) + 8 B/scored row)",
-            "moved": {"bytes": dom_moved, "GBps": gbps(dom_moved, dom_ms), "frac_of_hbm_peak": gbps(dom_moved, dom_ms) / HBM_PEAK_GBS,
-                      "what": "what this launch has to move given the plan representation: 32 B per carried-variant record in"
-                              + (" + 74 B per guide row out" if dom.endswith("<1>") else "")},
+    return {"bound": "hbm", "kernel": dom, "achieved": gbps(dom_moved, dom_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbps(dom_moved, dom_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_moved,
+            "pricing": "bytes the launch has to move given the plan representation: 32 B per carried-variant record in"
+                       + (" + 74 B per guide row out" if dom.endswith("<1>") else ""),
+            "survey_priced": {"bytes": dom_alg, "GBps": gbps(dom_alg, dom_ms),
+                              "what": "SURVEY 8(d): K2 0.75 B/position + K3 (L/8 B/hit, (L+20)/2 + 32 B/row) + K4 (2*ceil(L/2) + 8 B/scored row)"},
             "records": records, "row_bytes": ROW_BYTES, "record_bytes": REC_BYTES,
-            "other_kernel": {"kernel": oth, "launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_alg, "frac": gbps(oth_alg, oth_ms) / HBM_PEAK_GBS,
-                             "moved_bytes": oth_moved},
+            "other_kernel": {"kernel": oth, "launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_moved, "frac": gbps(oth_moved, oth_ms) / HBM_PEAK_GBS},
             "step_level": {"algorithmic_bytes": step_alg, "what": "SURVEY 8(d) K2 + K3 + K4, every unit priced once",
                            "moved_bytes": ROW_BYTES * rows + 2 * REC_BYTES * records}}
+
+
+def csearch_roofline(rows, ref_rows, positions, hits, L, scored, cl, templates_ms, count_ms, emit_ms, traffic_key=None):
+    """The cluster search of a plan view (hawk_csearch.hip): templates (once per distinct cluster) -> counts per instance ->
+    k_cs_emit, the dominant kernel, which copies template rows into the guide table.  `achieved` prices the launch as SURVEY
+    8(d) prices the work it stands for (K3's record written and K4's score for every row - the emit pass is where every
+    haplotype's rows come into being); `moved` is what the launch really moves through HBM: 74 B per row out, 20 B per cluster
+    instance in (cluster id, row, position, offset) - the 64-byte template rows come out of L2 / the memory-side cache."""
+    k2 = 0.75 * positions
+    k3_read, k3_write = hits * L / 8.0 + rows * (L + 20) / 2.0, rows * 32.0
+    k4 = rows * (2 * ((L + 1) // 2) + 8.0) if scored else 0.0
+    step_alg = k2 + k3_read + k3_write + k4
+    vrows = rows - ref_rows
+    emit_alg = k3_write / max(rows, 1) * vrows + (k4 / max(rows, 1) * vrows) + vrows * (L + 20) / 2.0
+    emit_moved = ROW_BYTES * vrows + 20.0 * cl["instances"]
+    gbps = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms else 0.0
+    traffic = None
+    if traffic_key and os.path.exists(PROFILE_TRAFFIC_R3):
+        tk = json.load(open(PROFILE_TRAFFIC_R3)).get(traffic_key, {}).get("k_cs_emit")
+        traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]
+    return {"bound": "hbm", "kernel": "k_cs_emit", "achieved": gbps(emit_moved, emit_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbps(emit_moved, emit_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": emit_ms,
+            "algorithmic_bytes_per_launch": emit_moved,
+            "pricing": "bytes the launch has to move: 74 B per guide row written + 20 B per cluster instance read (SURVEY 8(d)'s per-row "
+                       "figure for a finished row is (L + 20) / 2 + 32 + 2 ceil(L / 2) + 8 = %.1f B: the 74-byte row of the C ABI is what is written)"
+                       % ((L + 20) / 2.0 + 32 + 2 * ((L + 1) // 2) + 8),
+            "survey_priced": {"bytes": emit_alg, "GBps": gbps(emit_alg, emit_ms)},
+            "row_bytes": ROW_BYTES, "instance_bytes": 20, "template_row_bytes": 64,
+            "other_kernels": {"k_cs_templates": {"launch_ms": templates_ms, "distinct_clusters": cl["distinct"]},
+                              "k_cs_count": {"launch_ms": count_ms, "instances": cl["instances"], "moved_bytes": 24.0 * cl["instances"]}},
+            "step_level": {"algorithmic_bytes": step_alg, "what": "SURVEY 8(d) K2 + K3 + K4 over every haplotype position / hit / row, every unit priced once",
+                           "moved_bytes": ROW_BYTES * rows + 44.0 * cl["instances"]}}
+
+
+def tab_ref_rows(reg, pam, args, mm, pt, device):
+    """guide rows of the REF haplotype (row 0 of a plan view: written by the plane kernels, not by k_cs_emit)"""
+    from crisprhawk_hip.workload import _ref_only_set
+    ref_ds = _ref_only_set(reg.sequence, reg.startp, reg.stopp, len(pam), device)
+    t = ref_ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+    n = t.n_rows
+    t.close()
+    ref_ds.close()
+    return n
 
 
 def pam_scan_kernel(ds, pam):
@@ -323,16 +364,30 @@ def run_region(args, R: Ranks):
                          "variant_sites": len(reg.variants), "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
                          "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all})
         tkey = "c3" if workload.startswith("C3") and R.world == 1 else None
-        out["config"]["step"] = ("encode + search + CFDon from the expansion plan (REF planes + variant records resident; no haplotype plane written)"
-                                 if fused else "hawk_search over haplotype planes resident in HBM")
-        if fused:
+        out["config"]["step"] = ("encode + search + CFDon from the expansion plan (REF planes + variant records + their cluster dictionary resident; "
+                                 "no haplotype plane written)" if fused else "hawk_search over haplotype planes resident in HBM")
+        by_cluster = fused and int(tm[-1]["v_path"]) == 2
+        if by_cluster:
+            cl = plan.cluster_stats()
+            ref_rows = tab_ref_rows(reg, pam, args, mm, pt, R.device)
+            out["roofline"] = csearch_roofline(rows, ref_rows, positions, tab.n_hits, args.guidelen + len(pam), score, cl, avg("v_templates_ms"),
+                                               avg("v_count_ms") - avg("v_templates_ms"), avg("v_emit_ms"), tkey)
+            out["cluster_dictionary"] = dict(cl, what="built once per plan by hawk_xplan_view (hawk_csearch.hip): the rows' carried variants cut "
+                                             "into clusters (alleles within 64 nt), identical clusters of different rows numbered once; part of the "
+                                             "resident plan like the records it indexes, rebuilt in every end_to_end pass")
+        elif fused:
             out["roofline"] = vsearch_roofline(rows, int(plan_carried(ds)), positions, tab.n_hits, args.guidelen + len(pam), score,
                                                avg("v_count_ms"), avg("v_emit_ms"), tkey)
         else:
             out["roofline"] = search_roofline(pam, positions, rows, avg("count_ms"), avg("emit_list_ms"), avg("emit_ms"), tkey)
         sl = out["roofline"]["step_level"]
         sl["ms"] = avg("total_ms")
-        sl["frac"] = sl["algorithmic_bytes"] / (sl["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sl["ms"] else None
+        # a view's step is priced by the bytes it moves: the survey's per-position figures describe work the step no longer does
+        # (a fraction of peak over them would exceed 1) and are given as an equivalent rate only
+        sl_bytes = sl["moved_bytes"] if fused else sl["algorithmic_bytes"]
+        sl["frac"] = sl_bytes / (sl["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sl["ms"] else None
+        if fused:
+            sl["survey_equivalent_GBps"] = sl["algorithmic_bytes"] / (sl["ms"] * 1e-3) / 1e9 if sl["ms"] else None
         out["kernels_ms"] = {"count": avg("count_ms"), "offsets": avg("offsets_ms"), "emit": avg("emit_ms"), "emit_list": avg("emit_list_ms"),
                              "vsearch_count": avg("v_count_ms"), "vsearch_emit": avg("v_emit_ms"), "view_templates": avg("v_templates_ms"),
                              "view_path": {0: "planes", 1: "per dirty word (hawk_vsearch.hip)", 2: "per distinct cluster (hawk_csearch.hip)"}[int(tm[-1]["v_path"])],
