@@ -587,6 +587,10 @@ int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_
 }
 
 }  // extern "C"
+// The guide table's twelve arrays are written in lock step by the emit kernels (row o of every array at the same time), and where
+// the arrays lie relative to each other decides how the twelve streams spread over the HBM channels: the same emit pass took 0.50
+// to 0.66 ms from one reservation to the next (tools/cols_pad_probe.py).  Putting them in one block at chosen distances was
+// tried (profiles/r03_csearch_ablation.txt): every distance below 1 GiB gave the slow end, so they stay separate allocations.
 int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   int rc;
   const size_t sz[8] = {cap * 4, cap * 4, cap, cap * 8, cap * 8, cap, cap * 8, cap * 8 * HAWK_PLANES};
@@ -805,7 +809,8 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     nrows = 0;
   }
   if (!emitted) {
-    const uint64_t want = std::max<uint64_t>(nrows, 1);
+    const char* epad = getenv("HAWK_COLS_PAD");  // measurement: how the columns' relative placement affects the emit pass
+    const uint64_t want = std::max<uint64_t>(nrows, 1) + (epad ? strtoull(epad, nullptr, 10) : 0);
     if ((rc = hawk_reserve_cols(hs->colsA, std::max<uint64_t>(want, hs->cols_cap), &ca))) return rc;
     hs->cols_cap = ca.cap;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
