@@ -253,7 +253,8 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
                     &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->ctable, &hs->cocc, &hs->cdense, &hs->cgkey, &hs->cgslot, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
-                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_tbase, &hs->cs_trows};
+                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_tbase, &hs->cs_trows, &hs->cm_gid};
+  for (auto& b : hs->cmini) b.release();
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
   for (auto& b : hs->crep) b.release();
@@ -719,7 +720,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
   const uint32_t v_tiles = vx ? (uint32_t)ntile - plane_tiles : 0u;
   ClDict cd;
   memset(&cd, 0, sizeof(cd));
-  uint64_t tcap = 0;
+  uint64_t tcap = 0, t_rows_used = 0;
   if (by_cluster) {
     const auto& cl = vx->cl;
     cd.n_inst = cl.n_inst; cd.n_uniq = cl.n_uniq;
@@ -793,7 +794,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(&tot, h_block + 32, sizeof(tot));
     memcpy(&status, h_block, 4);
-    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } }
+    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } t_rows_used = tc; }
     nrows = tot.n_keep;
     emitted = nrows <= hs->cols_cap;
     if (!emitted) { status = 0; HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream)); }
@@ -801,7 +802,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(&tot, h_block + 32, sizeof(tot));
-    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } }
+    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } t_rows_used = tc; }
     nrows = tot.n_keep;
   }
   if (count_only) {  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
@@ -849,6 +850,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
   t->hs = hs; t->ctx = ctx; t->gen = hs->cols_gen;
   t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = ca; t->cap = ca.cap;
   t->guidelen = p->guidelen; t->pamlen = p->pamlen; t->right = p->right ? 1 : 0; t->n_groups = 0; t->collapsed = false;
+  t->by_cluster = by_cluster; t->plane_tiles = plane_tiles; t->t_rows = by_cluster ? t_rows_used : 0;
   *out = t;
   return HAWK_OK;
 }
@@ -909,9 +911,17 @@ int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** stra
   return HAWK_OK;
 }
 
+static int collapse_rows(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms);
+static int collapse_by_templates(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms);
 int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms) {
   if (!t || !n_groups || !t->hs || hawk_table_stale(t)) return HAWK_E_INVALID;
   if (flank_up > HAWK_PAD || flank_down > HAWK_PAD) return HAWK_E_UNSUPPORTED;
+  // A table the cluster search wrote is grouped on its template rows (HAWK_COLLAPSE_TEMPLATES=0: on its own rows, as any table)
+  const char* et = getenv("HAWK_COLLAPSE_TEMPLATES");
+  if (t->by_cluster && t->n_rows && !(et && et[0] == '0')) return collapse_by_templates(t, flank_up, flank_down, n_groups, kernel_ms);
+  return collapse_rows(t, flank_up, flank_down, n_groups, kernel_ms);
+}
+static int collapse_rows(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms) {
   hawk_hapset* hs = t->hs;
   hawk_ctx* ctx = hs->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1038,6 +1048,97 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
   return HAWK_OK;
   }
   return HAWK_E_UNSUPPORTED;
+}
+
+// The collapse of a table the cluster search wrote.  Every non-REF row is a copy of one of the search's template rows in all the
+// grouping compares (start, stop, strand, origin, windows), so the grouping - hashing, sorting, the exact verification - runs on
+// REF's rows + the template rows (C3: 2.8 x 10^5 instead of 2.8 x 10^7; a C4 tile 10^6 instead of 10^8), and the table's rows
+// only inherit their template row's group number before the one sort that orders them by (group, row).  Same groups, same
+// order, same members as collapse_rows on the table itself (tests/test_gpu_vsearch.py, tools/stress_views.py).
+static int collapse_by_templates(hawk_table* t, uint32_t flank_up, uint32_t flank_down, uint64_t* n_groups, float* kernel_ms) {
+  hawk_hapset* hs = t->hs;
+  hawk_ctx* ctx = hs->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const hawk_xplan* vx = hs->vplan;
+  if (!vx || !vx->cl.usable) return HAWK_E_INVALID;
+  const uint64_t n = t->n_rows;
+  if (n > 0xffffffffull) return HAWK_E_UNSUPPORTED;
+  t->collapsed = false;
+  *n_groups = 0;
+  if (kernel_ms) *kernel_ms = 0.f;
+  // the template rows of the search: every distinct cluster's rows [tbase[u], tbase[u] + n0 + n1) of the template array (its
+  // reservation may be longer: kept window starts that turned out to repeat REF); numbered densely here
+  const uint32_t nu = vx->cl.n_uniq;
+  PoolScope tmp;
+  uint32_t* d_ucnt;
+  uint64_t* d_moff;
+  unsigned long long *d_partial, *d_shards;
+  ScanTotals* d_tot;
+  TEMPCHK(tmp, &d_ucnt, (size_t)std::max<uint32_t>(nu, 1) * 4);
+  TEMPCHK(tmp, &d_moff, ((size_t)nu + 2) * 8);
+  TEMPCHK(tmp, &d_partial, ((size_t)nu / 1024 + 2) * 8);
+  TEMPCHK(tmp, &d_shards, 512 * 8);
+  TEMPCHK(tmp, &d_tot, sizeof(ScanTotals));
+  HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), ctx->stream));
+  uint64_t r0 = 0;  // REF's rows come first: as many as the first cluster instance's offset says
+  ScanTotals tot;
+  memset(&tot, 0, sizeof(tot));
+  if (nu) {
+    hawk_launch_cc_ucnt(ctx->stream, hs->cs_res.p, nu, d_ucnt);
+    hawk_launch_mscan(ctx->stream, d_ucnt, nu, d_partial, d_shards, d_moff, d_tot);
+    HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipMemcpyAsync(&r0, hs->offsets.as<uint64_t>() + t->plane_tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  const uint64_t t_live = tot.n_keep;
+  const uint64_t nm = r0 + t_live;
+  if (r0 > n || nm == 0 || nm > 0xffffffffull || r0 + 0 > n) return HAWK_E_INVALID;
+  int rc;
+  GuideCols mini;
+  if ((rc = hawk_reserve_cols(hs->cmini, nm, &mini)) || (rc = hs->cm_gid.reserve(nm * 4))) return rc;
+  float ms_a = 0.f, ms_b = 0.f, ms_c = 0.f;
+  HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
+  hawk_launch_cc_mini(ctx->stream, t->cols, r0, hs->cs_trows.p, t_live, d_moff, hs->cs_tbase.as<uint32_t>(), nu, hs->ref_startp, mini);
+  HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
+  HIPCHK(hipGetLastError());
+  hawk_table tm;  // the mini table borrows the set's collapse workspace like any table of the set
+  tm.hs = hs; tm.ctx = ctx; tm.n_rows = nm; tm.n_cand = tm.n_hits = 0; tm.cap = mini.cap; tm.cols = mini;
+  tm.guidelen = t->guidelen; tm.pamlen = t->pamlen; tm.right = t->right; tm.n_groups = 0; tm.collapsed = false; tm.gen = t->gen;
+  uint64_t G = 0;
+  if ((rc = collapse_rows(&tm, flank_up, flank_down, &G, &ms_b))) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipEventElapsedTime(&ms_a, ctx->ev[8], ctx->ev[9]);
+  // every mini row's group number, then every table row's; the table's rows sorted by (group, row)
+  unsigned gbits = 1;
+  while (gbits < 32 && (G >> gbits) != 0) ++gbits;
+  const size_t tb = hawk_collapse_expand_temp_bytes(n);
+  HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
+  hawk_launch_cc_gidm(ctx->stream, hs->cvals.as<uint32_t>() + nm, hs->cgoff.as<uint64_t>(), nm, G, hs->cm_gid.as<uint32_t>());
+  if ((rc = hs->ckeys.reserve(2 * n * 4)) || (rc = hs->cvals.reserve(2 * n * 4)) || (rc = hs->cgoff.reserve((std::max<uint64_t>(G, nm) + 1) * 8)) ||
+      (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ctemp.reserve(tb + 16)) || (rc = hs->cflags.reserve(n * 4)))
+    return rc;
+  ClDict cd;
+  memset(&cd, 0, sizeof(cd));
+  cd.n_inst = vx->cl.n_inst; cd.n_uniq = vx->cl.n_uniq; cd.inst_uid = vx->cl.inst_uid.as<uint32_t>();
+  hawk_launch_cs_gid(ctx->stream, cd, hs->cs_res.p, d_moff, hs->offsets.as<uint64_t>() + t->plane_tiles, r0, n,
+                     hs->cm_gid.as<uint32_t>(), hs->ckeys.as<uint32_t>(), hs->cvals.as<uint32_t>());
+  if (hawk_launch_collapse_expand(ctx->stream, t->cols, n, gbits, (int)t->guidelen, (int)t->pamlen, (int)t->right, hs->ctemp.p, tb, hs->ckeys.as<uint32_t>(),
+                                  hs->cvals.as<uint32_t>(), hs->cgoff.as<uint64_t>(), hs->cgc.as<uint8_t>(), hs->cgc.as<uint8_t>() + n))
+    return HAWK_E_HIP;
+  HIPCHK(hipMemcpyAsync(hs->cgoff.as<uint64_t>() + G, &n, 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipEventElapsedTime(&ms_c, ctx->ev[8], ctx->ev[9]);
+  if (kernel_ms) *kernel_ms = ms_a + ms_b + ms_c;
+  hs->collapse_gen = t->gen;
+  hs->last_groups = G;
+  if (hs->plan_groups) *hs->plan_groups = G;
+  t->n_groups = G; t->collapsed = true;
+  *n_groups = G;
+  return HAWK_OK;
 }
 
 int hawk_table_collapse(hawk_table* t, uint64_t* n_groups, float* kernel_ms) {

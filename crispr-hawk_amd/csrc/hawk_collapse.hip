@@ -415,3 +415,20 @@ int hawk_launch_collapse_hash2(hipStream_t st, const GuideCols& c, uint64_t n, u
   hipLaunchKernelGGL(k_cg_groups, grid, dim3(256), 0, st, c, n, vals + n, gid + n, guidelen, pamlen, right, group_off, gc_num, gc_den);
   return 0;
 }
+
+// the tail of the grouping for a table whose rows already know their group number (collapse_by_templates): rows sorted by
+// (group, row), CSR offsets and G/C counts from each group's first member.  gid / vals: 2 * n words each (sort ping-pong)
+size_t hawk_collapse_expand_temp_bytes(uint64_t n) {
+  size_t d = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
+                                  (hipStream_t)0);
+  return d;
+}
+int hawk_launch_collapse_expand(hipStream_t st, const GuideCols& c, uint64_t n, unsigned gbits, int guidelen, int pamlen, int right, void* temp,
+                                size_t temp_bytes, uint32_t* gid, uint32_t* vals, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den) {
+  size_t tb = temp_bytes;
+  if (rocprim::radix_sort_pairs(temp, tb, gid, gid + n, vals, vals + n, (size_t)n, 0, gbits, st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_cg_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, n, vals + n, gid + n, guidelen, pamlen, right, group_off, gc_num,
+                     gc_den);
+  return 0;
+}

@@ -777,3 +777,108 @@ void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, cons
   hipLaunchKernelGGL(k_cs_emit, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), tbase,
                      static_cast<const CsRow*>(trows), offsets, startp, t_count, t_cap, out, status);
 }
+
+// ---- the collapse of a cluster-searched table (hawk_api.hip: collapse_by_templates) ---------------------------------------
+// REF's rows + the template rows as a table of their own: the grouping compares nothing that differs between a template row and
+// its copies (start, stop, strand, REF-or-not, the windows)
+__global__ __launch_bounds__(256) void k_cc_ucnt(const uint4* __restrict__ res, uint32_t nu, uint32_t* __restrict__ cnt) {
+  const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+  if (u < nu) { const uint4 r = res[u]; cnt[u] = r.x + r.y; }
+}
+// mini row r0 + moff[u] + k is row k of distinct cluster u: template row tbase[u] + k
+__global__ __launch_bounds__(256) void k_cc_mini(GuideCols c, uint64_t r0, const CsRow* __restrict__ trows, uint64_t t_rows,
+                                                 const uint64_t* __restrict__ moff, const uint32_t* __restrict__ tbase, uint32_t nu, int64_t startp,
+                                                 GuideCols m) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= r0 + t_rows) return;
+  if (i < r0) {
+    m.hap[i] = c.hap[i]; m.pos[i] = c.pos[i]; m.strand[i] = c.strand[i]; m.start[i] = c.start[i]; m.stop[i] = c.stop[i];
+    m.flags[i] = c.flags[i]; m.cfdon[i] = c.cfdon[i];
+#pragma unroll
+    for (int pl = 0; pl < HAWK_PLANES; ++pl) m.win[(size_t)pl * m.cap + i] = c.win[(size_t)pl * c.cap + i];
+    return;
+  }
+  uint32_t lo = 0, hi = nu;  // last u with moff[u] <= i - r0
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (moff[mid] <= i - r0) lo = mid; else hi = mid;
+  }
+  const uint4* __restrict__ tp = reinterpret_cast<const uint4*>(trows + (tbase[lo] + (i - r0 - moff[lo])));
+  const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+  const int64_t start = startp + (int64_t)(int32_t)a.z;
+  m.hap[i] = 1u;  // any row but REF's: the grouping asks for the origin only
+  m.pos[i] = a.x; m.strand[i] = (uint8_t)(a.y & 0xffu); m.flags[i] = (uint8_t)((a.y >> 8) & 0xffu);
+  m.start[i] = start; m.stop[i] = start + (int64_t)(int32_t)a.w;
+  m.cfdon[i] = __longlong_as_double((long long)((uint64_t)b.x | ((uint64_t)b.y << 32)));
+  m.win[0 * m.cap + i] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+  m.win[1 * m.cap + i] = (uint64_t)cc.x | ((uint64_t)cc.y << 32);
+  m.win[2 * m.cap + i] = (uint64_t)cc.z | ((uint64_t)cc.w << 32);
+  m.win[3 * m.cap + i] = (uint64_t)d.x | ((uint64_t)d.y << 32);
+  m.win[4 * m.cap + i] = (uint64_t)d.z | ((uint64_t)d.w << 32);
+}
+// group number of every mini row from the mini collapse's (permutation, CSR offsets)
+__global__ __launch_bounds__(256) void k_cc_gidm(const uint32_t* __restrict__ perm, const uint64_t* __restrict__ goff, uint64_t nm, uint64_t G,
+                                                 uint32_t* __restrict__ gidm) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nm) return;
+  uint64_t lo = 0, hi = G;  // last g with goff[g] <= j
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (goff[mid] <= j) lo = mid; else hi = mid;
+  }
+  gidm[perm[j]] = (uint32_t)lo;
+}
+// every table row's group number = its template row's (REF's rows: their own), next to its index: the pairs the sort orders
+__global__ __launch_bounds__(256) void k_cs_gid(ClDict cd, const uint4* __restrict__ res, const uint64_t* __restrict__ moff,
+                                                const uint64_t* __restrict__ offsets, uint64_t r0, uint64_t n, const uint32_t* __restrict__ gidm,
+                                                uint32_t* __restrict__ gid, uint32_t* __restrict__ vals) {
+  __shared__ uint32_t s_ex[4][WAVE + 1];
+  __shared__ uint32_t s_tb[4][WAVE];
+  const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t cnt = 0, tb = 0;
+  uint64_t off = 0;
+  if (i < cd.n_inst) {
+    const uint32_t u = cd.inst_uid[i];
+    off = offsets[i];
+    if (u != CL_NONE) { const uint4 r = res[u]; cnt = r.x + r.y; tb = (uint32_t)moff[u]; }
+  }
+  const uint32_t inc = wave_incl_scan(cnt);
+  const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+  const uint64_t o0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off) |
+                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32);
+  s_ex[wv][lane] = inc - cnt;
+  s_tb[wv][lane] = tb;
+  __syncthreads();
+  if (o0 + Wt > n) return;  // cannot happen for the table these offsets were scanned for
+  for (uint32_t t = lane; t < Wt; t += WAVE) {
+    uint32_t l = 0;
+#pragma unroll
+    for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;
+    const uint64_t o = o0 + t;
+    gid[o] = gidm[r0 + s_tb[wv][l] + (t - s_ex[wv][l])];
+    vals[o] = (uint32_t)o;
+  }
+}
+__global__ __launch_bounds__(256) void k_cc_refgid(uint64_t r0, const uint32_t* __restrict__ gidm, uint32_t* __restrict__ gid, uint32_t* __restrict__ vals) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < r0) { gid[i] = gidm[i]; vals[i] = (uint32_t)i; }
+}
+void hawk_launch_cc_ucnt(hipStream_t st, const void* res, uint32_t nu, uint32_t* cnt) {
+  hipLaunchKernelGGL(k_cc_ucnt, dim3((nu + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(res), nu, cnt);
+}
+void hawk_launch_cc_mini(hipStream_t st, const GuideCols& c, uint64_t r0, const void* trows, uint64_t t_rows, const uint64_t* moff, const uint32_t* tbase,
+                         uint32_t nu, int64_t startp, GuideCols m) {
+  const uint64_t nm = r0 + t_rows;
+  hipLaunchKernelGGL(k_cc_mini, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, c, r0, static_cast<const CsRow*>(trows), t_rows, moff, tbase, nu,
+                     startp, m);
+}
+void hawk_launch_cc_gidm(hipStream_t st, const uint32_t* perm, const uint64_t* goff, uint64_t nm, uint64_t G, uint32_t* gidm) {
+  hipLaunchKernelGGL(k_cc_gidm, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, perm, goff, nm, G, gidm);
+}
+void hawk_launch_cs_gid(hipStream_t st, const ClDict& cd, const void* res, const uint64_t* moff, const uint64_t* offsets, uint64_t r0, uint64_t n,
+                        const uint32_t* gidm, uint32_t* gid, uint32_t* vals) {
+  if (r0) hipLaunchKernelGGL(k_cc_refgid, dim3((unsigned)((r0 + 255) / 256)), dim3(256), 0, st, r0, gidm, gid, vals);
+  if (cd.n_inst) hipLaunchKernelGGL(k_cs_gid, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), moff, offsets, r0, n,
+                                    gidm, gid, vals);
+}

@@ -206,6 +206,15 @@ void hawk_launch_collapse_verify_rows(hipStream_t st, const GuideCols& c, const 
                                       const uint64_t* group_off, void* full /* 64 B per group */, unsigned long long* mismatches);
 void hawk_launch_rows_equal(hipStream_t st, const HapSetDev& hs, uint32_t n_pairs, const uint32_t* ra, const uint32_t* rb, uint8_t* equal);
 size_t hawk_collapse_full_bytes(uint64_t n);
+size_t hawk_collapse_expand_temp_bytes(uint64_t n);
+int hawk_launch_collapse_expand(hipStream_t st, const GuideCols& c, uint64_t n, unsigned gbits, int guidelen, int pamlen, int right, void* temp,
+                                size_t temp_bytes, uint32_t* gid, uint32_t* vals, uint64_t* group_off, uint8_t* gc_num, uint8_t* gc_den);
+void hawk_launch_cc_ucnt(hipStream_t st, const void* res, uint32_t nu, uint32_t* cnt);
+void hawk_launch_cc_mini(hipStream_t st, const GuideCols& c, uint64_t r0, const void* trows, uint64_t t_rows, const uint64_t* moff, const uint32_t* tbase,
+                         uint32_t nu, int64_t startp, GuideCols m);
+void hawk_launch_cc_gidm(hipStream_t st, const uint32_t* perm, const uint64_t* goff, uint64_t nm, uint64_t G, uint32_t* gidm);
+void hawk_launch_cs_gid(hipStream_t st, const ClDict& cd, const void* res, const uint64_t* moff, const uint64_t* offsets, uint64_t r0, uint64_t n,
+                        const uint32_t* gidm, uint32_t* gid, uint32_t* vals);
 size_t hawk_collapse_hash_temp_bytes(uint64_t n, uint32_t C);
 int hawk_launch_collapse_hash1(hipStream_t st, const GuideCols& c, const uint8_t* is_ref, uint64_t n, int guidelen, int pamlen, int flank_up,
                                int flank_down, int64_t base, uint64_t seed, void* temp, size_t temp_bytes, void* table, uint32_t C,

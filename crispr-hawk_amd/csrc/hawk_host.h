@@ -118,7 +118,8 @@ struct hawk_hapset {
   DevBuf vcnt0;               // per tile: rows of strand 0 (k_vsearch<0> -> k_vsearch<1>)
   DevBuf refhp;               // REF's PAM hits + prefix counts per strand (k_ref_hits), keyed like refbits
   uint64_t cs_tcap = 0;       // template rows a search of this view may need (raised to the plan's bound after an overflow)
-  DevBuf cs_res, cs_tbase, cs_trows;  // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}, first template row; template rows
+  DevBuf cs_res, cs_tbase, cs_trows;
+  DevBuf cmini[8], cm_gid;   // hawk_table_collapse of such a table: REF's rows + the template rows as a table of their own, their groups  // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}, first template row; template rows
   DevBuf colsA[8];
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
 };
@@ -184,6 +185,11 @@ struct hawk_table {
   bool collapsed;
   uint64_t gen;     // hs->cols_gen when the table was written
   DevBuf own[8];
+  // written by the cluster search of a plan view (hawk_csearch.hip): rows [0, offsets[plane_tiles]) are REF's, every other row is
+  // a copy of one of t_rows template rows - which lets the collapse group the template rows instead of the table
+  bool by_cluster = false;
+  uint32_t plane_tiles = 0;
+  uint64_t t_rows = 0;
 };
 // HAWK_E_INVALID when a later hawk_search on the same set has overwritten the table's columns
 inline bool hawk_table_stale(const hawk_table* t) { return t->hs && t->gen != t->hs->cols_gen; }
