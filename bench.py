@@ -795,20 +795,27 @@ def run_c4(args, R: Ranks):
                          "right": args.right, "tiles": len(trs.tiles), "tile_nt": args.tile_nt, "variant_sites": len(panel.pos),
                          "partition": "sample blocks of one panel, REF on every rank" if not args.weak else "own columns per rank",
                          "step": "per tile: search (+CFDon, NA on N) straight from the tile's expansion plan (hawk_xplan_view: no plane "
-                                 "written) -> hawk_table_collapse; tiles without variants search their REF planes",
+                                 "written; once per distinct variant cluster) -> hawk_table_collapse (on the search's template rows); tiles "
+                                 "without variants search their REF planes",
                          "candidates_per_step": cand_all, "guide_rows_rank0": rows, "report_groups_rank0": groups,
                          "scanned_positions_per_step": pos_all})
         records = sum(s.get("records", 0) for s in st)
+        instances = sum(s.get("instances", 0) for s in st)
+        by_cluster = any(s.get("v_path", 0) == 2 for s in st)
         emit_ms = sum(s.get("v_emit_ms", 0.0) for s in st)
-        step_bytes = ROW_BYTES * rows + 2 * REC_BYTES * records
-        emit_bytes = ROW_BYTES * rows + REC_BYTES * records
-        out["roofline"] = {"bound": "hbm", "kernel": "k_vsearch<1> (summed over tiles)",
+        # what the tiles' searches move: rows out + per cluster instance 44 B (count + scan + emit passes) or, per dirty word, the records twice
+        step_bytes = ROW_BYTES * rows + (44 * instances if by_cluster else 2 * REC_BYTES * records)
+        emit_bytes = ROW_BYTES * rows + (20 * instances if by_cluster else REC_BYTES * records)
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_cs_emit" if by_cluster else "k_vsearch<1>") + " (summed over tiles)",
                            "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9 if emit_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": emit_bytes / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if emit_ms else 0.0, "traffic": None, "launch_ms": emit_ms,
-                           "algorithmic_bytes_per_launch": emit_bytes, "records": records,
+                           "algorithmic_bytes_per_launch": emit_bytes, "records": records, "cluster_instances": instances,
+                           "pricing": "bytes the launches have to move: 74 B per guide row written + " +
+                                      ("20 B per cluster instance read" if by_cluster else "32 B per carried-variant record read"),
                            "step_level": {"algorithmic_bytes": step_bytes, "ms": search_ms,
                                           "frac": step_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if search_ms else None,
-                                          "what": "records read by both passes (32 B each) + rows written once (74 B), all tiles"},
+                                          "what": "all search kernels of all tiles: rows written once (74 B) + what the passes read per cluster "
+                                                  "instance / record"},
                            "survey_priced": {"bytes": 0.75 * positions + ROW_BYTES * rows,
                                              "effective_GBps": (0.75 * positions + ROW_BYTES * rows) / (search_ms * 1e-3) / 1e9 if search_ms else None}}
         if R.world == 1 and not args.no_cpu_baseline:
