@@ -142,14 +142,18 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         samples = v.samples if v is not None else []
         try:
-            ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device)
+            ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device, keep_plan=True)
         except HaplotypeBuildError:
             # records the device expansion does not take (overlapping records on one chromosome copy, deletions with a
             # multi-base alt): the host builder mirrors the reference's own construction, the search stays on the device
             paths[str(coord)] = _search_host_built(coord, seq, v, True, pam, guidelen, right, outdir, mmt if score else None,
                                                    pt if score else None, debug, ot)
             continue
-        tab = ds.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mmt, pt, download=False)
+        # the search runs from the expansion plan (hawk_xplan_view: once per distinct cluster of neighbouring variants when the
+        # panel shares them, per row otherwise; no planes read) - a region without variants has no plan and searches REF's planes
+        plan = getattr(ds, "plan", None)
+        target = plan.view() if plan is not None else ds
+        tab = target.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mmt, pt, download=False)
         labels = hap_labels(coord.contig, vt, ds, info, kept)
         bed_start, bed_stop = coord.start + PADDING, coord.stop - PADDING  # reports.py:1036-1041
         # With a model scorer on, the reference's groupby includes its score column (reports.py:978-1003): rows that
@@ -171,6 +175,8 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         otcb = None if ot is None else (lambda spacers: _offtargets(spacers, pam, ot, coord, guidelen, right, outdir, debug))
         df = reports.report_from_groups(groups, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score,
                                         is_ref_hap=np.asarray(ds.is_ref, dtype=bool), offtargets=otcb)
+        if plan is not None:
+            plan.close()
         ds.close()
         path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
         with open(path, "w") as f:

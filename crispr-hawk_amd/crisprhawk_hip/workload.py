@@ -831,11 +831,12 @@ class VcfVariants:
 
 
 def expand_from_vcf(region_seq: str, startp: int, stopp: int, block, samples: List[str], pamlen: int, phased: bool = True,
-                    device: Optional[int] = None):
+                    device: Optional[int] = None, keep_plan: bool = False):
     """f3 -> f1: the records of a VCF block (readers.VCF.fetch_block) straight to device haplotypes.  The sample
     columns are parsed on the device (hawk_gt_parse) and inverted into carried-variant lists there
     (hawk_gt_lists); the host handles the fixed columns of the records only.
-    Returns (DeviceHapSet, [HapInfo], kernel ms {parse, lists, expand}, kept rows, VcfVariants)."""
+    Returns (DeviceHapSet, [HapInfo], kernel ms {parse, lists, expand}, kept rows, VcfVariants); with `keep_plan` the
+    expansion plan stays attached as `ds.plan` (its view searches without planes: hawk_xplan_view)."""
     import ctypes as C
     from . import _lib
     from .hapset import _p
@@ -874,7 +875,8 @@ def expand_from_vcf(region_seq: str, startp: int, stopp: int, block, samples: Li
             ref_set.alias = np.zeros(1, dtype=np.int64)
             return ref_set, [HapInfo(["REF"], ())], {"parse": float(ms_parse.value), "lists": float(ms_lists.value), "expand": 0.0}, [0], vt
         handed = True
-        ds, info, ms_expand, kept = _expand_rows_gt(ref_set, region_seq, startp, stopp, pamlen, samples, tab, g, col_off, device)
+        ds, info, ms_expand, kept = _expand_rows_gt(ref_set, region_seq, startp, stopp, pamlen, samples, tab, g, col_off, device,
+                                                    keep_plan=keep_plan)
     finally:
         if not locals().get("handed", False):
             L.hawk_gt_destroy(g)
