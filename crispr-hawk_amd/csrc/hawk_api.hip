@@ -591,7 +591,8 @@ int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_
 // The guide table's twelve arrays are written in lock step by the emit kernels (row o of every array at the same time), and where
 // the arrays lie relative to each other decides how the twelve streams spread over the HBM channels: the same emit pass took 0.50
 // to 0.66 ms from one reservation to the next (tools/cols_pad_probe.py).  Putting them in one block at chosen distances was
-// tried (profiles/r03_csearch_ablation.txt): every distance below 1 GiB gave the slow end, so they stay separate allocations.
+// tried (profiles/r03_csearch_ablation.txt): every distance below 1 GiB gave the slow end, and skewing the arrays' starts by
+// 256 B .. 16 KB changes nothing - it is which physical blocks the allocator hands out; they stay separate allocations.
 int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   int rc;
   const size_t sz[8] = {cap * 4, cap * 4, cap, cap * 8, cap * 8, cap, cap * 8, cap * 8 * HAWK_PLANES};

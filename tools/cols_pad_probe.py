@@ -13,7 +13,7 @@ synth.add_phased_variants(reg, 1003_1, 31000, 2504)
 pam = PAM("NGG", False, True); pam.encode(0)
 mm, pt = synth.cfd_tables()
 for pad in [int(x) for x in (sys.argv[1:] or "0 0 1000 4096 12345 65536 100000 262144 1000003 0".split())]:
-    os.environ["HAWK_COLS_PAD"] = str(pad)
+    os.environ[os.environ.get("PROBE_VAR", "HAWK_COLS_PAD")] = str(pad)
     ds, info, ms, kept = expand_on_device(reg, 3, keep_plan=True)
     v = ds.plan.view()
     t = [v.search(pam.bits, pam.bitsrc, 3, 20, False, mm, pt, download=False).timing for _ in range(8)]
