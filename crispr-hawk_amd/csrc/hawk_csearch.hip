@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
         }
         const bool pamfirst = (p.right != 0) != (s != 0);
         const int64_t ds = start - ri.startp, de = stop - start;
-        if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED */);
+        if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED */);
         const uint64_t sc = (uint64_t)__double_as_longlong(score);
         uint4* __restrict__ tp = reinterpret_cast<uint4*>(trows + k);
         tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)s | (has_ref ? 0x100u : 0u),
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   __syncthreads();
   const uint32_t gex = (uint32_t)__shfl((int)bex, CS_G - 1, CS_G);  // the leader's exclusive offset = rows of the groups before
   const uint64_t tb = s_base + gex;
-  if (tb + want > 0xffffffffull) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
+  if (tb + want > 0xffffffffull) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
   if (!one_round) {
     if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
     if (!live || n0 + n1 == 0) return;  // no barrier below
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
           }
           const bool pamfirst = (p.right != 0) != (sd != 0);
           const int64_t ds = start - ri.startp, de = stop - start;
-          if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -8 /* HAWK_E_UNSUPPORTED */);
+          if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED */);
           const uint64_t sc = (uint64_t)__double_as_longlong(score);
           uint4* __restrict__ tp = reinterpret_cast<uint4*>(trows + k);
           tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)sd | (has_ref ? 0x100u : 0u),
