@@ -664,6 +664,9 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
   __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH];  // start, stop, cfdon, win0..4
   if (*t_count > t_cap) return;  // the template rows outgrew their reservation (k_cs_count left no counts): the host reruns the search
   __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];  // hap, pos
+  __shared__ uint8_t s_c1[4][2][CE_CH];                                // strand, flags
+  __shared__ uint32_t s_src[4][CE_CH];                                 // per row of the chunk: its template row,
+  __shared__ int32_t s_rdq[4][CE_CH];                                  // ... its position shift
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   uint32_t cnt = 0, tb = 0, h = 0;
@@ -694,6 +697,7 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
                              out.win, out.win + out.cap, out.win + 2 * out.cap, out.win + 3 * out.cap, out.win + 4 * out.cap};
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < Wt; c0 += CE_CH) {
+    // which template row each of the chunk's rows copies, its haplotype row and position shift
 #pragma unroll
     for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {
       const uint32_t r = sub * WAVE + lane, t = c0 + r;
@@ -701,27 +705,32 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
         uint32_t l = 0;
 #pragma unroll
         for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;  // l + step <= 63
-        const uint32_t k = t - s_ex[wv][l];
-        const uint4* __restrict__ tp = reinterpret_cast<const uint4*>(trows + (s_tb[wv][l] + k));
-        uint4 a, b, c, d;
-        if (CS_ABL & 1) { a = make_uint4(t, k, l, t); b = a; c = a; d = a; }
-        else { a = tp[0]; b = tp[1]; c = tp[2]; d = tp[3]; }
-        const int64_t start = startp + (int64_t)(int32_t)a.z;
-        const uint64_t o = o0 + t;
-        if (!(CS_ABL & 8)) {
-        __builtin_nontemporal_store((uint8_t)(a.y & 0xffu), out.strand + o);
-        __builtin_nontemporal_store((uint8_t)((a.y >> 8) & 0xffu), out.flags + o);
-        }
+        s_src[wv][r] = s_tb[wv][l] + (t - s_ex[wv][l]);
         s_c4[wv][0][r] = s_h[wv][l];
-        s_c4[wv][1][r] = (uint32_t)((int32_t)a.x + s_dq[wv][l]);
-        s_c8[wv][0][r] = (uint64_t)start;
-        s_c8[wv][1][r] = (uint64_t)(start + (int64_t)(int32_t)a.w);
-        s_c8[wv][2][r] = (uint64_t)b.x | ((uint64_t)b.y << 32);
-        s_c8[wv][3][r] = (uint64_t)b.z | ((uint64_t)b.w << 32);
-        s_c8[wv][4][r] = (uint64_t)c.x | ((uint64_t)c.y << 32);
-        s_c8[wv][5][r] = (uint64_t)c.z | ((uint64_t)c.w << 32);
-        s_c8[wv][6][r] = (uint64_t)d.x | ((uint64_t)d.y << 32);
-        s_c8[wv][7][r] = (uint64_t)d.z | ((uint64_t)d.w << 32);
+        s_rdq[wv][r] = s_dq[wv][l];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // four lanes per template row, 16 bytes each: a load instruction touches 16 rows' lines instead of 64 (one row per lane with
+    // four loads took a quarter of the kernel in cache look-ups alone)
+    const uint32_t qd = lane & 3u;
+#pragma unroll
+    for (uint32_t j = 0; j < CE_CH / 16; ++j) {
+      const uint32_t r = j * 16 + (lane >> 2), t = c0 + r;
+      if (t < Wt) {
+        const uint4 v = reinterpret_cast<const uint4*>(trows + s_src[wv][r])[qd];
+        uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        if (qd == 0) {  // {position, strand | flags << 8, start - REF's first position, stop - start}
+          const int64_t start = startp + (int64_t)(int32_t)v.z;
+          s_c4[wv][1][r] = (uint32_t)((int32_t)v.x + s_rdq[wv][r]);
+          s_c1[wv][0][r] = (uint8_t)(v.y & 0xffu);
+          s_c1[wv][1][r] = (uint8_t)((v.y >> 8) & 0xffu);
+          lo = (uint64_t)start;
+          hi = (uint64_t)(start + (int64_t)(int32_t)v.w);
+        }
+        s_c8[wv][2 * qd][r] = lo;       // quarter q holds columns 2 q and 2 q + 1: (start, stop) (cfdon, win0) (win1, win2) (win3, win4)
+        s_c8[wv][2 * qd + 1][r] = hi;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -738,6 +747,14 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
         } else if (r < nc) {
           __builtin_nontemporal_store(s_c8[wv][cl][r], col8[cl] + ob + r);
         }
+      }
+    }
+#pragma unroll
+    for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {  // byte columns: a row per lane
+      const uint32_t r = sub * WAVE + lane;
+      if (r < nc) {
+        __builtin_nontemporal_store(s_c1[wv][0][r], out.strand + ob + r);
+        __builtin_nontemporal_store(s_c1[wv][1][r], out.flags + ob + r);
       }
     }
     {  // 4-byte columns: rows 4 lane .. 4 lane + 3
