@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
       if (outside) { cls = 0; key = 0; }
       else if (!interior) { cls = 2; key = cl_mix(h ^ 0xA4093822299F31D0ull, (uint64_t)row + 1u); }
       if (cls && key == 0) key = 1;
-      ci.o[i] = o_first; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb;
+      // the clean run in front, [pa, o_first - (L - 1)), lies inside every range of both strands for every geometry: its count
+      // then needs neither the row nor its bounds (bit 31 of pa)
+      const bool run_inside = pa >= (ss > HAWK_PAD ? ss : HAWK_PAD) && o_first <= se - 44 && o_first <= hl - 44 - HAWK_PAD + 1;
+      ci.o[i] = o_first; ci.row[i] = row; ci.pa[i] = pa | (run_inside ? (int32_t)0x80000000 : 0); ci.rb[i] = rb;
       ci.rec[i] = (uint32_t)j; ci.n[i] = n; ci.key[i] = key; ci.cls[i] = cls;
       const uint32_t b = (uint32_t)(o_first + rb > 0 ? o_first + rb : 0) >> bshift;  // REF position of the first allele
       ci.bkt[i] = (uint16_t)(b < n_bkt ? b : n_bkt - 1);
@@ -616,11 +619,23 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
   const bool ovf = *t_count > t_cap;  // the template rows outgrew their reservation: no table (the host reruns the search)
   uint32_t cand = 0, hits = 0;
   if (i < cd.n_inst) {
-    const uint32_t h = cd.inst_row[i], u = cd.inst_uid[i];
-    const VcRanges rg = cs_ranges(hs, p, h);
-    const int32_t pa = cd.inst_pa[i], o = cd.inst_o[i];
+    const uint32_t u = cd.inst_uid[i];
+    const int32_t paf = cd.inst_pa[i], o = cd.inst_o[i], rbs = cd.inst_rb[i];
+    const int32_t pa = paf & 0x7fffffff;
     const int32_t pb = o - (p.L - 1);
-    if (pb > pa) vc_count_run(va, rg, pa, pb, cd.inst_rb[i], cand, hits);
+    if (pb > pa) {
+      if (paf < 0) {  // inside every range (k_cl_fill): REF's hits of both strands between the run's ends, two 16-byte entries
+        const uint32_t ra = (uint32_t)(pa + rbs), rb2 = (uint32_t)(pb + rbs);
+        const uint4 ea = va.hp[ra >> 5], eb = va.hp[rb2 >> 5];
+        const uint32_t ma = (1u << (ra & 31u)) - 1u, mb = (1u << (rb2 & 31u)) - 1u;
+        const uint32_t hc = (eb.y + (uint32_t)__popc(eb.x & mb)) - (ea.y + (uint32_t)__popc(ea.x & ma)) +
+                            (eb.w + (uint32_t)__popc(eb.z & mb)) - (ea.w + (uint32_t)__popc(ea.z & ma));
+        hits += hc; cand += hc;
+      } else {
+        const VcRanges rg = cs_ranges(hs, p, cd.inst_row[i]);
+        vc_count_run(va, rg, pa, pb, rbs, cand, hits);
+      }
+    }
     uint32_t c = 0;
     if (u != CL_NONE) {
       const uint4 r = res[u];
