@@ -676,7 +676,8 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
   __shared__ uint32_t s_ex[4][WAVE + 1];
   __shared__ uint32_t s_tb[4][WAVE], s_h[4][WAVE];
   __shared__ int32_t s_dq[4][WAVE];
-  __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH];  // start, stop, cfdon, win0..4
+  // (+ 2: the four lanes of a template row write columns 2 q and 2 q + 1 of ONE row - an unpadded column stride of 1 KB put them in one bank)
+  __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH + 2];  // start, stop, cfdon, win0..4
   if (*t_count > t_cap) return;  // the template rows outgrew their reservation (k_cs_count left no counts): the host reruns the search
   __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];  // hap, pos
   __shared__ uint8_t s_c1[4][2][CE_CH];                                // strand, flags
