@@ -211,8 +211,9 @@ typedef struct {          /* kernel times of the last hawk_search (HIP events on
   float total_ms;   /* first kernel start to last kernel end, including the host round trip for the row count */
   uint64_t scanned_positions; /* sum over haplotypes of (scan_stop - scan_start) */
   float emit_list_ms; /* k_emit_list alone (0 when the hand-over lists are switched off) */
-  float v_count_ms;   /* a plan view (hawk_xplan_view): k_vsearch<0> alone - count_ms also holds the REF row's plane kernel */
-  float v_emit_ms;    /* ... k_vsearch<1> alone */
+  float v_count_ms;   /* a plan view (hawk_xplan_view): its count side alone (v_path 1: k_vsearch<0>; 2: k_cs_templates + k_cs_count) -
+                         count_ms also holds the REF row's plane kernel */
+  float v_emit_ms;    /* ... its emit side alone (k_vsearch<1> / k_cs_emit) */
   float v_templates_ms; /* the cluster path of a view: k_cs_templates alone (v_count_ms: templates + k_cs_count; v_emit_ms: k_cs_emit) */
   uint32_t v_path;    /* 0: planes, 1: a view searched per dirty word (k_vsearch), 2: a view searched per distinct cluster (hawk_csearch.hip) */
   float reserved[2];
@@ -226,9 +227,10 @@ void hawk_table_destroy(hawk_table* t);
 int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candidates, uint64_t* n_hits);
 /* Column download (each array n_rows long; any pointer may be NULL; destinations may be host or
  * device memory - the copy kind is inferred, so a table can be exported into buffers a
- * collective library owns without a host bounce).  Rows are ordered by (haplotype, 32 768-position tile,
- * strand, position): the kernels emit tile by tile, so the two strands of a haplotype interleave per tile;
- * sorting by (haplotype, strand, position) gives the reference's pre-dedup emission order.
+ * collective library owns without a host bounce).  Rows are haplotype-major; within a haplotype they are ordered by
+ * (32 768-position tile, strand, position) - the plane kernels emit tile by tile - or, for a plan view searched per
+ * distinct variant cluster (hawk_timing.v_path == 2), by (cluster along the row, strand, position);
+ * sorting by (haplotype, strand, position) gives the reference's pre-dedup emission order either way.
  * Lifetime: the columns live in the haplotype set's workspace.  The next hawk_search (or hawk_hapset_set_meta) on
  * the same set overwrites them; from then on every call below on the older table returns HAWK_E_INVALID.
  *   pos: relative PAM position (what retrieve_guides iterates), start/stop: genomic
