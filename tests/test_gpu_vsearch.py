@@ -175,3 +175,31 @@ def test_cluster_search_reruns_when_the_template_rows_outgrow_their_reservation(
     monkeypatch.setenv("HAWK_CLUSTER_ROWS0", "64")
     a = _same_table(reg, "NGN", 20, False)
     assert a.n_rows > 64
+
+
+def test_cluster_dictionary_against_a_host_count():
+    """the dictionary's cluster instances, counted independently on the host: a row's carried variants sorted by position, a
+    new cluster wherever more than 64 reference bases separate one variant's end from the next one's start (equal to the gap
+    between their alleles in the row), + one closing instance per searched row; distinct clusters = distinct variant tuples
+    (clusters near a row's ends stay the row's own, so the device may count a few more)."""
+    reg = synth.make_region(8701, "chrD", 400_000, 2_000, 395_000)
+    synth.add_phased_variants(reg, 8702, 9000, 150, frac_snv=0.85, frac_del=0.08, max_indel=6, af_min=0.005, af_max=0.5)
+    ds, info, _ms, kept = expand_on_device(reg, 3, keep_plan=True)
+    ds.plan.view()
+    st = ds.plan.cluster_stats()
+    pos = np.array([v.pos for v in reg.variants], dtype=np.int64)
+    end = pos + np.array([len(v.ref) for v in reg.variants], dtype=np.int64)
+    inst, distinct = 0, set()
+    for r, inf in zip(kept, info):
+        idx = np.sort(np.asarray(inf.variant_idx, dtype=np.int64))
+        if len(idx) == 0:
+            continue  # REF
+        brk = np.flatnonzero(pos[idx[1:]] - end[idx[:-1]] > 64) + 1
+        for part in np.split(idx, brk):
+            distinct.add(tuple(part.tolist()))
+        inst += len(brk) + 2  # clusters + the closing instance
+    assert st["instances"] == inst
+    assert len(distinct) <= st["distinct"] <= len(distinct) + 4 * len(kept)
+    assert st["usable"] and st["status"] == 0
+    ds.plan.close()
+    ds.close()
