@@ -1698,7 +1698,7 @@ static int xplan_build_dict(hawk_xplan* x) {
   HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
   hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
                       t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls, d_bkt, bshift, n_bkt, d_cnt_br, d_first_rb, d_status);
-  hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_flag);
+  hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_flag, d_status);
   hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
   ScanTotals tot;
   HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));

@@ -173,24 +173,26 @@ __global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_
 
 __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
                                                    unsigned long long* __restrict__ tkey, uint32_t* __restrict__ trep, uint32_t mask,
-                                                   uint32_t* __restrict__ inst_slot) {
+                                                   uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_inst) return;
   if (!cls[i]) { inst_slot[i] = CL_NONE; return; }
   const unsigned long long k = key[i];
   uint32_t s = (uint32_t)(k >> 17) & mask;
-  for (;;) {  // the table has >= 2 slots per instance: a free slot is always met
+  bool placed = false;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {  // the table has >= 2 slots per instance: a free slot is met long before the bound
     const unsigned long long cur = atomicCAS(&tkey[s], 0ull, k);
-    if (cur == 0ull || cur == k) break;
+    if (cur == 0ull || cur == k) { placed = true; break; }
     s = (s + 1u) & mask;
   }
+  if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, 2u); return; }  // cannot happen; the dictionary is then not used
   inst_slot[i] = s;
   atomicMin(&trep[s], i);
 }
 __global__ __launch_bounds__(256) void k_cl_flag(uint32_t n_inst, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ inst_slot,
                                                  const uint32_t* __restrict__ trep, uint32_t* __restrict__ flag) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_inst) flag[i] = (cls[i] && trep[inst_slot[i]] == i) ? 1u : 0u;
+  if (i < n_inst) flag[i] = (cls[i] && inst_slot[i] != CL_NONE && trep[inst_slot[i]] == i) ? 1u : 0u;
 }
 struct ClUniq {  // per distinct cluster
   uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* seg; uint32_t* span2;
@@ -225,7 +227,9 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
   if (i >= n_inst) return;
   const uint8_t c = ci.cls[i];
   if (!c) { inst_uid[i] = CL_NONE; return; }
-  const uint32_t s = inst_slot[i], r = trep[s];
+  const uint32_t s = inst_slot[i];
+  if (s == CL_NONE) { inst_uid[i] = CL_NONE; return; }  // found no slot (k_cl_insert flagged the dictionary)
+  const uint32_t r = trep[s];
   inst_uid[i] = slot_uid[s];
   if (r == i) return;
   // exactness: same hash is not same cluster until the variant identities have been compared
@@ -258,9 +262,9 @@ void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, ui
   hipLaunchKernelGGL(k_cl_permute, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, n_rows, n_bkt, bkt, base_br, first_rb, pm);
 }
 void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep, uint32_t mask,
-                           uint32_t* inst_slot, uint32_t* flag) {
+                           uint32_t* inst_slot, uint32_t* flag, uint32_t* status) {
   const uint32_t nb = (n_inst + 255) / 256;
-  hipLaunchKernelGGL(k_cl_insert, dim3(nb), dim3(256), 0, st, n_inst, key, cls, static_cast<unsigned long long*>(tkey), trep, mask, inst_slot);
+  hipLaunchKernelGGL(k_cl_insert, dim3(nb), dim3(256), 0, st, n_inst, key, cls, static_cast<unsigned long long*>(tkey), trep, mask, inst_slot, status);
   hipLaunchKernelGGL(k_cl_flag, dim3(nb), dim3(256), 0, st, n_inst, cls, inst_slot, trep, flag);
 }
 void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
