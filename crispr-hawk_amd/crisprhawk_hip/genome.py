@@ -35,16 +35,22 @@ def read_fasta(path: str) -> Dict[str, str]:
 
 def encode_guides(guides: Sequence[str]) -> np.ndarray:
     """Spacers (5'->3', ACGT only) -> one uint64 each, base i at bits 2i,2i+1 (A0 C1 G2 T3)."""
-    out = np.zeros(len(guides), dtype=np.uint64)
-    lut = {"A": 0, "C": 1, "G": 2, "T": 3}
-    for k, g in enumerate(guides):
-        v = 0
-        for i, c in enumerate(g.upper()):
-            if c not in lut:
-                raise ValueError(f"guide {g!r} holds a non-ACGT base")
-            v |= lut[c] << (2 * i)
-        out[k] = v
-    return out
+    n = len(guides)
+    out = np.zeros(n, dtype=np.uint64)
+    if n == 0:
+        return out
+    lens = {len(g) for g in guides}
+    if len(lens) != 1 or not 0 < next(iter(lens)) <= 32:
+        raise ValueError("guides must share one length of 1..32 bases")
+    L = next(iter(lens))
+    m = np.frombuffer("".join(guides).upper().encode("ascii"), dtype=np.uint8).reshape(n, L)
+    lut = np.full(256, 255, dtype=np.uint8)
+    lut[[65, 67, 71, 84]] = (0, 1, 2, 3)
+    codes = lut[m]
+    bad = np.flatnonzero((codes == 255).any(axis=1))
+    if len(bad):
+        raise ValueError(f"guide {guides[int(bad[0])]!r} holds a non-ACGT base")
+    return (codes.astype(np.uint64) << (2 * np.arange(L, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
 
 
 def decode_window(code: int, nmask: int, length: int) -> str:
