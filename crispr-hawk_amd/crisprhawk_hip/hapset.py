@@ -357,7 +357,7 @@ class GuideTable:
         _lib.check(self._hs._L.hawk_table_download(self._t, ptr(hap), ptr(pos), ptr(strand), ptr(start), ptr(stop),
                                                    ptr(flags), ptr(cfdon), ptr(win)), "hawk_table_download")
 
-    def collapse(self, flank: Tuple[int, int] = (0, 0), download_perm: bool = True) -> "GuideTable":
+    def collapse(self, flank: Tuple[int, int] = (0, 0), download_perm: bool = True, download: bool = True) -> "GuideTable":
         """Group the rows the guide report merges (reports.py:958-1008) on the device, before download():
         `group_perm` (row indices ordered by (start, strand, group)), `group_off` (CSR into it),
         `gc_num / gc_den` per group (gc_content of the spacer, annotation.py:513-541), `collapse_ms`.
@@ -369,6 +369,13 @@ class GuideTable:
         _lib.check(self._hs._L.hawk_table_collapse_ex(self._t, int(flank[0]), int(flank[1]), C.byref(ng), C.byref(ms)),
                    "hawk_table_collapse_ex")
         self.n_groups, self.collapse_ms, self.collapse_flank = ng.value, ms.value, (int(flank[0]), int(flank[1]))
+        self.group_perm = self.group_off = self.gc_num = self.gc_den = None
+        if download:  # (`download=False`: the results stay in HBM until export_groups() / collapse_results() asks for them)
+            self.collapse_results(download_perm)
+        return self
+
+    def collapse_results(self, download_perm: bool = False) -> "GuideTable":
+        """hawk_table_collapse_download: the CSR offsets and G/C counts of the groups (and the row permutation) to the host."""
         self.group_perm = np.empty(self.n_rows, np.uint32) if download_perm else None
         self.group_off = np.zeros(self.n_groups + 1, np.uint64)
         self.gc_num = np.empty(self.n_groups, np.uint8)
@@ -388,6 +395,8 @@ class GuideTable:
         _lib.check(self._hs._L.hawk_table_collapse_export(self._t, _p(g.rep_row), _p(g.pos), _p(g.strand), _p(g.start), _p(g.stop),
                                                           _p(g.flags), _p(g.cfdon), _p(g.win), _p(g.member_hap), C.byref(ms)),
                    "hawk_table_collapse_export")
+        if self.group_off is None:
+            self.collapse_results(False)
         g.member_off = self.group_off.astype(np.int64)
         g.gc_num, g.gc_den = self.gc_num, self.gc_den
         g.export_ms = ms.value
