@@ -663,9 +663,9 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
 
 // the guide table: a wave per 64 consecutive instances copies their clusters' template rows, patching haplotype row and
 // position.  The instances' offsets are consecutive, so a wave's rows are ONE contiguous piece of every column: the rows go
-// through LDS 128 at a time and leave as 16-byte nontemporal stores per lane (two rows of an 8-byte column, four of a
-// 4-byte one).  The 8-byte columns are staged four at a time - the two halves of a template row one after the other -
-// which takes the kernel from 12 to 20 waves per CU (30 KB of LDS, 81 VGPRs) for 5 % (profiles/r03_csearch_ablation.txt).
+// through LDS 128 at a time and leave as 16-byte stores per lane (two rows of an 8-byte column, four of a 4-byte one) - the
+// kernel is bound by store instructions, not bytes: a lane storing one 8-byte field per row took 0.58 ms for the 2.08 GB,
+// twice what a fill of that size takes (profiles/r03_csearch_ablation.txt).
 #define CE_CH 128
 // 16 bytes to a 4-byte-aligned address, past the caches' allocation (`nt`): the table is written once and read by a later kernel;
 // with plain stores the 2 GB of rows went through L2 at 4.1 TB/s, streaming at 4.8 (profiles/r03_csearch_ablation.txt).
@@ -680,13 +680,13 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
   __shared__ uint32_t s_ex[4][WAVE + 1];
   __shared__ uint32_t s_tb[4][WAVE], s_h[4][WAVE];
   __shared__ int32_t s_dq[4][WAVE];
-  // (+ 2: the two lanes of a template row write columns 2 q and 2 q + 1 of ONE row - an unpadded column stride of 1 KB put them in one bank)
-  __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][4][CE_CH + 2];  // (start, stop, cfdon, win0), then (win1 .. win4)
-  __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];      // hap, pos
-  __shared__ uint8_t s_c1[4][2][CE_CH];                                    // strand, flags
-  __shared__ uint32_t s_src[4][CE_CH];                                     // per row of the chunk: its template row,
-  __shared__ int32_t s_rdq[4][CE_CH];                                      // ... its position shift
+  // (+ 2: the four lanes of a template row write columns 2 q and 2 q + 1 of ONE row - an unpadded column stride of 1 KB put them in one bank)
+  __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH + 2];  // start, stop, cfdon, win0..4
   if (*t_count > t_cap) return;  // the template rows outgrew their reservation (k_cs_count left no counts): the host reruns the search
+  __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];  // hap, pos
+  __shared__ uint8_t s_c1[4][2][CE_CH];                                // strand, flags
+  __shared__ uint32_t s_src[4][CE_CH];                                 // per row of the chunk: its template row,
+  __shared__ int32_t s_rdq[4][CE_CH];                                  // ... its position shift
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   uint32_t cnt = 0, tb = 0, h = 0;
@@ -715,7 +715,6 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
   if (o0 + Wt > out.cap) { if (lane == 0) atomicExch(status, -3 /* HAWK_E_CAPACITY */); return; }
   uint64_t* const col8[8] = {reinterpret_cast<uint64_t*>(out.start), reinterpret_cast<uint64_t*>(out.stop), reinterpret_cast<uint64_t*>(out.cfdon),
                              out.win, out.win + out.cap, out.win + 2 * out.cap, out.win + 3 * out.cap, out.win + 4 * out.cap};
-  uint32_t* const col4[2] = {out.hap, out.pos};
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < Wt; c0 += CE_CH) {
     // which template row each of the chunk's rows copies, its haplotype row and position shift
@@ -733,63 +732,66 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const uint32_t nc = Wt - c0 < CE_CH ? Wt - c0 : CE_CH;
-    const uint64_t ob = o0 + c0;
+    // four lanes per template row, 16 bytes each: a load instruction touches 16 rows' lines instead of 64 (one row per lane with
+    // four loads took a quarter of the kernel in cache look-ups alone)
+    const uint32_t qd = lane & 3u;
 #pragma unroll
-    for (uint32_t half = 0; half < 2; ++half) {  // unrolled: the column pointers must be compile-time choices (a run-time index into them is a waterfall loop)
-      // two lanes per template row, 16 bytes each: quarters 2 half and 2 half + 1 of the 64-byte row (a load instruction touches
-      // 32 rows' lines; one row per lane with four loads spent a quarter of the kernel in cache look-ups)
-      const uint32_t ql = lane & 1u, qd = 2 * half + ql;
-#pragma unroll
-      for (uint32_t j = 0; j < CE_CH / 32; ++j) {
-        const uint32_t r = j * 32 + (lane >> 1);
-        if (r < nc) {
-          uint4 v;
-          if (CS_ABL & 1) v = make_uint4(r, j, lane, r);
-          else v = reinterpret_cast<const uint4*>(trows + s_src[wv][r])[qd];
-          uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-          if (qd == 0) {  // {position, strand | flags << 8, start - REF's first position, stop - start}
-            const int64_t start = startp + (int64_t)(int32_t)v.z;
-            s_c4[wv][1][r] = (uint32_t)((int32_t)v.x + s_rdq[wv][r]);
-            s_c1[wv][0][r] = (uint8_t)(v.y & 0xffu);
-            s_c1[wv][1][r] = (uint8_t)((v.y >> 8) & 0xffu);
-            lo = (uint64_t)start;
-            hi = (uint64_t)(start + (int64_t)(int32_t)v.w);
-          }
-          s_c8[wv][2 * ql][r] = lo;       // quarter q holds columns 2 q and 2 q + 1: (start, stop) (cfdon, win0) (win1, win2) (win3, win4)
-          s_c8[wv][2 * ql + 1][r] = hi;
+    for (uint32_t j = 0; j < CE_CH / 16; ++j) {
+      const uint32_t r = j * 16 + (lane >> 2), t = c0 + r;
+      if (t < Wt) {
+        const uint4 v = reinterpret_cast<const uint4*>(trows + s_src[wv][r])[qd];
+        uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        if (qd == 0) {  // {position, strand | flags << 8, start - REF's first position, stop - start}
+          const int64_t start = startp + (int64_t)(int32_t)v.z;
+          s_c4[wv][1][r] = (uint32_t)((int32_t)v.x + s_rdq[wv][r]);
+          s_c1[wv][0][r] = (uint8_t)(v.y & 0xffu);
+          s_c1[wv][1][r] = (uint8_t)((v.y >> 8) & 0xffu);
+          lo = (uint64_t)start;
+          hi = (uint64_t)(start + (int64_t)(int32_t)v.w);
         }
+        s_c8[wv][2 * qd][r] = lo;       // quarter q holds columns 2 q and 2 q + 1: (start, stop) (cfdon, win0) (win1, win2) (win3, win4)
+        s_c8[wv][2 * qd + 1][r] = hi;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (!(CS_ABL & 2)) {
-        const uint32_t r = 2 * lane;  // 8-byte columns: rows 2 lane, 2 lane + 1
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-          uint64_t* const dst = col8[4 * half + cl] + ob + r;
-          if (r + 1 < nc) nt_store4(reinterpret_cast<uint32_t*>(dst), *reinterpret_cast<const uint4*>(&s_c8[wv][cl][r]));
-          else if (r < nc) __builtin_nontemporal_store(s_c8[wv][cl][r], dst);
-        }
-        if (half == 0) {
-#pragma unroll
-          for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {  // byte columns: a row per lane
-            const uint32_t rb = sub * WAVE + lane;
-            if (rb < nc) {
-              __builtin_nontemporal_store(s_c1[wv][0][rb], out.strand + ob + rb);
-              __builtin_nontemporal_store(s_c1[wv][1][rb], out.flags + ob + rb);
-            }
-          }
-          const uint32_t r4 = 4 * lane;  // 4-byte columns: rows 4 lane .. 4 lane + 3
-#pragma unroll
-          for (int cl = 0; cl < 2; ++cl) {
-            if (r4 + 3 < nc) nt_store4(col4[cl] + ob + r4, *reinterpret_cast<const uint4*>(&s_c4[wv][cl][r4]));
-            else for (uint32_t q = r4; q < nc && q < r4 + 4; ++q) __builtin_nontemporal_store(s_c4[wv][cl][q], col4[cl] + ob + q);
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nc = (CS_ABL & 2) ? (s_c8[wv][0][5] == 0x123456789ull ? 1u : 0u) : (Wt - c0 < CE_CH ? Wt - c0 : CE_CH);
+    const uint64_t ob = o0 + c0;
+    {  // 8-byte columns: rows 2 lane, 2 lane + 1
+      const uint32_t r = 2 * lane;
+#pragma unroll
+      for (int cl = 0; cl < 8; ++cl) {
+        if (r + 1 < nc) {
+          const uint4 v = *reinterpret_cast<const uint4*>(&s_c8[wv][cl][r]);
+          nt_store4(reinterpret_cast<uint32_t*>(col8[cl] + ob + r), v);
+        } else if (r < nc) {
+          __builtin_nontemporal_store(s_c8[wv][cl][r], col8[cl] + ob + r);
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {  // byte columns: a row per lane
+      const uint32_t r = sub * WAVE + lane;
+      if (r < nc) {
+        __builtin_nontemporal_store(s_c1[wv][0][r], out.strand + ob + r);
+        __builtin_nontemporal_store(s_c1[wv][1][r], out.flags + ob + r);
+      }
+    }
+    {  // 4-byte columns: rows 4 lane .. 4 lane + 3
+      const uint32_t r = 4 * lane;
+      uint32_t* const col4[2] = {out.hap, out.pos};
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        if (r + 3 < nc) {
+          const uint4 v = *reinterpret_cast<const uint4*>(&s_c4[wv][cl][r]);
+          nt_store4(col4[cl] + ob + r, v);
+        } else {
+          for (uint32_t q = r; q < nc && q < r + 4; ++q) __builtin_nontemporal_store(s_c4[wv][cl][q], col4[cl] + ob + q);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
