@@ -154,7 +154,7 @@ def context(device: Optional[int] = None):
 
 # ---------------------------------------------------------------------------- page-locked result buffers
 _PINNED_FREE = {}  # bytes -> [address]: blocks given back by arrays that died (hipHostMalloc costs milliseconds per 100 MB)
-_PINNED_MIN = 1 << 20
+_PINNED_MIN = int(os.environ.get("HAWK_PINNED_MIN", 1 << 20))  # bytes from which a host array is page-locked
 
 
 def pinned_empty(n: int, dtype, device: Optional[int] = None):

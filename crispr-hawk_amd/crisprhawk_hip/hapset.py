@@ -304,9 +304,10 @@ class GroupTable:
     def __init__(self, guidelen: int, pamlen: int, right: bool, n_groups: int, n_rows: int):
         self.guidelen, self.pamlen, self.right, self.n_groups, self.n_rows = guidelen, pamlen, right, n_groups, n_rows
         ng = n_groups
-        self.rep_row = np.empty(ng, np.uint32); self.pos = np.empty(ng, np.uint32); self.strand = np.empty(ng, np.uint8)
-        self.start = np.empty(ng, np.int64); self.stop = np.empty(ng, np.int64); self.flags = np.empty(ng, np.uint8)
-        self.cfdon = np.empty(ng, np.float64); self.win = np.empty((5, ng), np.uint64)
+        pe = _lib.pinned_empty  # page-locked once an array reaches 1 MB: the export's copies then run at link speed, unstaged
+        self.rep_row = pe(ng, np.uint32); self.pos = pe(ng, np.uint32); self.strand = np.empty(ng, np.uint8)
+        self.start = pe(ng, np.int64); self.stop = pe(ng, np.int64); self.flags = np.empty(ng, np.uint8)
+        self.cfdon = pe(ng, np.float64); self.win = pe(5 * ng, np.uint64).reshape(5, ng)
         self.member_hap = _lib.pinned_empty(n_rows, np.uint32)  # C3: 112 MB, the bulk of the export
         self.member_off = np.zeros(ng + 1, np.int64)
         self.gc_num = np.zeros(ng, np.uint8); self.gc_den = np.zeros(ng, np.uint8)
@@ -377,7 +378,8 @@ class GuideTable:
     def collapse_results(self, download_perm: bool = False) -> "GuideTable":
         """hawk_table_collapse_download: the CSR offsets and G/C counts of the groups (and the row permutation) to the host."""
         self.group_perm = np.empty(self.n_rows, np.uint32) if download_perm else None
-        self.group_off = np.zeros(self.n_groups + 1, np.uint64)
+        self.group_off = _lib.pinned_empty(self.n_groups + 1, np.uint64)
+        self.group_off[-1:] = 0
         self.gc_num = np.empty(self.n_groups, np.uint8)
         self.gc_den = np.empty(self.n_groups, np.uint8)
         _lib.check(self._hs._L.hawk_table_collapse_download(self._t, _p(self.group_perm), _p(self.group_off), _p(self.gc_num),
