@@ -187,24 +187,35 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
   return k;
 }
-// hash[2h], hash[2h+1]: sums of two differently seeded mixes of (plane, word index, word) over the row
+__device__ __forceinline__ uint64_t rotl64(uint64_t k, int r) { return r ? (k << r) | (k >> (64 - r)) : k; }
+// hash[2h], hash[2h+1]: two multilinear sums over the row's non-zero words, sum_(plane, word index) word x key(plane, index)
+// mod 2^64, with keys mixed from the word index once and rotated per plane (zero words - row padding included - contribute
+// nothing, so rows of different stride hash alike).  Only a FILTER: rows whose hashes agree are compared word for word
+// (hawk_hapset_rows_equal) before they are treated as one haplotype.  Four words per plane and thread, 16-byte loads; the first
+// version mixed every word twice through fmix64 and ran at 2.3 TB/s (1.36 ms on C3), VALU-bound.
 __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_hash(const uint32_t* pA, const uint32_t* pC, const uint32_t* pG, const uint32_t* pT,
                                                          const uint32_t* pV, uint32_t S, uint32_t wpr, unsigned long long* hash) {
   __shared__ unsigned long long s_h[2];
   const uint32_t h = blockIdx.x / wpr, wb = blockIdx.x % wpr;
-  const uint32_t w = wb * HAWK_BLOCK + threadIdx.x;
+  const uint32_t w = (wb * HAWK_BLOCK + threadIdx.x) * 4;
   if (threadIdx.x < 2) s_h[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long a = 0, b = 0;
-  if (w < S) {
+  if (w < S) {  // S is a multiple of 4: the four words exist
     const size_t o = (size_t)h * S + w;
-    const uint32_t x[5] = {pA[o], pC[o], pG[o], pT[o], pV[o]};
+    const uint32_t* const pl[5] = {pA, pC, pG, pT, pV};
+    uint4 x[5];
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
-      if (!x[p]) continue;  // zero words (incl. row padding) contribute nothing: rows of different stride hash alike
-      const uint64_t key = ((uint64_t)(p + 1) << 56) | ((uint64_t)w << 32) | x[p];
-      a += fmix64(key ^ 0x9e3779b97f4a7c15ull);
-      b += fmix64(key * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
+    for (int p = 0; p < 5; ++p) x[p] = *reinterpret_cast<const uint4*>(pl[p] + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t k = fmix64((uint64_t)(w + j) + 0x9e3779b97f4a7c15ull) | 1ull, k2 = fmix64(k ^ 0xd6e8feb86659fd93ull) | 1ull;
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        const uint32_t xv = j == 0 ? x[p].x : j == 1 ? x[p].y : j == 2 ? x[p].z : x[p].w;
+        a += (uint64_t)xv * rotl64(k, 11 * p);
+        b += (uint64_t)xv * rotl64(k2, 7 * p + 3);
+      }
     }
   }
   // wave sums first (64-bit as two 32-bit halves with carry-free 64-bit shuffles), then one LDS atomic per wave
@@ -215,6 +226,6 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_hx_hash(const uint32_t* pA, cons
   if (threadIdx.x == 0 && (s_h[0] | s_h[1])) { atomicAdd(&hash[2 * h], s_h[0]); atomicAdd(&hash[2 * h + 1], s_h[1]); }
 }
 void hawk_launch_hx_hash(hipStream_t st, uint32_t* const* plane, uint32_t n_hap, uint32_t S, unsigned long long* hash) {
-  const uint32_t wpr = (S + HAWK_BLOCK - 1) / HAWK_BLOCK;
+  const uint32_t wpr = (S / 4 + HAWK_BLOCK - 1) / HAWK_BLOCK;  // four words per thread
   hipLaunchKernelGGL(k_hx_hash, dim3(n_hap * wpr), dim3(HAWK_BLOCK), 0, st, plane[0], plane[1], plane[2], plane[3], plane[4], S, wpr, hash);
 }
