@@ -90,25 +90,47 @@ __global__ __launch_bounds__(256) void k_gt_parse(const uint8_t* __restrict__ te
   if (tid == 0) flags[rec] = (uint8_t)s_flag;
 }
 
-// one wave per column: ballots[col][chunk] = which of variants 64*chunk .. +63 the column carries
-// col_count[col], col_count[n_cols + col]: carried variants, carried indels (var_chain != 0) of the column
+// ballots[col][chunk] = which of variants 64*chunk .. +63 the column carries;
+// col_count[col], col_count[n_cols + col]: carried variants, carried indels (var_chain != 0) of the column (zeroed by the launcher).
+// A wave takes 64 neighbouring columns and GT_CPW chunks of variants: lane = column, so a variant's 64 codes are one coalesced
+// 64-byte read and every lane shifts its own ballot word together (the first version gave a wave one column and its lanes 64
+// variants - 64 cache lines per load for 64 bytes of use: 0.74 ms on C3 where the matrix is 155 MB).
+#define GT_CPW 4
 __global__ __launch_bounds__(256) void k_gt_count(const uint8_t* __restrict__ codes, uint32_t n_cols, const uint32_t* __restrict__ var_line,
                                                   const uint8_t* __restrict__ var_allele, const int32_t* __restrict__ var_chain, uint32_t n_var,
                                                   uint32_t n_chunk, unsigned long long* __restrict__ ballots, uint32_t* __restrict__ col_count) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (col >= n_cols) return;  // wave-uniform
+  const uint32_t col = blockIdx.x * 64u + lane;
+  const uint32_t ch0 = (blockIdx.y * 4u + (threadIdx.x >> 6)) * GT_CPW;
+  if (ch0 >= n_chunk) return;  // wave-uniform
+  const bool live = col < n_cols;
   uint32_t cnt = 0, cnt_indel = 0;
-  for (uint32_t ch = 0; ch < n_chunk; ++ch) {
-    const uint32_t j = ch * 64u + lane;
-    bool carried = false;
-    if (j < n_var) carried = codes[(size_t)var_line[j] * n_cols + col] == var_allele[j];
-    const unsigned long long b = __ballot(carried);
-    if (lane == 0) ballots[(size_t)col * n_chunk + ch] = b;
+  for (uint32_t ch = ch0; ch < ch0 + GT_CPW && ch < n_chunk; ++ch) {
+    unsigned long long b = 0, bi = 0;
+    const uint32_t j0 = ch * 64u, nj = j0 + 64u <= n_var ? 64u : n_var - j0;
+    // the chunk's 64 variants: line, allele and chain read once by the lanes, handed round by v_readlane (compile-time lane: the loop
+    // is unrolled) - the 64 byte loads of a lane then depend on nothing but each other's issue
+    const uint32_t jl = j0 + (lane < nj ? lane : 0u);
+    const uint32_t my_line = var_line[jl], my_meta = (uint32_t)var_allele[jl] | (var_chain[jl] != 0 ? 0x100u : 0u);
+    uint8_t c[64];
+#pragma unroll
+    for (int jj = 0; jj < 64; ++jj) {
+      const uint32_t line = (uint32_t)__builtin_amdgcn_readlane((int)my_line, jj);
+      c[jj] = (live && (uint32_t)jj < nj) ? codes[(size_t)line * n_cols + col] : (uint8_t)254;  // 254: no allele of a variant (they are <= 253)
+    }
+#pragma unroll
+    for (int jj = 0; jj < 64; ++jj) {
+      const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, jj);
+      const bool carried = (uint32_t)jj < nj && c[jj] == (uint8_t)(meta & 0xffu);
+      b |= (unsigned long long)carried << jj;
+      bi |= (unsigned long long)(carried && (meta & 0x100u)) << jj;
+    }
+    if (live) ballots[(size_t)col * n_chunk + ch] = b;
     cnt += (uint32_t)__popcll(b);
-    if (b) cnt_indel += (uint32_t)__popcll(__ballot(carried && var_chain[j] != 0));
+    cnt_indel += (uint32_t)__popcll(bi);
   }
-  if (lane == 0) { col_count[col] = cnt; col_count[n_cols + col] = cnt_indel; }
+  if (live && cnt) atomicAdd(&col_count[col], cnt);
+  if (live && cnt_indel) atomicAdd(&col_count[n_cols + col], cnt_indel);
 }
 
 __global__ __launch_bounds__(256) void k_gt_fill(uint32_t n_cols, const int32_t* __restrict__ var_r0, const int32_t* __restrict__ var_chain,
@@ -150,8 +172,9 @@ void hawk_launch_gt_parse(hipStream_t st, const uint8_t* text, const uint64_t* l
 void hawk_launch_gt_count(hipStream_t st, const uint8_t* codes, uint32_t n_cols, const uint32_t* var_line, const uint8_t* var_allele,
                           const int32_t* var_chain, uint32_t n_var, unsigned long long* ballots, uint32_t* col_count /* [2 * n_cols] */) {
   const uint32_t n_chunk = (n_var + 63u) / 64u;
-  hipLaunchKernelGGL(k_gt_count, dim3((n_cols + 3u) / 4u), dim3(256), 0, st, codes, n_cols, var_line, var_allele, var_chain, n_var, n_chunk,
-                     ballots, col_count);
+  (void)hipMemsetAsync(col_count, 0, (size_t)2 * n_cols * 4, st);
+  hipLaunchKernelGGL(k_gt_count, dim3((n_cols + 63u) / 64u, (n_chunk + 4u * GT_CPW - 1u) / (4u * GT_CPW)), dim3(256), 0, st, codes, n_cols, var_line,
+                     var_allele, var_chain, n_var, n_chunk, ballots, col_count);
 }
 void hawk_launch_gt_fill(hipStream_t st, uint32_t n_cols, const int32_t* var_r0, const int32_t* var_chain, uint32_t n_var,
                          const unsigned long long* ballots, const uint64_t* col_off, uint32_t* hv_idx, int32_t* hv_o, int64_t* col_delta,
