@@ -1670,8 +1670,15 @@ static int xplan_build_dict(hawk_xplan* x) {
   int32_t *t_o, *t_pa, *t_rb;
   uint16_t* d_bkt;
   uint64_t* d_base_br;
-  TEMPCHK(tmp, &t_uid, (size_t)n_inst * 4); TEMPCHK(tmp, &t_row, (size_t)n_inst * 4); TEMPCHK(tmp, &t_o, (size_t)n_inst * 4);
-  TEMPCHK(tmp, &t_pa, (size_t)n_inst * 4); TEMPCHK(tmp, &t_rb, (size_t)n_inst * 4); TEMPCHK(tmp, &d_bkt, (size_t)n_inst * 2);
+  const bool in_place = n_bkt == 1;  // one stretch: the order the instances are built in is the order they stay in
+  if (in_place) {
+    t_uid = cl.inst_uid.as<uint32_t>(); t_row = cl.inst_row.as<uint32_t>(); t_o = cl.inst_o.as<int32_t>();
+    t_pa = cl.inst_pa.as<int32_t>(); t_rb = cl.inst_rb.as<int32_t>();
+  } else {
+    TEMPCHK(tmp, &t_uid, (size_t)n_inst * 4); TEMPCHK(tmp, &t_row, (size_t)n_inst * 4); TEMPCHK(tmp, &t_o, (size_t)n_inst * 4);
+    TEMPCHK(tmp, &t_pa, (size_t)n_inst * 4); TEMPCHK(tmp, &t_rb, (size_t)n_inst * 4);
+  }
+  TEMPCHK(tmp, &d_bkt, (size_t)n_inst * 2);
   TEMPCHK(tmp, &d_cnt_br, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_first_rb, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_base_br, ((size_t)n * n_bkt + 1) * 8);
   uint32_t *d_rec, *d_n, *d_slot, *d_flag, *d_trep, *d_slot_uid;
   uint64_t *d_key, *d_rank;
@@ -1723,9 +1730,11 @@ static int xplan_build_dict(hawk_xplan* x) {
     HIPCHK(hipMemsetAsync(t_uid, 0xff, (size_t)n_inst * 4, st));
     tot.n_keep = 0;
   }
-  hawk_launch_mscan(st, d_cnt_br, (uint64_t)n * n_bkt, d_partial, d_shards, d_base_br, d_tot);
-  hawk_launch_cl_permute(st, n_inst, n, n_bkt, d_bkt, d_base_br, d_first_rb, t_uid, t_o, t_row, t_pa, t_rb, cl.inst_uid.as<uint32_t>(),
-                         cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(), cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>());
+  if (!in_place) {
+    hawk_launch_mscan(st, d_cnt_br, (uint64_t)n * n_bkt, d_partial, d_shards, d_base_br, d_tot);
+    hawk_launch_cl_permute(st, n_inst, n, n_bkt, d_bkt, d_base_br, d_first_rb, t_uid, t_o, t_row, t_pa, t_rb, cl.inst_uid.as<uint32_t>(),
+                           cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(), cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>());
+  }
   uint32_t status = 0;
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[9], st));

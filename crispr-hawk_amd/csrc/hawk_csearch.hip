@@ -181,13 +181,16 @@ __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64
   uint32_t s = (uint32_t)(k >> 17) & mask;
   bool placed = false;
   for (uint32_t probe = 0; probe <= mask; ++probe) {  // the table has >= 2 slots per instance: a free slot is met long before the bound
-    const unsigned long long cur = atomicCAS(&tkey[s], 0ull, k);
+    // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
+    // atomic on it would queue them all at one address (a stale read only sends the instance to the CAS, which answers with the truth)
+    unsigned long long cur = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) cur = atomicCAS(&tkey[s], 0ull, k);
     if (cur == 0ull || cur == k) { placed = true; break; }
     s = (s + 1u) & mask;
   }
   if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, 2u); return; }  // cannot happen; the dictionary is then not used
   inst_slot[i] = s;
-  atomicMin(&trep[s], i);
+  if (__hip_atomic_load(&trep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&trep[s], i);  // (the minimum only falls)
 }
 __global__ __launch_bounds__(256) void k_cl_flag(uint32_t n_inst, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ inst_slot,
                                                  const uint32_t* __restrict__ trep, uint32_t* __restrict__ flag) {
@@ -253,7 +256,7 @@ void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_of
   ClInst ci{o, row, pa, rb, rec, n, key, cls, bkt};
   hipLaunchKernelGGL(k_cl_fill, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, hap_len, ss, se, inst_off, ci, bshift, n_bkt,
                      status);
-  hipLaunchKernelGGL(k_cl_bucket, dim3(n_rows), dim3(256), 0, st, inst_off, bkt, n_rows, n_bkt, cnt_br, first_rb);
+  if (n_bkt > 1) hipLaunchKernelGGL(k_cl_bucket, dim3(n_rows), dim3(256), 0, st, inst_off, bkt, n_rows, n_bkt, cnt_br, first_rb);
 }
 void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* bkt, const uint64_t* base_br,
                             const uint32_t* first_rb, const uint32_t* uid, const int32_t* o, const uint32_t* row, const int32_t* pa, const int32_t* rb,
