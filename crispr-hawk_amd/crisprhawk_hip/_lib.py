@@ -27,7 +27,7 @@ EXPORTS = [
     "hawk_device_count", "hawk_init", "hawk_destroy", "hawk_strerror", "hawk_last_hip_error", "hawk_stream",
     "hawk_sync", "hawk_hapset_create", "hawk_hapset_destroy", "hawk_hapset_pack_ascii", "hawk_hapset_set_meta",
     "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan", "hawk_pam_scan_time",
-    "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_cfd",
+    "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_table_layout", "hawk_table_download_rows", "hawk_table_device_rows", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
     "hawk_table_collapse", "hawk_table_collapse_download", "hawk_gt_parse", "hawk_gt_destroy", "hawk_gt_codes", "hawk_gt_lists",
     "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_xplan_cluster_stats", "hawk_host_gather_plan", "hawk_xplan_create_gt", "hawk_xplan_rows",
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
         L.hawk_gt_destroy.restype = None
         L.hawk_xplan_destroy.restype = None
         L.hawk_comm_destroy.restype = None
+        L.hawk_host_free.restype = None
         L.hawk_comm_last_error.restype = C.c_char_p
         for name in EXPORTS:
             fn = getattr(L, name)
@@ -153,28 +154,78 @@ def context(device: Optional[int] = None):
 
 
 # ---------------------------------------------------------------------------- page-locked result buffers
-_PINNED_FREE = {}  # bytes -> [address]: blocks given back by arrays that died (hipHostMalloc costs milliseconds per 100 MB)
+# Blocks given back by arrays that died are kept for the next request of their size class (hipHostMalloc costs milliseconds per
+# 100 MB) - in power-of-two classes, so that the differently sized exports of a per-tile loop share blocks, and only up to
+# HAWK_PINNED_CACHE_MAX bytes (default 1 GiB): beyond that a returned block goes back to the driver (hawk_host_free), as does
+# everything cached when the interpreter exits.  Page-locked memory is a scarce, unswappable resource.
+_PINNED_FREE = {}  # size class (bytes) -> [address]
+_PINNED_CACHED = [0]  # bytes sitting in _PINNED_FREE
 _PINNED_MIN = int(os.environ.get("HAWK_PINNED_MIN", 1 << 20))  # bytes from which a host array is page-locked
+_PINNED_CACHE_MAX = int(os.environ.get("HAWK_PINNED_CACHE_MAX", 1 << 30))
+
+
+def _pinned_release(size: int, addr: int) -> None:
+    if _lib is None:
+        return
+    if _PINNED_CACHED[0] + size <= _PINNED_CACHE_MAX:
+        _PINNED_FREE.setdefault(size, []).append(addr)
+        _PINNED_CACHED[0] += size
+    else:
+        _lib.hawk_host_free(C.c_void_p(addr))
+
+
+def pinned_trim() -> None:
+    """hand every cached page-locked block back to the driver"""
+    for size, pool in _PINNED_FREE.items():
+        while pool:
+            addr = pool.pop()
+            if _lib is not None:
+                _lib.hawk_host_free(C.c_void_p(addr))
+    _PINNED_CACHED[0] = 0
+
+
+def pinned_stats() -> dict:
+    return {"cached_bytes": _PINNED_CACHED[0], "blocks": sum(len(v) for v in _PINNED_FREE.values()), "cache_max": _PINNED_CACHE_MAX}
+
+
+def _size_class(nbytes: int) -> int:
+    """smallest of {2^k, 3 * 2^(k-2)} (k >= 20) holding nbytes: at most a third of a block is padding"""
+    k = max(20, (nbytes - 1).bit_length())
+    mid = 3 << (k - 2)
+    return mid if (k > 20 and mid >= nbytes) else 1 << k
 
 
 def pinned_empty(n: int, dtype, device: Optional[int] = None):
     """np.empty(n, dtype) in page-locked host memory when the array is large (a device-to-host copy into it runs at link
-    speed); small arrays are plain numpy.  The block goes back to a free list when the array is collected."""
+    speed); small arrays - and any array the driver refuses to page-lock - are plain numpy.  `device` names the device whose
+    context allocates (the table's own; default: the process default).  The block returns to the cache when the array is collected."""
     import numpy as np
     import weakref
     dt = np.dtype(dtype)
     nbytes = int(n) * dt.itemsize
     if nbytes < _PINNED_MIN:
         return np.empty(n, dtype=dt)
-    size = (nbytes + (1 << 20) - 1) >> 20 << 20
-    pool = _PINNED_FREE.setdefault(size, [])
+    size = _size_class(nbytes)
+    pool = _PINNED_FREE.get(size)
     if pool:
         addr = pool.pop()
+        _PINNED_CACHED[0] -= size
     else:
         p = C.c_void_p()
-        check(lib().hawk_host_alloc(context(device), C.c_uint64(size), C.byref(p)), "hawk_host_alloc")
+        rc = lib().hawk_host_alloc(context(device), C.c_uint64(size), C.byref(p))
+        if rc != HAWK_OK or not p.value:
+            if _PINNED_CACHED[0]:  # make room once, then try again
+                pinned_trim()
+                rc = lib().hawk_host_alloc(context(device), C.c_uint64(size), C.byref(p))
+            if rc != HAWK_OK or not p.value:
+                return np.empty(n, dtype=dt)  # pageable: slower copies, same result
         addr = p.value
     buf = (C.c_uint8 * size).from_address(addr)
     arr = np.frombuffer(buf, dtype=dt, count=int(n))
-    weakref.finalize(buf, pool.append, addr)
+    weakref.finalize(buf, _pinned_release, size, addr)
     return arr
+
+
+import atexit  # noqa: E402
+
+atexit.register(pinned_trim)

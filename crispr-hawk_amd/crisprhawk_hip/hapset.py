@@ -98,6 +98,7 @@ class DeviceHapSet:
         self = cls.__new__(cls)
         self._L = _lib.lib()
         self._ctx = _lib.context(device)
+        self.device = device
         self._h = handle
         self.hap_len = np.asarray(hap_len, dtype=np.uint32)
         self.n_hap = len(self.hap_len)
@@ -109,6 +110,7 @@ class DeviceHapSet:
     def __init__(self, haps: Sequence[HostHaplotype], device: Optional[int] = None):
         L = _lib.lib()
         self._ctx = _lib.context(device)
+        self.device = device
         self._L = L
         self.n_hap = len(haps)
         if self.n_hap == 0:
@@ -301,14 +303,16 @@ def _meta_arrays(haps: Sequence["HostHaplotype"]):
 class GroupTable:
     """Report groups of one collapsed guide table: representative rows as columns + CSR member haplotypes."""
 
-    def __init__(self, guidelen: int, pamlen: int, right: bool, n_groups: int, n_rows: int):
+    def __init__(self, guidelen: int, pamlen: int, right: bool, n_groups: int, n_rows: int, device: Optional[int] = None):
         self.guidelen, self.pamlen, self.right, self.n_groups, self.n_rows = guidelen, pamlen, right, n_groups, n_rows
         ng = n_groups
-        pe = _lib.pinned_empty  # page-locked once an array reaches 1 MB: the export's copies then run at link speed, unstaged
+
+        def pe(n, dt):  # page-locked once an array reaches 1 MB (by the table's own device context): the export's copies then run at link speed, unstaged
+            return _lib.pinned_empty(n, dt, device)
         self.rep_row = pe(ng, np.uint32); self.pos = pe(ng, np.uint32); self.strand = np.empty(ng, np.uint8)
         self.start = pe(ng, np.int64); self.stop = pe(ng, np.int64); self.flags = np.empty(ng, np.uint8)
         self.cfdon = pe(ng, np.float64); self.win = pe(5 * ng, np.uint64).reshape(5, ng)
-        self.member_hap = _lib.pinned_empty(n_rows, np.uint32)  # C3: 112 MB, the bulk of the export
+        self.member_hap = pe(n_rows, np.uint32)  # C3: 112 MB, the bulk of the export
         self.member_off = np.zeros(ng + 1, np.int64)
         self.gc_num = np.zeros(ng, np.uint8); self.gc_den = np.zeros(ng, np.uint8)
 
@@ -345,6 +349,20 @@ class GuideTable:
         _lib.check(hs._L.hawk_table_counts(handle, C.byref(n), C.byref(c), C.byref(h)), "hawk_table_counts")
         self.n_rows, self.n_candidates, self.n_hits = n.value, c.value, h.value
         self._downloaded = False
+        lay, sp0 = C.c_uint32(), C.c_int64()
+        _lib.check(hs._L.hawk_table_layout(handle, C.byref(lay), C.byref(sp0)), "hawk_table_layout")
+        self._layout = "rows" if lay.value == 1 else "columns"
+
+    def layout(self) -> str:
+        """'columns' (plane kernels, per-word search of a view) or 'rows' (the cluster search's packed 64-byte rows, include/hawk.h);
+        download() hands out columns either way."""
+        return self._layout
+
+    def download_rows(self) -> np.ndarray:
+        """the packed rows as they lie in HBM: [n_rows, 16] uint32 (hawk_table_download_rows; layout 'rows' only)"""
+        out = np.empty((self.n_rows, 16), np.uint32)
+        _lib.check(self._hs._L.hawk_table_download_rows(self._t, _p(out)), "hawk_table_download_rows")
+        return out
 
     def close(self) -> None:
         if self._t:
@@ -378,7 +396,7 @@ class GuideTable:
     def collapse_results(self, download_perm: bool = False) -> "GuideTable":
         """hawk_table_collapse_download: the CSR offsets and G/C counts of the groups (and the row permutation) to the host."""
         self.group_perm = np.empty(self.n_rows, np.uint32) if download_perm else None
-        self.group_off = _lib.pinned_empty(self.n_groups + 1, np.uint64)
+        self.group_off = _lib.pinned_empty(self.n_groups + 1, np.uint64, getattr(self._hs, 'device', None))
         self.group_off[-1:] = 0
         self.gc_num = np.empty(self.n_groups, np.uint8)
         self.gc_den = np.empty(self.n_groups, np.uint8)
@@ -392,7 +410,7 @@ class GuideTable:
         if self._t is None or not hasattr(self, "n_groups"):
             raise RuntimeError("export_groups() needs collapse() on the device-resident table")
         ng, n = self.n_groups, self.n_rows
-        g = GroupTable(self.guidelen, self.pamlen, self.right, ng, n)
+        g = GroupTable(self.guidelen, self.pamlen, self.right, ng, n, getattr(self._hs, 'device', None))
         ms = C.c_float()
         _lib.check(self._hs._L.hawk_table_collapse_export(self._t, _p(g.rep_row), _p(g.pos), _p(g.strand), _p(g.start), _p(g.stop),
                                                           _p(g.flags), _p(g.cfdon), _p(g.win), _p(g.member_hap), C.byref(ms)),

@@ -588,11 +588,7 @@ int hawk_gbt_predict(hawk_ctx* ctx, const double* feats, uint64_t n, uint32_t n_
 }
 
 }  // extern "C"
-// The guide table's twelve arrays are written in lock step by the emit kernels (row o of every array at the same time), and where
-// the arrays lie relative to each other decides how the twelve streams spread over the HBM channels: the same emit pass took 0.50
-// to 0.66 ms from one reservation to the next (tools/cols_pad_probe.py).  Putting them in one block at chosen distances was
-// tried (profiles/r03_csearch_ablation.txt): every distance below 1 GiB gave the slow end, and skewing the arrays' starts by
-// 256 B .. 16 KB changes nothing - it is which physical blocks the allocator hands out; they stay separate allocations.
+// The columnar layout of a guide table: eight separate allocations (see GuideCols in hawk_device.h for the packed layout).
 int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   int rc;
   const size_t sz[8] = {cap * 4, cap * 4, cap, cap * 8, cap * 8, cap, cap * 8, cap * 8 * HAWK_PLANES};
@@ -600,6 +596,7 @@ int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c) {
   c->hap = b[0].as<uint32_t>(); c->pos = b[1].as<uint32_t>(); c->strand = b[2].as<uint8_t>();
   c->start = b[3].as<int64_t>(); c->stop = b[4].as<int64_t>(); c->flags = b[5].as<uint8_t>();
   c->cfdon = b[6].as<double>(); c->win = b[7].as<uint64_t>(); c->cap = cap;
+  c->rows = nullptr; c->startp = 0;
   return HAWK_OK;
 }
 extern "C" {
@@ -751,12 +748,38 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
                           GuideCols{}, d_status, plane_tiles, v_tiles);
     }
   };
-  auto view_emit = [&](const GuideCols& cols) {
-    if (by_cluster) hawk_launch_cs_emit(ctx->stream, cd, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
-                                        ri.startp, d_tcount, tcap, cols, d_status);
-    else hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards,
-                             hs->offsets.as<uint64_t>(), cols, d_status, plane_tiles, v_tiles);
+  // the emit side.  Plane kernels (all rows of a set with planes; REF's rows of a view) and the per-word search of a view write
+  // columns; the cluster search writes packed rows (k_cs_emit_rows), and REF's rows - staged as columns - are packed in front of them
+  const uint64_t stage_cap = by_cluster ? 2ull * hs->hap_len[hs->ref_index] + 64 : 0;  // REF keeps at most every window start of both strands
+  auto emit_all = [&](const GuideCols& cols, const GuideCols& packed) {
+    hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
+                       hs->offsets.as<uint64_t>(), cols, d_status, d_lists, d_big_count, d_big, ctx->ev[5], plane_tiles);
+    if (!vx) return;
+    (void)hipEventRecord(ctx->ev[7], ctx->stream);
+    if (by_cluster) {
+      hawk_launch_rows_pack(ctx->stream, cols, hs->offsets.as<uint64_t>() + plane_tiles, 0, std::min<uint64_t>(stage_cap, packed.cap), packed.rows,
+                            packed.startp, d_status);
+      hawk_launch_cs_emit_rows(ctx->stream, cd, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
+                               d_tcount, tcap, packed.rows, packed.cap, d_status);
+    } else {
+      hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards,
+                          hs->offsets.as<uint64_t>(), cols, d_status, plane_tiles, v_tiles);
+    }
   };
+  // reserve for `cap` rows: `cols` is what the column emitters write, `table` what the finished table is
+  auto reserve_table = [&](uint64_t cap, GuideCols* cols, GuideCols* table) -> int {
+    int r;
+    if (!by_cluster) {
+      if ((r = hawk_reserve_cols(hs->colsA, cap, cols))) return r;
+      *table = *cols;
+      return HAWK_OK;
+    }
+    if ((r = hawk_reserve_cols(hs->colsA, stage_cap, cols)) || (r = hs->rowsA.reserve(cap * 64))) return r;
+    memset(table, 0, sizeof(*table));
+    table->rows = hs->rowsA.as<uint4>(); table->cap = cap; table->startp = ri.startp;
+    return HAWK_OK;
+  };
+  uint64_t& table_cap = by_cluster ? hs->rows_cap : hs->cols_cap;
   GuideCols none = {};
   hipEvent_t* ev = ctx->ev;
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
@@ -775,35 +798,43 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
 #else
   const bool count_only = false;
 #endif
-  GuideCols ca;
+  GuideCols ca, tc;
   int status = 0;
   uint64_t nrows = 0;
   bool emitted = false;
-  if (hs->cols_cap && !count_only) {
-    // Columns from an earlier search on this set are still reserved: launch the emit pass straight behind the offset
+  auto template_overflow = [&](uint64_t tc_used) {  // the rerun reserves what this search asked for (+ 1/8), at most the plan's bound
+    hs->cs_tcap = std::min<uint64_t>(vx->cl.slots, tc_used + tc_used / 8 + 64);
+  };
+  if (table_cap && !count_only) {
+    // The table of an earlier search on this set is still reserved: launch the emit pass straight behind the offset
     // scan instead of waiting for the row count to cross PCIe (the kernels take their offsets from HBM and refuse to
     // write past the capacity).  If the table turns out larger, the normal path below runs after a reserve.
-    if ((rc = hawk_reserve_cols(hs->colsA, hs->cols_cap, &ca))) return rc;
+    if ((rc = reserve_table(table_cap, &ca, &tc))) return rc;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
-    hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                       hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5], plane_tiles);
-    if (vx) HIPCHK(hipEventRecord(ev[7], ctx->stream));
-    if (vx) view_emit(ca);
+    emit_all(ca, tc);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(&tot, h_block + 32, sizeof(tot));
     memcpy(&status, h_block, 4);
-    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } t_rows_used = tc; }
+    if (by_cluster) { uint64_t tcu; memcpy(&tcu, h_block + 8, 8); if (tcu > tcap) { template_overflow(tcu); return HAWK_RETRY_TEMPLATES; } t_rows_used = tcu; }
     nrows = tot.n_keep;
-    emitted = nrows <= hs->cols_cap;
-    if (!emitted) { status = 0; HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream)); }
+    emitted = nrows <= table_cap;
+    if (!emitted) {
+      // only the capacity refusal of the emit pass is answered by emitting again; any other status was raised by the count side
+      // (a strict-mode CFD error, an unsupported coordinate range) and stands - the kernels keep the FIRST status they raise
+      if (status && status != HAWK_E_CAPACITY) return status;
+      status = 0;
+      HIPCHK(hipMemsetAsync(d_status, 0, 4, ctx->stream));
+    }
   } else {
     HIPCHK(hipMemcpyAsync(h_block, d_block, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(&tot, h_block + 32, sizeof(tot));
-    if (by_cluster) { uint64_t tc; memcpy(&tc, h_block + 8, 8); if (tc > tcap) { hs->cs_tcap = vx->cl.slots; return HAWK_RETRY_TEMPLATES; } t_rows_used = tc; }
+    memcpy(&status, h_block, 4);
+    if (by_cluster) { uint64_t tcu; memcpy(&tcu, h_block + 8, 8); if (tcu > tcap) { template_overflow(tcu); return HAWK_RETRY_TEMPLATES; } t_rows_used = tcu; }
+    if (status) return status;
     nrows = tot.n_keep;
   }
   if (count_only) {  // measurement hook: time the count pass of an experimental build whose counts the emit pass cannot use
@@ -811,17 +842,10 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     nrows = 0;
   }
   if (!emitted) {
-    const char* epad = getenv("HAWK_COLS_PAD");  // measurement: how the columns' relative placement affects the emit pass
-    const uint64_t want = std::max<uint64_t>(nrows, 1) + (epad ? strtoull(epad, nullptr, 10) : 0);
-    if ((rc = hawk_reserve_cols(hs->colsA, std::max<uint64_t>(want, hs->cols_cap), &ca))) return rc;
-    hs->cols_cap = ca.cap;
+    if ((rc = reserve_table(std::max<uint64_t>(std::max<uint64_t>(nrows, 1), table_cap), &ca, &tc))) return rc;
+    table_cap = tc.cap;
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
-    if (nrows) {
-      hawk_launch_search(ctx->stream, 1, d, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), d_shards,
-                         hs->offsets.as<uint64_t>(), ca, d_status, d_lists, d_big_count, d_big, ev[5], plane_tiles);
-      if (vx) HIPCHK(hipEventRecord(ev[7], ctx->stream));
-      if (vx) view_emit(ca);
-    }
+    if (nrows) emit_all(ca, tc);
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_block, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -849,7 +873,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
   hawk_table* t = new (std::nothrow) hawk_table();
   if (!t) return HAWK_E_INVALID;
   t->hs = hs; t->ctx = ctx; t->gen = hs->cols_gen;
-  t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = ca; t->cap = ca.cap;
+  t->n_rows = nrows; t->n_cand = tot.n_cand; t->n_hits = tot.n_hits; t->cols = tc; t->cap = tc.cap;
   t->guidelen = p->guidelen; t->pamlen = p->pamlen; t->right = p->right ? 1 : 0; t->n_groups = 0; t->collapsed = false;
   t->by_cluster = by_cluster; t->plane_tiles = plane_tiles; t->t_rows = by_cluster ? t_rows_used : 0;
   *out = t;
@@ -881,7 +905,24 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
   HIPCHK(hipSetDevice(ctx->device));
   const uint64_t n = t->n_rows;
   if (!n) return HAWK_OK;
-  const GuideCols& c = t->cols;
+  GuideCols c = t->cols;
+  PoolScope tmp;
+  if (c.rows) {  // packed rows: the asked-for columns are cut out on the device first
+    GuideCols u;
+    memset(&u, 0, sizeof(u));
+    u.cap = n;
+    if (hap) TEMPCHK(tmp, &u.hap, n * 4);
+    if (pos) TEMPCHK(tmp, &u.pos, n * 4);
+    if (strand) TEMPCHK(tmp, &u.strand, n);
+    if (start) TEMPCHK(tmp, &u.start, n * 8);
+    if (stop) TEMPCHK(tmp, &u.stop, n * 8);
+    if (flags) TEMPCHK(tmp, &u.flags, n);
+    if (cfdon) TEMPCHK(tmp, &u.cfdon, n * 8);
+    if (win) TEMPCHK(tmp, &u.win, n * 8 * HAWK_PLANES);
+    hawk_launch_rows_unpack(ctx->stream, c.rows, n, c.startp, u);
+    HIPCHK(hipGetLastError());
+    c = u;
+  }
   if (hap) HIPCHK(hipMemcpyAsync(hap, c.hap, n * 4, hipMemcpyDefault, ctx->stream));
   if (pos) HIPCHK(hipMemcpyAsync(pos, c.pos, n * 4, hipMemcpyDefault, ctx->stream));
   if (strand) HIPCHK(hipMemcpyAsync(strand, c.strand, n, hipMemcpyDefault, ctx->stream));
@@ -896,10 +937,35 @@ int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* st
   return HAWK_OK;
 }
 
+int hawk_table_layout(const hawk_table* t, uint32_t* layout, int64_t* startp) {
+  if (!t || !layout) return HAWK_E_INVALID;
+  *layout = t->cols.rows ? HAWK_LAYOUT_ROWS : HAWK_LAYOUT_COLUMNS;
+  if (startp) *startp = t->cols.rows ? t->cols.startp : 0;
+  return HAWK_OK;
+}
+
+int hawk_table_download_rows(hawk_table* t, void* rows64) {
+  if (!t || hawk_table_stale(t) || !rows64) return HAWK_E_INVALID;
+  if (!t->cols.rows) return HAWK_E_UNSUPPORTED;
+  HIPCHK(hipSetDevice(t->ctx->device));
+  if (t->n_rows) HIPCHK(hipMemcpyAsync(rows64, t->cols.rows, t->n_rows * 64, hipMemcpyDefault, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return HAWK_OK;
+}
+
+int hawk_table_device_rows(hawk_table* t, void** rows64, int64_t* startp) {
+  if (!t || hawk_table_stale(t) || !rows64) return HAWK_E_INVALID;
+  if (!t->cols.rows) return HAWK_E_UNSUPPORTED;
+  *rows64 = t->cols.rows;
+  if (startp) *startp = t->cols.startp;
+  return HAWK_OK;
+}
+
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,
                               void** flags, void** cfdon, void** win, uint64_t* win_plane_stride) {
   if (!t || hawk_table_stale(t)) return HAWK_E_INVALID;
   const GuideCols& c = t->cols;
+  if (c.rows) return HAWK_E_UNSUPPORTED;  // packed rows: hawk_table_device_rows
   if (hap) *hap = c.hap;
   if (pos) *pos = c.pos;
   if (strand) *strand = c.strand;

@@ -44,15 +44,15 @@ struct RowKey {
 // Rows are stored on the + strand: a strand-1 guide's 5' side is the window's right side.
 __device__ __forceinline__ RowKey row_key(const GuideCols& c, const uint8_t* __restrict__ is_ref, uint64_t i, int L, int up, int down) {
   RowKey k;
-  k.start = c.start[i];
-  k.stop = c.stop[i];
-  const uint32_t strand = c.strand[i];
-  k.sr = strand | ((uint32_t)(is_ref[c.hap[i]] != 0) << 1);
+  k.start = gc_start(c, i);
+  k.stop = gc_stop(c, i);
+  const uint32_t strand = gc_strand(c, i);
+  k.sr = strand | ((uint32_t)(is_ref[gc_hap(c, i)] != 0) << 1);
   const int fl = strand ? down : up, fr = strand ? up : down;
   const int width = L + fl + fr;
   const uint64_t mask = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
 #pragma unroll
-  for (int pl = 0; pl < HAWK_PLANES; ++pl) k.core[pl] = (c.win[(size_t)pl * c.cap + i] >> (HAWK_PAD - fl)) & mask;
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) k.core[pl] = (gc_win(c, pl, i) >> (HAWK_PAD - fl)) & mask;
   return k;
 }
 __device__ __forceinline__ bool same_row(const RowKey& a, const RowKey& b) {
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(256) void k_collapse_groups(GuideCols c, uint64_t n
   group_off[g] = j;
   const uint64_t r = vals[j];
   // the spacer inside the stored (+ strand) core: behind the PAM when the PAM comes first (right ^ strand)
-  const bool pamfirst = (right != 0) != (c.strand[r] != 0);
+  const bool pamfirst = (right != 0) != (gc_strand(c, r) != 0);
   const int sh = HAWK_PAD + (pamfirst ? pamlen : 0);
   const uint64_t m = guidelen >= 64 ? ~0ull : ((1ull << guidelen) - 1ull);
-  const uint64_t A = (c.win[r] >> sh) & m, C = (c.win[c.cap + r] >> sh) & m, G = (c.win[2 * c.cap + r] >> sh) & m,
-                 T = (c.win[3 * c.cap + r] >> sh) & m;
+  const uint64_t A = (gc_win(c, 0, r) >> sh) & m, C = (gc_win(c, 1, r) >> sh) & m, G = (gc_win(c, 2, r) >> sh) & m,
+                 T = (gc_win(c, 3, r) >> sh) & m;
   const uint64_t gc = (C | G) & ~(A | T);  // C, G, S
   const uint64_t at = (A | T) & ~(C | G);  // A, T, W
   gc_num[g] = (uint8_t)__popcll(gc);
@@ -257,18 +257,18 @@ __global__ __launch_bounds__(256) void k_collapse_export(GuideCols c, uint64_t n
                                                          const uint64_t* __restrict__ group_off, GuideCols rep,
                                                          uint32_t* __restrict__ member_hap) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j < n) member_hap[j] = c.hap[perm[j]];
+  if (j < n) member_hap[j] = gc_hap(c, perm[j]);
   if (j < ng) {
     const uint64_t r = perm[group_off[j]];  // the group's first member in table order
     rep.hap[j] = (uint32_t)r;               // the representative's row index in the full table
-    rep.pos[j] = c.pos[r];
-    rep.strand[j] = c.strand[r];
-    rep.start[j] = c.start[r];
-    rep.stop[j] = c.stop[r];
-    rep.flags[j] = c.flags[r];
-    rep.cfdon[j] = c.cfdon[r];
+    rep.pos[j] = gc_pos(c, r);
+    rep.strand[j] = (uint8_t)gc_strand(c, r);
+    rep.start[j] = gc_start(c, r);
+    rep.stop[j] = gc_stop(c, r);
+    rep.flags[j] = (uint8_t)gc_flags(c, r);
+    rep.cfdon[j] = gc_cfdon(c, r);
 #pragma unroll
-    for (int pl = 0; pl < HAWK_PLANES; ++pl) rep.win[(size_t)pl * rep.cap + j] = c.win[(size_t)pl * c.cap + r];
+    for (int pl = 0; pl < HAWK_PLANES; ++pl) rep.win[(size_t)pl * rep.cap + j] = gc_win(c, pl, r);
   }
 }
 void hawk_launch_collapse_export(hipStream_t st, const GuideCols& c, uint64_t n, uint64_t ng, const uint32_t* perm,
@@ -359,11 +359,11 @@ __global__ __launch_bounds__(256) void k_cg_groups(GuideCols c, uint64_t n, cons
   if (j && gid[j - 1] == g) return;
   group_off[g] = j;
   const uint64_t r = vals[j];  // the group's first member in table order
-  const bool pamfirst = (right != 0) != (c.strand[r] != 0);
+  const bool pamfirst = (right != 0) != (gc_strand(c, r) != 0);
   const int sh = HAWK_PAD + (pamfirst ? pamlen : 0);
   const uint64_t m = guidelen >= 64 ? ~0ull : ((1ull << guidelen) - 1ull);
-  const uint64_t A = (c.win[r] >> sh) & m, C = (c.win[c.cap + r] >> sh) & m, G = (c.win[2 * c.cap + r] >> sh) & m,
-                 T = (c.win[3 * c.cap + r] >> sh) & m;
+  const uint64_t A = (gc_win(c, 0, r) >> sh) & m, C = (gc_win(c, 1, r) >> sh) & m, G = (gc_win(c, 2, r) >> sh) & m,
+                 T = (gc_win(c, 3, r) >> sh) & m;
   const uint64_t gc = (C | G) & ~(A | T), at = (A | T) & ~(C | G);
   gc_num[g] = (uint8_t)__popcll(gc);
   gc_den[g] = (uint8_t)__popcll(gc | at);

@@ -265,14 +265,34 @@ int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst,
   hawk_table* m = nullptr;
   GuideCols mc = {};
   int prep = HAWK_OK;  // what this rank has to say before any send is posted
+  GuideCols sc = t->cols;
+  const uint64_t n = t->n_rows;
+  PoolScope tmp;  // a table in packed rows travels as columns (the merged table is columnar): cut them out first
+  if (sc.rows) {
+    GuideCols u;
+    memset(&u, 0, sizeof(u));
+    u.cap = std::max<uint64_t>(n, 1);
+    int ra = tmp.alloc((void**)&u.hap, u.cap * 4);
+    if (!ra) ra = tmp.alloc((void**)&u.pos, u.cap * 4);
+    if (!ra) ra = tmp.alloc((void**)&u.strand, u.cap);
+    if (!ra) ra = tmp.alloc((void**)&u.start, u.cap * 8);
+    if (!ra) ra = tmp.alloc((void**)&u.stop, u.cap * 8);
+    if (!ra) ra = tmp.alloc((void**)&u.flags, u.cap);
+    if (!ra) ra = tmp.alloc((void**)&u.cfdon, u.cap * 8);
+    if (!ra) ra = tmp.alloc((void**)&u.win, u.cap * 8 * HAWK_PLANES);
+    if (!ra) hawk_launch_rows_unpack(st, sc.rows, n, sc.startp, u);
+    sc = u;
+    if (ra) prep = ra;  // said in the go / no-go word below
+  }
   if (root) {
     m = new (std::nothrow) hawk_table();
-    if (!m) prep = HAWK_E_INVALID;
+    if (!m && !prep) prep = HAWK_E_INVALID;
     if (m) {
       m->hs = nullptr; m->ctx = ctx; m->gen = 0;
       m->n_rows = totals[0]; m->n_cand = totals[1]; m->n_hits = totals[2];
       m->guidelen = t->guidelen; m->pamlen = t->pamlen; m->right = t->right; m->n_groups = 0; m->collapsed = false;
-      prep = hawk_reserve_cols(m->own, std::max<uint64_t>(totals[0], 1), &mc);
+      const int rr = hawk_reserve_cols(m->own, std::max<uint64_t>(totals[0], 1), &mc);
+      if (rr) prep = rr;
       m->cols = mc; m->cap = mc.cap;
     }
   }
@@ -291,8 +311,6 @@ int hawk_table_gather(hawk_comm* c, hawk_table* t, uint32_t hap_offset, int dst,
       return HAWK_E_COMM;
     }
   }
-  const GuideCols& sc = t->cols;
-  const uint64_t n = t->n_rows;
   const void* sp[HAWK_GATHER_COLS] = {sc.hap, sc.pos, sc.strand, sc.start, sc.stop, sc.flags, sc.cfdon, sc.win, sc.win + sc.cap, sc.win + 2 * sc.cap,
                                       sc.win + 3 * sc.cap, sc.win + 4 * sc.cap};
   void* rp[HAWK_GATHER_COLS] = {mc.hap, mc.pos, mc.strand, mc.start, mc.stop, mc.flags, mc.cfdon, mc.win, mc.win + mc.cap, mc.win + 2 * mc.cap,

@@ -28,11 +28,8 @@
 #define CL_FAR (1 << 29)     // "position" of a row's closing instance: the clean run in front of it reaches the row's end
 #define CL_MAXWALK 4096      // records per cluster the dictionary accepts (longer chains: the per-word search takes the plan)
 #define CS_G 8               // lanes per distinct cluster in k_cs_templates: one 32-window word each per round
-#ifndef CS_ABL
-#define CS_ABL 0             // ablation builds only (tools/ab_cs.sh)
-#endif
 
-// a template row, 64 bytes = one L2 sector pair: {position relative to the cluster's first allele, strand | flags << 8,
+// a template row, 64 bytes = one L2 sector pair: {position relative to the cluster's first allele, strand | flags << 1,
 // start - REF's first position, stop - start} {cfdon, win0} {win1, win2} {win3, win4}
 struct __attribute__((aligned(16))) CsRow { uint4 a, b, c, d; };
 static_assert(sizeof(CsRow) == 64, "template row layout");
@@ -96,16 +93,23 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
     const uint32_t ex = block_excl_scan<256 / WAVE>(st ? 1u : 0u, s_w, &tot);
     if (st) {
       const uint32_t i = at + ex;
-      uint64_t e = j, h = 0x243F6A8885A308D3ull;
+      // A cluster's identity is WHERE in REF its first allele starts and, record by record, where the allele lies relative to
+      // that, where REF resumes behind it, and which alt bases it puts there (length + offset into alt_codes) - not the offset
+      // alone: the ABI lets a caller pool alt alleles (one shared "A" for every x>A SNV), and the same offset at two loci is not
+      // the same variant.
+      const int32_t o_first = recs[j].o;
+      int32_t pa = 0, rb = 0;
+      if (j > lo) { pa = recs[j - 1].o + (int32_t)recs[j - 1].alt_len; rb = (int32_t)recs[j - 1].rs - pa; }
+      uint64_t e = j, h = cl_mix(0x243F6A8885A308D3ull, (uint64_t)(uint32_t)(o_first + rb));
       uint32_t n = 0;
       do {
-        h = cl_mix(h, recs[e].alt_off);
+        const HxVar r = recs[e];
+        h = cl_mix(h, (uint64_t)r.alt_off | ((uint64_t)r.alt_len << 32));
+        h = cl_mix(h, (uint64_t)r.rs | ((uint64_t)(uint32_t)(r.o - o_first) << 32));
         ++n; ++e;
       } while (e < hi && !cl_starts(recs, e, lo) && n < CL_MAXWALK);
       if (e < hi && !cl_starts(recs, e, lo)) atomicOr(status, 1u);  // a chain too long for this path
-      const int32_t o_first = recs[j].o, o_end = recs[e - 1].o + (int32_t)recs[e - 1].alt_len;
-      int32_t pa = 0, rb = 0;
-      if (j > lo) { pa = recs[j - 1].o + (int32_t)recs[j - 1].alt_len; rb = (int32_t)recs[j - 1].rs - pa; }
+      const int32_t o_end = recs[e - 1].o + (int32_t)recs[e - 1].alt_len;
       // window starts the cluster can touch: [o_first - (L - 1), o_end), L <= 44; the ranges they are tested against
       // (search_guides.py:49-84, 395-420) are [ss - po, se - po) and [PAD, len - L - PAD], po in {0, guidelen}
       const bool outside = o_end <= ss - 44 || o_first - 43 >= se;
@@ -236,11 +240,13 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
   inst_uid[i] = slot_uid[s];
   if (r == i) return;
   // exactness: same hash is not same cluster until the variant identities have been compared
-  bool bad = c != 1 || ci.cls[r] != 1 || ci.n[r] != ci.n[i];
+  bool bad = c != 1 || ci.cls[r] != 1 || ci.n[r] != ci.n[i] || ci.o[i] + ci.rb[i] != ci.o[r] + ci.rb[r];  // same REF position of the first allele
   if (!bad) {
     const HxVar* a = recs + ci.rec[i];
     const HxVar* b = recs + ci.rec[r];
-    for (uint32_t k = 0; k < ci.n[i]; ++k) bad = bad || a[k].alt_off != b[k].alt_off;
+    const int32_t oa = a[0].o, ob = b[0].o;
+    for (uint32_t k = 0; k < ci.n[i]; ++k)
+      bad = bad || a[k].alt_off != b[k].alt_off || a[k].alt_len != b[k].alt_len || a[k].rs != b[k].rs || a[k].o - oa != b[k].o - ob;
   }
   if (bad) atomicOr(status, 2u);
 }
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
         if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED */);
         const uint64_t sc = (uint64_t)__double_as_longlong(score);
         uint4* __restrict__ tp = reinterpret_cast<uint4*>(trows + k);
-        tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)s | (has_ref ? 0x100u : 0u),
+        tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)s | (has_ref ? 2u : 0u),
                            (uint32_t)(int32_t)ds, (uint32_t)(int32_t)de);
         tp[1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), win[0].lo, win[0].hi);
         tp[2] = make_uint4(win[1].lo, win[1].hi, win[2].lo, win[2].hi);
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
           if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED */);
           const uint64_t sc = (uint64_t)__double_as_longlong(score);
           uint4* __restrict__ tp = reinterpret_cast<uint4*>(trows + k);
-          tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)sd | (has_ref ? 0x100u : 0u),
+          tp[0] = make_uint4((uint32_t)((int32_t)(pamfirst ? q : q + (uint32_t)p.guidelen) - o_first), (uint32_t)sd | (has_ref ? 2u : 0u),
                              (uint32_t)(int32_t)ds, (uint32_t)(int32_t)de);
           tp[1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), win[0].lo, win[0].hi);
           tp[2] = make_uint4(win[1].lo, win[1].hi, win[2].lo, win[2].hi);
@@ -664,32 +670,27 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
   }
 }
 
-// the guide table: a wave per 64 consecutive instances copies their clusters' template rows, patching haplotype row and
-// position.  The instances' offsets are consecutive, so a wave's rows are ONE contiguous piece of every column: the rows go
-// through LDS 128 at a time and leave as 16-byte stores per lane (two rows of an 8-byte column, four of a 4-byte one) - the
-// kernel is bound by store instructions, not bytes: a lane storing one 8-byte field per row took 0.58 ms for the 2.08 GB,
-// twice what a fill of that size takes (profiles/r03_csearch_ablation.txt).
-#define CE_CH 128
-// 16 bytes to a 4-byte-aligned address, past the caches' allocation (`nt`): the table is written once and read by a later kernel;
-// with plain stores the 2 GB of rows went through L2 at 4.1 TB/s, streaming at 4.8 (profiles/r03_csearch_ablation.txt).
+// 16 bytes to a 16-byte-aligned address, past the caches' allocation (`nt`): the table is written once and read by a later kernel.
 // The four dword stores to consecutive addresses are merged into one global_store_dwordx4 ... nt by the compiler.
 __device__ __forceinline__ void nt_store4(uint32_t* q, const uint4& v) {
   __builtin_nontemporal_store(v.x, q); __builtin_nontemporal_store(v.y, q + 1);
   __builtin_nontemporal_store(v.z, q + 2); __builtin_nontemporal_store(v.w, q + 3);
 }
-__global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restrict__ res, const uint32_t* __restrict__ tbase,
-                                                 const CsRow* __restrict__ trows, const uint64_t* __restrict__ offsets, int64_t startp,
-                                                 const unsigned long long* __restrict__ t_count, uint64_t t_cap, GuideCols out, int* status) {
+// ---- packed rows (round 4): the guide table of a cluster search as ONE array of 64-byte rows -----------------------------
+// {pos, strand | flags << 1 | haplotype row << 9, start - startp, stop - start} {cfdon, win0} {win1, win2} {win3, win4}: a template
+// row with two words patched.  A wave's rows are contiguous, four lanes move one row (16 bytes each), so every store
+// instruction writes 1 KB of consecutive addresses and the whole table is a single linear write stream - twelve column
+// streams whose relative placement decided the speed before (profiles/r03_csearch_ablation.txt).
+__global__ __launch_bounds__(256) void k_cs_emit_rows(ClDict cd, const uint4* __restrict__ res, const uint32_t* __restrict__ tbase,
+                                                      const CsRow* __restrict__ trows, const uint64_t* __restrict__ offsets,
+                                                      const unsigned long long* __restrict__ t_count, uint64_t t_cap, uint4* __restrict__ rows,
+                                                      uint64_t cap, int* status) {
   __shared__ uint32_t s_ex[4][WAVE + 1];
   __shared__ uint32_t s_tb[4][WAVE], s_h[4][WAVE];
   __shared__ int32_t s_dq[4][WAVE];
-  // (+ 2: the four lanes of a template row write columns 2 q and 2 q + 1 of ONE row - an unpadded column stride of 1 KB put them in one bank)
-  __shared__ __attribute__((aligned(16))) uint64_t s_c8[4][8][CE_CH + 2];  // start, stop, cfdon, win0..4
-  if (*t_count > t_cap) return;  // the template rows outgrew their reservation (k_cs_count left no counts): the host reruns the search
-  __shared__ __attribute__((aligned(16))) uint32_t s_c4[4][2][CE_CH];  // hap, pos
-  __shared__ uint8_t s_c1[4][2][CE_CH];                                // strand, flags
-  __shared__ uint32_t s_src[4][CE_CH];                                 // per row of the chunk: its template row,
-  __shared__ int32_t s_rdq[4][CE_CH];                                  // ... its position shift
+  __shared__ uint32_t s_src[4][WAVE], s_rh[4][WAVE];
+  __shared__ int32_t s_rdq[4][WAVE];
+  if (*t_count > t_cap) return;
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   uint32_t cnt = 0, tb = 0, h = 0;
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
   if (i < cd.n_inst) {
     const uint32_t u = cd.inst_uid[i];
     h = cd.inst_row[i];
-    dq = cd.inst_o[i];  // template positions are relative to the cluster's first allele
+    dq = cd.inst_o[i];
     off = offsets[i];
     if (u != CL_NONE) {
       const uint4 r = res[u];
@@ -708,94 +709,55 @@ __global__ __launch_bounds__(256) void k_cs_emit(ClDict cd, const uint4* __restr
   }
   const uint32_t inc = wave_incl_scan(cnt);
   const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
-  // the wave's first row: the offset of its first instance (offsets are cumulative over ALL instances, with or without rows)
   const uint64_t o0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off) |
                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32);
   s_ex[wv][lane] = inc - cnt;
   s_tb[wv][lane] = tb; s_h[wv][lane] = h; s_dq[wv][lane] = dq;
   __syncthreads();
-  if (Wt == 0) return;  // wave-uniform; no workgroup barrier below
-  if (o0 + Wt > out.cap) { if (lane == 0) atomicExch(status, -3 /* HAWK_E_CAPACITY */); return; }
-  uint64_t* const col8[8] = {reinterpret_cast<uint64_t*>(out.start), reinterpret_cast<uint64_t*>(out.stop), reinterpret_cast<uint64_t*>(out.cfdon),
-                             out.win, out.win + out.cap, out.win + 2 * out.cap, out.win + 3 * out.cap, out.win + 4 * out.cap};
+  if (Wt == 0) return;
+  if (o0 + Wt > cap) { if (lane == 0) atomicCAS(status, 0, -3 /* HAWK_E_CAPACITY */); return; }
+  const uint32_t qd = lane & 3u;
+  uint4* __restrict__ const dst = rows + o0 * 4;
 #pragma unroll 1
-  for (uint32_t c0 = 0; c0 < Wt; c0 += CE_CH) {
-    // which template row each of the chunk's rows copies, its haplotype row and position shift
+  for (uint32_t c0 = 0; c0 < Wt; c0 += WAVE) {
+    const uint32_t t = c0 + lane;
+    if (t < Wt) {
+      uint32_t l = 0;
 #pragma unroll
-    for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {
-      const uint32_t r = sub * WAVE + lane, t = c0 + r;
-      if (t < Wt) {
-        uint32_t l = 0;
-#pragma unroll
-        for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;  // l + step <= 63
-        s_src[wv][r] = s_tb[wv][l] + (t - s_ex[wv][l]);
-        s_c4[wv][0][r] = s_h[wv][l];
-        s_rdq[wv][r] = s_dq[wv][l];
-      }
+      for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;
+      s_src[wv][lane] = s_tb[wv][l] + (t - s_ex[wv][l]);
+      s_rh[wv][lane] = s_h[wv][l];
+      s_rdq[wv][lane] = s_dq[wv][l];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // four lanes per template row, 16 bytes each: a load instruction touches 16 rows' lines instead of 64 (one row per lane with
-    // four loads took a quarter of the kernel in cache look-ups alone)
-    const uint32_t qd = lane & 3u;
+    uint4 v[4];
 #pragma unroll
-    for (uint32_t j = 0; j < CE_CH / 16; ++j) {
-      const uint32_t r = j * 16 + (lane >> 2), t = c0 + r;
-      if (t < Wt) {
-        const uint4 v = reinterpret_cast<const uint4*>(trows + s_src[wv][r])[qd];
-        uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-        if (qd == 0) {  // {position, strand | flags << 8, start - REF's first position, stop - start}
-          const int64_t start = startp + (int64_t)(int32_t)v.z;
-          s_c4[wv][1][r] = (uint32_t)((int32_t)v.x + s_rdq[wv][r]);
-          s_c1[wv][0][r] = (uint8_t)(v.y & 0xffu);
-          s_c1[wv][1][r] = (uint8_t)((v.y >> 8) & 0xffu);
-          lo = (uint64_t)start;
-          hi = (uint64_t)(start + (int64_t)(int32_t)v.w);
-        }
-        s_c8[wv][2 * qd][r] = lo;       // quarter q holds columns 2 q and 2 q + 1: (start, stop) (cfdon, win0) (win1, win2) (win3, win4)
-        s_c8[wv][2 * qd + 1][r] = hi;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nc = (CS_ABL & 2) ? (s_c8[wv][0][5] == 0x123456789ull ? 1u : 0u) : (Wt - c0 < CE_CH ? Wt - c0 : CE_CH);
-    const uint64_t ob = o0 + c0;
-    {  // 8-byte columns: rows 2 lane, 2 lane + 1
-      const uint32_t r = 2 * lane;
-#pragma unroll
-      for (int cl = 0; cl < 8; ++cl) {
-        if (r + 1 < nc) {
-          const uint4 v = *reinterpret_cast<const uint4*>(&s_c8[wv][cl][r]);
-          nt_store4(reinterpret_cast<uint32_t*>(col8[cl] + ob + r), v);
-        } else if (r < nc) {
-          __builtin_nontemporal_store(s_c8[wv][cl][r], col8[cl] + ob + r);
-        }
-      }
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t r = j * 16 + (lane >> 2);
+      if (c0 + r < Wt) v[j] = reinterpret_cast<const uint4*>(trows + s_src[wv][r])[qd];
     }
 #pragma unroll
-    for (uint32_t sub = 0; sub < CE_CH / WAVE; ++sub) {  // byte columns: a row per lane
-      const uint32_t r = sub * WAVE + lane;
-      if (r < nc) {
-        __builtin_nontemporal_store(s_c1[wv][0][r], out.strand + ob + r);
-        __builtin_nontemporal_store(s_c1[wv][1][r], out.flags + ob + r);
-      }
-    }
-    {  // 4-byte columns: rows 4 lane .. 4 lane + 3
-      const uint32_t r = 4 * lane;
-      uint32_t* const col4[2] = {out.hap, out.pos};
-#pragma unroll
-      for (int cl = 0; cl < 2; ++cl) {
-        if (r + 3 < nc) {
-          const uint4 v = *reinterpret_cast<const uint4*>(&s_c4[wv][cl][r]);
-          nt_store4(col4[cl] + ob + r, v);
-        } else {
-          for (uint32_t q = r; q < nc && q < r + 4; ++q) __builtin_nontemporal_store(s_c4[wv][cl][q], col4[cl] + ob + q);
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t r = j * 16 + (lane >> 2);
+      if (c0 + r < Wt) {
+        uint4 w = v[j];
+        if (qd == 0) {
+          w.x = (uint32_t)((int32_t)w.x + s_rdq[wv][r]);
+          w.y |= s_rh[wv][r] << HAWK_ROW_HAP_SHIFT;
         }
+        nt_store4(reinterpret_cast<uint32_t*>(dst + (size_t)(c0 + r) * 4 + qd), w);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+}
+void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
+                              const unsigned long long* t_count, uint64_t t_cap, void* rows, uint64_t cap, int* status) {
+  if (!cd.n_inst) return;
+  hipLaunchKernelGGL(k_cs_emit_rows, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), tbase,
+                     static_cast<const CsRow*>(trows), offsets, t_count, t_cap, static_cast<uint4*>(rows), cap, status);
 }
 
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const GuideParams& gp,
@@ -811,11 +773,55 @@ void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va,
   hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), t_count, t_cap, counts,
                      shards);
 }
-void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
-                         int64_t startp, const unsigned long long* t_count, uint64_t t_cap, GuideCols out, int* status) {
-  if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_emit, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), tbase,
-                     static_cast<const CsRow*>(trows), offsets, startp, t_count, t_cap, out, status);
+
+// columns -> packed rows (REF's rows, which the plane kernels write as columns; a columnar table before an exchange) and back
+__global__ __launch_bounds__(256) void k_rows_pack(GuideCols c, const uint64_t* __restrict__ n_dev, uint64_t n_host, uint4* __restrict__ rows, int64_t startp,
+                                                   int* status) {
+  const uint64_t n = n_dev ? *n_dev : n_host;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t start = c.start[i], ds = start - startp, de = c.stop[i] - start;
+  const uint32_t h = c.hap[i];
+  if (ds < INT32_MIN || ds > INT32_MAX || de < INT32_MIN || de > INT32_MAX || h >= HAWK_ROW_MAX_HAP) atomicCAS(status, 0, -7 /* HAWK_E_UNSUPPORTED */);
+  const uint64_t sc = (uint64_t)__double_as_longlong(c.cfdon[i]);
+  uint64_t w[HAWK_PLANES];
+#pragma unroll
+  for (int pl = 0; pl < HAWK_PLANES; ++pl) w[pl] = c.win[(size_t)pl * c.cap + i];
+  uint4* __restrict__ r = rows + i * 4;
+  r[0] = make_uint4(c.pos[i], (uint32_t)(c.strand[i] & 1u) | ((uint32_t)c.flags[i] << 1) | (h << HAWK_ROW_HAP_SHIFT), (uint32_t)(int32_t)ds, (uint32_t)(int32_t)de);
+  r[1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), (uint32_t)w[0], (uint32_t)(w[0] >> 32));
+  r[2] = make_uint4((uint32_t)w[1], (uint32_t)(w[1] >> 32), (uint32_t)w[2], (uint32_t)(w[2] >> 32));
+  r[3] = make_uint4((uint32_t)w[3], (uint32_t)(w[3] >> 32), (uint32_t)w[4], (uint32_t)(w[4] >> 32));
+}
+__global__ __launch_bounds__(256) void k_rows_unpack(const uint4* __restrict__ rows, uint64_t n, int64_t startp, GuideCols d) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4* __restrict__ r = rows + i * 4;
+  const uint4 a = r[0], b = r[1], cc = r[2], e = r[3];
+  const int64_t start = startp + (int64_t)(int32_t)a.z;
+  if (d.hap) d.hap[i] = a.y >> HAWK_ROW_HAP_SHIFT;
+  if (d.pos) d.pos[i] = a.x;
+  if (d.strand) d.strand[i] = (uint8_t)(a.y & 1u);
+  if (d.flags) d.flags[i] = (uint8_t)((a.y >> 1) & 0xffu);
+  if (d.start) d.start[i] = start;
+  if (d.stop) d.stop[i] = start + (int64_t)(int32_t)a.w;
+  if (d.cfdon) d.cfdon[i] = __longlong_as_double((long long)((uint64_t)b.x | ((uint64_t)b.y << 32)));
+  if (d.win) {
+    d.win[i] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+    d.win[d.cap + i] = (uint64_t)cc.x | ((uint64_t)cc.y << 32);
+    d.win[2 * d.cap + i] = (uint64_t)cc.z | ((uint64_t)cc.w << 32);
+    d.win[3 * d.cap + i] = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    d.win[4 * d.cap + i] = (uint64_t)e.z | ((uint64_t)e.w << 32);
+  }
+}
+void hawk_launch_rows_pack(hipStream_t st, const GuideCols& src, const uint64_t* n_dev, uint64_t n_host, uint64_t max_rows, uint4* rows, int64_t startp,
+                           int* status) {
+  if (!max_rows) return;
+  hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)((max_rows + 255) / 256)), dim3(256), 0, st, src, n_dev, n_host, rows, startp, status);
+}
+void hawk_launch_rows_unpack(hipStream_t st, const uint4* rows, uint64_t n, int64_t startp, const GuideCols& dst) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_rows_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, n, startp, dst);
 }
 
 // ---- the collapse of a cluster-searched table (hawk_api.hip: collapse_by_templates) ---------------------------------------
@@ -832,10 +838,10 @@ __global__ __launch_bounds__(256) void k_cc_mini(GuideCols c, uint64_t r0, const
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= r0 + t_rows) return;
   if (i < r0) {
-    m.hap[i] = c.hap[i]; m.pos[i] = c.pos[i]; m.strand[i] = c.strand[i]; m.start[i] = c.start[i]; m.stop[i] = c.stop[i];
-    m.flags[i] = c.flags[i]; m.cfdon[i] = c.cfdon[i];
+    m.hap[i] = gc_hap(c, i); m.pos[i] = gc_pos(c, i); m.strand[i] = (uint8_t)gc_strand(c, i); m.start[i] = gc_start(c, i); m.stop[i] = gc_stop(c, i);
+    m.flags[i] = (uint8_t)gc_flags(c, i); m.cfdon[i] = gc_cfdon(c, i);
 #pragma unroll
-    for (int pl = 0; pl < HAWK_PLANES; ++pl) m.win[(size_t)pl * m.cap + i] = c.win[(size_t)pl * c.cap + i];
+    for (int pl = 0; pl < HAWK_PLANES; ++pl) m.win[(size_t)pl * m.cap + i] = gc_win(c, pl, i);
     return;
   }
   uint32_t lo = 0, hi = nu;  // last u with moff[u] <= i - r0
@@ -847,7 +853,7 @@ __global__ __launch_bounds__(256) void k_cc_mini(GuideCols c, uint64_t r0, const
   const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
   const int64_t start = startp + (int64_t)(int32_t)a.z;
   m.hap[i] = 1u;  // any row but REF's: the grouping asks for the origin only
-  m.pos[i] = a.x; m.strand[i] = (uint8_t)(a.y & 0xffu); m.flags[i] = (uint8_t)((a.y >> 8) & 0xffu);
+  m.pos[i] = a.x; m.strand[i] = (uint8_t)(a.y & 1u); m.flags[i] = (uint8_t)((a.y >> 1) & 0xffu);
   m.start[i] = start; m.stop[i] = start + (int64_t)(int32_t)a.w;
   m.cfdon[i] = __longlong_as_double((long long)((uint64_t)b.x | ((uint64_t)b.y << 32)));
   m.win[0 * m.cap + i] = (uint64_t)b.z | ((uint64_t)b.w << 32);

@@ -53,7 +53,16 @@ struct ScanTotals {
   uint64_t n_hits;     // PAM hits inside the scan range
 };
 
-struct GuideCols {  // SoA guide table, capacity rows
+// The guide table.  Two layouts:
+//  * columns (SoA) - what the plane kernels and the per-word search of a view write: hap, pos, strand, start, stop, flags, cfdon,
+//    win[5][cap]; `rows` is null;
+//  * packed rows (`rows` != null; the column pointers are null) - what the cluster search of a view writes (hawk_csearch.hip):
+//    ONE array of 64-byte rows, a single linear write stream.  Row i = 16 words:
+//      [0] pos   [1] strand | flags << 1 | haplotype row << 9   [2] start - startp   [3] stop - start   [4,5] cfdon
+//      [6 + 2 p, 7 + 2 p] window slice of plane p
+//    (`startp` = genomic position of REF's base 0; haplotype rows < 2^23 and both differences within int32 are checked where the
+//    rows are made).
+struct GuideCols {
   uint32_t* hap;
   uint32_t* pos;
   uint8_t* strand;
@@ -63,7 +72,40 @@ struct GuideCols {  // SoA guide table, capacity rows
   double* cfdon;
   uint64_t* win;  // [5][cap]
   uint64_t cap;
+  uint4* rows;    // packed layout
+  int64_t startp;
 };
+#define HAWK_ROW_HAP_SHIFT 9
+#define HAWK_ROW_MAX_HAP (1u << 23)
+#ifdef __HIPCC__
+// field access for either layout (the branch is uniform over a launch)
+__device__ __forceinline__ const uint32_t* gc_roww(const GuideCols& c, uint64_t i) { return reinterpret_cast<const uint32_t*>(c.rows) + i * 16; }
+__device__ __forceinline__ uint32_t gc_hap(const GuideCols& c, uint64_t i) { return c.rows ? gc_roww(c, i)[1] >> HAWK_ROW_HAP_SHIFT : c.hap[i]; }
+__device__ __forceinline__ uint32_t gc_pos(const GuideCols& c, uint64_t i) { return c.rows ? gc_roww(c, i)[0] : c.pos[i]; }
+__device__ __forceinline__ uint32_t gc_strand(const GuideCols& c, uint64_t i) { return c.rows ? (gc_roww(c, i)[1] & 1u) : (uint32_t)c.strand[i]; }
+__device__ __forceinline__ uint32_t gc_flags(const GuideCols& c, uint64_t i) { return c.rows ? ((gc_roww(c, i)[1] >> 1) & 0xffu) : (uint32_t)c.flags[i]; }
+__device__ __forceinline__ int64_t gc_start(const GuideCols& c, uint64_t i) { return c.rows ? c.startp + (int64_t)(int32_t)gc_roww(c, i)[2] : c.start[i]; }
+__device__ __forceinline__ int64_t gc_stop(const GuideCols& c, uint64_t i) {
+  if (!c.rows) return c.stop[i];
+  const uint32_t* w = gc_roww(c, i);
+  return c.startp + (int64_t)(int32_t)w[2] + (int64_t)(int32_t)w[3];
+}
+__device__ __forceinline__ double gc_cfdon(const GuideCols& c, uint64_t i) {
+  if (!c.rows) return c.cfdon[i];
+  const uint32_t* w = gc_roww(c, i);
+  return __longlong_as_double((long long)((uint64_t)w[4] | ((uint64_t)w[5] << 32)));
+}
+__device__ __forceinline__ uint64_t gc_win(const GuideCols& c, int pl, uint64_t i) {
+  if (!c.rows) return c.win[(size_t)pl * c.cap + i];
+  const uint32_t* w = gc_roww(c, i);
+  return (uint64_t)w[6 + 2 * pl] | ((uint64_t)w[7 + 2 * pl] << 32);
+}
+#endif
+// columns [0, n) -> packed rows [0, n) (n read on the device: *n_dev, or n_host when n_dev is null) and back (null destination
+// columns are skipped).  Packing reports HAWK_E_UNSUPPORTED through *status for a row the layout cannot hold.
+void hawk_launch_rows_pack(hipStream_t st, const GuideCols& src, const uint64_t* n_dev, uint64_t n_host, uint64_t max_rows, uint4* rows, int64_t startp,
+                           int* status);
+void hawk_launch_rows_unpack(hipStream_t st, const uint4* rows, uint64_t n, int64_t startp, const GuideCols& dst);
 
 struct GuideParams {
   int32_t pamlen, guidelen, right, L;
@@ -132,8 +174,8 @@ void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs&
                               const struct RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status);
 void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
                           const unsigned long long* t_count, uint64_t t_cap, uint32_t* counts, unsigned long long* shards);
-void hawk_launch_cs_emit(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
-                         int64_t startp, const unsigned long long* t_count, uint64_t t_cap, struct GuideCols out, int* status);
+void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
+                              const unsigned long long* t_count, uint64_t t_cap, void* rows, uint64_t cap, int* status);
 // hawk_meta.hip: the rows' metadata of an expansion plan, built on the device
 void hawk_launch_list_check(hipStream_t st, const uint64_t* row_off, uint32_t n_rows, const uint32_t* hv_idx, const int32_t* hv_o,
                             const int32_t* v_r0, const int32_t* v_span, const int32_t* v_chain, uint32_t n_var, uint32_t ref_len,

@@ -121,6 +121,8 @@ struct hawk_hapset {
   DevBuf cs_res, cs_tbase, cs_trows;
   DevBuf cmini[8], cm_gid;   // hawk_table_collapse of such a table: REF's rows + the template rows as a table of their own, their groups  // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}, first template row; template rows
   DevBuf colsA[8];
+  DevBuf rowsA;               // packed rows of a cluster-searched table (colsA then stages REF's rows only)
+  uint64_t rows_cap = 0;
   DevBuf crep[8];  // hawk_table_collapse_export: one representative row per group
 };
 

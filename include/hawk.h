@@ -239,6 +239,18 @@ int hawk_table_counts(const hawk_table* t, uint64_t* n_rows, uint64_t* n_candida
  *   A,C,G,T,V for the guidelen+pamlen+20-nt window, bit 0 = leftmost base. */
 int hawk_table_download(hawk_table* t, uint32_t* hap, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
                         uint8_t* flags, double* cfdon, uint64_t* win);
+/* Layout of a table in HBM.  The plane kernels and the per-word search of a view write COLUMNS (the arrays above); the cluster
+ * search of a plan view (hawk_timing.v_path == 2) writes PACKED ROWS: one array of 64-byte rows, a single linear write stream,
+ *   word 0 pos | 1 strand + (flags << 1) + (haplotype row << 9) | 2 start - startp | 3 stop - start | 4-5 cfdon | 6 + 2p, 7 + 2p
+ *   window slice of plane p (little-endian 32-bit words; startp = genomic position of the region string's base 0).
+ * hawk_table_download hands out columns whichever layout the table has (a packed table is cut into the asked-for columns on the
+ * device first); hawk_table_download_rows / hawk_table_device_rows give the packed rows as they lie (HAWK_E_UNSUPPORTED on a
+ * columnar table), hawk_table_device_columns the column pointers (HAWK_E_UNSUPPORTED on a packed table). */
+#define HAWK_LAYOUT_COLUMNS 0u
+#define HAWK_LAYOUT_ROWS 1u
+int hawk_table_layout(const hawk_table* t, uint32_t* layout, int64_t* startp);
+int hawk_table_download_rows(hawk_table* t, void* rows64 /* n_rows x 64 bytes, host or device */);
+int hawk_table_device_rows(hawk_table* t, void** rows64, int64_t* startp);
 /* Device pointers of the same columns (valid until the next hawk_search on the same set);
  * plane p of the window slices starts at win + p * win_plane_stride (in uint64 elements). */
 int hawk_table_device_columns(hawk_table* t, void** hap, void** pos, void** strand, void** start, void** stop,

@@ -1,6 +1,8 @@
 """Parity at BASELINE.json's full size (C3: 1 Mb x 2504 phased samples, 5009 haplotype rows, 5.0e9 scanned positions,
 2.8e7 guide rows) through size-independent properties, plus exact comparison with the oracle on haplotypes sampled
-out of the full table.  One module-scoped workload; ~20 s on an MI355X."""
+out of the full table.  The table under test is the one bench.py's timed step produces: the search of the expansion plan's
+VIEW, once per distinct variant cluster (hawk_csearch.hip, hawk_timing.v_path == 2, packed 64-byte rows); the search over
+materialised planes must give the same rows.  One module-scoped workload; ~30 s on an MI355X."""
 import ctypes as C
 
 import numpy as np
@@ -20,13 +22,33 @@ PAM_S, GUIDELEN = "NGG", 20
 @pytest.fixture(scope="module")
 def c3():
     reg = synth.config_c3()
-    ds, info, _, kept = expand_on_device(reg, len(PAM_S))
+    ds, info, _, kept = expand_on_device(reg, len(PAM_S), keep_plan=True)
     pam = PAM(PAM_S, False, True)
     pam.encode(0)
     mm, pt = synth.cfd_tables()
-    tab = ds.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, mm, pt, download=False, collapse=True)
+    view = ds.plan.view()
+    st = ds.plan.cluster_stats()
+    assert st["usable"] and st["instances"] >= 3 * st["distinct"]   # the dictionary is used by default on this panel
+    tab = view.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, mm, pt, download=False, collapse=True)
+    assert tab.timing["v_path"] == 2                                 # the headline step's kernels, not a fall-back
+    assert tab.layout() == "rows"
     tab.download()
-    return dict(reg=reg, ds=ds, info=info, kept=kept, pam=pam, tab=tab, mm=mm, pt=pt)
+    return dict(reg=reg, ds=ds, view=view, info=info, kept=kept, pam=pam, tab=tab, mm=mm, pt=pt)
+
+
+def test_plane_search_gives_the_same_rows_in_canonical_order(c3):
+    # hawk_xplan_run's planes through k_search_count / k_emit_list: the same rows, a haplotype's by tile instead of by cluster
+    ds, pam, tab = c3["ds"], c3["pam"], c3["tab"]
+    t2 = ds.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, c3["mm"], c3["pt"])
+    assert t2.timing["v_path"] == 0 and t2.layout() == "columns"
+    assert (t2.n_rows, t2.n_candidates, t2.n_hits) == (tab.n_rows, tab.n_candidates, tab.n_hits)
+    oa, ob = np.lexsort((tab.pos, tab.strand, tab.hap)), np.lexsort((t2.pos, t2.strand, t2.hap))
+    for col in ("hap", "pos", "strand", "start", "stop", "flags"):
+        assert np.array_equal(getattr(tab, col)[oa], getattr(t2, col)[ob]), col
+    assert np.array_equal(tab.cfdon[oa], t2.cfdon[ob], equal_nan=True)
+    for p in range(5):
+        assert np.array_equal(tab.win[p][oa], t2.win[p][ob]), p
+    t2.close()
 
 
 def test_counts_agree_with_the_independent_scan_kernel(c3):
@@ -80,8 +102,9 @@ def test_ref_partner_flags_and_cfdon(c3):
 def test_search_is_deterministic_and_additive(c3):
     # same set, second search: identical table (bit for bit); a set without the second half of the rows' scan ranges
     # is exercised by the sampled-haplotype test below, additivity here is on the group structure
-    ds, pam, tab = c3["ds"], c3["pam"], c3["tab"]
-    t2 = ds.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, c3["mm"], c3["pt"])
+    view, pam, tab = c3["view"], c3["pam"], c3["tab"]
+    t2 = view.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, c3["mm"], c3["pt"])
+    assert t2.timing["v_path"] == 2
     for col in ("hap", "pos", "strand", "start", "stop", "flags", "win"):
         assert np.array_equal(getattr(tab, col), getattr(t2, col)), col
     assert np.array_equal(np.nan_to_num(tab.cfdon, nan=-1.0), np.nan_to_num(t2.cfdon, nan=-1.0))

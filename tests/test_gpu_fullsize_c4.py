@@ -34,6 +34,7 @@ def c4():
     mm, ptab = synth.cfd_tables()
     view = pt.plan.view()
     tab = view.search(pam.bits, pam.bitsrc, 3, GUIDELEN, False, mm, ptab, download=False, collapse=True, cfd_na_on_ambiguous=True)
+    assert tab.timing["v_path"] == 2 and tab.layout() == "rows"  # the bench's per-tile step: the cluster search, not a fall-back
     groups = tab.export_groups()
     tab.download()
     return dict(seq=seq, panel=panel, pam=pam, trs=trs, pt=pt, view=view, tab=tab, groups=groups, mm=mm, ptab=ptab)

@@ -12,7 +12,7 @@ import pytest
 from crisprhawk_hip import _lib, synth
 from crisprhawk_hip.workload import expand_on_device
 from oracle import oracle as ora
-from util import load_golden, synth_region_from_fixture
+from util import load_golden, oracle_haplotypes, synth_region_from_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,34 @@ def _canonical(t):
     return {c: getattr(t, c)[o] for c in COLS} | {"win": t.win[:, o], "cfdon": t.cfdon[o]}
 
 
-def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False):
+def _oracle_rows(reg, pam_s, guidelen, right, mm, pt):
+    """the ORACLE's search of the region (haplotypes built by the oracle from the raw variant calls, util.oracle_haplotypes):
+    a multiset of (carrier labels, start, stop, strand, position, window, CFDon) - rows named by WHO carries the haplotype, so the
+    comparison does not depend on how either side numbers its haplotype rows"""
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, len(pam_s)) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    want = ora.search(hs, pam_s, guidelen, right)
+    cfd = None
+    if mm is not None:
+        _, _, _, cfd, _ = ora.reverse_and_cfdon(want, hs.is_ref, guidelen, len(pam_s), mm, pt)
+    g, wins = want.guides, want.windows
+    lab = [tuple(sorted(h["samples"])) for h in haps]
+    rows = sorted((lab[int(g["hap"][i])], int(g["start"][i]), int(g["stop"][i]), int(g["strand"][i]), int(g["pos"][i]), wins[i],
+                   None if cfd is None or np.isnan(cfd[i]) else float(cfd[i])) for i in range(len(g)))
+    return rows, want.n_candidates, want.n_hits
+
+
+def _table_rows(t, info, kept, with_cfd):
+    lab = {int(r): tuple(sorted(inf.samples)) for r, inf in zip(kept, info)}
+    wins = t.windows()
+    return sorted((lab[int(t.hap[i])], int(t.start[i]), int(t.stop[i]), int(t.strand[i]), int(t.pos[i]), wins[i],
+                   None if not with_cfd or np.isnan(t.cfdon[i]) else float(t.cfdon[i])) for i in range(t.n_rows))
+
+
+def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False, oracle=False):
     bits, bitsrc, _, _ = ora.pam_encode(pam_s)
     mm, pt = synth.cfd_tables() if cfd else (None, None)
     ds, _info, _ms, _kept = expand_on_device(reg, len(pam_s), keep_plan=True)
@@ -57,8 +84,12 @@ def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False):
     st = ds.plan.cluster_stats()
     assert st["usable"], st
     c = view.search(bits, bitsrc, len(pam_s), guidelen, right, mm, pt, cfd_na_on_ambiguous=na_on_ambiguous)
-    assert c.timing["v_path"] == 2
+    assert c.timing["v_path"] == 2 and c.layout() == "rows" and a.layout() == "columns"
     assert (c.n_rows, c.n_candidates, c.n_hits) == (a.n_rows, a.n_candidates, a.n_hits)
+    if oracle:  # the cluster search's table against the oracle directly (not only through the plane path)
+        want, n_cand, n_hits = _oracle_rows(reg, pam_s, guidelen, right, mm, pt)
+        assert (c.n_candidates, c.n_hits) == (n_cand, n_hits)
+        assert _table_rows(c, _info, _kept, mm is not None) == want
     ca, cc = _canonical(a), _canonical(c)
     for k in COLS:
         assert np.array_equal(ca[k], cc[k]), k
@@ -78,7 +109,7 @@ def _same_table(reg, pam_s, guidelen, right, cfd=True, na_on_ambiguous=False):
 def test_view_search_on_reference_fixture_inputs(case):
     fx = load_golden(f"g3_search_{case}.json.gz")
     reg = synth_region_from_fixture(fx)
-    a = _same_table(reg, fx["pam"], fx["guidelen"], fx["right"], cfd="cfdon" in fx)
+    a = _same_table(reg, fx["pam"], fx["guidelen"], fx["right"], cfd="cfdon" in fx, oracle=True)
     assert a.n_rows == len(fx["guides"])
 
 
@@ -87,7 +118,7 @@ def test_view_search_on_reference_fixture_inputs(case):
 def test_view_search_pam_and_guide_shapes(pam_s, guidelen, right):
     reg = synth.make_region(8101, "chrV", 150_000, 3_000, 140_000)
     synth.add_phased_variants(reg, 8102, 2500, 6, frac_snv=0.8, frac_del=0.1, max_indel=8, af_min=0.05, af_max=0.6)
-    _same_table(reg, pam_s, guidelen, right, cfd=(pam_s == "NGG" and guidelen == 20))
+    _same_table(reg, pam_s, guidelen, right, cfd=(pam_s == "NGG" and guidelen == 20), oracle=pam_s in ("NGG", "TTTV", "NNGRRT"))
 
 
 @pytest.mark.parametrize("region_len", [32_568, 32_569, 32_600, 65_336, 65_400, 70_000])
@@ -164,7 +195,7 @@ def test_view_search_random_campaign():
                                   frac_del=float(rng.choice([0.05, 0.3])), max_indel=max_indel,
                                   af_min=0.05, af_max=float(rng.choice([0.3, 0.9])))
         pam_s, guidelen, right = shapes[it % len(shapes)]
-        _same_table(reg, pam_s, guidelen, right, cfd=(pam_s in ("NGG", "NRG", "NGK") and not right))
+        _same_table(reg, pam_s, guidelen, right, cfd=(pam_s in ("NGG", "NRG", "NGK") and not right), oracle=(it % 3 == 0 and n < 60_000))
 
 
 def test_cluster_search_reruns_when_the_template_rows_outgrow_their_reservation(monkeypatch):
@@ -203,3 +234,29 @@ def test_cluster_dictionary_against_a_host_count():
     assert st["usable"] and st["status"] == 0
     ds.plan.close()
     ds.close()
+
+
+def test_cluster_dictionary_with_a_shared_alt_pool(monkeypatch):
+    """The C ABI takes alt alleles as offsets into one code array and does not require them distinct: a caller may keep ONE copy
+    of "A" for every x>A SNV.  A cluster's identity therefore has to be its locus + alleles, not the offsets (with
+    the offset as identity two SNVs to the same base at different loci were merged and every instance copied the wrong rows)."""
+    from crisprhawk_hip import workload
+    orig = workload._variant_table
+
+    def pooled(pos, refs, alts, seq, startp):
+        r0, span, chain, altlen, alt_off, alt_codes = orig(pos, refs, alts, seq, startp)
+        pool, where, codes = {}, np.zeros(len(alts), dtype=np.int64), []
+        at = 0
+        for i, a in enumerate(alts):
+            if a not in pool:
+                pool[a] = at
+                codes.append(alt_codes[int(alt_off[i]):int(alt_off[i]) + int(altlen[i])])
+                at += int(altlen[i])
+            where[i] = pool[a]
+        assert len(pool) < len(alts) // 4  # the pool really is shared
+        return r0, span, chain, altlen, where, np.concatenate(codes)
+    monkeypatch.setattr(workload, "_variant_table", pooled)
+    reg = synth.make_region(8901, "chrP", 90_000, 2_000, 86_000)
+    synth.add_phased_variants(reg, 8902, 1500, 24, frac_snv=0.9, frac_del=0.05, max_indel=4, af_min=0.05, af_max=0.6)
+    _same_table(reg, "NGG", 20, False, oracle=True)
+    _same_table(reg, "TTTV", 23, True, cfd=False)
