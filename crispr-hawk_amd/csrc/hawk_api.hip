@@ -253,7 +253,7 @@ void hawk_hapset_destroy(hawk_hapset* hs) {
   DevBuf* bufs[] = {&hs->keepF, &hs->keepR, &hs->counts, &hs->offsets, &hs->totals, &hs->misc, &hs->cfd, &hs->partial,
                     &hs->sites, &hs->hits, &hs->guides, &hs->lists, &hs->ckeys, &hs->cvals, &hs->cflags, &hs->cgidx,
                     &hs->ctemp, &hs->cgoff, &hs->cgc, &hs->ccnt, &hs->cfull, &hs->ctable, &hs->cocc, &hs->cdense, &hs->cgkey, &hs->cgslot, &hs->otoff, &hs->otcode, &hs->otid, &hs->othit, &hs->refbits,
-                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_tbase, &hs->cs_trows, &hs->cm_gid};
+                    &hs->big, &hs->refhp, &hs->vcnt0, &hs->cs_res, &hs->cs_tbase, &hs->cs_trows, &hs->cs_itb, &hs->cs_icnt, &hs->rowsA, &hs->cm_gid};
   for (auto& b : hs->cmini) b.release();
   for (auto* b : bufs) b->release();
   for (auto& b : hs->colsA) b.release();
@@ -624,7 +624,9 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
   // over REF's tiles + one count per cluster instance.  HAWK_VIEW_SEARCH=words keeps the per-word search (hawk_vsearch.hip).
   bool by_cluster = hs->vplan && hs->vplan->cl.built && hs->vplan->cl.usable && hs->ref_index == 0;
   if (by_cluster) { const char* e = getenv("HAWK_VIEW_SEARCH"); if (e && e[0] == 'w') by_cluster = false; }
-  const uint64_t nscan = by_cluster ? (uint64_t)sp.bph + hs->vplan->cl.n_inst : ntile;
+  // what the offset scan runs over: the plane kernels' tiles, then - for a cluster search - one entry per 64 consecutive cluster
+  // instances (a wave of the count / emit kernels: its rows are one contiguous stretch of the table), else the view's tiles
+  const uint64_t nscan = by_cluster ? (uint64_t)sp.bph + ((uint64_t)hs->vplan->cl.n_inst + 63) / 64 : ntile;
   if ((rc = hs->counts.reserve(nscan * 4)) || (rc = hs->offsets.reserve((nscan + 1) * 8)) ||
       (rc = hs->misc.reserve(512 * 8 + 64)) ||
       (rc = hs->cfd.reserve(336 * 8)) || (rc = hs->partial.reserve((nscan / 1024 + 2) * 8)))
@@ -733,7 +735,8 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     const uint64_t first = e0 ? strtoull(e0, nullptr, 10) : 16ull * cl.n_uniq + 65536;
     tcap = std::max<uint64_t>(std::min<uint64_t>(cl.slots, std::max<uint64_t>(hs->cs_tcap, first)), 1);
     if ((rc = hs->cs_res.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 16)) || (rc = hs->cs_tbase.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 4)) ||
-        (rc = hs->cs_trows.reserve((size_t)tcap * hawk_cs_row_bytes())))
+        (rc = hs->cs_trows.reserve((size_t)tcap * hawk_cs_row_bytes())) || (rc = hs->cs_itb.reserve((size_t)std::max<uint32_t>(cl.n_inst, 1) * 4)) ||
+        (rc = hs->cs_icnt.reserve((size_t)std::max<uint32_t>(cl.n_inst, 1) * 4)))
       return rc;
   }
   // the view's share of the two passes: per dirty word of every row, or per distinct cluster + a copy per instance
@@ -742,7 +745,8 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     if (by_cluster) {
       hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, d_tcount, tcap, d_status);
       (void)hipEventRecord(ctx->ev[8], ctx->stream);
-      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, d_tcount, tcap, d_counts_v, d_shards);
+      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), d_tcount, tcap, d_counts_v, hs->cs_icnt.as<uint32_t>(),
+                           hs->cs_itb.as<uint32_t>(), d_shards);
     } else {
       hawk_launch_vsearch(ctx->stream, 0, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, nullptr,
                           GuideCols{}, d_status, plane_tiles, v_tiles);
@@ -759,7 +763,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     if (by_cluster) {
       hawk_launch_rows_pack(ctx->stream, cols, hs->offsets.as<uint64_t>() + plane_tiles, 0, std::min<uint64_t>(stage_cap, packed.cap), packed.rows,
                             packed.startp, d_status);
-      hawk_launch_cs_emit_rows(ctx->stream, cd, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
+      hawk_launch_cs_emit_rows(ctx->stream, cd, hs->cs_icnt.as<uint32_t>(), hs->cs_itb.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
                                d_tcount, tcap, packed.rows, packed.cap, d_status);
     } else {
       hawk_launch_vsearch(ctx->stream, 1, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards,

@@ -625,12 +625,13 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
 
 // every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it
 __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, const uint4* __restrict__ res,
-                                                  const unsigned long long* __restrict__ t_count, uint64_t t_cap,
-                                                  uint32_t* __restrict__ counts, unsigned long long* __restrict__ shards) {
+                                                  const uint32_t* __restrict__ tbase, const unsigned long long* __restrict__ t_count, uint64_t t_cap,
+                                                  uint32_t* __restrict__ group_counts, uint32_t* __restrict__ counts, uint32_t* __restrict__ inst_tb,
+                                                  unsigned long long* __restrict__ shards) {
   __shared__ uint32_t s_red[256 / WAVE][2];
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const bool ovf = *t_count > t_cap;  // the template rows outgrew their reservation: no table (the host reruns the search)
-  uint32_t cand = 0, hits = 0;
+  uint32_t cand = 0, hits = 0, rows_i = 0;
   if (i < cd.n_inst) {
     const uint32_t u = cd.inst_uid[i];
     const int32_t paf = cd.inst_pa[i], o = cd.inst_o[i], rbs = cd.inst_rb[i];
@@ -649,13 +650,20 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
         vc_count_run(va, rg, pa, pb, rbs, cand, hits);
       }
     }
-    uint32_t c = 0;
+    uint32_t c = 0, tb = 0;
     if (u != CL_NONE) {
       const uint4 r = res[u];
       c = r.x + r.y; hits += r.z; cand += r.w;
+      tb = tbase[u];
     }
-    counts[i] = ovf ? 0u : c;
+    rows_i = ovf ? 0u : c;
+    counts[i] = rows_i;
+    inst_tb[i] = tb;  // the instance's first template row: the emit pass reads it next to the count instead of going through u
   }
+  // what the offset scan runs over: the rows of 64 consecutive instances (one wave here, one wave's contiguous stretch of the table in
+  // the emit pass) - 1.4 x 10^5 entries on C3 instead of 8.8 x 10^6
+  const uint32_t gsum = wave_sum(rows_i);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && blockIdx.x * 256 + threadIdx.x < cd.n_inst) group_counts[(blockIdx.x * 256 + threadIdx.x) / WAVE] = gsum;
   const uint32_t a = wave_sum(cand), b = wave_sum(hits);
   if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
   __syncthreads();
@@ -681,83 +689,114 @@ __device__ __forceinline__ void nt_store4(uint32_t* q, const uint4& v) {
 // row with two words patched.  A wave's rows are contiguous, four lanes move one row (16 bytes each), so every store
 // instruction writes 1 KB of consecutive addresses and the whole table is a single linear write stream - twelve column
 // streams whose relative placement decided the speed before (profiles/r03_csearch_ablation.txt).
-__global__ __launch_bounds__(256) void k_cs_emit_rows(ClDict cd, const uint4* __restrict__ res, const uint32_t* __restrict__ tbase,
+// NI x 64 consecutive instances per wave, their rows one contiguous stretch of the table.  What bounds the pass is not bytes but
+// how long a wave's loads take while 1.8 GB of stores are queued at the memory controllers (the same kernel runs 0.36 ms with its
+// 160 MB read set cache-resident and 0.53 with it in HBM): so a wave asks for all its instance data at once, up front, and
+// keeps the template loads of the next 128 rows in flight while it stores the current 128.
+template <int NI, int CE_CH>
+__global__ __launch_bounds__(256) void k_cs_emit_rows(uint32_t n_inst, const uint32_t* __restrict__ inst_row, const int32_t* __restrict__ inst_o,
+                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ inst_tb,
                                                       const CsRow* __restrict__ trows, const uint64_t* __restrict__ offsets,
                                                       const unsigned long long* __restrict__ t_count, uint64_t t_cap, uint4* __restrict__ rows,
                                                       uint64_t cap, int* status) {
-  __shared__ uint32_t s_ex[4][WAVE + 1];
-  __shared__ uint32_t s_tb[4][WAVE], s_h[4][WAVE];
-  __shared__ int32_t s_dq[4][WAVE];
-  __shared__ uint32_t s_src[4][WAVE], s_rh[4][WAVE];
-  __shared__ int32_t s_rdq[4][WAVE];
-  if (*t_count > t_cap) return;
+  // everything below is private to a wave (its own LDS slices, no workgroup barrier): the four waves of a workgroup drift apart freely
+  constexpr int NE = NI * WAVE;
+  constexpr int CE_SUB = CE_CH / 16;  // 16-byte loads per lane and chunk
+  __shared__ uint32_t s_ex[4][NE + 1];
+  __shared__ uint32_t s_tb[4][NE], s_h[4][NE];
+  __shared__ int32_t s_dq[4][NE];
+  __shared__ uint32_t s_src[4][2][CE_CH], s_rh[4][2][CE_CH];
+  __shared__ int32_t s_rdq[4][2][CE_CH];
+  if (*t_count > t_cap) return;  // the template rows outgrew their reservation (k_cs_count left no counts): the host reruns the search
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  uint32_t cnt = 0, tb = 0, h = 0;
-  int32_t dq = 0;
-  uint64_t off = 0;
-  if (i < cd.n_inst) {
-    const uint32_t u = cd.inst_uid[i];
-    h = cd.inst_row[i];
-    dq = cd.inst_o[i];
-    off = offsets[i];
-    if (u != CL_NONE) {
-      const uint4 r = res[u];
-      cnt = r.x + r.y;
-      tb = tbase[u];
-    }
+  const uint32_t i0 = (blockIdx.x * 4 + wv) * NE;  // the wave's first instance
+  if (i0 >= n_inst) return;
+  // per instance: four independent streaming loads (k_cs_count left the row count and the first template row of each instance, so
+  // nothing here waits for a gather through the cluster number); lane l takes instances i0 + 64 c + l
+  uint32_t cnt[NI], tb[NI], h[NI];
+  int32_t dq[NI];
+#pragma unroll
+  for (int c = 0; c < NI; ++c) {
+    const uint32_t i = i0 + c * WAVE + lane;
+    const bool in = i < n_inst;
+    const uint32_t ii = in ? i : n_inst - 1;
+    cnt[c] = counts[ii]; tb[c] = inst_tb[ii]; h[c] = inst_row[ii]; dq[c] = inst_o[ii];
+    if (!in) cnt[c] = 0;
   }
-  const uint32_t inc = wave_incl_scan(cnt);
-  const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
-  const uint64_t o0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off) |
-                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32);
-  s_ex[wv][lane] = inc - cnt;
-  s_tb[wv][lane] = tb; s_h[wv][lane] = h; s_dq[wv][lane] = dq;
-  __syncthreads();
-  if (Wt == 0) return;
+  // the wave's first row
+  const uint64_t o0 = offsets[i0 / WAVE];  // one offset per 64 instances (k_cs_count's groups); wave-uniform: a scalar load
+  uint32_t Wt = 0;
+#pragma unroll
+  for (int c = 0; c < NI; ++c) {
+    const uint32_t inc = wave_incl_scan(cnt[c]);
+    s_ex[wv][c * WAVE + lane] = Wt + inc - cnt[c];
+    s_tb[wv][c * WAVE + lane] = tb[c]; s_h[wv][c * WAVE + lane] = h[c] << HAWK_ROW_HAP_SHIFT; s_dq[wv][c * WAVE + lane] = dq[c];
+    Wt += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+  }
+  if (Wt == 0) return;  // wave-uniform
   if (o0 + Wt > cap) { if (lane == 0) atomicCAS(status, 0, -3 /* HAWK_E_CAPACITY */); return; }
-  const uint32_t qd = lane & 3u;
-  uint4* __restrict__ const dst = rows + o0 * 4;
-#pragma unroll 1
-  for (uint32_t c0 = 0; c0 < Wt; c0 += WAVE) {
-    const uint32_t t = c0 + lane;
-    if (t < Wt) {
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t qd = lane & 3u, rq = lane >> 2;
+  uint4* __restrict__ const dst = rows + o0 * 4 + qd;
+  // which template row each of a chunk's rows copies, its haplotype row and position shift (rows past the wave's last are
+  // clamped onto it: every lane then loads a valid template row and the loads need no branch)
+  auto meta = [&](uint32_t c0, uint32_t buf) {
+#pragma unroll
+    for (uint32_t sub = 0; sub < (CE_CH + WAVE - 1) / WAVE; ++sub) {
+      const uint32_t r = sub * WAVE + lane;
+      if (CE_CH < WAVE && r >= CE_CH) break;
+      const uint32_t t = c0 + r < Wt ? c0 + r : Wt - 1;
       uint32_t l = 0;
 #pragma unroll
-      for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;
-      s_src[wv][lane] = s_tb[wv][l] + (t - s_ex[wv][l]);
-      s_rh[wv][lane] = s_h[wv][l];
-      s_rdq[wv][lane] = s_dq[wv][l];
+      for (uint32_t step = NE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= t) ? step : 0u;  // l + step <= NE - 1
+      s_src[wv][buf][r] = s_tb[wv][l] + (t - s_ex[wv][l]);
+      s_rh[wv][buf][r] = s_h[wv][l];
+      s_rdq[wv][buf][r] = s_dq[wv][l];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint4 v[4];
+  };
+  // four lanes per row, 16 bytes each
+  auto fetch = [&](uint4 (&v)[CE_SUB], uint32_t buf) {
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t r = j * 16 + (lane >> 2);
-      if (c0 + r < Wt) v[j] = reinterpret_cast<const uint4*>(trows + s_src[wv][r])[qd];
-    }
+    for (uint32_t j = 0; j < CE_SUB; ++j) v[j] = reinterpret_cast<const uint4*>(trows + s_src[wv][buf][j * 16 + rq])[qd];
+  };
+  auto store = [&](const uint4 (&v)[CE_SUB], uint32_t c0, uint32_t buf) {
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t r = j * 16 + (lane >> 2);
-      if (c0 + r < Wt) {
-        uint4 w = v[j];
-        if (qd == 0) {
-          w.x = (uint32_t)((int32_t)w.x + s_rdq[wv][r]);
-          w.y |= s_rh[wv][r] << HAWK_ROW_HAP_SHIFT;
-        }
-        nt_store4(reinterpret_cast<uint32_t*>(dst + (size_t)(c0 + r) * 4 + qd), w);
+    for (uint32_t j = 0; j < CE_SUB; ++j) {
+      const uint32_t r = j * 16 + rq;
+      uint4 w = v[j];
+      if (qd == 0) {
+        w.x = (uint32_t)((int32_t)w.x + s_rdq[wv][buf][r]);
+        w.y |= s_rh[wv][buf][r];
       }
+      if (c0 + r < Wt) nt_store4(reinterpret_cast<uint32_t*>(dst + (size_t)(c0 + r) * 4), w);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  uint4 va[CE_SUB], vb[CE_SUB];
+  meta(0, 0);
+  fetch(va, 0);
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < Wt; c0 += 2 * CE_CH) {
+    const bool more1 = c0 + CE_CH < Wt, more2 = c0 + 2 * CE_CH < Wt;  // wave-uniform
+    if (more1) { meta(c0 + CE_CH, 1); fetch(vb, 1); }
+    store(va, c0, 0);
     __builtin_amdgcn_wave_barrier();
+    if (more1) {
+      if (more2) { meta(c0 + 2 * CE_CH, 0); fetch(va, 0); }
+      store(vb, c0 + CE_CH, 1);
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
-void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
+void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const uint32_t* counts, const uint32_t* inst_tb, const void* trows, const uint64_t* offsets,
                               const unsigned long long* t_count, uint64_t t_cap, void* rows, uint64_t cap, int* status) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_emit_rows, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, cd, static_cast<const uint4*>(res), tbase,
-                     static_cast<const CsRow*>(trows), offsets, t_count, t_cap, static_cast<uint4*>(rows), cap, status);
+  // 256 instances per wave, 256 rows in flight per wave (184 VGPRs: two waves per SIMD).  Measured on C3 (profiles/r04_emit_rows.md):
+  // 64 / 128 / 256 rows in flight at 8 / 4 / 2 waves per SIMD: 0.53 / 0.47 / 0.45 ms before the offset scan went to one entry per
+  // 64 instances, 0.39 (128 rows, 128 instances) / 0.38 after - few waves with long contiguous bursts write best
+  constexpr int NI = 4, CH = 256;
+  hipLaunchKernelGGL((k_cs_emit_rows<NI, CH>), dim3((cd.n_inst + 256 * NI - 1) / (256 * NI)), dim3(256), 0, st, cd.n_inst, cd.inst_row, cd.inst_o, counts,
+                     inst_tb, static_cast<const CsRow*>(trows), offsets, t_count, t_cap, static_cast<uint4*>(rows), cap, status);
 }
 
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const GuideParams& gp,
@@ -767,11 +806,12 @@ void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs&
   hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), tbase, static_cast<CsRow*>(trows),
                      t_count, t_cap, status);
 }
-void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
-                          const unsigned long long* t_count, uint64_t t_cap, uint32_t* counts, unsigned long long* shards) {
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const uint32_t* tbase,
+                          const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
+                          unsigned long long* shards) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), t_count, t_cap, counts,
-                     shards);
+  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), tbase, t_count, t_cap,
+                     group_counts, counts, inst_tb, shards);
 }
 
 // columns -> packed rows (REF's rows, which the plane kernels write as columns; a columnar table before an exchange) and back
@@ -883,16 +923,14 @@ __global__ __launch_bounds__(256) void k_cs_gid(ClDict cd, const uint4* __restri
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   uint32_t cnt = 0, tb = 0;
-  uint64_t off = 0;
   if (i < cd.n_inst) {
     const uint32_t u = cd.inst_uid[i];
-    off = offsets[i];
     if (u != CL_NONE) { const uint4 r = res[u]; cnt = r.x + r.y; tb = (uint32_t)moff[u]; }
   }
   const uint32_t inc = wave_incl_scan(cnt);
   const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
-  const uint64_t o0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off) |
-                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32);
+  const uint32_t i0 = blockIdx.x * 256 + wv * WAVE;
+  const uint64_t o0 = i0 < cd.n_inst ? offsets[i0 / WAVE] : 0;  // one offset per 64 instances (k_cs_count's groups)
   s_ex[wv][lane] = inc - cnt;
   s_tb[wv][lane] = tb;
   __syncthreads();

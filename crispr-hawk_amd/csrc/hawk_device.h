@@ -172,9 +172,10 @@ void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag
                            uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
                               const struct RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status);
-void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
-                          const unsigned long long* t_count, uint64_t t_cap, uint32_t* counts, unsigned long long* shards);
-void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const void* res, const uint32_t* tbase, const void* trows, const uint64_t* offsets,
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const uint32_t* tbase,
+                          const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
+                          unsigned long long* shards);
+void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const uint32_t* counts, const uint32_t* inst_tb, const void* trows, const uint64_t* offsets,
                               const unsigned long long* t_count, uint64_t t_cap, void* rows, uint64_t cap, int* status);
 // hawk_meta.hip: the rows' metadata of an expansion plan, built on the device
 void hawk_launch_list_check(hipStream_t st, const uint64_t* row_off, uint32_t n_rows, const uint32_t* hv_idx, const int32_t* hv_o,
