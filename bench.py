@@ -224,36 +224,44 @@ def vsearch_roofline(rows, records, positions, hits, L, scored, count_ms, emit_m
                            "moved_bytes": ROW_BYTES * rows + 2 * REC_BYTES * records}}
 
 
+PACKED_ROW_BYTES = 64     # a packed guide row of the cluster search (include/hawk.h)
+CS_INSTANCE_BYTES = 16    # what k_cs_emit_rows reads per cluster instance: row count, first template row, haplotype row, position
+PROFILE_TRAFFIC_R4 = os.path.join(ROOT, "profiles", "r04_traffic.json")
+
+
 def csearch_roofline(rows, ref_rows, positions, hits, L, scored, cl, templates_ms, count_ms, emit_ms, traffic_key=None):
     """The cluster search of a plan view (hawk_csearch.hip): templates (once per distinct cluster) -> counts per instance ->
-    k_cs_emit, the dominant kernel, which copies template rows into the guide table.  `achieved` prices the launch as SURVEY
-    8(d) prices the work it stands for (K3's record written and K4's score for every row - the emit pass is where every
-    haplotype's rows come into being); `moved` is what the launch really moves through HBM: 74 B per row out, 20 B per cluster
-    instance in (cluster id, row, position, offset) - the 64-byte template rows come out of L2 / the memory-side cache."""
+    k_cs_emit_rows, the dominant kernel, which copies 64-byte template rows into the guide table (packed 64-byte rows, one
+    linear write stream).  `achieved` = the bytes the launch has to move through HBM - 64 B per row out, 16 B per cluster
+    instance in (count, first template row, haplotype row, position) + one 8-byte offset per 64 instances; the template rows
+    (17 MB on C3) come out of L2 / the memory-side cache - over its HIP-event duration.  SURVEY 8(d)'s per-unit figures price
+    work this step no longer does position by position; they are given as `survey_priced` only."""
     k2 = 0.75 * positions
     k3_read, k3_write = hits * L / 8.0 + rows * (L + 20) / 2.0, rows * 32.0
     k4 = rows * (2 * ((L + 1) // 2) + 8.0) if scored else 0.0
     step_alg = k2 + k3_read + k3_write + k4
     vrows = rows - ref_rows
     emit_alg = k3_write / max(rows, 1) * vrows + (k4 / max(rows, 1) * vrows) + vrows * (L + 20) / 2.0
-    emit_moved = ROW_BYTES * vrows + 20.0 * cl["instances"]
+    emit_moved = PACKED_ROW_BYTES * vrows + (CS_INSTANCE_BYTES + 8.0 / 64) * cl["instances"]
     gbps = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms else 0.0
     traffic = None
-    if traffic_key and os.path.exists(PROFILE_TRAFFIC_R3):
-        tk = json.load(open(PROFILE_TRAFFIC_R3)).get(traffic_key, {}).get("k_cs_emit")
+    if traffic_key and os.path.exists(PROFILE_TRAFFIC_R4):
+        tk = json.load(open(PROFILE_TRAFFIC_R4)).get(traffic_key, {}).get("k_cs_emit_rows")
         traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]
-    return {"bound": "hbm", "kernel": "k_cs_emit", "achieved": gbps(emit_moved, emit_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    count_moved = 24.0 * cl["instances"]  # cluster id, run start, position, REF shift in; row count + first template row out
+    return {"bound": "hbm", "kernel": "k_cs_emit_rows", "achieved": gbps(emit_moved, emit_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbps(emit_moved, emit_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": emit_ms,
             "algorithmic_bytes_per_launch": emit_moved,
-            "pricing": "bytes the launch has to move: 74 B per guide row written + 20 B per cluster instance read (SURVEY 8(d)'s per-row "
-                       "figure for a finished row is (L + 20) / 2 + 32 + 2 ceil(L / 2) + 8 = %.1f B: the 74-byte row of the C ABI is what is written)"
-                       % ((L + 20) / 2.0 + 32 + 2 * ((L + 1) // 2) + 8),
+            "pricing": "bytes the launch has to move: 64 B per guide row written (packed row: include/hawk.h) + 16 B per cluster instance read "
+                       "+ 8 B per 64 instances (their offset); SURVEY 8(d)'s per-row figure for a finished row is (L + 20) / 2 + 32 + 2 ceil(L / 2) + 8 "
+                       "= %.1f B" % ((L + 20) / 2.0 + 32 + 2 * ((L + 1) // 2) + 8),
             "survey_priced": {"bytes": emit_alg, "GBps": gbps(emit_alg, emit_ms)},
-            "row_bytes": ROW_BYTES, "instance_bytes": 20, "template_row_bytes": 64,
+            "row_bytes": PACKED_ROW_BYTES, "instance_bytes": CS_INSTANCE_BYTES, "template_row_bytes": 64,
             "other_kernels": {"k_cs_templates": {"launch_ms": templates_ms, "distinct_clusters": cl["distinct"]},
-                              "k_cs_count": {"launch_ms": count_ms, "instances": cl["instances"], "moved_bytes": 24.0 * cl["instances"]}},
+                              "k_cs_count": {"launch_ms": count_ms, "instances": cl["instances"], "moved_bytes": count_moved,
+                                             "frac": gbps(count_moved, count_ms) / HBM_PEAK_GBS}},
             "step_level": {"algorithmic_bytes": step_alg, "what": "SURVEY 8(d) K2 + K3 + K4 over every haplotype position / hit / row, every unit priced once",
-                           "moved_bytes": ROW_BYTES * rows + 44.0 * cl["instances"]}}
+                           "moved_bytes": PACKED_ROW_BYTES * vrows + ROW_BYTES * ref_rows + (CS_INSTANCE_BYTES + 24.0) * cl["instances"]}}
 
 
 def tab_ref_rows(reg, pam, args, mm, pt, device):
@@ -306,7 +314,7 @@ def run_region(args, R: Ranks):
     else:
         reg = synth.make_region(1003, "chr22", args.region_len + 200_000, 100_000, 100_000 + args.region_len)
         # strong scaling: ONE panel, block-partitioned; --weak: every rank its own panel (round 1's measurement)
-        synth.add_phased_variants(reg, 1003_1 + (7919 * R.rank if args.weak else 0), args.sites, args.samples)
+        synth.add_phased_variants(reg, 1003_1 + (7919 * R.rank if args.weak else 0), args.sites, args.samples, panel=args.panel)
     pam = PAM(args.pam, args.right, True)
     pam.encode(0)
     n_samples = len(reg.samples)
@@ -326,14 +334,26 @@ def run_region(args, R: Ranks):
     # `--planes` times the round-2 step instead (hawk_search over planes already materialised in HBM).
     fused = plan is not None and not args.planes
     target = plan.view() if fused else ds
+    # The cluster dictionary of the plan (hawk_csearch.hip) is derived from the resident inputs and does not depend on the PAM - but
+    # the product builds ONE per plan and searches it once (pipeline.search_files, TiledRegionSearch.run_tile), so a timed step
+    # builds it too: `value` is the rate of dictionary + search; the dictionary-resident rate (several PAMs on one plan) is
+    # measured right after and reported as `value_dictionary_resident`.
+    with_dict = fused and plan.cluster_stats()["usable"]
 
-    def step(keep=False):
+    def step(keep=False, rebuild=with_dict):
+        if rebuild:
+            plan.rebuild_dictionary()
         tab = target.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
         if not keep:
             tab.close()
         return tab
 
     elapsed, tabs = timed_steps(R, step, args.steps, args.warmup)
+    elapsed_resident = None
+    if with_dict:
+        for t in tabs:
+            t.close()
+        elapsed_resident, tabs = timed_steps(R, lambda keep=False: step(keep, rebuild=False), args.steps, 1)
     tab = tabs[-1]
     tm = [t.timing for t in tabs]
     avg = lambda k: float(np.mean([t[k] for t in tm]))
@@ -367,14 +387,21 @@ def run_region(args, R: Ranks):
         out["config"]["step"] = ("encode + search + CFDon from the expansion plan (REF planes + variant records + their cluster dictionary resident; "
                                  "no haplotype plane written)" if fused else "hawk_search over haplotype planes resident in HBM")
         by_cluster = fused and int(tm[-1]["v_path"]) == 2
+        if elapsed_resident is not None:
+            out["value_dictionary_resident"] = cand_all * args.steps / elapsed_resident
+            out["ms_per_step_dictionary_resident"] = elapsed_resident / args.steps * 1e3
+            out["config"]["step"] = ("cluster dictionary of the plan + encode + search + CFDon (REF planes + variant records resident; no haplotype plane "
+                                     "written); value_dictionary_resident: the same without the dictionary build (a second PAM on the same plan)")
         if by_cluster:
             cl = plan.cluster_stats()
             ref_rows = tab_ref_rows(reg, pam, args, mm, pt, R.device)
             out["roofline"] = csearch_roofline(rows, ref_rows, positions, tab.n_hits, args.guidelen + len(pam), score, cl, avg("v_templates_ms"),
-                                               avg("v_count_ms") - avg("v_templates_ms"), avg("v_emit_ms"), tkey)
-            out["cluster_dictionary"] = dict(cl, what="built once per plan by hawk_xplan_view (hawk_csearch.hip): the rows' carried variants cut "
-                                             "into clusters (alleles within 64 nt), identical clusters of different rows numbered once; part of the "
-                                             "resident plan like the records it indexes, rebuilt in every end_to_end pass")
+                                               avg("v_count_ms") - avg("v_templates_ms"), avg("v_emit_rows_ms"), tkey)
+            out["cluster_dictionary"] = dict(cl, share=cl["instances"] / max(cl["distinct"], 1),
+                                             what="built once per plan (hawk_csearch.hip): the rows' carried variants cut into clusters (alleles "
+                                             "within 64 nt), identical clusters of different rows numbered once; `share` = instances per distinct "
+                                             "cluster (below 3 the per-word search of hawk_vsearch.hip takes the plan); inside every timed step and every "
+                                             "end_to_end pass")
         elif fused:
             out["roofline"] = vsearch_roofline(rows, int(plan_carried(ds)), positions, tab.n_hits, args.guidelen + len(pam), score,
                                                avg("v_count_ms"), avg("v_emit_ms"), tkey)
@@ -413,6 +440,21 @@ def run_region(args, R: Ranks):
                 "plus_expansion_ms": expand_ms, "candidates_per_s_with_expansion": cand / (dt + expand_ms * 1e-3),
                 "what": "round 2's step: hawk_search over planes hawk_xplan_run has already written; with the expansion kernels added it is "
                         "the same work as the fused step"}
+            if by_cluster:  # what the step costs when a plan's clusters are not shared (dictionary unusable): the per-word search of the view
+                os.environ["HAWK_VIEW_SEARCH"] = "words"
+                try:
+                    R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+                    step(rebuild=False)
+                    t_a = time.perf_counter()
+                    for _ in range(k):
+                        step(rebuild=False)
+                    R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+                    dt = (time.perf_counter() - t_a) / k
+                finally:
+                    del os.environ["HAWK_VIEW_SEARCH"]
+                out["search_per_dirty_word"] = {"ms_per_step": dt * 1e3, "candidates_per_s": cand / dt,
+                                                "what": "the same view searched per dirty word of every row (hawk_vsearch.hip): the path a plan takes when "
+                                                        "fewer than 3 instances share a distinct cluster, or a variant chain exceeds 4096 records"}
     for t in tabs:
         t.close()
 
@@ -437,6 +479,7 @@ def run_region(args, R: Ranks):
     if R.rank == 0 and R.world == 1:
         if not args.no_end_to_end:
             out["end_to_end"] = end_to_end(args, R, reg, pam, mm, pt, info, kept, c1)
+            out["value_end_to_end"] = out["end_to_end"].get("candidates_per_s")  # records + genotypes in host memory -> report groups on the host
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reg, pam, args, mm, pt)
             if not c1 and os.path.exists(REFERENCE_TIMING):
@@ -964,6 +1007,9 @@ def build_parser():
     ap.add_argument("--guides", type=int, default=10_000, help="c5: unique spacers")
     ap.add_argument("--mm", type=int, default=4)
     ap.add_argument("--cpu-haps", type=int, default=1280, help="haplotypes in the cpu_baseline sample (about 12 s of single-thread oracle work on C3)")
+    ap.add_argument("--panel", choices=["independent", "linked"], default="independent",
+                    help="c3: genotypes drawn independently per site and column (SURVEY 8(d): no LD, worst case for sharing) or as mosaics of "
+                         "128 founder haplotypes (linkage blocks of ~100 kb)")
     ap.add_argument("--planes", action="store_true", help="c3: time round 2's step (hawk_search over materialised planes) instead of the fused step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true")

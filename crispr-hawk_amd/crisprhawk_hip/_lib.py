@@ -30,7 +30,7 @@ EXPORTS = [
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_table_layout", "hawk_table_download_rows", "hawk_table_device_rows", "hawk_cfd",
     "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
     "hawk_table_collapse", "hawk_table_collapse_download", "hawk_gt_parse", "hawk_gt_destroy", "hawk_gt_codes", "hawk_gt_lists",
-    "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_xplan_cluster_stats", "hawk_host_gather_plan", "hawk_xplan_create_gt", "hawk_xplan_rows",
+    "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_xplan_cluster_stats", "hawk_xplan_cluster_rebuild", "hawk_host_gather_plan", "hawk_xplan_create_gt", "hawk_xplan_rows",
     "hawk_xplan_finish_meta", "hawk_xplan_segments", "hawk_xplan_install_meta", "hawk_host_alloc", "hawk_host_free", "hawk_hapset_rows_equal",
     "hawk_xplan_destroy", "hawk_hapset_set_ref_partner_range", "hawk_xplan_set_ref_partner_range", "hawk_table_collapse_ex", "hawk_table_collapse_export", "hawk_comm_unique_id", "hawk_comm_init",
     "hawk_comm_destroy", "hawk_comm_last_error", "hawk_comm_allgather_u64", "hawk_comm_gatherv", "hawk_table_gather", "hawk_host_ragged_join", "hawk_host_group_join", "hawk_host_group_samples", "hawk_gbt_predict", "hawk_gt_from_codes",
@@ -67,7 +67,7 @@ class Timing(C.Structure):
     _fields_ = [
         ("count_ms", C.c_float), ("offsets_ms", C.c_float), ("emit_ms", C.c_float), ("total_ms", C.c_float),
         ("scanned_positions", C.c_uint64), ("emit_list_ms", C.c_float), ("v_count_ms", C.c_float), ("v_emit_ms", C.c_float),
-        ("v_templates_ms", C.c_float), ("v_path", C.c_uint32), ("reserved", C.c_float * 2),
+        ("v_templates_ms", C.c_float), ("v_path", C.c_uint32), ("v_emit_rows_ms", C.c_float), ("reserved", C.c_float),
     ]
 
 

@@ -260,6 +260,10 @@ class ExpansionPlan:
             self._view = v
         return v
 
+    def rebuild_dictionary(self) -> None:
+        """hawk_xplan_cluster_rebuild: the cluster dictionary built again (bench.py's timed step; the result is the same)"""
+        _lib.check(self._L.hawk_xplan_cluster_rebuild(self._x), "hawk_xplan_cluster_rebuild")
+
     def cluster_stats(self) -> dict:
         """hawk_xplan_cluster_stats: the cluster dictionary the first view() built - how many cluster instances the rows hold,
         how many distinct clusters those are, and whether searches of the view run per distinct cluster."""

@@ -120,12 +120,19 @@ def add_phased_variants(
     af_min: Optional[float] = None,
     af_max: float = 0.5,
     edge_margin: int = 1,
+    panel: str = "independent",
+    n_founders: int = 128,
+    block_sites: int = 3000,
 ) -> SynthRegion:
     """Place ``n_sites`` non-overlapping variant sites inside the padded region.
 
     SNV / deletion / insertion mix 90/5/5 %, indel length 1+Geometric(0.5) capped at
     ``max_indel``; AF log-uniform on [af_min, af_max]; every one of the 2*n_samples
-    haplotype columns carries the alt independently with probability AF.
+    haplotype columns carries the alt independently with probability AF
+    (``panel="independent"``: no linkage, the worst case for haplotype uniqueness - SURVEY 8(d)'s C3).
+    ``panel="linked"``: the columns are mosaics of ``n_founders`` founder haplotypes (drawn as above), switching founder after
+    Geometric(1 / block_sites) sites (~100 kb at C3's density) - linkage blocks as in a real phased panel: neighbouring
+    variants travel together, so variant clusters are shared by more chromosome copies.
     """
     rng = np.random.default_rng(seed)
     n_hap = 2 * n_samples
@@ -149,9 +156,21 @@ def add_phased_variants(
     out: List[VariantSite] = []
     ks: List[int] = []  # row of gt_all behind every record of `out`
     gt_all = np.empty((n_sites, n_hap), dtype=np.uint8)
-    for k0 in range(0, n_sites, 4096):  # chunked: 31k x 5008 float64 would be 1.2 GB at once
-        k1 = min(n_sites, k0 + 4096)
-        gt_all[k0:k1] = rng.random((k1 - k0, n_hap)) < afs[k0:k1, None]
+    if panel == "linked":
+        founders = (rng.random((n_sites, n_founders)) < afs[:, None]).astype(np.uint8)
+        lrng = np.random.default_rng(seed ^ 0x5EED1)
+        for c in range(n_hap):
+            k = 0
+            while k < n_sites:
+                k1 = min(n_sites, k + int(lrng.geometric(1.0 / block_sites)))
+                gt_all[k:k1, c] = founders[k:k1, int(lrng.integers(0, n_founders))]
+                k = k1
+    elif panel == "independent":
+        for k0 in range(0, n_sites, 4096):  # chunked: 31k x 5008 float64 would be 1.2 GB at once
+            k1 = min(n_sites, k0 + 4096)
+            gt_all[k0:k1] = rng.random((k1 - k0, n_hap)) < afs[k0:k1, None]
+    else:
+        raise ValueError(f"unknown panel kind {panel!r}")
     empty = np.flatnonzero(~gt_all.any(axis=1))  # keep every site carried by at least one haplotype
     gt_all[empty, rng.integers(0, n_hap, size=len(empty))] = 1
     for k in range(n_sites):

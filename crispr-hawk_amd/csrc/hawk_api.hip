@@ -763,6 +763,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     if (by_cluster) {
       hawk_launch_rows_pack(ctx->stream, cols, hs->offsets.as<uint64_t>() + plane_tiles, 0, std::min<uint64_t>(stage_cap, packed.cap), packed.rows,
                             packed.startp, d_status);
+      (void)hipEventRecord(ctx->ev[9], ctx->stream);
       hawk_launch_cs_emit_rows(ctx->stream, cd, hs->cs_icnt.as<uint32_t>(), hs->cs_itb.as<uint32_t>(), hs->cs_trows.p, hs->offsets.as<uint64_t>() + plane_tiles,
                                d_tcount, tcap, packed.rows, packed.cap, d_status);
     } else {
@@ -868,6 +869,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
       if (nrows) (void)hipEventElapsedTime(&timing->v_emit_ms, ev[7], ev[4]);
       timing->v_path = by_cluster ? 2u : 1u;
       if (by_cluster) (void)hipEventElapsedTime(&timing->v_templates_ms, ev[6], ev[8]);
+      if (by_cluster && nrows) (void)hipEventElapsedTime(&timing->v_emit_rows_ms, ev[9], ev[4]);
     }
     uint64_t pos = 0;
     for (uint32_t h = 0; h < hs->n_hap; ++h) pos += (uint64_t)std::max(0, hs->scan_stop[h] - hs->scan_start[h]);
@@ -1755,8 +1757,14 @@ static int xplan_build_dict(hawk_xplan* x) {
   uint8_t* d_cls;
   unsigned long long *d_tkey, *d_partial, *d_shards;
   ScanTotals* d_tot;
+  // the hash table of distinct clusters: at least two slots per instance would always do, but on a shared panel the distinct
+  // clusters are a small fraction of the instances and clearing 12 bytes x 2^25 slots costs as much as a kernel of this build
+  // (C3: 0.08 ms) - so the first attempt takes four slots per distinct cluster EXPECTED (the last build's count, else an eighth
+  // of the instances), gives up after 64 probes (status bit 8), and the insert is repeated with the full size
   uint32_t tsize = 1024;
   while (tsize < 2u * n_inst && tsize < (1u << 31)) tsize <<= 1;
+  uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
+  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 4 : (uint64_t)n_inst / 2; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
   TEMPCHK(tmp, &d_rec, (size_t)n_inst * 4);
   TEMPCHK(tmp, &d_n, (size_t)n_inst * 4);
   TEMPCHK(tmp, &d_slot, (size_t)n_inst * 4);
@@ -1770,19 +1778,36 @@ static int xplan_build_dict(hawk_xplan* x) {
   TEMPCHK(tmp, &d_partial, ((size_t)std::max<uint64_t>(n_inst, (uint64_t)n * n_bkt) / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
-  HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsize * 8, st));
-  HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsize * 4, st));
+  HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsmall * 8, st));
+  HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsmall * 4, st));
   HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
   hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
                       t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls, d_bkt, bshift, n_bkt, d_cnt_br, d_first_rb, d_status);
-  hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_flag, d_status);
+  hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsmall - 1, d_slot, d_status, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u);
+  hawk_launch_cl_flag(st, n_inst, d_cls, d_slot, d_trep, d_flag);
   hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
   ScanTotals tot;
+  uint32_t st_now = 0;
   HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&st_now, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
+  if (st_now & 8u) {  // the small table filled up: once more with two slots per instance
+    st_now &= ~8u;
+    HIPCHK(hipMemcpyAsync(d_status, &st_now, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsize * 8, st));
+    HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsize * 4, st));
+    HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
+    HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
+    hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_status, 0xffffffffu, 2u);
+    hawk_launch_cl_flag(st, n_inst, d_cls, d_slot, d_trep, d_flag);
+    hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
+    HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+  }
   const uint32_t n_uniq = (uint32_t)tot.n_keep;
-  cl.n_inst = n_inst; cl.n_uniq = n_uniq;
+  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.last_uniq = n_uniq;
   if (n_uniq) {
     uint32_t* d_span2;
     TEMPCHK(tmp, &d_span2, (size_t)n_uniq * 4);
@@ -1835,6 +1860,13 @@ int hawk_xplan_cluster_stats(const hawk_xplan* x, uint32_t* usable, uint32_t* n_
   if (build_ms) *build_ms = x->cl.build_ms;
   if (status) *status = x->cl.built ? x->cl.status : 0xffffffffu;
   return HAWK_OK;
+}
+
+int hawk_xplan_cluster_rebuild(hawk_xplan* x) {
+  if (!x || !x->has_meta || x->ref_index != 0) return HAWK_E_INVALID;
+  HIPCHK(hipSetDevice(x->ctx->device));
+  x->cl.built = false;
+  return xplan_build_dict(x);
 }
 
 int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out) {

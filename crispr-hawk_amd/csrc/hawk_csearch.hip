@@ -177,14 +177,16 @@ __global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_
 
 __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
                                                    unsigned long long* __restrict__ tkey, uint32_t* __restrict__ trep, uint32_t mask,
-                                                   uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status) {
+                                                   uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status, uint32_t max_probe, uint32_t fail_bit) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_inst) return;
   if (!cls[i]) { inst_slot[i] = CL_NONE; return; }
   const unsigned long long k = key[i];
   uint32_t s = (uint32_t)(k >> 17) & mask;
   bool placed = false;
-  for (uint32_t probe = 0; probe <= mask; ++probe) {  // the table has >= 2 slots per instance: a free slot is met long before the bound
+  // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
+  // for the distinct clusters expected gives up after max_probe slots and the host repeats the insert with the full size)
+  for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
     // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
     // atomic on it would queue them all at one address (a stale read only sends the instance to the CAS, which answers with the truth)
     unsigned long long cur = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64
     if (cur == 0ull || cur == k) { placed = true; break; }
     s = (s + 1u) & mask;
   }
-  if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, 2u); return; }  // cannot happen; the dictionary is then not used
+  if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, fail_bit); return; }  // full-size table: cannot happen; the dictionary is then not used
   inst_slot[i] = s;
   if (__hip_atomic_load(&trep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&trep[s], i);  // (the minimum only falls)
 }
@@ -245,8 +247,10 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
     const HxVar* a = recs + ci.rec[i];
     const HxVar* b = recs + ci.rec[r];
     const int32_t oa = a[0].o, ob = b[0].o;
-    for (uint32_t k = 0; k < ci.n[i]; ++k)
-      bad = bad || a[k].alt_off != b[k].alt_off || a[k].alt_len != b[k].alt_len || a[k].rs != b[k].rs || a[k].o - oa != b[k].o - ob;
+    for (uint32_t k = 0; k < ci.n[i]; ++k) {  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record, one load per side
+      const uint4 ra = *reinterpret_cast<const uint4*>(a + k), rb = *reinterpret_cast<const uint4*>(b + k);
+      bad = bad || ra.w != rb.w || ra.z != rb.z || ra.y != rb.y || (int32_t)ra.x - oa != (int32_t)rb.x - ob;
+    }
   }
   if (bad) atomicOr(status, 2u);
 }
@@ -271,10 +275,12 @@ void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, ui
   hipLaunchKernelGGL(k_cl_permute, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, n_rows, n_bkt, bkt, base_br, first_rb, pm);
 }
 void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep, uint32_t mask,
-                           uint32_t* inst_slot, uint32_t* flag, uint32_t* status) {
-  const uint32_t nb = (n_inst + 255) / 256;
-  hipLaunchKernelGGL(k_cl_insert, dim3(nb), dim3(256), 0, st, n_inst, key, cls, static_cast<unsigned long long*>(tkey), trep, mask, inst_slot, status);
-  hipLaunchKernelGGL(k_cl_flag, dim3(nb), dim3(256), 0, st, n_inst, cls, inst_slot, trep, flag);
+                           uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
+  hipLaunchKernelGGL(k_cl_insert, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, key, cls, static_cast<unsigned long long*>(tkey), trep, mask, inst_slot,
+                     status, max_probe, fail_bit);
+}
+void hawk_launch_cl_flag(hipStream_t st, uint32_t n_inst, const uint8_t* cls, const uint32_t* inst_slot, const uint32_t* trep, uint32_t* flag) {
+  hipLaunchKernelGGL(k_cl_flag, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, cls, inst_slot, trep, flag);
 }
 void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
                            const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,

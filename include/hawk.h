@@ -156,6 +156,9 @@ int hawk_xplan_view(hawk_xplan* x, hawk_hapset** out);
  * No reference counterpart: the reference searches every haplotype string on its own (search_guides.py:510-548). */
 int hawk_xplan_cluster_stats(const hawk_xplan* x, uint32_t* usable, uint32_t* n_instances, uint32_t* n_distinct, uint64_t* template_slots,
                              float* build_ms, uint32_t* status);
+/* Builds the dictionary again from the plan's records (same result; buffers reused).  What bench.py calls inside its timed
+ * step so that `value` carries the dictionary's cost: the product builds one per plan and searches it once (pipeline.search_files). */
+int hawk_xplan_cluster_rebuild(hawk_xplan* x);
 /* Plan creation straight from the genotype inversion: `g` is a hawk_gt after hawk_gt_lists, whose carried-variant lists
  * are still in HBM - they are used in place (rows = REF + every chromosome copy with a non-empty list, in column order),
  * nothing is downloaded, and what the host used to do over every list entry runs as kernels: the ascending /
@@ -213,10 +216,11 @@ typedef struct {          /* kernel times of the last hawk_search (HIP events on
   float emit_list_ms; /* k_emit_list alone (0 when the hand-over lists are switched off) */
   float v_count_ms;   /* a plan view (hawk_xplan_view): its count side alone (v_path 1: k_vsearch<0>; 2: k_cs_templates + k_cs_count) -
                          count_ms also holds the REF row's plane kernel */
-  float v_emit_ms;    /* ... its emit side alone (k_vsearch<1> / k_cs_emit) */
-  float v_templates_ms; /* the cluster path of a view: k_cs_templates alone (v_count_ms: templates + k_cs_count; v_emit_ms: k_cs_emit) */
+  float v_emit_ms;    /* ... its emit side alone (k_vsearch<1> / k_rows_pack + k_cs_emit_rows) */
+  float v_templates_ms; /* the cluster path of a view: k_cs_templates alone (v_count_ms: templates + k_cs_count) */
   uint32_t v_path;    /* 0: planes, 1: a view searched per dirty word (k_vsearch), 2: a view searched per distinct cluster (hawk_csearch.hip) */
-  float reserved[2];
+  float v_emit_rows_ms; /* the cluster path: k_cs_emit_rows alone (v_emit_ms also holds k_rows_pack, which packs REF's staged rows) */
+  float reserved;
 } hawk_timing;
 
 /* Runs the whole device pipeline; the guide table stays in HBM. `timing` may be NULL. */

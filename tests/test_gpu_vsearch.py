@@ -260,3 +260,19 @@ def test_cluster_dictionary_with_a_shared_alt_pool(monkeypatch):
     synth.add_phased_variants(reg, 8902, 1500, 24, frac_snv=0.9, frac_del=0.05, max_indel=4, af_min=0.05, af_max=0.6)
     _same_table(reg, "NGG", 20, False, oracle=True)
     _same_table(reg, "TTTV", 23, True, cfd=False)
+
+
+def test_cluster_dictionary_outgrows_its_first_hash_table():
+    """The dictionary's first hash table is sized for the distinct clusters EXPECTED (an eighth of the instances); a panel of
+    private variants - every cluster its own - fills it, the insert gives up and is repeated with two slots per instance."""
+    reg = synth.make_region(9001, "chrU", 2_050_000, 20_000, 2_020_000)
+    synth.add_phased_variants(reg, 9002, 400_000, 8, frac_snv=0.9, frac_del=0.05, max_indel=2, af_min=1 / 16, af_max=1 / 16)
+    ds, _info, _ms, _kept = expand_on_device(reg, 3, keep_plan=True)
+    ds.plan.view()
+    st = ds.plan.cluster_stats()
+    assert st["usable"] and st["status"] == 0, st
+    first_table = 1 << max(16, (st["instances"] // 2 - 1).bit_length())
+    assert st["distinct"] > first_table, (st, first_table)  # more distinct clusters than the first table has slots
+    ds.plan.close()
+    ds.close()
+    _same_table(reg, "NGG", 20, False)
