@@ -28,7 +28,7 @@ EXPORTS = [
     "hawk_sync", "hawk_hapset_create", "hawk_hapset_destroy", "hawk_hapset_pack_ascii", "hawk_hapset_set_meta",
     "hawk_hapset_stride", "hawk_hapset_download_plane", "hawk_hapset_upload_planes", "hawk_pam_scan", "hawk_pam_scan_time",
     "hawk_search", "hawk_table_destroy", "hawk_table_counts", "hawk_table_download", "hawk_table_device_columns", "hawk_table_layout", "hawk_table_download_rows", "hawk_table_device_rows", "hawk_cfd",
-    "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_hapset_expand",
+    "hawk_genome_finalize", "hawk_offtarget_scan", "hawk_deepcpf1", "hawk_azimuth", "hawk_tm_nn", "hawk_hapset_expand",
     "hawk_table_collapse", "hawk_table_collapse_download", "hawk_gt_parse", "hawk_gt_destroy", "hawk_gt_codes", "hawk_gt_lists",
     "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_xplan_cluster_stats", "hawk_xplan_cluster_rebuild", "hawk_host_gather_plan", "hawk_xplan_create_gt", "hawk_xplan_rows",
     "hawk_xplan_finish_meta", "hawk_xplan_segments", "hawk_xplan_install_meta", "hawk_host_alloc", "hawk_host_free", "hawk_hapset_rows_equal",

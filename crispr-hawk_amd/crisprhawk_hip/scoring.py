@@ -230,6 +230,21 @@ def set_azimuth_model(model) -> None:
     _AZIMUTH_MODEL = model if isinstance(model, dict) else azimuth_model_from_sklearn(model)
 
 
+def tm_nn(seqs) -> List[float]:
+    """Bio.SeqUtils.MeltingTemp.Tm_NN with Biopython's defaults for equally long A/C/G/T strings of <= 32 bases, on the device
+    (hawk_tm_nn: the function behind Azimuth's four Tm features, featurization.py:358-397)."""
+    seqs = [str(x) for x in seqs]
+    if not seqs:
+        return []
+    ln = len(seqs[0])
+    if any(len(x) != ln for x in seqs):
+        raise ValueError("tm_nn: sequences of one length per call")
+    out = np.empty(len(seqs), dtype=np.float64)
+    _lib.check(_lib.lib().hawk_tm_nn(_lib.context(), "".join(seqs).encode("ascii"), C.c_uint32(ln), C.c_uint64(len(seqs)),
+                                     out.ctypes.data_as(C.c_void_p)), "hawk_tm_nn")
+    return list(out)
+
+
 def azimuth(guides, debug: bool = True, return_features: bool = False):
     """scores/crisprhawk_scores.py:31-44 (azimuth.model_comparison.predict) on the GPU: 30-mers -> scores."""
     if _AZIMUTH_MODEL is None:

@@ -2242,6 +2242,26 @@ int hawk_deepcpf1(hawk_ctx* ctx, const char* seqs34, uint64_t n, const float* we
 }
 
 // ---------------------------------------------------------------------------- K5 Azimuth
+int hawk_tm_nn(hawk_ctx* ctx, const char* seqs, uint32_t len, uint64_t n, double* out) {
+  if (!ctx || (n && (!seqs || !out))) return HAWK_E_INVALID;
+  if (len < 2 || len > 32) return HAWK_E_UNSUPPORTED;
+  if (!n) return HAWK_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  PoolScope tmp;
+  char* d_s; double* d_o; int* d_status;
+  TEMPCHK(tmp, &d_s, n * len); TEMPCHK(tmp, &d_o, n * 8); TEMPCHK(tmp, &d_status, 4);
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(d_s, seqs, n * len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_status, 0, 4, st));
+  hawk_launch_tm_nn(st, d_s, len, n, d_o, d_status);
+  HIPCHK(hipGetLastError());
+  int status = 0;
+  HIPCHK(hipMemcpyAsync(out, d_o, n * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return status;
+}
+
 int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_model* m, double* out, double* feats_out) {
   if (!ctx || !m || !m->tree_off || !m->feature || !m->left || !m->right || !m->threshold || !m->value ||
       (n && (!seqs30 || !out)))

@@ -283,6 +283,7 @@ void hawk_launch_mscan(hipStream_t st, const uint32_t* counts, uint64_t n, unsig
 void hawk_launch_cfd(hipStream_t st, const char* wt, const char* sg, uint32_t len, const char* pam2, uint64_t n,
                      const double* mm, const double* pamtab, double* out, int* status);
 void hawk_launch_deepcpf1(hipStream_t st, const char* seqs, uint64_t n, const float* w, float* out, int* status);
+void hawk_launch_tm_nn(hipStream_t st, const char* seqs, uint32_t len, uint64_t n, double* out, int* status);
 void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t n_trees, const int32_t* tree_off,
                          const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold,
                          const double* value, double init, double lr, double* out, double* feats_out, int* status);

@@ -213,6 +213,23 @@ __global__ __launch_bounds__(HAWK_BLOCK) void k_azimuth(const char* __restrict__
   out[i] = acc;
 }
 
+// az_tm on its own: sequences of `len` <= 32 bases (A, C, G, T only)
+__global__ __launch_bounds__(256) void k_tm_nn(const char* __restrict__ seqs, uint32_t len, uint64_t n, double* __restrict__ out, int* status) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t codes = 0;
+  bool bad = false;
+  for (uint32_t k = 0; k < len; ++k) {
+    const int c = az_code(seqs[i * len + k]);
+    bad = bad || c < 0;
+    codes |= (uint64_t)(c & 3) << (2 * k);
+  }
+  if (bad) { atomicExch(status, -4); out[i] = __longlong_as_double(0x7ff8000000000000ll); return; }
+  out[i] = az_tm(codes, 0, (int)len);
+}
+void hawk_launch_tm_nn(hipStream_t st, const char* seqs, uint32_t len, uint64_t n, double* out, int* status) {
+  hipLaunchKernelGGL(k_tm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seqs, len, n, out, status);
+}
 void hawk_launch_azimuth(hipStream_t st, const char* seqs, uint64_t n, uint32_t n_trees, const int32_t* tree_off,
                          const int32_t* feature, const int32_t* left, const int32_t* right, const double* threshold,
                          const double* value, double init, double lr, double* out, double* feats_out, int* status) {

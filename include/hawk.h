@@ -439,6 +439,10 @@ typedef struct {
   const double* value;
   double init, learning_rate;
 } hawk_gbt_model;
+/* The melting temperature behind Azimuth's four Tm features on its own - Biopython's MeltingTemp.Tm_NN with its defaults
+ * (featurization.py:358-397 calls it on the 30-mer and three of its slices) - for n sequences of `len` <= 32 bases each,
+ * A/C/G/T only (HAWK_E_IUPAC otherwise).  The same device function k_azimuth uses; tests hold it to the value Biopython documents. */
+int hawk_tm_nn(hawk_ctx* ctx, const char* seqs, uint32_t len, uint64_t n, double* out);
 int hawk_azimuth(hawk_ctx* ctx, const char* seqs30, uint64_t n, const hawk_gbt_model* model, double* out, double* feats_out);
 
 /* The same tree evaluator over a feature matrix the caller supplies (feats[n][n_features], host, row-major doubles):

@@ -268,6 +268,15 @@ def offtargets(genome: str, guides: Sequence[str], pam: str, right: bool, max_mm
     return out[:n].copy()
 
 
+def tm_nn(seq: str) -> float:
+    """Biopython's Tm_NN with its defaults, restated (hawk_oracle.c: tm_nn)"""
+    out = C.c_double()
+    rc = lib().ora_tm_nn(seq.encode("ascii"), len(seq), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value
+
+
 def azimuth_features(seqs: Sequence[str]) -> np.ndarray:
     """[n, 627] feature matrix (Tm columns 623..626: parity unpinned, see hawk_oracle.c)."""
     out = np.zeros((len(seqs), 627), dtype=np.float64)

@@ -7,7 +7,7 @@ import types
 import numpy as np
 import pytest
 
-from crisprhawk_hip import scoring, synth
+from crisprhawk_hip import _lib, scoring, synth
 from crisprhawk_hip.annotation import reverse_guides
 from crisprhawk_hip.crisprhawk_error import (CrisprHawkAzimuthScoreError, CrisprHawkDeepCpf1ScoreError, CrisprHawkOffTargetsError,
                                              CrisprHawkRs3ScoreError)
@@ -17,6 +17,7 @@ from crisprhawk_hip.pam import PAM
 from crisprhawk_hip.search_guides import search
 from crisprhawk_hip.search_offtargets import offtargets_search
 from test_gpu_api import _build
+from oracle import oracle as ora
 from util import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +59,22 @@ SLOTS = ("azimuth_score", "rs3_score", "plmcrispr_score", "cfdon_score", "crispr
 
 def _filled(guides):
     return {s for s in SLOTS if any(getattr(g, s) != "NA" for g in guides)}
+
+
+def test_device_tm_nn_against_biopythons_documented_value():
+    """hawk_tm_nn runs the device function behind k_azimuth's Tm columns (az_tm) on the 28-mer whose Tm_NN Biopython documents
+    (60.32 with the defaults the reference calls it with, featurization.py:358-397), and agrees with the oracle on random k-mers."""
+    from crisprhawk_hip import scoring
+    from test_oracle_golden import TM_NN_KNOWN
+    seq, want = TM_NN_KNOWN
+    got = scoring.tm_nn([seq])[0]
+    assert f"{got:0.2f}" == f"{want:0.2f}" and abs(got - ora.tm_nn(seq)) < 1e-9
+    rng = np.random.default_rng(77)
+    for ln in (5, 8, 30, 32):
+        seqs = ["".join("ACGT"[b] for b in rng.integers(0, 4, ln)) for _ in range(300)]
+        assert np.allclose(scoring.tm_nn(seqs), [ora.tm_nn(x) for x in seqs], rtol=0, atol=1e-9)
+    with pytest.raises(_lib.HawkStatusError):
+        scoring.tm_nn(["ACGTN"])
 
 
 def test_scoring_guides_dispatch_by_cas_system():
