@@ -340,6 +340,28 @@ def _merge_at_seam(acc, part, seam: int, reach: int, guidelen: int, pamlen: int,
     return _concat([_take(acc, a_far), near, _take(part, b_far)])
 
 
+def gather_tile_groups(comm, part: Optional[Dict[str, np.ndarray]], seam_lo: Optional[int], L: int, guidelen: int, pamlen: int,
+                       flank_key: Tuple[int, int] = (0, 0), dst: int = 0):
+    """The exchange of a REGION-sharded search (one stretch of the interval x all samples per rank, ranks in stretch order): every
+    rank hands its collapsed report groups (`_groups_of_tile`: one representative row per group + the members' haplotype ids) to
+    `dst`, which folds them together in rank order, merging on the full key around each seam (`seam_lo` = the genomic position
+    where this rank's stretch starts, None for the first).  What crosses the links is 75 B per report group + 8 B per member -
+    not the 64-byte guide rows.  Returns (parts dict, bytes received) on `dst`, (None, 0) elsewhere."""
+    if part is None:
+        raise ValueError("every rank contributes a (possibly empty) part")
+    keys = sorted(part.keys())
+    seams = comm.allgather_i64([-1 if seam_lo is None else int(seam_lo)])[:, 0]
+    got = {k: comm.gatherv_bytes(np.ascontiguousarray(part[k]), dst) for k in keys}
+    if comm.rank != dst:
+        return None, 0
+    nbytes = sum(a.nbytes for k in keys for r, a in enumerate(got[k]) if r != dst)
+    acc = None
+    for r in range(comm.world):
+        p = {k: got[k][r] for k in keys}
+        acc = p if acc is None else _merge_at_seam(acc, p, int(seams[r]), L + 64, guidelen, pamlen, flank_key)
+    return acc, nbytes
+
+
 class MergedGroups:
     """Report groups of a whole region: representative columns, CSR members over the region-wide haplotype numbering
     and one RowLabel per haplotype row."""

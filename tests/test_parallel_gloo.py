@@ -245,3 +245,140 @@ def test_table_gather_plan_world3_with_a_fake_transport():
     assert np.array_equal(hap == 0, local == 0) and hap.max() <= 2 + 3
     assert L.hawk_host_gather_plan(3, 3, 0, dir4.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
                                    tot.ctypes.data_as(C.c_void_p), None, 0, C.byref(n_ops)) == _lib.HAWK_E_INVALID
+
+
+# ---- region split: one stretch of the interval x all samples per rank, collapsed groups exchanged and merged at the seam ----
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _region_rows():
+    """The UNTILED oracle's guide rows of a small region (all samples) + every haplotype's position map."""
+    from crisprhawk_hip import synth
+    from oracle import oracle as ora
+    from util import oracle_haplotypes
+    reg = synth.make_region(8811, "chrM", 24_000, 1_000, 23_000)
+    synth.add_phased_variants(reg, 8812, 260, 6, frac_snv=0.7, frac_del=0.15, max_indel=6, af_min=0.3, af_max=0.8)
+    fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
+              variants=[[v.pos, v.ref, v.alt, v.af, ["".join(str(int(x)) for x in row) for row in v.gt]] for v in reg.variants])
+    haps = oracle_haplotypes(fx)
+    scan = [ora.scan_bounds(h["posmap"], reg.startp, reg.stopp, 3) for h in haps]
+    hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
+    res = ora.search(hs, "NGG", 20, False)
+    return reg, hs, res
+
+
+def _window_planes(windows):
+    """[n, 5] plane slices (A, C, G, T, V; bit j = base j) of equally long cased windows"""
+    if not windows:
+        return np.zeros((0, 5), dtype=np.uint64)
+    a = np.frombuffer("".join(windows).encode("ascii"), dtype=np.uint8).reshape(len(windows), -1)
+    sh = np.arange(a.shape[1], dtype=np.uint64)
+    win = np.zeros((len(windows), 5), dtype=np.uint64)
+    for p, ch in enumerate(b"ACGT"):
+        win[:, p] = ((((a & 0xDF) == ch).astype(np.uint64)) << sh).sum(axis=1, dtype=np.uint64)
+    win[:, 4] = ((((a & 0x20) != 0).astype(np.uint64)) << sh).sum(axis=1, dtype=np.uint64)
+    return win
+
+
+@functools.lru_cache(maxsize=None)
+def _stretch_part(rank, world):
+    """What rank `rank` of a region-sharded search holds after its own collapse: the report groups of the rows its stretch OWNS
+    (a PAM hit belongs to the stretch whose scan range holds its relative position; a seam maps into every haplotype by the
+    posmap_rev rule, workload._seam_rel - the rule tests/test_gpu_tiling.py holds the device tiles to), as tiling._groups_of_tile
+    lays them out.  Rows come from the untiled oracle run, so haplotype ids are region-wide."""
+    from crisprhawk_hip.hapset import PosSegments, segments_from_posmap
+    from crisprhawk_hip.workload import _seam_rel
+    from oracle import oracle as ora
+    reg, hs, res = _region_rows()
+    lo, hi = reg.startp + 100, reg.stopp - 100
+    seams = [lo + (hi - lo) * r // world for r in range(world + 1)]
+    g = res.guides
+    rel_lo = np.zeros(len(hs.seqs), dtype=np.int64)
+    rel_hi = np.zeros(len(hs.seqs), dtype=np.int64)
+    for h, pm in enumerate(hs.posmaps):
+        r_, g_ = segments_from_posmap(pm)
+        seg = PosSegments(r_, g_, len(pm))
+        rel_lo[h] = 0 if rank == 0 else _seam_rel(seg, seams[rank])
+        rel_hi[h] = len(pm) + 1 if rank == world - 1 else _seam_rel(seg, seams[rank + 1])
+    own = (g["pos"] >= rel_lo[g["hap"]]) & (g["pos"] < rel_hi[g["hap"]])
+    idx = np.flatnonzero(own)
+    all_w = res.windows
+    wins = [all_w[i] for i in idx]
+    isref_row = np.asarray(hs.is_ref)[g["hap"][idx]]
+    groups, _ = ora.collapse_rows(g["start"][idx], g["stop"][idx], g["strand"][idx], isref_row, wins, 20, 3, False)
+    first = np.array([rows[0] for rows in groups.values()], dtype=np.int64)
+    order = np.lexsort((g["strand"][idx][first], g["start"][idx][first]))  # a collapsed table is ordered by (start, strand)
+    glist = [list(groups.values())[k] for k in order]
+    first = first[order]
+    n = len(glist)
+    win = _window_planes(wins)
+    part = {"pos": g["pos"][idx][first].astype(np.uint32), "strand": g["strand"][idx][first].astype(np.uint8),
+            "start": g["start"][idx][first].astype(np.int64), "stop": g["stop"][idx][first].astype(np.int64),
+            "flags": np.zeros(n, np.uint8), "cfdon": np.full(n, np.nan), "gc_num": np.zeros(n, np.uint8), "gc_den": np.zeros(n, np.uint8),
+            "win": win[first], "origin": isref_row[first].astype(np.uint8), "sizes": np.array([len(r) for r in glist], dtype=np.int64),
+            "members": np.concatenate([np.sort(g["hap"][idx][np.array(r)]) for r in glist]).astype(np.int64) if n else np.zeros(0, np.int64)}
+    return part, (None if rank == 0 else seams[rank]), int(own.sum())
+
+
+def _worker_region(rank, world, port, out_dir):
+    import sys
+    sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+    import torch.distributed as dist
+    from crisprhawk_hip.tiling import gather_tile_groups
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import GlooComm
+    part, seam, n_own = _stretch_part(rank, world)
+    acc, nbytes = gather_tile_groups(GlooComm(), part, seam, 23, 20, 3)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "region.npz"), nbytes=nbytes, **acc)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_region_split_world2_gloo_against_the_untiled_oracle(tmp_path):
+    """Two ranks, each a stretch of the region x all samples: per-rank report groups -> gather_tile_groups -> merged at the seam
+    on rank 0 must be the grouping of the untiled oracle's rows (groups whose members lie on both sides of the seam - an indel
+    upstream shifts a haplotype's PAM position across it - are united; no row is lost or counted twice)."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as ora
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_region, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "region.npz")
+    reg, hs, res = _region_rows()
+    g = res.guides
+    isref_row = np.asarray(hs.is_ref)[g["hap"]]
+    want = {}
+    all_w = res.windows
+    for i in range(len(g)):
+        key = (int(g["start"][i]), int(g["stop"][i]), int(g["strand"][i]), bool(isref_row[i]), all_w[i][10:-10])
+        want.setdefault(key, set()).add(int(g["hap"][i]))
+    # every row is owned by exactly one stretch
+    owned = [_stretch_part(r, 2)[2] for r in range(2)]
+    assert sum(owned) == len(g) and min(owned) > 0
+    sizes, members = got["sizes"], got["members"]
+    assert len(sizes) == len(want) and int(sizes.sum()) == len(members)
+    assert (np.diff(got["start"]) >= 0).all()
+    moff = np.concatenate(([0], np.cumsum(sizes)))
+    mask = np.uint64((1 << 23) - 1)
+    seen = set()
+    for k in range(len(sizes)):
+        core = (got["win"][k] >> np.uint64(10)) & mask
+        seq = ""
+        for j in range(23):
+            bits = [(int(core[p]) >> j) & 1 for p in range(5)]
+            ch = "ACGT"[bits[:4].index(1)]
+            seq += ch.lower() if bits[4] else ch
+        mem = set(int(x) for x in members[moff[k]:moff[k + 1]])
+        key = (int(got["start"][k]), int(got["stop"][k]), int(got["strand"][k]), bool(got["origin"][k]), seq)
+        assert key in want and want[key] == mem and key not in seen, key
+        seen.add(key)
+    # both stretches have groups inside the seam's merge window (tiling._merge_at_seam's `near` path ran on real groups)
+    seam = _stretch_part(1, 2)[1]
+    parts = [_stretch_part(r, 2)[0] for r in range(2)]
+    assert (parts[0]["start"] > seam - 87).any() and (parts[1]["start"] < seam + 87).any()
+    assert int(got["nbytes"]) > 0
