@@ -246,8 +246,8 @@ def csearch_roofline(rows, ref_rows, positions, hits, L, scored, cl, templates_m
     gbps = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms else 0.0
     traffic = None
     if traffic_key and os.path.exists(PROFILE_TRAFFIC_R4):
-        tk = json.load(open(PROFILE_TRAFFIC_R4)).get(traffic_key, {}).get("k_cs_emit_rows")
-        traffic = tk and tk["fetch_bytes"] + tk["write_bytes"]
+        tk = [v for k, v in json.load(open(PROFILE_TRAFFIC_R4)).get(traffic_key, {}).items() if k.startswith("k_cs_emit_rows")]
+        traffic = tk[0]["fetch_bytes"] + tk[0]["write_bytes"] if tk else None
     count_moved = 24.0 * cl["instances"]  # cluster id, run start, position, REF shift in; row count + first template row out
     return {"bound": "hbm", "kernel": "k_cs_emit_rows", "achieved": gbps(emit_moved, emit_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbps(emit_moved, emit_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": emit_ms,
@@ -298,6 +298,79 @@ def base_line(args, R: Ranks, value, elapsed, scaling, dtype, config):
             "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": config}
 
 
+def region_tiles(args, R, reg, pam, n_tiles):
+    """The C3 region cut into `n_tiles` stretches (tiling.TiledRegionSearch: exact seams, flanks, REF partners across seams) -
+    the REGION shard of a multi-GPU run: rank r takes stretch r x all samples, so rows, distinct variant clusters, REF work and
+    template rows all divide by the number of ranks (a sample block still carries nearly every distinct cluster of the panel)."""
+    from crisprhawk_hip.tiling import DenseGenotypes, TiledRegionSearch, VariantPanel
+    vs = reg.variants
+    panel = VariantPanel(np.array([v.pos for v in vs], dtype=np.int64), [v.ref for v in vs], [v.alt for v in vs],
+                         [f"{reg.contig}-{v.pos}-{v.ref}/{v.alt}" for v in vs], np.array([v.af for v in vs], dtype=np.float64),
+                         list(reg.samples), DenseGenotypes(reg.gt_matrix if reg.gt_matrix is not None else np.stack([v.gt.reshape(-1) for v in vs])))
+    span = reg.bed_stop - reg.bed_start
+    trs = TiledRegionSearch(lambda lo, hi: reg.contig_seq[lo - 1:hi], reg.contig, reg.startp, reg.stopp, panel, pam, args.guidelen, args.right,
+                            tile_nt=-(-span // n_tiles), device=R.device)
+    if len(trs.tiles) != n_tiles:
+        raise RuntimeError(f"region of {span} nt cut into {len(trs.tiles)} stretches, {n_tiles} asked for")
+    return trs
+
+
+def time_plan_steps(R, plan, pam, args, mm, pt, steps):
+    """(ms per step with the dictionary built inside the step, ms per step with it resident, last table's counts) for one plan"""
+    view = plan.view()
+    use_dict = plan.cluster_stats()["usable"]
+
+    def step(rebuild):
+        if rebuild and use_dict:
+            plan.rebuild_dictionary()
+        t = view.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
+        c = (t.n_candidates, t.n_rows, int(t.timing["v_path"]))
+        t.close()
+        return c
+    out = []
+    for rebuild in (True, False):
+        step(rebuild)
+        R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c = step(rebuild)
+        R._lib.check(R._lib.lib().hawk_sync(R.ctx), "hawk_sync")
+        out.append((time.perf_counter() - t0) / steps * 1e3)
+    return out[0], out[1], c
+
+
+def shares_projection(args, R, reg, pam, mm, pt, whole_ms, whole_resident_ms):
+    """What ONE rank's share of an N-way split of this workload takes on this one GPU, for both partitions, N = 2 / 4 / 8: the
+    step's scaling before any exchange.  NOT a multi-GPU measurement - no N > 1 run has existed so far - but it shows which
+    partition can scale: efficiency_before_exchange = whole-panel step / (N x share)."""
+    from crisprhawk_hip.parallel import shard_range
+    from crisprhawk_hip.workload import expand_on_device
+    res = {"what": "one rank's share of an N-way split timed on this one GPU (step = dictionary + search; *_resident: search only); "
+                   "efficiency_before_exchange = whole / (N x share); unmeasured on N GPUs",
+           "whole_ms": whole_ms, "whole_resident_ms": whole_resident_ms, "region": {}, "samples": {}}
+    k = max(5, min(20, args.steps))
+    for n in (2, 4, 8):
+        trs = region_tiles(args, R, reg, pam, n)
+        ptile = trs.prepare_tile(n // 2, keep_plan=True)
+        if ptile._first is not None:
+            ptile._first.close()
+            ptile._first = None
+        ms, ms_res, c = time_plan_steps(R, ptile.plan, pam, args, mm, pt, k)
+        res["region"][str(n)] = {"ms_per_step": ms, "ms_per_step_dictionary_resident": ms_res, "share_of_whole": ms / whole_ms,
+                                 "efficiency_before_exchange": whole_ms / (n * ms), "efficiency_dictionary_resident": whole_resident_ms / (n * ms_res),
+                                 "candidates": c[0], "rows": c[1], "v_path": c[2], "haplotype_rows": ptile.n_hap}
+        trs.close()
+        lo, hi = shard_range(len(reg.samples), n // 2, n)
+        ds2, _i, _m, _k = expand_on_device(reg, len(pam), device=R.device, sample_range=(lo, hi), keep_plan=True)
+        ms, ms_res, c = time_plan_steps(R, ds2.plan, pam, args, mm, pt, k)
+        res["samples"][str(n)] = {"ms_per_step": ms, "ms_per_step_dictionary_resident": ms_res, "share_of_whole": ms / whole_ms,
+                                  "efficiency_before_exchange": whole_ms / (n * ms), "efficiency_dictionary_resident": whole_resident_ms / (n * ms_res),
+                                  "candidates": c[0], "rows": c[1], "v_path": c[2], "haplotype_rows": ds2.n_hap}
+        ds2.plan.close()
+        ds2.close()
+    return res
+
+
 # ---------------------------------------------------------------------------------------------------
 # c3 / c1: one region, haplotype planes resident
 # ---------------------------------------------------------------------------------------------------
@@ -318,9 +391,19 @@ def run_region(args, R: Ranks):
     pam = PAM(args.pam, args.right, True)
     pam.encode(0)
     n_samples = len(reg.samples)
-    slo, shi = (0, n_samples) if (args.weak or c1) else shard_range(n_samples, R.rank, R.world)
+    # N > 1, one panel: `--shard region` (default) gives rank r the r-th stretch of the interval x all samples, `--shard samples`
+    # the r-th block of the samples x the whole interval (north_star's wording; REF then on every rank)
+    by_region = R.world > 1 and not (args.weak or c1) and args.shard == "region"
+    slo, shi = (0, n_samples) if (args.weak or c1 or by_region) else shard_range(n_samples, R.rank, R.world)
     t1 = time.time()
-    ds, info, expand_ms, kept = expand_on_device(reg, len(pam), device=R.device, sample_range=(slo, shi), keep_plan=True)
+    trs = ptile = None
+    if by_region:
+        trs = region_tiles(args, R, reg, pam, R.world)
+        ptile = trs.prepare_tile(R.rank, keep_plan=True)
+        ds, info, expand_ms, kept = ptile._first, None, 0.0, None
+        ds.plan = ptile.plan
+    else:
+        ds, info, expand_ms, kept = expand_on_device(reg, len(pam), device=R.device, sample_range=(slo, shi), keep_plan=True)
     region_nt = int(ds.hap_len[0])
     log(f"workload: {ds.n_hap} haplotype rows x {region_nt} nt (samples {slo}..{shi} of {n_samples}), {len(reg.variants)} sites; "
         f"synthesised in {t1 - t0:.1f}s, expanded on the device in {time.time() - t1:.1f}s (kernels {expand_ms:.2f} ms, "
@@ -360,14 +443,14 @@ def run_region(args, R: Ranks):
     cand, rows, positions = tab.n_candidates, tab.n_rows, tab.timing["scanned_positions"]
     # REF is scanned by every rank: count it once in the whole-job totals
     ref_c = ref_r = ref_p = 0
-    if R.world > 1 and not args.weak and not c1:
+    if R.world > 1 and not args.weak and not c1 and not by_region:
         ref_ds = _ref_only_set(reg.sequence, reg.startp, reg.stopp, len(pam), R.device)
         rt = ref_ds.search(pam.bits, pam.bitsrc, len(pam), args.guidelen, args.right, mm, pt, download=False)
         ref_c, ref_r, ref_p = rt.n_candidates, rt.n_rows, rt.timing["scanned_positions"]
         rt.close()
         ref_ds.close()
     tot = R.sum_ints([cand, rows, positions, ds.n_hap])
-    dup = R.world - 1
+    dup = 0 if by_region else R.world - 1
     cand_all, rows_all, pos_all = tot[0] - dup * ref_c, tot[1] - dup * ref_r, tot[2] - dup * ref_p
     if c1:  # replicas: every rank searched the same haplotype
         cand_all, rows_all, pos_all = cand * R.world, rows * R.world, positions * R.world
@@ -380,7 +463,9 @@ def run_region(args, R: Ranks):
         out = base_line(args, R, cand_all * args.steps / elapsed, elapsed, "weak" if (args.weak or c1) else "strong", "u32",
                         {"workload": workload, "pam": args.pam, "guidelen": args.guidelen, "right": args.right, "region_nt": region_nt,
                          "haplotypes_rank0": ds.n_hap, "haplotype_rows_all_ranks": tot[3] - dup, "samples": n_samples,
-                         "partition": "replicas" if c1 else ("own panel per rank" if args.weak else "sample blocks of one panel, REF on every rank"),
+                         "partition": "replicas" if c1 else ("own panel per rank" if args.weak else
+                                                                 "stretches of the region x all samples (exact seams)" if by_region else
+                                                                 "sample blocks of one panel, REF on every rank"),
                          "variant_sites": len(reg.variants), "scored": "CFDon (synthetic tables, seed 2001)" if score else "none",
                          "candidates_per_step": cand_all, "guide_rows_per_step": rows_all, "scanned_positions_per_step": pos_all})
         tkey = "c3" if workload.startswith("C3") and R.world == 1 else None
@@ -394,7 +479,7 @@ def run_region(args, R: Ranks):
                                      "written); value_dictionary_resident: the same without the dictionary build (a second PAM on the same plan)")
         if by_cluster:
             cl = plan.cluster_stats()
-            ref_rows = tab_ref_rows(reg, pam, args, mm, pt, R.device)
+            ref_rows = tab_ref_rows(reg, pam, args, mm, pt, R.device) // (R.world if by_region else 1)  # (a stretch holds its share of REF's rows)
             out["roofline"] = csearch_roofline(rows, ref_rows, positions, tab.n_hits, args.guidelen + len(pam), score, cl, avg("v_templates_ms"),
                                                avg("v_count_ms") - avg("v_templates_ms"), avg("v_emit_rows_ms"), tkey)
             out["cluster_dictionary"] = dict(cl, share=cl["instances"] / max(cl["distinct"], 1),
@@ -472,7 +557,7 @@ def run_region(args, R: Ranks):
         wd = threading.Timer(args.gather_timeout, _bail)
         wd.daemon = True
         wd.start()
-        g = gather_once(R, ds, step, tot[3])
+        g = gather_region(R, trs, cfd=(mm, pt) if score else None) if by_region else gather_once(R, ds, step, tot[3])
         wd.cancel()
         if R.rank == 0:
             out["gather"] = g
@@ -490,10 +575,52 @@ def run_region(args, R: Ranks):
                                            "measured": "build container, 8 vCPU, single thread (profiles/r02_reference_python_timing.json); not on this host"}
             if not c1 and not args.no_cpu_all_cores:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
-    if plan is not None:
+    if R.rank == 0 and R.world == 1 and not c1 and not args.no_shares and fused and out.get("ms_per_step_dictionary_resident"):
+        out["shares_on_one_gpu"] = shares_projection(args, R, reg, pam, mm, pt, out["ms_per_step"], out["ms_per_step_dictionary_resident"])
+    if trs is not None:
+        trs.close()
+    elif plan is not None:
         plan.close()
-    ds.close()
+    if trs is None:
+        ds.close()
     return out
+
+
+def gather_region(R: Ranks, trs, cfd):
+    """The one exchange of a region-sharded job: per rank search -> collapse -> export of its stretch (device), then the
+    collapsed report groups - one representative row per group + the members' haplotype rows - travel to rank 0 over RCCL
+    (hawk_comm_gatherv) and are merged at the seams (tiling.gather_tile_groups).  Measured once after the timed loop."""
+    from crisprhawk_hip import parallel
+    from crisprhawk_hip.tiling import _groups_of_tile, gather_tile_groups
+    if R.backend != "rccl":
+        comm = R.ctl
+    else:
+        comm = None
+    res = {}
+    try:
+        t0 = time.perf_counter()
+        g, st = trs.run_tile(R.rank, cfd)
+        n_all = R.ctl.allgather_i64([st["n_hap"]])[:, 0]
+        part = _groups_of_tile(g, int(n_all[:R.rank].sum()))
+        t1 = time.perf_counter()
+        if comm is None:
+            comm = parallel.RcclComm(R.ctl, R.device)
+        comm.barrier()
+        t2 = time.perf_counter()
+        acc, nbytes = gather_tile_groups(comm, part, trs.tiles[R.rank].own_lo, trs.L, trs.guidelen, len(trs.pam))
+        comm.barrier()
+        t3 = time.perf_counter()
+        rows = R.sum_ints([st["rows"]])[0]
+        if R.rank == 0:
+            res["collapsed_region"] = {"search_collapse_export_s": t1 - t0, "exchange_and_seam_merge_s": t3 - t2, "bytes_to_rank0": int(nbytes),
+                                       "groups": int(len(acc["sizes"])), "members": int(len(acc["members"])), "guide_rows_behind_them": int(rows),
+                                       "backend": R.backend}
+        if comm is not R.ctl:
+            comm.close()
+    except Exception as e:  # the value line must survive a failed exchange
+        res["error"] = f"{type(e).__name__}: {e}"
+        log(f"gather failed: {res['error']}")
+    return res
 
 
 def gather_once(R: Ranks, ds, step, n_hap_total):
@@ -1010,6 +1137,10 @@ def build_parser():
     ap.add_argument("--panel", choices=["independent", "linked"], default="independent",
                     help="c3: genotypes drawn independently per site and column (SURVEY 8(d): no LD, worst case for sharing) or as mosaics of "
                          "128 founder haplotypes (linkage blocks of ~100 kb)")
+    ap.add_argument("--shard", choices=["region", "samples"], default="region",
+                    help="c3, N > 1: what a rank takes of the one panel - a stretch of the region x all samples (default; everything "
+                         "divides by N), or a block of the samples x the whole region (REF and nearly every distinct cluster on every rank)")
+    ap.add_argument("--no-shares", action="store_true", help="skip shares_on_one_gpu (one rank's share of a 2 / 4 / 8-way split, timed on this GPU)")
     ap.add_argument("--planes", action="store_true", help="c3: time round 2's step (hawk_search over materialised planes) instead of the fused step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true")

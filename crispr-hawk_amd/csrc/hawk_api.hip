@@ -1724,8 +1724,9 @@ static int xplan_build_dict(hawk_xplan* x) {
   HIPCHK(hipEventRecord(ctx->ev[8], st));
   hawk_launch_cl_count(st, x->recs.p, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_cnt);
   hawk_launch_scan_u32(st, d_cnt, n, d_off);
-  uint32_t n_inst = 0;
+  uint32_t n_inst = 0, n_head = 0;  // n_head: the instances of the first 48 rows (hawk_launch_cl_insert)
   HIPCHK(hipMemcpyAsync(&n_inst, d_off + n, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&n_head, d_off + std::min<uint32_t>(n, 49), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
   int rc;
@@ -1752,7 +1753,8 @@ static int xplan_build_dict(hawk_xplan* x) {
   }
   TEMPCHK(tmp, &d_bkt, (size_t)n_inst * 2);
   TEMPCHK(tmp, &d_cnt_br, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_first_rb, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_base_br, ((size_t)n * n_bkt + 1) * 8);
-  uint32_t *d_rec, *d_n, *d_slot, *d_flag, *d_trep, *d_slot_uid;
+  uint32_t *d_rec, *d_n, *d_slot, *d_flag, *d_trep;
+  void* d_slot_uid;  // 16 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
   uint64_t *d_key, *d_rank;
   uint8_t* d_cls;
   unsigned long long *d_tkey, *d_partial, *d_shards;
@@ -1774,7 +1776,6 @@ static int xplan_build_dict(hawk_xplan* x) {
   TEMPCHK(tmp, &d_cls, (size_t)n_inst);
   TEMPCHK(tmp, &d_tkey, (size_t)tsize * 8);
   TEMPCHK(tmp, &d_trep, (size_t)tsize * 4);
-  TEMPCHK(tmp, &d_slot_uid, (size_t)tsize * 4);
   TEMPCHK(tmp, &d_partial, ((size_t)std::max<uint64_t>(n_inst, (uint64_t)n * n_bkt) / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
@@ -1783,7 +1784,7 @@ static int xplan_build_dict(hawk_xplan* x) {
   HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
   hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
                       t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls, d_bkt, bshift, n_bkt, d_cnt_br, d_first_rb, d_status);
-  hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsmall - 1, d_slot, d_status, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u);
+  hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tkey, d_trep, tsmall - 1, d_slot, d_status, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u);
   hawk_launch_cl_flag(st, n_inst, d_cls, d_slot, d_trep, d_flag);
   hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
   ScanTotals tot;
@@ -1792,14 +1793,16 @@ static int xplan_build_dict(hawk_xplan* x) {
   HIPCHK(hipMemcpyAsync(&st_now, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
+  uint32_t tused = tsmall;
   if (st_now & 8u) {  // the small table filled up: once more with two slots per instance
+    tused = tsize;
     st_now &= ~8u;
     HIPCHK(hipMemcpyAsync(d_status, &st_now, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsize * 8, st));
     HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsize * 4, st));
     HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
     HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
-    hawk_launch_cl_insert(st, n_inst, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_status, 0xffffffffu, 2u);
+    hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_status, 0xffffffffu, 2u);
     hawk_launch_cl_flag(st, n_inst, d_cls, d_slot, d_trep, d_flag);
     hawk_launch_mscan(st, d_flag, n_inst, d_partial, d_shards, d_rank, d_tot);
     HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
@@ -1807,6 +1810,7 @@ static int xplan_build_dict(hawk_xplan* x) {
     HIPCHK(hipGetLastError());
   }
   const uint32_t n_uniq = (uint32_t)tot.n_keep;
+  TEMPCHK(tmp, &d_slot_uid, (size_t)tused * 16);
   cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.last_uniq = n_uniq;
   if (n_uniq) {
     uint32_t* d_span2;

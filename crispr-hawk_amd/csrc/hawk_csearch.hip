@@ -177,8 +177,9 @@ __global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_
 
 __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
                                                    unsigned long long* __restrict__ tkey, uint32_t* __restrict__ trep, uint32_t mask,
-                                                   uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status, uint32_t max_probe, uint32_t fail_bit) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+                                                   uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status, uint32_t max_probe, uint32_t fail_bit,
+                                                   uint32_t i_first) {
+  const uint32_t i = i_first + blockIdx.x * 256 + threadIdx.x;
   if (i >= n_inst) return;
   if (!cls[i]) { inst_slot[i] = CL_NONE; return; }
   const unsigned long long k = key[i];
@@ -210,12 +211,14 @@ struct ClUniq {  // per distinct cluster
 __global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
                                                    const uint32_t* __restrict__ inst_slot, ClInst ci, const HxVar* __restrict__ recs,
                                                    const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
-                                                   uint32_t* __restrict__ slot_uid, ClUniq cu) {
+                                                   uint4* __restrict__ slot_desc, ClUniq cu) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_inst || !flag[i]) return;
   const uint32_t u = (uint32_t)rank[i];
-  slot_uid[inst_slot[i]] = u;
   const uint32_t r = ci.rec[i], n = ci.n[i];
+  // what every other instance of the cluster needs to know about its representative, as ONE 16-byte record per table slot (k_cl_uid
+  // gathered six arrays through the representative's index before): {cluster number, first record, records | class << 16, REF position of the first allele}
+  slot_desc[inst_slot[i]] = make_uint4(u, r, n | ((uint32_t)ci.cls[i] << 16), (uint32_t)(ci.o[i] + ci.rb[i]));
   const int32_t o_first = recs[r].o, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
   const uint32_t row = ci.row[i];
   cu.rec[u] = r; cu.n[u] = n; cu.row[u] = row; cu.o[u] = o_first;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32
   cu.seg[u] = lo;
 }
 __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint32_t* __restrict__ trep,
-                                                const uint32_t* __restrict__ slot_uid, ClInst ci, const HxVar* __restrict__ recs,
+                                                const uint4* __restrict__ slot_desc, ClInst ci, const HxVar* __restrict__ recs,
                                                 uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_inst) return;
@@ -238,16 +241,17 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
   if (!c) { inst_uid[i] = CL_NONE; return; }
   const uint32_t s = inst_slot[i];
   if (s == CL_NONE) { inst_uid[i] = CL_NONE; return; }  // found no slot (k_cl_insert flagged the dictionary)
-  const uint32_t r = trep[s];
-  inst_uid[i] = slot_uid[s];
-  if (r == i) return;
+  const uint4 d = slot_desc[s];
+  inst_uid[i] = d.x;
+  if (d.y == ci.rec[i]) return;  // the representative itself
   // exactness: same hash is not same cluster until the variant identities have been compared
-  bool bad = c != 1 || ci.cls[r] != 1 || ci.n[r] != ci.n[i] || ci.o[i] + ci.rb[i] != ci.o[r] + ci.rb[r];  // same REF position of the first allele
+  const uint32_t n = ci.n[i];
+  bool bad = c != 1 || (d.z >> 16) != 1 || (d.z & 0xffffu) != n || (uint32_t)(ci.o[i] + ci.rb[i]) != d.w;  // same REF position of the first allele
   if (!bad) {
     const HxVar* a = recs + ci.rec[i];
-    const HxVar* b = recs + ci.rec[r];
+    const HxVar* b = recs + d.y;
     const int32_t oa = a[0].o, ob = b[0].o;
-    for (uint32_t k = 0; k < ci.n[i]; ++k) {  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record, one load per side
+    for (uint32_t k = 0; k < n; ++k) {  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record, one load per side
       const uint4 ra = *reinterpret_cast<const uint4*>(a + k), rb = *reinterpret_cast<const uint4*>(b + k);
       bad = bad || ra.w != rb.w || ra.z != rb.z || ra.y != rb.y || (int32_t)ra.x - oa != (int32_t)rb.x - ob;
     }
@@ -274,24 +278,32 @@ void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, ui
   ClPerm pm{uid, o, row, pa, rb, uid2, o2, row2, pa2, rb2};
   hipLaunchKernelGGL(k_cl_permute, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, n_rows, n_bkt, bkt, base_br, first_rb, pm);
 }
-void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep, uint32_t mask,
-                           uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
-  hipLaunchKernelGGL(k_cl_insert, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, key, cls, static_cast<unsigned long long*>(tkey), trep, mask, inst_slot,
-                     status, max_probe, fail_bit);
+// Two launches: the instances of the first rows, then the rest.  A common cluster - a frequent SNV without a neighbour - has
+// thousands of instances, half of which are in flight at once in a single launch: they all find its slot empty, all try the CAS,
+// then all lower `trep` - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's size).  After
+// the head launch (<= `n_head` instances: a few dozen rows) every common cluster's key and its lowest instance are in the table,
+// so the rest only look.
+void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep,
+                           uint32_t mask, uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
+  n_head = n_head < n_inst ? n_head : n_inst;
+  if (n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_head + 255) / 256), dim3(256), 0, st, n_head, key, cls, static_cast<unsigned long long*>(tkey), trep, mask,
+                                 inst_slot, status, max_probe, fail_bit, 0u);
+  if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + 255) / 256), dim3(256), 0, st, n_inst, key, cls,
+                                          static_cast<unsigned long long*>(tkey), trep, mask, inst_slot, status, max_probe, fail_bit, n_head);
 }
 void hawk_launch_cl_flag(hipStream_t st, uint32_t n_inst, const uint8_t* cls, const uint32_t* inst_slot, const uint32_t* trep, uint32_t* flag) {
   hipLaunchKernelGGL(k_cl_flag, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, cls, inst_slot, trep, flag);
 }
 void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
                            const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* slot_uid, uint32_t* u_rec,
+                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec,
                            uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
   const uint32_t nb = (n_inst + 255) / 256;
   ClInst ci{o, row, pa, rb, rec, n, key, cls, nullptr};
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
   hipLaunchKernelGGL(k_cl_assign, dim3(nb), dim3(256), 0, st, n_inst, flag, rank, inst_slot, ci, static_cast<const HxVar*>(recs), seg_off, seg_rel,
-                     slot_uid, cu);
-  hipLaunchKernelGGL(k_cl_uid, dim3(nb), dim3(256), 0, st, n_inst, inst_slot, trep, slot_uid, ci, static_cast<const HxVar*>(recs), inst_uid, status);
+                     static_cast<uint4*>(slot_desc), cu);
+  hipLaunchKernelGGL(k_cl_uid, dim3(nb), dim3(256), 0, st, n_inst, inst_slot, trep, static_cast<const uint4*>(slot_desc), ci, static_cast<const HxVar*>(recs), inst_uid, status);
 }
 
 // ---- per search ------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-args="--steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end"
+args="--steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-shares"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $root/bench.py $args > $out/bench_kt.json 2> $out/kt.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 $root/bench.py $args > /dev/null 2> $out/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 $root/bench.py $args > /dev/null 2> $out/pmc_write.log
