@@ -95,7 +95,8 @@ def _search_host_built(coord, seq: str, vcf, phased: bool, pam: PAM, guidelen: i
 
 def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidelen: int, right: bool, outdir: str,
                  cfd_tables=None, azimuth_model=None, deepcpf1_weights=None, device: Optional[int] = None,
-                 debug: bool = True, estimate_offtargets=None, mm: int = 4, bdna: int = 0, brna: int = 0) -> Dict[str, str]:
+                 debug: bool = True, estimate_offtargets=None, mm: int = 4, bdna: int = 0, brna: int = 0,
+                 timings: Optional[Dict[str, float]] = None) -> Dict[str, str]:
     """One report per BED interval; returns {str(coordinate): path}.  `cfd_tables = (mm[20,4,4], pam[16])` adds the
     CFDon column for SpCas9-class PAMs (scoring.py:352-387); `azimuth_model` (a fitted sklearn GBR or the flattened
     dict of scoring.azimuth_model_from_sklearn) and `deepcpf1_weights` (scoring.set_deepcpf1_weights layout) switch
@@ -104,6 +105,14 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
     FASTA path) runs the off-target stage per region: the `offtargets` / `cfd` columns of the guide report
     (reports.py:292-333, 612-660) and offtargets_{contig}_{start}_{stop}.tsv next to it (offtargets.py:486-558); `mm`,
     `bdna`, `brna` as on the reference's command line (bulges are refused).  The per-site CFD needs `cfd_tables`."""
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def lap(stage: str) -> None:  # stage seconds into `timings` (bench.py's files_to_tsv line); no-op without it
+        if timings is not None:
+            now = _time.perf_counter()
+            timings[stage] = timings.get(stage, 0.0) + now - _t[0]
+            _t[0] = now
     ot = None
     if estimate_offtargets is not None:
         from .genome import GenomeIndex, read_fasta
@@ -131,6 +140,7 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
     mmt, pt = cfd_tables if score else (None, None)
     os.makedirs(outdir, exist_ok=True)
     paths = {}
+    lap("open inputs (FASTA index, VCF header + line index)")
     for coord in Bed(bedfile, PADDING, debug):
         seq = fastas[coord.contig].fetch(coord).sequence
         v = vcf_by_contig.get(coord.contig)
@@ -141,6 +151,7 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         from .readers import VcfBlock
         blk = v.fetch_block(coord) if v is not None else VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         samples = v.samples if v is not None else []
+        lap("fetch region + VCF record text")
         try:
             ds, info, _, kept, vt = expand_from_vcf(seq, coord.start, coord.stop, blk, samples, len(pam), True, device, keep_plan=True)
         except HaplotypeBuildError:
@@ -151,6 +162,7 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
             continue
         # the search runs from the expansion plan (hawk_xplan_view: once per distinct cluster of neighbouring variants when the
         # panel shares them, per row otherwise; no planes read) - a region without variants has no plan and searches REF's planes
+        lap("genotype parse + plan on the device")
         plan = getattr(ds, "plan", None)
         target = plan.view() if plan is not None else ds
         tab = target.search(pam.bits, pam.bitsrc, len(pam), guidelen, right, mmt, pt, download=False)
@@ -163,6 +175,7 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         tab.collapse((4, 3) if (azimuth_on or deepcpf1_on) else (0, 0), download_perm=False)
         groups = tab.export_groups()
         tab.close()
+        lap("dictionary + search + collapse + export of the groups")
         # model-based scorers run once per report row, on the group representatives (scoring.py:749-813), when the
         # caller has supplied their parameters
         scores = {}
@@ -173,13 +186,16 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
             if deepcpf1_on:
                 scores["score_deepcpf1"] = np.asarray(scoring.deepcpf1(kmers, debug), dtype=np.float64)
         otcb = None if ot is None else (lambda spacers: _offtargets(spacers, pam, ot, coord, guidelen, right, outdir, debug))
-        df = reports.report_from_groups(groups, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score,
-                                        is_ref_hap=np.asarray(ds.is_ref, dtype=bool), offtargets=otcb)
+        # the report as columns (no Python string per row: the carriers' columns of a 2504-sample panel are 0.6 GB of text), written
+        # by the library's TSV writer
+        cols, order, plain = reports.group_columns(groups, labels, pam, coord.contig, f"{coord.contig}:{bed_start}-{bed_stop}", scores, score,
+                                                   is_ref_hap=np.asarray(ds.is_ref, dtype=bool), offtargets=otcb)
         if plan is not None:
             plan.close()
         ds.close()
+        lap("report assembly")
         path = os.path.join(outdir, reports.report_filename(coord.contig, bed_start, bed_stop, pam, guidelen))
-        with open(path, "w") as f:
-            f.write(reports.to_tsv(df))
+        reports.write_report_tsv(path, cols, order, plain)
         paths[str(coord)] = path
+        lap("TSV text + write")
     return paths

@@ -268,6 +268,9 @@ class VCF:
             exception_handler(FileNotFoundError, f"Cannot find input VCF {fname}", os.EX_DATAERR, debug)
         self._fname = fname
         self._src = _TextSource(fname)
+        self._mm = self._gt_abs = None
+        if self._src.kind == "plain" and self._index_mapped():
+            return
         starts_l, ends_l, pos_l = [], [], []
         contigs = set()
         header_last = None
@@ -310,6 +313,59 @@ class VCF:
         if len(self._starts):
             first = bytes(self._read(int(self._starts[0]), int(self._ends[0]))).decode().strip().split()
             self._phased = len(first) > 9 and "|" in first[9]
+
+    def _index_mapped(self) -> bool:
+        """The index pass of a plain-text VCF by the library's host helper (hawk_host_vcf_index: the file mapped, every byte
+        walked once by all cores) instead of the numpy stream below - same index, plus where every record's sample columns begin,
+        so that fetch_block hands out views of the mapping.  False (nothing set) when the helper does not apply: an empty file,
+        no trailing newline, a library without the helper."""
+        import ctypes as C
+        size = os.path.getsize(self._fname)
+        if size == 0:
+            return False
+        try:
+            from . import _lib
+            L = _lib.lib()
+            fn = L.hawk_host_vcf_index
+        except Exception:
+            return False
+        mm = np.memmap(self._fname, dtype=np.uint8, mode="r")
+        if mm[-1] != 10:
+            return False
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        n, multi = C.c_uint64(0), C.c_uint32(0)
+        rc = fn(p(mm), C.c_uint64(size), C.c_uint64(0), None, None, None, None, C.byref(n), C.byref(multi))
+        if rc not in (_lib.HAWK_OK, _lib.HAWK_E_CAPACITY):
+            return False
+        nl = int(n.value)
+        ls = np.zeros(nl + 1, dtype=np.uint64)
+        pos = np.zeros(nl, dtype=np.int64)
+        gt = np.zeros(nl, dtype=np.uint64)
+        cl = np.zeros(nl, dtype=np.uint32)
+        _lib.check(fn(p(mm), C.c_uint64(size), C.c_uint64(nl), p(ls), p(pos), p(gt), p(cl), C.byref(n), C.byref(multi)), "hawk_host_vcf_index")
+        bad = np.flatnonzero(pos == -2)
+        if len(bad):
+            exception_handler(ValueError, f"Malformed VCF record near byte {int(ls[bad[0]])} of {self._fname}", os.EX_DATAERR, self._debug)
+        hdr = np.flatnonzero((pos == -1) & (ls[1:] - ls[:-1] > 1))
+        header_last = bytes(mm[int(ls[hdr[-1]]):int(ls[hdr[-1] + 1]) - 1]).decode() if len(hdr) else None
+        if header_last is None or not header_last.startswith("#CHROM"):
+            exception_handler(ValueError, f"Input VCF {self._fname} has no #CHROM header line", os.EX_DATAERR, self._debug)
+        self._samples = header_last.strip().split()[9:]  # variant.py:657
+        body = np.flatnonzero(pos >= 0)
+        self._total = size
+        self._starts, self._ends, self._pos = ls[body].astype(np.int64), ls[body + 1].astype(np.int64), pos[body]
+        self._gt_abs = gt[body]
+        if multi.value:  # variant.py:650-656: one contig per VCF
+            exception_handler(ValueError, f"Input VCF {self._fname} store variants belonging to multiple contigs", os.EX_DATAERR, self._debug)
+        self._contig = bytes(mm[int(ls[body[0]]):int(ls[body[0]]) + int(cl[body[0]])]).decode() if len(body) else ""
+        if len(self._pos) > 1 and np.any(np.diff(self._pos) < 0):
+            exception_handler(ValueError, f"Input VCF {self._fname} is not sorted by position", os.EX_DATAERR, self._debug)
+        self._phased = False  # variant.py:700-708: decided by the first record's first genotype
+        if len(self._starts):
+            first = bytes(mm[int(self._starts[0]):int(self._ends[0])]).decode().strip().split()
+            self._phased = len(first) > 9 and "|" in first[9]
+        self._mm = mm
+        return True
 
     def _index_lines(self, buf, base, starts, nl, starts_l, ends_l, pos_l, contigs) -> None:
         """CHROM and POS of every body line of a chunk, without a Python loop: the first 64 bytes of each line as a matrix,
@@ -380,8 +436,18 @@ class VCF:
         if a == b:
             return VcfBlock(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint64), [])
         s0, e1 = int(self._starts[a]), int(self._ends[b - 1])
-        text = self._read(s0, e1)
         line_off = np.concatenate((self._starts[a:b] - s0, [e1 - s0])).astype(np.uint64)
+        if self._mm is not None:  # a view of the mapping; the sample columns' offsets are in the index already
+            text = self._mm[s0:e1]
+            gabs = self._gt_abs[a:b]
+            short = np.flatnonzero(gabs == 0)
+            if len(short):
+                exception_handler(ValueError, f"VCF record at byte {int(self._starts[a + short[0]])} has no sample columns", os.EX_DATAERR, self._debug)
+            gt_off = (gabs - np.uint64(s0)).astype(np.uint64)
+            lo_l, g_l = line_off[:-1].tolist(), gt_off.tolist()
+            fixed = [bytes(text[lo:g - 1]).decode().split("\t") for lo, g in zip(lo_l, g_l)]
+            return VcfBlock(text, line_off, gt_off, fixed)
+        text = self._read(s0, e1)
         gt_off = np.zeros(b - a, dtype=np.uint64)
         fixed = []
         for i in range(b - a):

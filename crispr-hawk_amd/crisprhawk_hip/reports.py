@@ -382,30 +382,72 @@ class ReportGroups:
                    np.asarray(inp.stop)[reps], cfd, win, np.asarray(inp.gc_num), np.asarray(inp.gc_den), off, np.asarray(inp.hap)[perm])
 
 
-def _ragged_join(item_label: np.ndarray, group_off: np.ndarray, strings: Sequence[str]) -> List[str]:
-    """Per group: ",".join(strings[l] for its items) through the library's host helper (hawk_host_ragged_join)."""
+class Ragged:
+    """A column of byte strings as ONE blob + offsets (row g = blob[off[g]:off[g + 1]]) - how the report's text columns are kept
+    until they are written (write_report_tsv hands blob and offsets to the library's TSV writer; `strings()` makes the Python
+    strings the DataFrame route wants)."""
+
+    __slots__ = ("blob", "off")
+
+    def __init__(self, blob: np.ndarray, off: np.ndarray):
+        self.blob, self.off = np.ascontiguousarray(blob, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint64)
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    @classmethod
+    def from_strings(cls, strings: Sequence[str]) -> "Ragged":
+        return cls(*_pool(strings))
+
+    def strings(self) -> List[str]:
+        return _decode_groups(self.blob, self.off)
+
+    def take(self, rows) -> List[str]:
+        buf, o = memoryview(self.blob), self.off
+        return [str(buf[int(o[g]):int(o[g + 1])], "ascii") for g in np.asarray(rows).tolist()]
+
+    def select(self, labels: np.ndarray) -> "Ragged":
+        """row g of the result = row labels[g] of this column (a gather of byte strings: hawk_host_ragged_join, one item per row)"""
+        labels = np.ascontiguousarray(labels, dtype=np.uint32)
+        n = len(labels)
+        return _ragged_join_raw(labels, np.arange(n + 1, dtype=np.uint64), self.blob, self.off)
+
+    def extended(self, more: Sequence[str]) -> "Ragged":
+        """this column followed by the rows `more`"""
+        if not more:
+            return self
+        b2, o2 = _pool(more)
+        return Ragged(np.concatenate([self.blob, b2]), np.concatenate([self.off, o2[1:] + self.off[-1]]))
+
+
+def _ragged_join_raw(item_label: np.ndarray, group_off: np.ndarray, pool: np.ndarray, pool_off: np.ndarray) -> Ragged:
+    """Per group: the pool strings its items name, joined by commas (hawk_host_ragged_join), as a Ragged column."""
     import ctypes as C
     from . import _lib
     ng = len(group_off) - 1
-    if ng == 0:
-        return []
-    enc = [s.encode("ascii") for s in strings]
-    pool = np.frombuffer(b"".join(enc), dtype=np.uint8) if enc else np.zeros(0, np.uint8)
-    pool_off = np.zeros(len(enc) + 1, dtype=np.uint64)
-    pool_off[1:] = np.cumsum([len(e) for e in enc])
+    if ng <= 0:
+        return Ragged(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    pool_off = np.ascontiguousarray(pool_off, dtype=np.uint64)
     item = np.ascontiguousarray(item_label, dtype=np.uint32)
     goff = np.ascontiguousarray(group_off, dtype=np.uint64)
     out_off = np.zeros(ng + 1, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     L = _host_lib()
-    _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), C.c_uint64(len(enc)), C.c_uint8(44), None,
+    n_lab = C.c_uint64(len(pool_off) - 1)
+    _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), n_lab, C.c_uint8(44), None,
                                        C.c_uint64(0), p(out_off)), "hawk_host_ragged_join")
     out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
-    _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), C.c_uint64(len(enc)), C.c_uint8(44), p(out),
+    _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), n_lab, C.c_uint8(44), p(out),
                                        C.c_uint64(len(out)), p(out_off)), "hawk_host_ragged_join")
-    buf = memoryview(out)
-    o = out_off.tolist()
-    return [str(buf[o[g]:o[g + 1]], "ascii") for g in range(ng)]
+    return Ragged(out, out_off)
+
+
+def _ragged_join(item_label: np.ndarray, group_off: np.ndarray, strings: Sequence[str]) -> List[str]:
+    """Per group: ",".join(strings[l] for its items) through the library's host helper (hawk_host_ragged_join)."""
+    if len(group_off) - 1 <= 0:
+        return []
+    return _ragged_join_raw(item_label, group_off, *_pool(strings)).strings()
 
 
 def _host_lib():
@@ -444,13 +486,13 @@ def _hap_items(per_hap: List[List[str]]):
     return vocab, off, flat
 
 
-def _group_join(member_off, member_hap, per_hap: List[List[str]]) -> List[str]:
-    """Per group ",".join(sorted(set(items of its member haplotypes))) - hawk_host_group_join."""
+def _group_join_raw(member_off, member_hap, per_hap: List[List[str]]) -> Ragged:
+    """Per group ",".join(sorted(set(items of its member haplotypes))) - hawk_host_group_join - as a Ragged column."""
     import ctypes as C
     from . import _lib
     ng = len(member_off) - 1
-    if ng == 0:
-        return []
+    if ng <= 0:
+        return Ragged(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     vocab, hoff, flat = _hap_items(per_hap)
     pool, poff = _pool(vocab)
     moff = np.ascontiguousarray(member_off, dtype=np.uint64)
@@ -462,21 +504,25 @@ def _group_join(member_off, member_hap, per_hap: List[List[str]]) -> List[str]:
     _lib.check(L.hawk_host_group_join(*args, None, C.c_uint64(0), p(out_off)), "hawk_host_group_join")
     out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
     _lib.check(L.hawk_host_group_join(*args, p(out), C.c_uint64(len(out)), p(out_off)), "hawk_host_group_join")
-    return _decode_groups(out, out_off)
+    return Ragged(out, out_off)
 
 
-def _samples_column(member_off, member_hap, hap_samples: List[str]) -> List[str]:
+def _group_join(member_off, member_hap, per_hap: List[List[str]]) -> List[str]:
+    return _group_join_raw(member_off, member_hap, per_hap).strings() if len(member_off) > 1 else []
+
+
+def _samples_raw(member_off, member_hap, hap_samples: List[str]) -> Ragged:
     """reports.py:767-810 for every group: sorted unique `sample:genotype` entries, phased genotypes OR-ed per sample
     (hawk_host_group_samples).  `hap_samples[h]`: the samples label of haplotype row h ("" for rows that hold none)."""
     import ctypes as C
     from . import _lib
     per_hap = [x.split(",") if x else [] for x in hap_samples]
     ng = len(member_off) - 1
-    if ng == 0:
-        return []
+    if ng <= 0:
+        return Ragged(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     vocab, hoff, flat = _hap_items(per_hap)
     if not any("|" in e for e in vocab):
-        return _group_join(member_off, member_hap, per_hap)
+        return _group_join_raw(member_off, member_hap, per_hap)
     n_e = len(vocab)
     ok = np.zeros(n_e, dtype=np.uint8)
     a1, a2 = np.zeros(n_e, np.uint16), np.zeros(n_e, np.uint16)
@@ -504,15 +550,28 @@ def _samples_column(member_off, member_hap, hap_samples: List[str]) -> List[str]
     _lib.check(L.hawk_host_group_samples(*args, None, C.c_uint64(0), p(out_off), p(flags)), "hawk_host_group_samples")
     out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
     _lib.check(L.hawk_host_group_samples(*args, p(out), C.c_uint64(len(out)), p(out_off), p(flags)), "hawk_host_group_samples")
-    res = _decode_groups(out, out_off)
+    col = Ragged(out, out_off)
     odd = np.flatnonzero(flags == 3)  # a group mixing phased entries with others: the reference's own per-group walk
-    for g in odd.tolist():
-        res[g] = collapse_samples([hap_samples[int(x)] for x in member_hap[member_off[g]:member_off[g + 1]]])
-    return res
+    if len(odd):
+        fixed = [collapse_samples([hap_samples[int(x)] for x in member_hap[member_off[g]:member_off[g + 1]]]) for g in odd.tolist()]
+        labels = np.arange(ng, dtype=np.uint32)
+        labels[odd] = ng + np.arange(len(odd), dtype=np.uint32)
+        col = col.extended(fixed).select(labels)
+    return col
+
+
+def _samples_column(member_off, member_hap, hap_samples: List[str]) -> List[str]:
+    return _samples_raw(member_off, member_hap, hap_samples).strings() if len(member_off) > 1 else []
+
+
+
+
+def _hapids_raw(member_off, member_hap, hap_ids: List[str]) -> Ragged:
+    return _group_join_raw(member_off, member_hap, [x.split(",") if x else [] for x in hap_ids])
 
 
 def _hapids_column(member_off, member_hap, hap_ids: List[str]) -> List[str]:
-    return _group_join(member_off, member_hap, [x.split(",") if x else [] for x in hap_ids])
+    return _hapids_raw(member_off, member_hap, hap_ids).strings() if len(member_off) > 1 else []
 
 
 class HapLabels:
@@ -566,14 +625,15 @@ class HapLabels:
         return self._vt
 
 
-def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
-    """variant_id / af of every group from its representative (annotation.py:246-370).  Rows whose haplotype carries only
-    SNVs around the guide are resolved in bulk; rows with an indel among the candidates go through
+def _variant_columns_raw(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
+    """variant_id / af of every group from its representative (annotation.py:246-370), as two Ragged columns.  Rows whose
+    haplotype carries only SNVs around the guide are resolved in bulk; rows with an indel among the candidates go through
     polish_guide_variants exactly as report_frame does."""
     ng, L = G.n_groups, G.guidelen + G.pamlen
-    vid_col, af_col = ["NA"] * ng, ["NA"] * ng
+    na = Ragged.from_strings(["NA"])
+    all_na = lambda: na.select(np.zeros(ng, dtype=np.uint32))
     if len(lab.var_idx) == 0:
-        return vid_col, af_col
+        return all_na(), all_na()
     t_pos, t_snv, t_alt0, t_ref, t_alt, t_af = lab.variant_table()
     H = len(lab)
     cnt_h = np.diff(lab.var_off)
@@ -586,7 +646,7 @@ def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
         vkey, v_var = vkey[o], v_var[o]
     alt_rows = np.flatnonzero(~lab.is_ref[rep_hap] & (cnt_h[rep_hap] > 0))
     if len(alt_rows) == 0:
-        return vid_col, af_col
+        return all_na(), all_na()
     hh = rep_hap[alt_rows]
     start, stop = np.asarray(G.start, np.int64)[alt_rows], np.asarray(G.stop, np.int64)[alt_rows]
     a = np.searchsorted(vkey, hh * BIG + start, side="left")
@@ -614,18 +674,26 @@ def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
     keep[1:] = (pr[1:] != pr[:-1]) | (pv[1:] != pv[:-1])
     pr, pv = pr[keep], pv[keep]
     roff = np.concatenate(([0], np.cumsum(np.bincount(pr, minlength=len(alt_rows)))))
-    ids = _ragged_join(pv, roff, lab.vid)
+    n_alt = len(alt_rows)
+    ids = _ragged_join_raw(pv, roff, *_pool(lab.vid))
     af_names = sorted(set(t_af))
     af_rank = {s_: k for k, s_ in enumerate(af_names)}
     af_of_var = np.array([af_rank[x] for x in t_af], dtype=np.int64)
-    afs = _ragged_join(af_of_var[pv], roff, af_names)  # allele frequencies follow the ids' order (guide.py:311-328)
+    afs = _ragged_join_raw(af_of_var[pv], roff, *_pool(af_names))  # allele frequencies follow the ids' order (guide.py:311-328)
     na_id = af_rank.get("NA", -1)
-    some_af = np.zeros(len(alt_rows), dtype=bool)
+    some_af = np.zeros(n_alt, dtype=bool)
     np.logical_or.at(some_af, pr, af_of_var[pv] != na_id)
-    for k in np.flatnonzero(fast).tolist():
-        g = int(alt_rows[k])
-        vid_col[g] = ids[k]
-        af_col[g] = afs[k] if (some_af[k] and ids[k]) else "NA"
+    # per group: which row of (ids | afs, then "NA", then the slow rows' strings) it shows
+    NA = n_alt
+    vid_lab = np.full(ng, NA, dtype=np.uint32)
+    af_lab = np.full(ng, NA, dtype=np.uint32)
+    fk = np.flatnonzero(fast)
+    vid_lab[alt_rows[fk]] = fk
+    has_id = np.diff(ids.off.astype(np.int64))[fk] > 0
+    af_ok = some_af[fk] & has_id
+    af_lab[alt_rows[fk[af_ok]]] = fk[af_ok]
+    slow_vid: List[str] = []
+    slow_af: List[str] = []
     # ---- rows with an indel among the candidates (or a non-linear position map): the reference's own walk over the
     # candidates (variants elsewhere on the haplotype cannot match a position of this guide)
     slow = np.flatnonzero(~fast)
@@ -645,9 +713,15 @@ def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
             variant_id = polish_guide_variants(core, gen, int(G.stop[g]), parsed)
             vids = variant_id.split(",")
             afl = [t_af[_vid_index(lab, v)] for v in vids] if variant_id else []
-            vid_col[g] = ",".join(sorted(set(vids))) if variant_id else ""
-            af_col[g] = "NA" if not afl or (len(set(afl)) == 1 and afl[0] == "NA") else ",".join(afl)
-    return vid_col, af_col
+            vid_lab[g] = af_lab[g] = NA + 1 + len(slow_vid)
+            slow_vid.append(",".join(sorted(set(vids))) if variant_id else "")
+            slow_af.append("NA" if not afl or (len(set(afl)) == 1 and afl[0] == "NA") else ",".join(afl))
+    return ids.extended(["NA"] + slow_vid).select(vid_lab), afs.extended(["NA"] + slow_af).select(af_lab)
+
+
+def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
+    vid, af = _variant_columns_raw(G, rep_hap, cores, lab)
+    return vid.strings(), af.strings()
 
 
 def _vid_index(lab: HapLabels, v: str) -> int:
@@ -670,16 +744,117 @@ def group_kmers(G) -> List[str]:
     return out
 
 
-def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
-                       with_cfdon: bool = True, is_ref_hap: Optional[np.ndarray] = None, offtargets=None):
-    """report_frame's result from group-level inputs (hapset.GroupTable, tiling.MergedGroups.groups(), ReportGroups),
-    assembled column by column: same DataFrame, same order, same strings.  `scores[c]` is per GROUP here."""
-    import pandas as pd
-    cols = select_reportcols(pam, G.right, offtargets is not None)
+# ---- the report's columns as they are kept until they are written -------------------------------------------------------
+class ConstCol:
+    """the same text in every row"""
+
+    def __init__(self, text: str, n: int):
+        self.text, self.n = text, n
+
+    def array(self):
+        return np.full(self.n, self.text, dtype=object)
+
+    def take(self, rows):
+        return np.full(len(rows), self.text, dtype="U")
+
+
+class FixedCol:
+    """equally long ASCII strings as a byte matrix [rows, width]"""
+
+    def __init__(self, m: np.ndarray):
+        self.m = np.ascontiguousarray(m, dtype=np.uint8)
+
+    def array(self):
+        w = self.m.shape[1]
+        return self.m.view(f"S{w}").ravel().astype(f"U{w}")
+
+    def take(self, rows):
+        w = self.m.shape[1]
+        return np.ascontiguousarray(self.m[rows]).view(f"S{w}").ravel().astype(f"U{w}")
+
+
+class IntCol:
+    def __init__(self, v: np.ndarray):
+        self.v = np.ascontiguousarray(v, dtype=np.int64)
+
+    def array(self):
+        return self.v
+
+    def take(self, rows):
+        return self.v[rows]
+
+
+class VocabCol:
+    """a few distinct strings, one index per row; `as_object`: what dtype the DataFrame route had for the column"""
+
+    def __init__(self, idx: np.ndarray, vocab: Sequence[str], as_object: bool = True):
+        self.idx, self.vocab, self.as_object = np.ascontiguousarray(idx, dtype=np.uint32), list(vocab), as_object
+
+    def array(self):
+        v = np.array(self.vocab, dtype=object) if self.as_object else np.array(self.vocab)
+        return v[self.idx]
+
+    def take(self, rows):
+        return np.array(self.vocab, dtype="U")[self.idx[rows]]
+
+
+def _ragged_array(col: Ragged):
+    return np.array(col.strings(), dtype=object)
+
+
+def _col_array(col):
+    return _ragged_array(col) if isinstance(col, Ragged) else col.array()
+
+
+def _col_take(col, rows):
+    return np.array(col.take(rows), dtype="U") if isinstance(col, Ragged) else col.take(rows)
+
+
+_UNPLAIN = ('"', "\t", "\n", "\r")
+
+
+def _plain(strings) -> bool:
+    """no string holds a character csv's minimal quoting reacts to (DataFrame.to_csv would quote the field)"""
+    return not any(ch in x for x in strings for ch in _UNPLAIN)
+
+
+def _report_order(cols: Dict[str, object], gcols: List[str], n: int) -> np.ndarray:
+    """pandas groupby(sort=True) order over the group columns (reports.py:978-1003), then _format_report's stable sort on
+    (start, stop) = ONE lexicographic order with (start, stop) as the leading keys and the group columns, compared as strings,
+    behind them.  (start, stop) alone decides nearly every row: the string keys are only formed for the rows of a tie."""
+    start, stop = cols["start"].v, cols["stop"].v
+    order = np.lexsort((stop, start))
+    s_, e_ = start[order], stop[order]
+    same = np.zeros(n, dtype=bool)
+    same[1:] = (s_[1:] == s_[:-1]) & (e_[1:] == e_[:-1])
+    in_tie = same.copy()
+    in_tie[:-1] |= same[1:]
+    tpos = np.flatnonzero(in_tie)  # positions (in the (start, stop) order) of rows that share both with a neighbour
+    if len(tpos) == 0:
+        return order
+    rows = order[tpos]
+    run = np.cumsum(~same[tpos])  # tie runs, numbered in output order
+    keys = []
+    for c in reversed(gcols):
+        if c in ("chr", "start", "stop"):
+            continue
+        keys.append(_col_take(cols[c], rows))
+    keys.append(run)
+    order[tpos] = rows[np.lexsort(keys)]
+    return order
+
+
+def group_columns(G, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
+                  with_cfdon: bool = True, is_ref_hap: Optional[np.ndarray] = None, offtargets=None):
+    """The guide report of group-level inputs (hapset.GroupTable, tiling.MergedGroups.groups(), ReportGroups) as COLUMNS -
+    {name: ConstCol / FixedCol / IntCol / VocabCol / Ragged} in the report's column order - plus the row order and whether every
+    field is plain text (no character csv quoting reacts to).  Nothing here is a Python string per row: the two columns that list
+    every carrier of every row (C3: 0.64 GB) stay the byte blobs the library's helpers wrote.  `scores[c]` is per GROUP."""
+    names = select_reportcols(pam, G.right, offtargets is not None)
     ng = G.n_groups
     if ng == 0:
-        return pd.DataFrame({c: [] for c in cols})
-    L, W = G.guidelen + G.pamlen, G.guidelen + G.pamlen + 2 * GUIDESEQPAD
+        return {c: Ragged(np.zeros(0, np.uint8), np.zeros(1, np.uint64)) for c in names}, np.zeros(0, np.int64), True
+    L = G.guidelen + G.pamlen
     member_off = np.asarray(G.member_off, dtype=np.int64)
     member_hap = np.asarray(G.member_hap, dtype=np.int64)
     rep_hap = member_hap[member_off[:-1]]
@@ -692,7 +867,7 @@ def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores
     for p in range(5):
         code |= (((np.asarray(G.win[p])[:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
     cores = _CODE2CHAR[code]
-    vid_col, af_col = _variant_columns(G, rep_hap, cores, lab)
+    vid_col, af_col = _variant_columns_raw(G, rep_hap, cores, lab)
     # reverse_guides (annotation.py:27-51): strand-1 rows read as their reverse complement, case preserved
     strand = np.asarray(G.strand).astype(np.int64)
     guide = cores.copy()
@@ -702,32 +877,37 @@ def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores
         pam_b, sg_b = guide[:, :G.pamlen], guide[:, G.pamlen:]
     else:
         sg_b, pam_b = guide[:, :G.guidelen], guide[:, G.guidelen:]
-    to_str = lambda m: np.ascontiguousarray(m).view(f"S{m.shape[1]}").ravel().astype(f"U{m.shape[1]}")
-    data = {"chr": np.full(ng, contig, dtype=object), "start": np.asarray(G.start, dtype=np.int64), "stop": np.asarray(G.stop, dtype=np.int64),
-            "sgRNA_sequence": to_str(sg_b), "pam": to_str(pam_b), "pam_class": np.full(ng, compute_pam_class(pam), dtype=object),
-            "strand": np.where(rev, "-", "+")}
-    score_cols = [c for c in cols if c.startswith("score_")]
-    for c in score_cols:
+    data: Dict[str, object] = {"chr": ConstCol(contig, ng), "start": IntCol(G.start), "stop": IntCol(G.stop), "sgRNA_sequence": FixedCol(sg_b),
+                               "pam": FixedCol(pam_b), "pam_class": ConstCol(compute_pam_class(pam), ng),
+                               "strand": VocabCol(rev.astype(np.uint32), ["+", "-"], as_object=False)}
+    for c in [c for c in names if c.startswith("score_")]:
         vals = None
         if c == "score_cfdon" and with_cfdon and G.cfdon is not None:
             vals = np.asarray(G.cfdon, dtype=np.float64)
         elif scores and c in scores:
             vals = np.asarray(scores[c], dtype=np.float64)
-        data[c] = np.array(["NA"] * ng if vals is None else ["NA" if v != v else str(round_score(v)) for v in vals.tolist()], dtype=object)
-    num, den = np.asarray(G.gc_num).tolist(), np.asarray(G.gc_den).tolist()
-    data["gc_content"] = np.array([str(n / d if d else 0.0) for n, d in zip(num, den)], dtype=object)
-    data["origin"] = np.where(is_ref_hap[rep_hap], "ref", "alt")
-    data["samples"] = np.array(_samples_column(member_off, member_hap, lab.samples), dtype=object)
-    data["variant_id"] = np.array(vid_col, dtype=object)
-    data["af"] = np.array(af_col, dtype=object)
-    data["target"] = np.full(ng, target, dtype=object)
-    data["haplotype_id"] = np.array(_hapids_column(member_off, member_hap, lab.ids), dtype=object)
+        if vals is None:
+            data[c] = ConstCol("NA", ng)
+        else:  # str(round(score, 4)) once per distinct value ("NA" for a missing score)
+            uniq, inv = np.unique(vals, return_inverse=True)
+            data[c] = VocabCol(inv.reshape(-1), ["NA" if v != v else str(round_score(v)) for v in uniq.tolist()])
+    gkey = np.asarray(G.gc_num).astype(np.int64) * 65536 + np.asarray(G.gc_den).astype(np.int64)
+    uniq, inv = np.unique(gkey, return_inverse=True)
+    data["gc_content"] = VocabCol(inv.reshape(-1), [str((int(k) >> 16) / (int(k) & 0xffff) if (int(k) & 0xffff) else 0.0) for k in uniq.tolist()])
+    data["origin"] = VocabCol((~is_ref_hap[rep_hap]).astype(np.uint32), ["ref", "alt"], as_object=False)
+    data["samples"] = _samples_raw(member_off, member_hap, lab.samples)
+    data["variant_id"] = vid_col
+    data["af"] = af_col
+    data["target"] = ConstCol(target, ng)
+    data["haplotype_id"] = _hapids_raw(member_off, member_hap, lab.ids)
+    plain = _plain([contig, target]) and _plain(lab.samples) and _plain(lab.ids) and _plain(lab.vid)
     if offtargets is not None:  # a dict {SPACER: (count, cfd)} or a callable that builds it from the rows' spacers
+        spacers = data["sgRNA_sequence"].array()
         if callable(offtargets):
-            offtargets = offtargets(sorted(set(np.char.upper(data["sgRNA_sequence"]).tolist())))
-        data.update(_offtarget_columns(data["sgRNA_sequence"].tolist(), offtargets, pam.cas_system in (SPCAS9, XCAS9)))
-    # pandas groupby(sort=True) order over the group columns (reports.py:978-1003), then _format_report's stable sort on
-    # (start, stop): one lexsort with (start, stop) as the leading keys
+            offtargets = offtargets(sorted(set(np.char.upper(spacers).tolist())))
+        for c, arr in _offtarget_columns(spacers.tolist(), offtargets, pam.cas_system in (SPCAS9, XCAS9)).items():
+            data[c] = Ragged.from_strings([str(x) for x in arr.tolist()])
+            plain = plain and _plain(arr.tolist())
     gcols = REPORTCOLS[:5]
     if pam.cas_system in (SPCAS9, XCAS9):
         gcols = gcols + REPORTCOLS[6:12] + REPORTCOLS[13:14] + REPORTCOLS[15:17]
@@ -735,15 +915,66 @@ def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores
         gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[12:13] + REPORTCOLS[15:17]
     else:
         gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[15:17]
-    keys = []
-    for c in reversed(gcols):
-        if c in ("chr",):
-            continue
-        k = data[c]
-        keys.append(k if k.dtype.kind in "iuU" else k.astype("U"))
-    keys += [data["stop"], data["start"]]
-    order = np.lexsort(keys)
-    return pd.DataFrame({c: data[c][order] for c in cols})
+    order = _report_order(data, gcols, ng)
+    return {c: data[c] for c in names}, order, plain
+
+
+def report_from_groups(G, haplotypes, pam: PAM, contig: str, target: str, scores: Optional[Dict[str, np.ndarray]] = None,
+                       with_cfdon: bool = True, is_ref_hap: Optional[np.ndarray] = None, offtargets=None):
+    """report_frame's result from group-level inputs, assembled column by column (group_columns): same DataFrame, same order,
+    same strings."""
+    import pandas as pd
+    cols, order, _ = group_columns(G, haplotypes, pam, contig, target, scores, with_cfdon, is_ref_hap, offtargets)
+    if G.n_groups == 0:
+        return pd.DataFrame({c: [] for c in cols})
+    return pd.DataFrame({c: _col_array(col)[order] for c, col in cols.items()})
+
+
+def write_report_tsv(path: str, cols: Dict[str, object], order: np.ndarray, plain: bool = True) -> int:
+    """What _store_report writes (reports.py:739: DataFrame.to_csv(sep="\\t", index=False)) for the columns of group_columns,
+    by the library's TSV writer (hawk_host_tsv_write: multi-threaded, straight into a mapping of the file) - no row string, no
+    DataFrame.  Fields csv quoting would touch (`plain` False) go through pandas as before.  Returns the bytes written."""
+    import ctypes as C
+    from . import _lib
+    names = list(cols)
+    n = len(order)
+    if n == 0 or not plain:
+        import pandas as pd
+        df = pd.DataFrame({c: (_col_array(col)[order] if n else []) for c, col in cols.items()})
+        txt = to_tsv(df)
+        with open(path, "w") as f:
+            f.write(txt)
+        return len(txt)
+
+    class TsvCol(C.Structure):
+        _fields_ = [("kind", C.c_uint32), ("width", C.c_uint32), ("data", C.c_void_p), ("off", C.c_void_p), ("pool", C.c_void_p), ("n_vocab", C.c_uint64)]
+    keep = []  # arrays the descriptors point into
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    arr = (TsvCol * len(names))()
+    for k, c in enumerate(names):
+        col = cols[c]
+        if isinstance(col, ConstCol):
+            b = np.frombuffer(col.text.encode("ascii"), dtype=np.uint8).copy() if col.text else np.zeros(1, np.uint8)
+            keep.append(b)
+            arr[k] = TsvCol(0, len(col.text), p(b).value, None, None, 0)
+        elif isinstance(col, FixedCol):
+            arr[k] = TsvCol(1, col.m.shape[1], p(col.m).value, None, None, 0)
+        elif isinstance(col, Ragged):
+            arr[k] = TsvCol(2, 0, p(col.blob).value, p(col.off).value, None, 0)
+        elif isinstance(col, IntCol):
+            arr[k] = TsvCol(3, 0, p(col.v).value, None, None, 0)
+        else:
+            pool, poff = _pool(col.vocab)
+            if len(pool) == 0:
+                pool = np.zeros(1, np.uint8)
+            keep += [pool, poff]
+            arr[k] = TsvCol(4, 0, p(col.idx).value, p(poff).value, p(pool).value, len(col.vocab))
+    header = ("\t".join(names) + "\n").encode("ascii")
+    od = np.ascontiguousarray(order, dtype=np.uint64)
+    nbytes = C.c_uint64(0)
+    _lib.check(_host_lib().hawk_host_tsv_write(path.encode(), header, C.c_uint64(len(header)), C.c_uint64(n), p(od), C.c_uint32(len(names)), arr,
+                                               C.byref(nbytes)), "hawk_host_tsv_write")
+    return int(nbytes.value)
 
 
 def report_from_guides(guides, haplotypes, pam: PAM, contig: str, target: str, cfdon: Optional[Sequence[float]] = None,

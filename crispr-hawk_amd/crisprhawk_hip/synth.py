@@ -353,3 +353,30 @@ def contig_panel(seed: int, contig: str, contig_len: int, n_block: int, n_sample
     samples = [f"S{i:04d}" for i in range(n_samples)]
     return seq, VariantPanel(pos.astype(np.int64), ref, alt, vid, af.astype(np.float64), samples,
                              BlockGenotypes(seed + 1, af, n_cols))
+
+
+def write_region_files(reg: SynthRegion, directory: str, stem: str = "region"):
+    """The region as the FILES the reference's `crisprhawk search` takes - FASTA (60 columns), BED, phased VCF text (one `a|b`
+    per sample and record, `AF=` in INFO) - for the files -> TSV measurements and tests.  Returns (fasta, bed, vcf) paths."""
+    import os
+    fa, bed, vcf = (os.path.join(directory, f"{stem}.{ext}") for ext in ("fa", "bed", "vcf"))
+    with open(fa, "w") as f:
+        f.write(f">{reg.contig}\n")
+        s = reg.contig_seq
+        f.write("\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n")
+    with open(bed, "w") as f:
+        f.write(f"{reg.contig}\t{reg.bed_start}\t{reg.bed_stop}\n")
+    ns = len(reg.samples)
+    with open(vcf, "wb") as f:
+        f.write(b"##fileformat=VCFv4.2\n##contig=<ID=" + reg.contig.encode() + b">\n")
+        f.write(("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(reg.samples) + "\n").encode())
+        for v in reg.variants:
+            head = f"{reg.contig}\t{v.pos}\t.\t{v.ref}\t{v.alt}\t.\tPASS\tAF={v.af:.6g}\tGT\t".encode()
+            g = np.empty((ns, 4), np.uint8)
+            g[:, 0] = v.gt[:, 0] + 48
+            g[:, 1] = ord("|")
+            g[:, 2] = v.gt[:, 1] + 48
+            g[:, 3] = 9
+            f.write(head + g.reshape(-1).tobytes()[:-1] + b"\n")
+    return fa, bed, vcf
+

@@ -2,6 +2,7 @@
 // `samples` and `haplotype_id` columns list every carrier of every report row (C3: 28 M entries, ~330 MB of text);
 // joining them is a ragged byte gather that Python cannot do at memory speed, so it lives here, multi-threaded.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -17,6 +18,14 @@ template <class F> void par_groups(uint64_t n_groups, F f) {
   for (unsigned t = 1; t < nt; ++t)
     th.emplace_back([=] { f(std::min<uint64_t>(n_groups, t * per), std::min<uint64_t>(n_groups, (t + 1) * per)); });
   f(0, std::min<uint64_t>(n_groups, per));
+  for (auto& x : th) x.join();
+}
+template <class F> void par_groups_any(uint64_t n, F f) {  // the same split for few, heavy items
+  const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n, std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
+  const uint64_t per = (n + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { f(std::min<uint64_t>(n, t * per), std::min<uint64_t>(n, (t + 1) * per)); });
+  f(0, std::min<uint64_t>(n, per));
   for (auto& x : th) x.join();
 }
 inline unsigned dec_len(uint32_t v) { unsigned n = 1; while (v >= 10) { v /= 10; ++n; } return n; }
@@ -297,6 +306,229 @@ int hawk_host_posmap_rev(const uint64_t* seg_start, const uint32_t* seg_rel, con
       if (seg_gen[k] <= g && g <= last_gen) best = (int64_t)seg_rel[k] + (g - seg_gen[k]);  // later segments overwrite
     }
     out[r] = best;
+  }
+  return HAWK_OK;
+}
+
+}  // extern "C"
+
+// ---- the guide report as TSV text, written straight to its file ---------------------------------------------------------
+// The report of a C3 search is 2.2 x 10^5 rows and 0.64 GB of text (the `samples` / `haplotype_id` columns list every carrier of
+// every row).  Python needs seconds to turn columns into row strings and the rows into a file; here the columns arrive as they
+// are kept - constants, fixed-width byte matrices, ragged byte columns, integers, vocabulary indices - and the rows are
+// laid out in two parallel passes (lengths, then bytes) directly in a shared mapping of the output file.
+namespace {
+inline unsigned dec_len64(int64_t v) {
+  unsigned n = v < 0 ? 1u : 0u;
+  uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+  do { u /= 10; ++n; } while (u);
+  return n;
+}
+inline uint8_t* put_dec64(uint8_t* w, int64_t v) {
+  char tmp[24]; int n = 0;
+  uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+  do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) *w++ = '-';
+  while (n) *w++ = (uint8_t)tmp[--n];
+  return w;
+}
+inline uint64_t field_len(const hawk_tsv_col& c, uint64_t r) {
+  switch (c.kind) {
+    case HAWK_TSV_CONST: return c.width;
+    case HAWK_TSV_FIXED: return c.width;
+    case HAWK_TSV_RAGGED: return c.off[r + 1] - c.off[r];
+    case HAWK_TSV_INT64: return dec_len64(static_cast<const int64_t*>(c.data)[r]);
+    default: { const uint32_t k = static_cast<const uint32_t*>(c.data)[r]; return c.off[k + 1] - c.off[k]; }
+  }
+}
+inline uint8_t* field_put(const hawk_tsv_col& c, uint64_t r, uint8_t* w) {
+  switch (c.kind) {
+    case HAWK_TSV_CONST: memcpy(w, c.data, c.width); return w + c.width;
+    case HAWK_TSV_FIXED: memcpy(w, static_cast<const uint8_t*>(c.data) + r * c.width, c.width); return w + c.width;
+    case HAWK_TSV_RAGGED: { const uint64_t n = c.off[r + 1] - c.off[r]; memcpy(w, static_cast<const uint8_t*>(c.data) + c.off[r], n); return w + n; }
+    case HAWK_TSV_INT64: return put_dec64(w, static_cast<const int64_t*>(c.data)[r]);
+    default: {
+      const uint32_t k = static_cast<const uint32_t*>(c.data)[r];
+      const uint64_t n = c.off[k + 1] - c.off[k];
+      memcpy(w, static_cast<const uint8_t*>(c.pool) + c.off[k], n);
+      return w + n;
+    }
+  }
+}
+}  // namespace
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+extern "C" {
+
+int hawk_host_tsv_write(const char* path, const char* header, uint64_t header_len, uint64_t n_rows, const uint64_t* order, uint32_t n_cols,
+                        const hawk_tsv_col* cols, uint64_t* bytes_out) {
+  if (!path || !n_cols || !cols || (header_len && !header)) return HAWK_E_INVALID;
+  for (uint32_t c = 0; c < n_cols; ++c) {
+    const hawk_tsv_col& k = cols[c];
+    if (k.kind > HAWK_TSV_VOCAB) return HAWK_E_INVALID;
+    if (n_rows && k.kind != HAWK_TSV_CONST && !k.data) return HAWK_E_INVALID;
+    if ((k.kind == HAWK_TSV_RAGGED || k.kind == HAWK_TSV_VOCAB) && !k.off) return HAWK_E_INVALID;
+    if (k.kind == HAWK_TSV_VOCAB && !k.pool && k.n_vocab) return HAWK_E_INVALID;
+    if (k.kind == HAWK_TSV_CONST && k.width && !k.data) return HAWK_E_INVALID;
+  }
+  if (order) for (uint64_t i = 0; i < n_rows; ++i) if (order[i] >= n_rows) return HAWK_E_INVALID;
+  for (uint32_t c = 0; c < n_cols; ++c)
+    if (cols[c].kind == HAWK_TSV_VOCAB) {
+      const uint32_t* idx = static_cast<const uint32_t*>(cols[c].data);
+      for (uint64_t i = 0; i < n_rows; ++i) if (idx[i] >= cols[c].n_vocab) return HAWK_E_INVALID;
+    }
+  // pass 1: bytes of every output row (fields + tabs + newline)
+  std::vector<uint64_t> row_off(n_rows + 1, 0);
+  par_groups(n_rows, [&](uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; ++i) {
+      const uint64_t r = order ? order[i] : i;
+      uint64_t sz = n_cols;  // n_cols - 1 tabs + the newline
+      for (uint32_t c = 0; c < n_cols; ++c) sz += field_len(cols[c], r);
+      row_off[i + 1] = sz;
+    }
+  });
+  row_off[0] = header_len;
+  for (uint64_t i = 0; i < n_rows; ++i) row_off[i + 1] += row_off[i];
+  const uint64_t total = row_off[n_rows];
+  if (bytes_out) *bytes_out = total;
+  const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return HAWK_E_INVALID;
+  if (total == 0) { close(fd); return HAWK_OK; }
+  // The rows are laid out in anonymous memory (huge pages where the system grants them: first-touch faults of 4 KB pages were
+  // a third of the pass) and leave through parallel pwrite()s.  Measured on the GPU box's overlay file system, 0.63 GB of report:
+  // a shared mapping of the file 0.47 s, this 0.22 s, the layout alone 0.16 s (tools/_tsv_probe.py, round 4).
+  uint8_t* out = static_cast<uint8_t*>(mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (out == MAP_FAILED) { close(fd); return HAWK_E_INVALID; }
+#ifdef MADV_HUGEPAGE
+  (void)madvise(out, total, MADV_HUGEPAGE);
+#endif
+  if (header_len) memcpy(out, header, header_len);
+  par_groups(n_rows, [&](uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; ++i) {
+      const uint64_t r = order ? order[i] : i;
+      uint8_t* w = out + row_off[i];
+      for (uint32_t c = 0; c < n_cols; ++c) {
+        w = field_put(cols[c], r, w);
+        *w++ = c + 1 == n_cols ? '\n' : '\t';
+      }
+    }
+  });
+  int rc = HAWK_OK;
+  const uint64_t n_chunks = (total + (1u << 22) - 1) >> 22;  // 4 MB pieces
+  std::vector<int> bad(1, 0);
+  auto put = [&](uint64_t c0, uint64_t c1) {
+    uint64_t done = c0 << 22;
+    const uint64_t end = std::min<uint64_t>(total, c1 << 22);
+    while (done < end) {
+      const ssize_t k = pwrite(fd, out + done, end - done, (off_t)done);
+      if (k <= 0) { bad[0] = 1; return; }
+      done += (uint64_t)k;
+    }
+  };
+  if (n_chunks >= 16) par_groups_any(n_chunks, put); else put(0, n_chunks);
+  if (bad[0]) rc = HAWK_E_INVALID;
+  munmap(out, total);
+  if (close(fd) != 0) rc = HAWK_E_INVALID;
+  return rc;
+}
+
+// ---- the line index of a VCF text (f3: readers.VCF) ------------------------------------------------------------------------
+// A 2504-sample VCF is ~10 kB per record; the reader's index pass (where does every record start, what is its POS, where do its
+// sample columns begin) walks every byte of it once.  numpy did that at ~1.5 GB/s on one core; here the text - the reader maps the
+// file - is cut into pieces, one thread each: newlines counted, then every line's fields located.
+//   line_start[i]   offset of line i (header lines included), line_start[n_lines] = end of the last line (= len)
+//   pos[i]          POS of a record, -1 for a header line ('#'), -2 for a malformed record (no second tab / non-digit POS)
+//   gt_off[i]       offset of the record's first sample column (behind its 9th tab), 0 when the line has fewer than 9 tabs
+//   chrom_len[i]    bytes of the record's CHROM field
+// *n_lines: lines found (the text must end with a newline); with cap too small nothing but *n_lines is written and
+// HAWK_E_CAPACITY is returned.  *multi_contig: 1 when two records differ in CHROM.
+int hawk_host_vcf_index(const uint8_t* text, uint64_t len, uint64_t cap, uint64_t* line_start, int64_t* pos, uint64_t* gt_off,
+                        uint32_t* chrom_len, uint64_t* n_lines, uint32_t* multi_contig) {
+  if (!n_lines || (len && !text)) return HAWK_E_INVALID;
+  if (len && text[len - 1] != '\n') return HAWK_E_INVALID;
+  unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  if (len < (1u << 22)) nt = 1;
+  const uint64_t per = (len + nt - 1) / nt;
+  std::vector<uint64_t> cnt(nt + 1, 0);
+  auto count = [&](unsigned t) {
+    const uint64_t a = std::min<uint64_t>(len, t * per), b = std::min<uint64_t>(len, a + per);
+    uint64_t c = 0;
+    const uint8_t* p = text + a;
+    const uint8_t* e = text + b;
+    while (p < e) { const void* q = memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = static_cast<const uint8_t*>(q) + 1; }
+    cnt[t + 1] = c;
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(count, t);
+    count(0);
+    for (auto& x : th) x.join();
+  }
+  for (unsigned t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
+  const uint64_t n = cnt[nt];
+  *n_lines = n;
+  if (n > cap) return HAWK_E_CAPACITY;
+  if (!n) return HAWK_OK;
+  if (!line_start || !pos || !gt_off || !chrom_len) return HAWK_E_INVALID;
+  auto fill = [&](unsigned t) {  // line k + 1 starts behind the k-th newline
+    const uint64_t a = std::min<uint64_t>(len, t * per), b = std::min<uint64_t>(len, a + per);
+    uint64_t k = cnt[t];
+    const uint8_t* p = text + a;
+    const uint8_t* e = text + b;
+    while (p < e) {
+      const void* q = memchr(p, '\n', (size_t)(e - p));
+      if (!q) break;
+      p = static_cast<const uint8_t*>(q) + 1;
+      line_start[++k] = (uint64_t)(p - text);
+    }
+  };
+  line_start[0] = 0;
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(fill, t);
+    fill(0);
+    for (auto& x : th) x.join();
+  }
+  par_groups(n, [&](uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; ++i) {
+      const uint8_t* p = text + line_start[i];
+      const uint8_t* e = text + line_start[i + 1] - 1;  // the newline
+      gt_off[i] = 0; chrom_len[i] = 0;
+      if (p == e) { pos[i] = -1; continue; }        // empty line: skipped like a header
+      if (*p == '#') { pos[i] = -1; continue; }
+      const uint8_t* t1 = static_cast<const uint8_t*>(memchr(p, '\t', (size_t)(e - p)));
+      const uint8_t* t2 = t1 ? static_cast<const uint8_t*>(memchr(t1 + 1, '\t', (size_t)(e - t1 - 1))) : nullptr;
+      if (!t1 || !t2 || t2 == t1 + 1 || t2 - t1 > 19) { pos[i] = -2; continue; }
+      int64_t v = 0;
+      bool ok = true;
+      for (const uint8_t* q = t1 + 1; q < t2; ++q) { if (*q < '0' || *q > '9') { ok = false; break; } v = v * 10 + (*q - '0'); }
+      if (!ok) { pos[i] = -2; continue; }
+      pos[i] = v;
+      chrom_len[i] = (uint32_t)(t1 - p);
+      const uint8_t* q = t2;  // the 2nd tab; seven more end the FORMAT column
+      int tabs = 2;
+      while (tabs < 9) {
+        q = static_cast<const uint8_t*>(memchr(q + 1, '\t', (size_t)(e - q - 1)));
+        if (!q) break;
+        ++tabs;
+      }
+      if (q && tabs == 9) gt_off[i] = (uint64_t)(q + 1 - text);
+    }
+  });
+  if (multi_contig) {
+    *multi_contig = 0;
+    uint64_t f = n;
+    for (uint64_t i = 0; i < n; ++i) if (pos[i] >= 0) { f = i; break; }
+    if (f < n) {
+      const uint8_t* c0 = text + line_start[f];
+      const uint32_t l0 = chrom_len[f];
+      par_groups(n, [&](uint64_t i0, uint64_t i1) {
+        for (uint64_t i = i0; i < i1; ++i)
+          if (pos[i] >= 0 && (chrom_len[i] != l0 || memcmp(text + line_start[i], c0, l0) != 0)) { *multi_contig = 1; return; }
+      });
+    }
   }
   return HAWK_OK;
 }

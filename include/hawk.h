@@ -289,6 +289,39 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
 int hawk_table_collapse_export(hawk_table* t, uint32_t* rep_row, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
                                uint8_t* flags, double* cfdon, uint64_t* win, uint32_t* member_hap, float* kernel_ms);
 
+/* The line index of a VCF text held in (mapped) memory - replaces the streaming index pass of readers.VCF (variant.py:622-708: the
+ * reference opens the file through pysam / tabix): per line its start, POS (-1 header or empty line, -2 malformed record), where
+ * the sample columns begin (0: fewer than nine tabs) and the length of its CHROM field; line_start has n_lines + 1 entries.  The
+ * text must end with a newline.  HAWK_E_CAPACITY (only *n_lines written) when cap < lines.  Multi-threaded, no device work. */
+int hawk_host_vcf_index(const uint8_t* text, uint64_t len, uint64_t cap, uint64_t* line_start, int64_t* pos, uint64_t* gt_off,
+                        uint32_t* chrom_len, uint64_t* n_lines, uint32_t* multi_contig);
+
+/* The guide report written as TSV text straight to its file (what _store_report does with DataFrame.to_csv(sep="\t", index=False),
+ * reports.py:739) from COLUMNS as the assembly keeps them, so that no row string and no text column ever exists in Python - a C3
+ * report is 0.64 GB of text.  Output row i is source row order[i] (order == NULL: i), fields separated by tabs, rows ended by a
+ * newline; `header` (with its newline) goes first.  The caller guarantees that no field holds a tab, quote or line break (csv's
+ * minimal quoting would then apply; reports.write_report_tsv checks the vocabularies and falls back to pandas).  Column kinds:
+ *   HAWK_TSV_CONST   data = the text (width bytes), the same in every row
+ *   HAWK_TSV_FIXED   data = [n_rows][width] bytes
+ *   HAWK_TSV_RAGGED  data = bytes, off = [n_rows + 1] offsets into them
+ *   HAWK_TSV_INT64   data = int64[n_rows], written in decimal
+ *   HAWK_TSV_VOCAB   data = uint32[n_rows] indices into n_vocab strings: pool = their bytes, off = [n_vocab + 1] offsets
+ * Multi-threaded, two passes (row lengths, then bytes) into a shared mapping of the file (plain writes where mapping fails). */
+#define HAWK_TSV_CONST 0u
+#define HAWK_TSV_FIXED 1u
+#define HAWK_TSV_RAGGED 2u
+#define HAWK_TSV_INT64 3u
+#define HAWK_TSV_VOCAB 4u
+typedef struct {
+  uint32_t kind, width;
+  const void* data;
+  const uint64_t* off;
+  const void* pool;
+  uint64_t n_vocab;
+} hawk_tsv_col;
+int hawk_host_tsv_write(const char* path, const char* header, uint64_t header_len, uint64_t n_rows, const uint64_t* order, uint32_t n_cols,
+                        const hawk_tsv_col* cols, uint64_t* bytes_out);
+
 /* Host-side helper of the report assembly (no device work): the report's `samples` / `haplotype_id` columns list every
  * carrier of every report row (reports.py:767-857) - a ragged join of label strings.  Items item_label[group_off[g] ..
  * group_off[g+1]) of group g name byte strings pool[pool_off[l] .. pool_off[l+1]); the group's text is those strings

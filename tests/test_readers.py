@@ -348,3 +348,37 @@ def test_vcf_index_rejects_truncated_and_one_tab_lines(tmp_path):
     finally:
         readers._TextSource.CHUNK = old
     assert v.samples == names and v.phased and list(v._pos) == [100]
+
+
+def test_mapped_vcf_index_equals_the_streamed_one(tmp_path, monkeypatch):
+    """A plain-text VCF is indexed by the library's host helper over a mapping of the file (hawk_host_vcf_index: all cores, one
+    pass); the numpy stream stays for gzip / bgzip / unterminated files.  Both must build the same index and hand out the same
+    record blocks (text, line offsets, sample-column offsets, fixed fields)."""
+    reg = synth.make_region(9501, "chrC", 180_000, 4_000, 176_000)
+    synth.add_phased_variants(reg, 9502, 2500, 30, af_min=0.05, af_max=0.5)
+    rows = [reg.vcf_fields(v) for v in reg.variants]
+    plain = str(tmp_path / "p.vcf")
+    readers.write_vcf(plain, reg.contig, reg.samples, rows, False)
+    fast = readers.VCF(plain)
+    assert fast._mm is not None and fast._gt_abs is not None
+    monkeypatch.setattr(readers.VCF, "_index_mapped", lambda self: False)
+    slow = readers.VCF(plain)
+    assert slow._mm is None
+    for k in ("_starts", "_ends", "_pos"):
+        assert np.array_equal(getattr(fast, k), getattr(slow, k)), k
+    assert (fast.samples, fast.contig, fast.phased, fast._total) == (slow.samples, slow.contig, slow.phased, slow._total)
+    for lo, hi in ((4_000, 9_000), (100_000, 101_000), (1, 180_000), (50, 60)):
+        c = Coordinate("chrC", lo, hi, 0)
+        a, b = fast.fetch_block(c), slow.fetch_block(c)
+        assert len(a) == len(b) and bytes(a.text) == bytes(b.text)
+        assert np.array_equal(a.line_off, b.line_off) and np.array_equal(a.gt_off, b.gt_off) and a.fixed == b.fixed
+        assert [(g.position, g.ref, g.alt) for g in fast.fetch(c)] == [(g.position, g.ref, g.alt) for g in slow.fetch(c)]
+    # a record without sample columns is refused when its block is asked for, as by the stream
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    f = tmp_path / "nosamples.vcf"
+    f.write_text(head + "chrZ\t100\t.\tA\tG\t.\tPASS\tAF=0.5\n")
+    monkeypatch.undo()
+    v = readers.VCF(str(f), 0, True)
+    assert v._mm is not None
+    with pytest.raises(ValueError, match="no sample columns"):
+        v.fetch_block(Coordinate("chrZ", 1, 1000, 0))

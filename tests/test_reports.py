@@ -225,3 +225,58 @@ def test_pipeline_model_scorers_fill_their_columns(tmp_path):
             assert (got[c] == want[c]).all(), c
     # the report groups on the score column, so equal order also means the scores did not split or reorder groups
     assert (got["score_deepcpf1"] != "NA").all() and np.isfinite(got["score_deepcpf1"].astype(float)).all()
+
+
+def test_native_tsv_writer_equals_the_dataframe_route(tmp_path):
+    """reports.write_report_tsv (hawk_host_tsv_write: the columns as they are kept -> the file, multi-threaded) against
+    DataFrame -> to_tsv on every column kind, a permuted row order, empty fields, negative and large integers; a field csv
+    quoting would touch sends the report through pandas; an empty report is the header alone."""
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 5000):
+        cols = {"chr": reports.ConstCol("chr1", n), "start": reports.IntCol(rng.integers(-5, 10**15, n)),
+                "sgRNA_sequence": reports.FixedCol(rng.integers(65, 70, (n, 20)).astype(np.uint8)),
+                "strand": reports.VocabCol(rng.integers(0, 2, n), ["+", "-"], False),
+                "score": reports.VocabCol(rng.integers(0, 4, n), ["NA", "0.5", "1e-05", ""]),
+                "samples": reports.Ragged.from_strings([",".join(f"S{j}:1|0" for j in range(int(k))) for k in rng.integers(0, 40, n)]),
+                "blank": reports.ConstCol("", n)}
+        order = rng.permutation(n)
+        want = reports.to_tsv(pd.DataFrame({c: reports._col_array(col)[order] for c, col in cols.items()}))
+        path = str(tmp_path / f"r{n}.tsv")
+        assert reports.write_report_tsv(path, cols, order) == len(want)
+        assert open(path).read() == want
+    odd = dict(cols, samples=reports.Ragged.from_strings(['a"b'] * n))
+    want = reports.to_tsv(pd.DataFrame({c: reports._col_array(col)[order] for c, col in odd.items()}))
+    reports.write_report_tsv(path, odd, order, plain=False)
+    assert open(path).read() == want and '"a""b"' in want
+    empty = {c: reports.Ragged(np.zeros(0, np.uint8), np.zeros(1, np.uint64)) for c in ("chr", "start")}
+    reports.write_report_tsv(path, empty, np.zeros(0, np.int64))
+    assert open(path).read() == "chr\tstart\n"
+
+
+def test_report_order_resolves_ties_like_the_full_lexsort():
+    """_report_order sorts on (start, stop) and forms the string keys only for rows that tie on both: same permutation as one
+    lexsort over every group column"""
+    rng = np.random.default_rng(6)
+    n = 4000
+    start = rng.integers(0, 300, n)
+    stop = start + rng.integers(20, 23, n)
+    cols = {"chr": reports.ConstCol("c", n), "start": reports.IntCol(start), "stop": reports.IntCol(stop),
+            "sgRNA_sequence": reports.FixedCol(rng.integers(65, 68, (n, 3)).astype(np.uint8)), "pam": reports.FixedCol(rng.integers(65, 67, (n, 2)).astype(np.uint8)),
+            "strand": reports.VocabCol(rng.integers(0, 2, n), ["+", "-"], False),
+            "score_cfdon": reports.VocabCol(rng.integers(0, 3, n), ["NA", "0.25", "1.0"]),
+            "gc_content": reports.VocabCol(rng.integers(0, 3, n), ["0.5", "0.55", "1.0"]),
+            "origin": reports.VocabCol(rng.integers(0, 2, n), ["ref", "alt"], False)}
+    gcols = ["chr", "start", "stop", "sgRNA_sequence", "pam", "strand", "score_cfdon", "gc_content", "origin"]
+    got = reports._report_order(cols, gcols, n)
+    keys = []
+    for c in reversed(gcols):
+        if c == "chr":
+            continue
+        k = reports._col_array(cols[c])
+        keys.append(k if k.dtype.kind in "iuU" else k.astype("U"))
+    keys += [stop, start]
+    want = np.lexsort(keys)
+    # rows that agree in every key may come in either order: compare the keys along the two permutations
+    for k in keys:
+        assert np.array_equal(k[got], k[want])
