@@ -585,6 +585,7 @@ class HapLabels:
         self.var_off, self.var_idx = np.asarray(var_off, dtype=np.int64), np.asarray(var_idx, dtype=np.int64)
         self.vid, self.af, self.segments = vid, np.asarray(af, dtype=np.float64), segments
         self._vt = None
+        self.seg_csr = None  # optional (seg_start[H + 1], seg_rel, seg_gen): every row's position map as flat arrays
 
     def __len__(self):
         return len(self.samples)
@@ -611,7 +612,14 @@ class HapLabels:
                         af.append(float(h.afs[v]))
                     idx.append(k)
             off.append(len(idx))
-        return cls(samples, ids, np.array(is_ref, dtype=bool), np.array(off), np.array(idx, dtype=np.int64), vid, np.array(af), segs)
+        lab = cls(samples, ids, np.array(is_ref, dtype=bool), np.array(off), np.array(idx, dtype=np.int64), vid, np.array(af), segs)
+        if all(x is None or hasattr(x, "rel") for x in segs):  # the rows' position maps as flat arrays (rows without one: a single identity segment)
+            rel = [np.zeros(1, np.uint32) if x is None else np.asarray(x.rel, dtype=np.uint32) for x in segs]
+            gen = [np.zeros(1, np.int64) if x is None else np.asarray(x.gen, dtype=np.int64) for x in segs]
+            start = np.concatenate(([0], np.cumsum([len(r) for r in rel]))).astype(np.uint64)
+            lab.seg_csr = (start, np.ascontiguousarray(np.concatenate(rel)) if rel else np.zeros(0, np.uint32),
+                           np.ascontiguousarray(np.concatenate(gen)) if gen else np.zeros(0, np.int64))
+        return lab
 
     def variant_table(self):
         """(adjusted position, is SNV, SNV alt base, ref, alt, formatted AF) per variant of `vid` (annotation.py:53-62)."""
@@ -695,8 +703,28 @@ def _variant_columns_raw(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabe
     slow_vid: List[str] = []
     slow_af: List[str] = []
     # ---- rows with an indel among the candidates (or a non-linear position map): the reference's own walk over the
-    # candidates (variants elsewhere on the haplotype cannot match a position of this guide)
+    # candidates (variants elsewhere on the haplotype cannot match a position of this guide) - by the library's helper for all
+    # such rows at once when the rows' position maps are at hand as flat arrays, row by row in Python otherwise
     slow = np.flatnonzero(~fast)
+    polished = None
+    if len(slow) and lab.seg_csr is not None:
+        polished = _polish_rows_native(G, lab, alt_rows, hh, slow, a, cnt, v_var, cores, t_pos, t_ref, t_alt, name_rank)
+    if polished is not None:
+        p_off, p_var, need_py = polished
+        # ids in string order; allele frequencies in the ids' order, "NA" when the row shows nothing or every frequency is missing
+        s_ids = _ragged_join_raw(p_var, p_off, *_pool(lab.vid))
+        s_afs = _ragged_join_raw(af_of_var[p_var], p_off, *_pool(af_names))
+        n_shown = np.diff(p_off.astype(np.int64))
+        has_af = np.zeros(len(slow), dtype=bool)
+        if len(p_var):
+            row_of = np.repeat(np.arange(len(slow)), n_shown)
+            np.logical_or.at(has_af, row_of, af_of_var[p_var] != na_id)
+        base_v = NA + 1  # rows of the extended pools: ids / afs of the fast rows, "NA", then the slow rows' strings
+        gsl = alt_rows[slow]
+        vid_lab[gsl] = base_v + np.arange(len(slow))
+        af_lab[gsl] = np.where(has_af, base_v + np.arange(len(slow)), NA)
+        slow_vid, slow_af = s_ids.strings(), s_afs.strings()
+        slow = slow[need_py != 0]  # (rows on which the reference's own assertion fires: its Python mirror raises below)
     if len(slow):
         s_off = np.concatenate(([0], np.cumsum(cnt)))
         pvl = pair_var.tolist()
@@ -717,6 +745,57 @@ def _variant_columns_raw(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabe
             slow_vid.append(",".join(sorted(set(vids))) if variant_id else "")
             slow_af.append("NA" if not afl or (len(set(afl)) == 1 and afl[0] == "NA") else ",".join(afl))
     return ids.extended(["NA"] + slow_vid).select(vid_lab), afs.extended(["NA"] + slow_af).select(af_lab)
+
+
+def _polish_rows_native(G, lab: "HapLabels", alt_rows, hh, slow, a, cnt, v_var, cores, t_pos, t_ref, t_alt, name_rank):
+    """annotation.polish_guide_variants for the rows `slow` (indices into alt_rows) by hawk_host_polish_rows.  Returns (CSR offsets,
+    the shown variants in id order, need_python flags) or None when the helper is not available."""
+    import ctypes as C
+    from . import _lib
+    try:
+        fn = _host_lib().hawk_host_polish_rows
+    except AttributeError:
+        return None
+    L = G.guidelen + G.pamlen
+    n = len(slow)
+    # candidates of every slow row, ascending and without duplicates
+    c_cnt = cnt[slow]
+    c_off = np.concatenate(([0], np.cumsum(c_cnt))).astype(np.uint64)
+    tot = int(c_off[-1])
+    src = np.repeat(a[slow], c_cnt) + (np.arange(tot) - np.repeat(c_off[:-1].astype(np.int64), c_cnt))
+    cand = v_var[src].astype(np.uint32)
+    row = np.repeat(np.arange(n), c_cnt)
+    o = np.lexsort((cand, row))
+    cand, row = cand[o], row[o]
+    keep = np.ones(tot, dtype=bool)
+    keep[1:] = (row[1:] != row[:-1]) | (cand[1:] != cand[:-1])
+    cand, row = np.ascontiguousarray(cand[keep]), row[keep]
+    c_off = np.concatenate(([0], np.cumsum(np.bincount(row, minlength=n)))).astype(np.uint64)
+    g_rows = alt_rows[slow]
+    strand = np.asarray(G.strand)[g_rows].astype(bool)
+    stored_right = np.logical_xor(bool(G.right), strand)
+    pos = np.asarray(G.pos)[g_rows].astype(np.int64)
+    pivot = np.ascontiguousarray(np.where(stored_right, pos, pos - G.guidelen), dtype=np.int64)
+    stop = np.ascontiguousarray(np.asarray(G.stop, dtype=np.int64)[g_rows])
+    hp = np.ascontiguousarray(hh[slow], dtype=np.uint32)
+    cr = np.ascontiguousarray(cores[g_rows], dtype=np.uint8)
+    seg_start, seg_rel, seg_gen = lab.seg_csr
+    rpool, roff = _pool(t_ref)
+    apool, aoff = _pool(t_alt)
+    if len(rpool) == 0:
+        rpool = np.zeros(1, np.uint8)
+    if len(apool) == 0:
+        apool = np.zeros(1, np.uint8)
+    tp = np.ascontiguousarray(t_pos, dtype=np.int64)
+    nr = np.ascontiguousarray(name_rank, dtype=np.uint32)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    out_var = np.zeros(max(len(cand), 1), dtype=np.uint32)
+    need = np.zeros(n, dtype=np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    _lib.check(fn(C.c_uint64(n), C.c_uint32(L), p(cr), p(hp), p(pivot), p(stop), p(c_off), p(cand), p(seg_start), p(seg_rel), p(seg_gen),
+                  C.c_uint64(len(seg_start) - 1), p(tp), p(rpool), p(roff), p(apool), p(aoff), C.c_uint32(len(tp)), p(nr), p(out_off), p(out_var), p(need)),
+               "hawk_host_polish_rows")
+    return out_off, out_var[:int(out_off[-1])], need
 
 
 def _variant_columns(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabels):
@@ -867,7 +946,13 @@ def group_columns(G, haplotypes, pam: PAM, contig: str, target: str, scores: Opt
     for p in range(5):
         code |= (((np.asarray(G.win[p])[:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
     cores = _CODE2CHAR[code]
-    vid_col, af_col = _variant_columns_raw(G, rep_hap, cores, lab)
+    # the two columns that list every carrier of every row are byte gathers inside the library (no GIL held): they run on a
+    # second thread while this one works out the variant columns
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        carriers = pool.submit(lambda: (_samples_raw(member_off, member_hap, lab.samples), _hapids_raw(member_off, member_hap, lab.ids)))
+        vid_col, af_col = _variant_columns_raw(G, rep_hap, cores, lab)
+        samples_col, hapids_col = carriers.result()
     # reverse_guides (annotation.py:27-51): strand-1 rows read as their reverse complement, case preserved
     strand = np.asarray(G.strand).astype(np.int64)
     guide = cores.copy()
@@ -895,11 +980,11 @@ def group_columns(G, haplotypes, pam: PAM, contig: str, target: str, scores: Opt
     uniq, inv = np.unique(gkey, return_inverse=True)
     data["gc_content"] = VocabCol(inv.reshape(-1), [str((int(k) >> 16) / (int(k) & 0xffff) if (int(k) & 0xffff) else 0.0) for k in uniq.tolist()])
     data["origin"] = VocabCol((~is_ref_hap[rep_hap]).astype(np.uint32), ["ref", "alt"], as_object=False)
-    data["samples"] = _samples_raw(member_off, member_hap, lab.samples)
+    data["samples"] = samples_col
     data["variant_id"] = vid_col
     data["af"] = af_col
     data["target"] = ConstCol(target, ng)
-    data["haplotype_id"] = _hapids_raw(member_off, member_hap, lab.ids)
+    data["haplotype_id"] = hapids_col
     plain = _plain([contig, target]) and _plain(lab.samples) and _plain(lab.ids) and _plain(lab.vid)
     if offtargets is not None:  # a dict {SPACER: (count, cfd)} or a callable that builds it from the rows' spacers
         spacers = data["sgRNA_sequence"].array()

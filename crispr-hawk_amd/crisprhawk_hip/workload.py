@@ -907,6 +907,20 @@ def row_labels(reg: SynthRegion, ds, info: List[HapInfo], kept: List[int]) -> Li
     return out
 
 
+class _LazySegments:
+    """list-like: the PosSegments of a kept row on demand (host_meta[r].seg), None for rows that collapsed onto another"""
+
+    def __init__(self, host_meta, kept, n: int):
+        self._hm, self._kept, self._n = host_meta, set(int(r) for r in kept), n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, r):
+        r = int(r)
+        return self._hm[r].seg if r in self._kept else None
+
+
 def hap_labels(contig: str, variants, ds, info: List[HapInfo], kept: List[int]):
     """reports.HapLabels of an expanded set, straight from the carried-variant index lists (no per-row id strings):
     `variants` = the variant records in table order with .pos .ref .alt .af (synth.VariantSite) or a VcfVariants."""
@@ -917,14 +931,15 @@ def hap_labels(contig: str, variants, ds, info: List[HapInfo], kept: List[int]):
         vid = [f"{contig}-{v.pos}-{v.ref}/{v.alt}" for v in variants]
         af = np.array([float(v.af) for v in variants], dtype=np.float64)
     n = ds.n_hap
-    samples, ids, segs = [""] * n, [""] * n, [None] * n
+    samples, ids = [""] * n, [""] * n
+    hm = ds.host_meta
+    segs = _LazySegments(hm, kept, n)  # a row's PosSegments only when the report's Python fallback asks for it
     is_ref = np.zeros(n, dtype=bool)
     cnt = np.zeros(n, dtype=np.int64)
     parts = []
     for k, (r, inf) in enumerate(zip(kept, info)):
         samples[r] = ",".join(inf.samples)
         ids[r] = f"hap_{k:08d}"
-        segs[r] = ds.host_meta[r].seg
         is_ref[r] = r == 0 or samples[r] == "REF"
         idx = np.asarray(inf.variant_idx, dtype=np.int64)
         cnt[r] = len(idx)
@@ -932,4 +947,8 @@ def hap_labels(contig: str, variants, ds, info: List[HapInfo], kept: List[int]):
     for j in order.tolist():
         parts.append(np.asarray(info[j].variant_idx, dtype=np.int64))
     var_idx = np.concatenate(parts) if parts else np.zeros(0, np.int64)
-    return HapLabels(samples, ids, is_ref, np.concatenate(([0], np.cumsum(cnt))), var_idx, vid, af, segs)
+    lab = HapLabels(samples, ids, is_ref, np.concatenate(([0], np.cumsum(cnt))), var_idx, vid, af, segs)
+    if hasattr(hm, "seg_start"):  # the rows' position maps as flat CSR arrays: what the library's polish helper walks
+        lab.seg_csr = (np.ascontiguousarray(hm.seg_start, dtype=np.uint64), np.ascontiguousarray(hm.seg_rel, dtype=np.uint32),
+                       np.ascontiguousarray(hm.seg_gen, dtype=np.int64))
+    return lab

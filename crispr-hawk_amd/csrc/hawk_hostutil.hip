@@ -533,4 +533,116 @@ int hawk_host_vcf_index(const uint8_t* text, uint64_t len, uint64_t cap, uint64_
   return HAWK_OK;
 }
 
+
+// ---- which of a haplotype's variants a guide shows (annotation.py:246-284, polish_guide_variants) ----------------------------
+// The report's variant_id / af columns: for a row whose candidate variants are all SNVs the assembly answers in bulk (numpy); a
+// row with an indel among them - or a position map that is not linear over the guide - needs the reference's own walk over the
+// guide's positions, which took 25 us of Python per row (C3: 10^4 rows, a quarter of a second).  Here the walk itself, for all
+// such rows at once:
+//   row k: spacer + PAM `cores[k]` (L cased bytes, + strand), haplotype row hap[k] whose position map is segments
+//   [seg_start[h], seg_start[h + 1]) of (seg_rel, seg_gen), first guide position pivot[k], genomic `stop[k]`, candidates
+//   cand_var[cand_off[k] .. cand_off[k + 1]) - variant indices, ascending, no duplicates.
+//   variant v: adjusted position t_pos[v], alleles ref / alt (pools), name_rank[v] = rank of its id in string order.
+// Output: out_var[out_off[k] .. out_off[k + 1]) = the variants the guide shows, in id order (out_var holds cand_off[n] entries at
+// most); need_python[k] = 1 where the reference's code would trip its own assertion (annotation.py:185-189) - the caller runs
+// its Python mirror on those rows, which raises as the reference does.
+namespace {
+inline bool is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
+inline bool is_lower(uint8_t c) { return c >= 'a' && c <= 'z'; }
+inline uint8_t to_upper(uint8_t c) { return is_lower(c) ? (uint8_t)(c - 32) : c; }
+}  // namespace
+int hawk_host_polish_rows(uint64_t n, uint32_t L, const uint8_t* cores, const uint32_t* hap, const int64_t* pivot, const int64_t* stop,
+                          const uint64_t* cand_off, const uint32_t* cand_var, const uint64_t* seg_start, const uint32_t* seg_rel,
+                          const int64_t* seg_gen, uint64_t n_haps, const int64_t* t_pos, const uint8_t* ref_pool, const uint64_t* ref_off,
+                          const uint8_t* alt_pool, const uint64_t* alt_off, uint32_t n_var, const uint32_t* name_rank, uint64_t* out_off,
+                          uint32_t* out_var, uint8_t* need_python) {
+  if (!n) { if (out_off) out_off[0] = 0; return HAWK_OK; }
+  if (!cores || !hap || !pivot || !stop || !cand_off || !seg_start || !seg_rel || !seg_gen || !t_pos || !ref_off || !alt_off || !name_rank ||
+      !out_off || !out_var || !need_python || !L || L > 64)
+    return HAWK_E_INVALID;
+  for (uint64_t k = 0; k < n; ++k) if (hap[k] >= n_haps || cand_off[k + 1] < cand_off[k]) return HAWK_E_INVALID;
+  for (uint64_t i = 0; i < cand_off[n]; ++i) if (cand_var[i] >= n_var) return HAWK_E_INVALID;
+  std::vector<uint32_t> cnt(n, 0);
+  par_groups(n, [&](uint64_t k0, uint64_t k1) {
+    int64_t gen[64];
+    for (uint64_t k = k0; k < k1; ++k) {
+      need_python[k] = 0;
+      const uint8_t* g = cores + k * L;
+      // genomic position of every guide position: PosSegments.lookup (last segment with rel <= p)
+      const uint64_t s0 = seg_start[hap[k]], s1 = seg_start[hap[k] + 1];
+      uint64_t j = s0;
+      {
+        uint64_t lo = s0, hi = s1;  // last j in [s0, s1) with seg_rel[j] <= pivot (seg_rel[s0] = 0)
+        const int64_t p0 = pivot[k] < 0 ? 0 : pivot[k];
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if ((int64_t)seg_rel[mid] <= p0) lo = mid; else hi = mid; }
+        j = lo;
+      }
+      for (uint32_t i = 0; i < L; ++i) {
+        const int64_t p = pivot[k] + i;
+        while (j + 1 < s1 && (int64_t)seg_rel[j + 1] <= p) ++j;
+        gen[i] = seg_gen[j] + (p - (int64_t)seg_rel[j]);
+      }
+      uint32_t* w = out_var + cand_off[k];
+      uint32_t m = 0;
+      for (uint32_t i = 0; i < L && !need_python[k]; ++i) {
+        uint32_t offset = 0;
+        for (uint64_t c = cand_off[k]; c < cand_off[k + 1]; ++c) {
+          const uint32_t v = cand_var[c];
+          if (t_pos[v] != gen[i]) continue;
+          const uint64_t rl = ref_off[v + 1] - ref_off[v], al = alt_off[v + 1] - alt_off[v];
+          const uint8_t* alt = alt_pool + alt_off[v];
+          const bool is_snv = rl == al;
+          if (!is_snv) offset = rl < al ? (uint32_t)(al - rl) : 0u;
+          const uint32_t sl = std::min<uint32_t>(offset + 1, L - i);  // seg = guidepam[i : i + offset + 1]
+          const uint8_t* seg = g + i;
+          bool show = false;
+          if (!is_snv) {  // _check_insertion
+            if (i == 0) {
+              // _find_insertion_stop asserts a lower-case first base and at least one base that is not upper case
+              bool all_up = true;
+              for (uint32_t q = 0; q < sl; ++q) all_up = all_up && is_upper(seg[q]);
+              if (is_upper(seg[0]) || all_up) { need_python[k] = 1; break; }
+              uint32_t st = 0;
+              for (uint32_t q = 0; q < sl; ++q) if (is_upper(seg[q])) { st = q; break; }
+              bool ends = st <= al;  // alt.endswith(seg.upper()[:st])
+              for (uint32_t q = 0; q < st && ends; ++q) ends = alt[al - st + q] == to_upper(seg[q]);
+              show = ends;
+            }
+            if (!show && gen[i] == stop[k] && sl <= al) {  // alt.startswith(seg.upper())
+              bool starts = true;
+              for (uint32_t q = 0; q < sl && starts; ++q) starts = alt[q] == to_upper(seg[q]);
+              show = starts;
+            }
+          }
+          if (!show) {  // seg.islower() and seg.upper() == alt
+            bool low = true;
+            for (uint32_t q = 0; q < sl; ++q) low = low && is_lower(seg[q]);
+            if (low && sl == al) {
+              bool eq = true;
+              for (uint32_t q = 0; q < sl && eq; ++q) eq = alt[q] == to_upper(seg[q]);
+              show = eq;
+            }
+          }
+          if (show) {
+            bool dup = false;
+            for (uint32_t q = 0; q < m; ++q) dup = dup || w[q] == v;
+            if (!dup) w[m++] = v;
+          }
+        }
+      }
+      if (need_python[k]) m = 0;
+      std::sort(w, w + m, [&](uint32_t a, uint32_t b) { return name_rank[a] < name_rank[b]; });
+      cnt[k] = m;
+    }
+  });
+  // compact: out_var[out_off[k] ..) in place (rows only move towards the front)
+  out_off[0] = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t src = cand_off[k], dst = out_off[k];
+    if (dst != src) memmove(out_var + dst, out_var + src, (size_t)cnt[k] * 4);
+    out_off[k + 1] = dst + cnt[k];
+  }
+  return HAWK_OK;
+}
+
 }  // extern "C"

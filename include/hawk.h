@@ -289,6 +289,20 @@ int hawk_table_collapse_ex(hawk_table* t, uint32_t flank_up, uint32_t flank_down
 int hawk_table_collapse_export(hawk_table* t, uint32_t* rep_row, uint32_t* pos, uint8_t* strand, int64_t* start, int64_t* stop,
                                uint8_t* flags, double* cfdon, uint64_t* win, uint32_t* member_hap, float* kernel_ms);
 
+/* Host-side helper of the report assembly: which of its haplotype's variants a guide SHOWS - annotation.polish_guide_variants
+ * (annotation.py:185-284) - for many rows at once (the rows with an indel among their candidate variants; all-SNV rows are answered
+ * in bulk by the caller).  Row k: cores[k] = the + strand spacer + PAM (L cased bytes), hap[k] its haplotype row whose position map
+ * is segments [seg_start[h], seg_start[h + 1]) of (seg_rel, seg_gen), pivot[k] the guide's first position in the row, stop[k] its
+ * genomic stop, cand_var[cand_off[k] .. cand_off[k + 1]) the candidate variants (ascending indices, no duplicates).  Variant v:
+ * adjusted position t_pos[v], alleles in the ref / alt pools, name_rank[v] = rank of its id in string order.  out_var (capacity
+ * cand_off[n]) receives per row the variants shown, in id order, out_off their CSR offsets; need_python[k] = 1 where the
+ * reference's own assertion (annotation.py:185-189) would fire - the caller's Python mirror then raises as the reference does. */
+int hawk_host_polish_rows(uint64_t n, uint32_t L, const uint8_t* cores, const uint32_t* hap, const int64_t* pivot, const int64_t* stop,
+                          const uint64_t* cand_off, const uint32_t* cand_var, const uint64_t* seg_start, const uint32_t* seg_rel,
+                          const int64_t* seg_gen, uint64_t n_haps, const int64_t* t_pos, const uint8_t* ref_pool, const uint64_t* ref_off,
+                          const uint8_t* alt_pool, const uint64_t* alt_off, uint32_t n_var, const uint32_t* name_rank, uint64_t* out_off,
+                          uint32_t* out_var, uint8_t* need_python);
+
 /* The line index of a VCF text held in (mapped) memory - replaces the streaming index pass of readers.VCF (variant.py:622-708: the
  * reference opens the file through pysam / tabix): per line its start, POS (-1 header or empty line, -2 malformed record), where
  * the sample columns begin (0: fewer than nine tabs) and the length of its CHROM field; line_start has n_lines + 1 entries.  The

@@ -64,9 +64,32 @@ def test_report_from_oracle_rows_matches_reference_tsv(case):
     df = reports.report_frame(inp, labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     assert reports.to_tsv(df) == fx["report_tsv"]
     # the columnar assembler (group-level inputs, ragged joins in the library's host helper) writes the same text
-    df2 = reports.report_from_groups(reports.ReportGroups.from_report_input(inp), labels, _pam(fx), fx["contig"], fx["target"],
-                                     with_cfdon=fx["cfd"])
+    G = reports.ReportGroups.from_report_input(inp)
+    df2 = reports.report_from_groups(G, labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     assert reports.to_tsv(df2) == fx["report_tsv"]
+    # rows with an indel among their candidate variants: the library's polish helper (position maps as flat arrays) and the
+    # Python mirror of annotation.polish_guide_variants must name the same variants
+    lab = reports.HapLabels.from_objects(labels)
+    assert lab.seg_csr is not None
+    calls = []
+    orig = reports._polish_rows_native
+    reports._polish_rows_native = lambda *a, **k: (calls.append(len(a[4])), orig(*a, **k))[1]
+    try:
+        native = reports.group_columns(G, lab, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
+    finally:
+        reports._polish_rows_native = orig
+    lab.seg_csr = None
+    mirror = reports.group_columns(G, lab, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
+    for c in ("variant_id", "af"):
+        assert native[0][c].strings() == mirror[0][c].strings(), c
+    if case == "indel_dense":
+        assert calls and calls[0] > 50  # the helper really had rows to walk
+    # ... and the columns written by the library's TSV writer are the reference's text
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "r.tsv")
+        reports.write_report_tsv(path, *native)
+        assert open(path).read() == fx["report_tsv"]
 
 
 def test_samples_column_general_cases():
