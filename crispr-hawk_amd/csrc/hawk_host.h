@@ -199,3 +199,11 @@ inline bool hawk_table_stale(const hawk_table* t) { return t->hs && t->gen != t-
 
 int hawk_reserve_cols(DevBuf (&b)[8], uint64_t cap, GuideCols* c);
 
+// shared by the C-ABI translation units (hawk_api_*.hip)
+int hapset_create_impl(hawk_ctx* ctx, uint32_t n_hap, const uint32_t* hap_len, bool zero_planes, hawk_hapset** out, bool alloc_planes = true);
+HapSetDev make_dev(const hawk_hapset* hs);
+int make_scan_params(const hawk_hapset* hs, uint64_t pam_fwd, uint64_t pam_rev, uint32_t pamlen, uint32_t guidelen,
+                            uint32_t right, bool need_v, ScanParams* sp);
+int meta_build(uint32_t n, const std::vector<uint32_t>& hap_len, uint32_t bph, const uint8_t* is_ref, const int32_t* scan_start,
+                      const int32_t* scan_stop, const uint32_t* seg_off, const uint32_t* seg_rel, const int64_t* seg_gen,
+                      int32_t ref_index, std::vector<TileMeta>* t0, int64_t* min_gen, int64_t* max_gen);

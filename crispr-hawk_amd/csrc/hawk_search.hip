@@ -188,10 +188,7 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
 
   uint32_t nvalid = 0;  // this thread's share (PASS 0)
   uint32_t lrun = 0;  // valid survivors listed so far (list mode)
-#ifndef ABL
-#define ABL 0
-#endif
-  if (!stage || (PASS == 0 && !dedup && (!list_mode || T > LIST_CAP)) || (PASS == 0 && ABL == 1)) {
+  if (!stage || (PASS == 0 && !dedup && (!list_mode || T > LIST_CAP))) {
     if (tid == 0) nvalid = T;  // nothing can be redundant here and no list is wanted: the count is the survivor count
   } else if (T) {  // workgroup-uniform
     const int nloc = (int)s_acc[3];
@@ -284,7 +281,7 @@ __device__ __forceinline__ void search_tile(const HapSetDev& hs, const ScanParam
           }
           c_valid = 1;
           c_has_ref = isref;
-          if (dedup && ABL != 2) {  // workgroup-uniform
+          if (dedup) {  // workgroup-uniform
             // A REF guide shares (start, strand) iff REF has a candidate window starting at qr = start - startp: one bit of
             // the per-strand bitmaps k_ref_bits left in HBM (2 x 125 KB on C3, L2-resident).  The survivor is redundant
             // iff the four code planes agree as well: the planes the PAM names (just streamed, L2-hot) are compared for

@@ -19,9 +19,6 @@
 // The REF row itself (every candidate is a row) goes through the plane kernels of hawk_search.hip on the plan's REF planes.
 #include "hawk_vc.h"
 
-#ifndef VS_ABL
-#define VS_ABL 0  // ablation builds only (tools/ab_multi.sh): 1 = set-up, 2 = + dirty words, 3 = + strings / match, 4 = + clean runs
-#endif
 #define VC_BLOCK 128         // threads per workgroup: a C3 tile has ~110 dirty words
 #define VC_MAXV 128          // records staged per tile (32 B each)
 #define VC_SLOTS VC_BLOCK    // dirty words per chunk: one per thread
@@ -110,7 +107,6 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
   const bool ovf = k0 + NSEG < kend && hs.seg_rel[k0 + NSEG] < tile_end;  // rare: > NSEG segments in a tile
   if (PASS == 1 && gp.score_cfdon) for (uint32_t i = tid; i < 336; i += VC_BLOCK) s_cfd[i] = gp.cfd_mm[i];
   __syncthreads();
-  if (VS_ABL == 1) { if (PASS == 0 && tid == 0) { counts[tile] = 0; counts0[tile] = 0; } return; }
   const int n = (int)s_n;                                 // staged records within reach (a prefix: records are sorted)
   const bool all = n < VC_MAXV || avail <= VC_MAXV;       // nothing within reach lies beyond the staged ones
   // ---- dirty words: a record dirties the window starts [o - L + 1, o + alt_len - 1]
@@ -145,7 +141,6 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
     while (m) { s_words[o++] = (uint16_t)(tid * 32u + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
   }
   __syncthreads();
-  if (VS_ABL == 2) { if (PASS == 0 && tid == 0) { counts[tile] = 0; counts0[tile] = 0; } return; }
   const uint32_t n_tasks = s_bmpre[32];
   const uint32_t n_chunks = (n_tasks + VC_SLOTS - 1) / VC_SLOTS;
 
@@ -219,10 +214,6 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
       const int32_t p0c = p0 < 0 ? 0 : p0;
       int32_t shift_run = 0;
       bool have_shift = true;
-      if (VS_ABL == 5) {
-#pragma unroll
-        for (int pl = 0; pl < 5; ++pl) X[pl][0] = X[pl][1] = X[pl][2] = (uint32_t)q0 * 2654435761u;
-      } else
       if (!(all && vc_string_fast(va, s_v, n, p0c, haplen, q0 + 32, X, shift_run))) {
         have_shift = false;
         if (all) hx_words_t<true, 3>(va.alt_codes, s_v, first, n, n, false, p0c, haplen, ref32, X[0], X[1], X[2], X[3], X[4]);
@@ -261,7 +252,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
       if (PASS == 0) cand += __popc(f) + __popc(rv);
       kF = f & E;
       kR = rv & E;
-      if (PASS == 0 && (VS_ABL == 0 || VS_ABL == 4)) {  // the clean run behind the word, up to the next dirty word (or the end of the tile)
+      if (PASS == 0) {  // the clean run behind the word, up to the next dirty word (or the end of the tile)
         const int nd = next_dirty((int)wl);
         const int32_t pa = q0 + 32, pb = p_lo + 32 * (nd < nwt ? nd : nwt);
         if (pb > pa) vc_count_run(va, rg, pa, pb, have_shift ? shift_run : shift_at(pa), cand, hits);
@@ -274,7 +265,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
     const uint32_t exFR = block_excl_scan<VC_BLOCK / WAVE>(cF | (cR << 16), s_w, &TT);  // its barriers publish the slots
     s_ex[tid] = exFR;
     __syncthreads();
-    const uint32_t TF = TT & 0xffffu, TR = TT >> 16, T = (VS_ABL >= 3 && VS_ABL <= 6) || (VS_ABL == 9 && PASS == 1) ? 0u : TF + TR;
+    const uint32_t TF = TT & 0xffffu, TR = TT >> 16, T = TF + TR;
     // ---- phase C: survivors number i and i + VC_BLOCK of the chunk per thread (strand 0 in position order, then strand 1).
     // Two at a time so that their L2 gathers (REF's candidate bit, REF's core) are in flight together: the kernel is bound
     // by round trips per resident wave, not by bytes or instructions.
@@ -366,7 +357,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
         const uint32_t t0F = tot & 0xffu, t0R = (tot >> 8) & 0xffu, t1F = (tot >> 16) & 0xffu, t1R = tot >> 24;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          if (!valid[u] || VS_ABL == 8) continue;
+          if (!valid[u]) continue;
           const uint32_t s = sst[u], q = qq[u];
           const uint32_t rk = u == 0 ? (s ? (ex >> 8) & 0xffu : ex & 0xffu) : (s ? t0R + (ex >> 24) : t0F + ((ex >> 16) & 0xffu));
           const uint64_t o = (s ? row1 : row0) + rk;
@@ -393,7 +384,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_vsearch(HapSetDev hs, VcArgs va, S
 #pragma unroll
           for (int pl = 0; pl < HAWK_PLANES; ++pl) out.win[(size_t)pl * out.cap + o] = (uint64_t)win[u][pl].lo | ((uint64_t)win[u][pl].hi << 32);
           double score = __longlong_as_double(0x7ff8000000000000ll);  // NaN -> "NA"
-          if (VS_ABL != 7 && gp.score_cfdon && has_refv[u]) {
+          if (gp.score_cfdon && has_refv[u]) {
             bool err;
             score = cfdon_from_slices(core[u], rcore[u], s, L, cfdmask, s_cfd, err);
             if (err && gp.score_cfdon == 1) atomicExch(status, -5 /* HAWK_E_CFD; score_cfdon == 2 leaves NaN = "NA" */);

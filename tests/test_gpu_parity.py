@@ -396,10 +396,22 @@ def test_collapse_groups_against_oracle(pam, guidelen, right, exact, mode, monke
     _check_collapse(hs, tab, guidelen, len(pam), right)
 
 
-def test_collapse_verify_pass_catches_hash_collisions(monkeypatch):
-    """The grouping is verified against the full keys by default (k_collapse_verify).  With HAWK_COLLAPSE_WEAK_HASH=1 every
-    row of one (start, strand) hashes alike - the worst collision there can be: unverified, the groups come out merged
-    (fewer than the oracle's); verified, the call notices and reruns exactly, and the groups are the oracle's."""
+def test_collapse_verify_pass_catches_hash_collisions():
+    """The grouping's verification pass against deliberately colliding hashes - in the HOOKS build of the library
+    (libhawk_hip_hooks.so, -DHAWK_TEST_HOOKS): the product library can neither weaken its hash nor skip the verification, so the
+    check runs in a process of its own that loads the other library (tests/hooks_collapse_check.py).  The product library is
+    asked too: the same environment must leave its grouping untouched."""
+    import os
+    import subprocess
+    import sys
+    from crisprhawk_hip import _lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    hooks = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhawk_hip_hooks.so")
+    assert os.path.exists(hooks), "make -C crispr-hawk_amd/csrc builds libhawk_hip_hooks.so beside the product library"
+    env = dict(os.environ, CRISPRHAWK_HIP_LIB=hooks)
+    r = subprocess.run([sys.executable, os.path.join(here, "hooks_collapse_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hooks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    # the product library ignores both switches
     reg = synth.make_region(7501, "chrC", 40_000, 1_000, 38_000)
     synth.add_phased_variants(reg, 7502, 300, 6, af_min=0.3, af_max=0.8)
     fx = dict(region_seq=reg.sequence, startp=reg.startp, samples=reg.samples,
@@ -409,18 +421,13 @@ def test_collapse_verify_pass_catches_hash_collisions(monkeypatch):
     hs = ora.HapSet([h["seq"] for h in haps], [h["posmap"] for h in haps], [h["samples"] == ["REF"] for h in haps], scan)
     bits, bitsrc, _, _ = ora.pam_encode("NGG")
     ds = device_set(hs)
-    monkeypatch.delenv("HAWK_COLLAPSE_EXACT", raising=False)
-    monkeypatch.delenv("HAWK_COLLAPSE_MODE", raising=False)
     good = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
-    monkeypatch.setenv("HAWK_COLLAPSE_WEAK_HASH", "1")
-    monkeypatch.setenv("HAWK_COLLAPSE_VERIFY", "0")
-    merged = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
-    assert merged.n_groups < good.n_groups  # the collisions are real: without the check different rows share a group
-    monkeypatch.setenv("HAWK_COLLAPSE_VERIFY", "1")
-    tab = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
-    assert tab.n_groups == good.n_groups
-    assert np.array_equal(tab.group_perm, good.group_perm) and np.array_equal(tab.group_off, good.group_off)
-    _check_collapse(hs, tab, 20, 3, False)
+    os.environ["HAWK_COLLAPSE_WEAK_HASH"], os.environ["HAWK_COLLAPSE_VERIFY"] = "1", "0"
+    try:
+        same = ds.search(bits, bitsrc, 3, 20, False, collapse=True)
+    finally:
+        del os.environ["HAWK_COLLAPSE_WEAK_HASH"], os.environ["HAWK_COLLAPSE_VERIFY"]
+    assert same.n_groups == good.n_groups and np.array_equal(same.group_perm, good.group_perm)
 
 
 def test_haplotype_collapse_compares_rows_not_only_hashes():
