@@ -212,6 +212,15 @@ static int collapse_by_templates(hawk_table* t, uint32_t flank_up, uint32_t flan
   hawk_launch_cc_mini(ctx->stream, t->cols, r0, hs->cs_trows.p, t_live, d_moff, hs->cs_tbase.as<uint32_t>(), nu, hs->ref_startp, mini);
   HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
   HIPCHK(hipGetLastError());
+  // everything the rest of this call reserves in the set's collapse workspace is reserved HERE, for the full table, before the
+  // mini collapse fills it: a reservation after k_cc_gidm has been queued could hand the buffers it reads back to the pool
+  {
+    const size_t tb_full = hawk_collapse_expand_temp_bytes(n);
+    if ((rc = hs->ckeys.reserve(std::max<size_t>(2 * nm * 8, 2 * n * 4))) || (rc = hs->cvals.reserve(2 * n * 4)) ||
+        (rc = hs->cgoff.reserve((nm + 1) * 8)) || (rc = hs->cgc.reserve(2 * n)) || (rc = hs->ctemp.reserve(tb_full + 16)) ||
+        (rc = hs->cflags.reserve(n * 4)))
+      return rc;
+  }
   hawk_table tm;  // the mini table borrows the set's collapse workspace like any table of the set
   tm.hs = hs; tm.ctx = ctx; tm.n_rows = nm; tm.n_cand = tm.n_hits = 0; tm.cap = mini.cap; tm.cols = mini;
   tm.guidelen = t->guidelen; tm.pamlen = t->pamlen; tm.right = t->right; tm.n_groups = 0; tm.collapsed = false; tm.gen = t->gen;

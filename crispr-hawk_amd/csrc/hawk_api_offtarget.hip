@@ -59,10 +59,57 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
   // LDS variant: guides in chunks of OT_LDS_CHUNK, 4 key bases per block (nb * 8.5 KB of LDS must leave room for a few
   // workgroups per CU); HAWK_OT_SEED_GLOBAL=1 keeps the single-table global-gather kernel
   static const bool seed_global = [] { const char* e = getenv("HAWK_OT_SEED_GLOBAL"); return e && e[0] == '1'; }();
-  const bool seed_lds = seeded && !seed_global && nb <= 6;
+  // Pair seeds (max_mm + 2 blocks, buckets per pair of blocks: hawk_offtarget.hip k_ot_match_pairs) are the default where they
+  // apply: HAWK_OT_PAIRS=0 keeps the single-block seeds (the parity tests run every kernel against the brute force)
+  const char* e_pairs = getenv("HAWK_OT_PAIRS");
+  const int nb2 = (int)p->max_mm + 2;
+  const bool pairs = seeded && !seed_global && !(e_pairs && e_pairs[0] == '0') && nb2 <= OT_MAX_BLOCKS && nb2 <= G;
+  const bool seed_lds = seeded && !pairs && !seed_global && nb <= 6;
   const uint32_t chunk = seed_lds ? OT_LDS_CHUNK : n_guides;
   const uint32_t n_chunks = seeded ? (n_guides + chunk - 1) / chunk : 0;
-  if (seeded) {
+  OtPairSeeds ps;
+  memset(&ps, 0, sizeof(ps));
+  if (pairs) {
+    ps.nb = nb2;
+    int startb = 0;
+    for (int b = 0; b < nb2; ++b) {  // blocks of G / nb2 bases (the first G % nb2 one longer); key = a block's first <= 4 bases
+      const int len = G / nb2 + (b < G % nb2 ? 1 : 0), kl = std::min(len, 4);
+      ps.start[b] = startb; ps.klen[b] = kl;
+      for (int t = 0; t < kl; ++t) ps.pmask2[b] |= 1ull << (2 * (startb + t));
+      startb += len;
+    }
+    for (int bi = 0; bi < nb2; ++bi)
+      for (int bj = bi + 1; bj < nb2; ++bj) { ps.pi[ps.n_pairs] = (uint8_t)bi; ps.pj[ps.n_pairs] = (uint8_t)bj; ++ps.n_pairs; }
+    std::vector<uint32_t> goff;
+    std::vector<uint64_t> gcode((size_t)ps.n_pairs * n_guides, 0);
+    std::vector<uint32_t> gid((size_t)ps.n_pairs * n_guides, 0);
+    std::vector<uint32_t> keys(n_guides);
+    for (int q = 0; q < ps.n_pairs; ++q) {
+      const int bi = ps.pi[q], bj = ps.pj[q];
+      const uint32_t mi = (1u << (2 * ps.klen[bi])) - 1u, mj = (1u << (2 * ps.klen[bj])) - 1u;
+      const uint32_t nkeys = 1u << (2 * (ps.klen[bi] + ps.klen[bj]));
+      ps.off_base[q] = (uint32_t)goff.size();
+      std::vector<uint32_t> cnt(nkeys + 1, 0);
+      for (uint32_t g = 0; g < n_guides; ++g) {
+        keys[g] = ((uint32_t)(guides2[g] >> (2 * ps.start[bi])) & mi) | (((uint32_t)(guides2[g] >> (2 * ps.start[bj])) & mj) << (2 * ps.klen[bi]));
+        ++cnt[keys[g] + 1];
+      }
+      for (uint32_t v = 0; v < nkeys; ++v) cnt[v + 1] += cnt[v];
+      goff.insert(goff.end(), cnt.begin(), cnt.end());
+      std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+      for (uint32_t g = 0; g < n_guides; ++g) {  // counting sort: guides of one bucket stay in input order
+        const uint32_t slot = cur[keys[g]]++;
+        gcode[(size_t)q * n_guides + slot] = guides2[g];
+        gid[(size_t)q * n_guides + slot] = g;
+      }
+    }
+    if ((rc = hs->otoff.reserve(goff.size() * 4)) || (rc = hs->otcode.reserve(gcode.size() * 8)) || (rc = hs->otid.reserve(gid.size() * 4)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(hs->otoff.p, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs->otcode.p, gcode.data(), gcode.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs->otid.p, gid.data(), gid.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+  } else if (seeded) {
     sd.nb = nb;
     const int kmax = seed_lds ? 4 : 6;
     int startb = 0;
@@ -122,7 +169,10 @@ int hawk_offtarget_scan(hawk_hapset* hs, const hawk_ot_params* p, const uint64_t
   if (nsites) hawk_launch_ot_sites(ctx->stream, d, sp, hs->keepF.as<uint32_t>(), hs->keepR.as<uint32_t>(),
                                    hs->offsets.as<uint64_t>(), hs->sites.as<OtSite>());
   HIPCHK(hipEventRecord(ev[3], ctx->stream));
-  if (seeded) {
+  if (pairs) {
+    hawk_launch_ot_match_pairs(ctx->stream, hs->sites.as<OtSite>(), nsites, ps, hs->otoff.as<uint32_t>(), hs->otcode.as<uint64_t>(),
+                               hs->otid.as<uint32_t>(), n_guides, G, p->right ? (int)p->pamlen : 0, (int)p->max_mm, hs->hits.as<OtHit>(), cap, d_nhits);
+  } else if (seeded) {
     if (seed_lds)
       hawk_launch_ot_match_seeded_lds(ctx->stream, hs->sites.as<OtSite>(), nsites, sd, hs->otoff.as<uint32_t>(),
                                       hs->otcode.as<uint64_t>(), hs->otid.as<uint32_t>(), n_guides, n_chunks, G,

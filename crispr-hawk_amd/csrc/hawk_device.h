@@ -211,6 +211,22 @@ struct OtSeeds {
   uint64_t pmask2[OT_MAX_BLOCKS];
 };
 
+// Pair seeds: the spacer cut into max_mm + 2 blocks, so a pair within max_mm mismatches agrees exactly in at least TWO of them;
+// the guides are bucketed per PAIR of blocks (i < j) by the key bases of both (<= 4 each: tables of <= 4^8 buckets), which
+// leaves ~4^-8 of the site x guide pairs as candidates per table instead of ~4^-4.  off_base[p]: where pair p's bucket offsets
+// start in `goff`; its codes / guide ids are rows p of gcode / gid ([n_pairs][n_guides]).
+#define OT_MAX_PAIRS (OT_MAX_BLOCKS * (OT_MAX_BLOCKS - 1) / 2)
+struct OtPairSeeds {
+  int32_t nb, n_pairs;
+  int32_t start[OT_MAX_BLOCKS], klen[OT_MAX_BLOCKS];
+  uint64_t pmask2[OT_MAX_BLOCKS];
+  uint8_t pi[OT_MAX_PAIRS], pj[OT_MAX_PAIRS];
+  uint32_t off_base[OT_MAX_PAIRS];
+};
+void hawk_launch_ot_match_pairs(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtPairSeeds& sd, const uint32_t* goff,
+                                const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, int guidelen, int sp0, int max_mm,
+                                OtHit* hits, uint64_t cap, unsigned long long* n_hits);
+
 // launch wrappers
 void hawk_launch_ot_onehot(hipStream_t st, uint32_t* const* plane, uint64_t nwords);
 void hawk_launch_ot_sites(hipStream_t st, const HapSetDev& hs, const ScanParams& p, const uint32_t* keepF, const uint32_t* keepR,

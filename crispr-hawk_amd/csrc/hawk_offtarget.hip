@@ -260,6 +260,97 @@ void hawk_launch_ot_match_seeded_lds(hipStream_t st, const OtSite* sites, uint64
                      sp0, max_mm, hits, cap, n_hits);
 }
 
+// Pair seeds, candidates dealt evenly.  A wave takes 64 sites.  Per pair of blocks every lane looks its site's bucket up (two
+// adjacent offsets); the wave's candidates - the concatenation of the 64 buckets - are then walked 64 at a time, candidate c by lane
+// c: a 6-step search over the lanes' exclusive counts (LDS) names the owning site, whose code comes out of LDS, and the guide codes of
+// consecutive candidates are consecutive words of the bucketed table.  No lane idles because its own bucket is shorter than a
+// neighbour's (the per-lane bucket walks of k_ot_match_seeded(_lds) ran at a third of their lanes: profiles/r03_c5_pmc.json).
+// A pair that agrees in more than two blocks is met in several tables and reported in the first (lowest two agreeing blocks).
+__global__ __launch_bounds__(HAWK_BLOCK) void k_ot_match_pairs(const OtSite* __restrict__ sites, uint64_t n_sites, OtPairSeeds sd,
+                                                                const uint32_t* __restrict__ goff, const uint64_t* __restrict__ gcode,
+                                                                const uint32_t* __restrict__ gid, uint32_t n_guides, int guidelen,
+                                                                int sp0, int max_mm, OtHit* __restrict__ hits, uint64_t cap,
+                                                                unsigned long long* __restrict__ n_hits) {
+  __shared__ uint64_t s_code[HAWK_BLOCK / WAVE][WAVE], s_nm2[HAWK_BLOCK / WAVE][WAVE];
+  __shared__ uint32_t s_ex[HAWK_BLOCK / WAVE][WAVE + 1], s_lo[HAWK_BLOCK / WAVE][WAVE];
+  const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const uint64_t i0 = (uint64_t)blockIdx.x * HAWK_BLOCK + wv * WAVE;  // the wave's first site
+  if (i0 >= n_sites) return;                                            // wave-uniform; no workgroup barrier below
+  const uint64_t i = i0 + lane;
+  const uint64_t smask = guidelen >= 32 ? ~0ull : ((1ull << (2 * guidelen)) - 1ull);
+  uint64_t code = 0;
+  uint32_t nmsp = 0xffffffffu;
+  if (i < n_sites) {
+    const OtSite st = sites[i];
+    code = (st.code >> (2 * sp0)) & smask;
+    nmsp = (st.nmask >> sp0) & (guidelen >= 32 ? 0xffffffffu : ((1u << guidelen) - 1u));
+  }
+  const bool live = i < n_sites && __popc(nmsp) <= max_mm;  // more ambiguous bases than allowed mismatches: no guide can match
+  const uint64_t nm2 = spread(nmsp);
+  s_code[wv][lane] = code;
+  s_nm2[wv][lane] = nm2;
+  uint32_t blk_ok = 0;  // bit b: no ambiguous base among block b's key bases
+  for (int b = 0; b < sd.nb; ++b) blk_ok |= (((nmsp >> sd.start[b]) & ((1u << sd.klen[b]) - 1u)) == 0 ? 1u : 0u) << b;
+  __builtin_amdgcn_wave_barrier();
+  // (Tried and dropped, same 5.9 ms at the full C5 size: all 15 tables' look-ups in flight before the first is used - in registers,
+  // 73 VGPRs, or staged through LDS, 8.2 ms.  The wave's life is the chain per table - scan, owner search in LDS, guide load - at
+  // ~19 candidates per table and wave; profiles/r04_c5_pmc.json.)
+#pragma unroll 1
+  for (int p = 0; p < sd.n_pairs; ++p) {  // wave-uniform
+    {
+    const int bi = sd.pi[p], bj = sd.pj[p];
+    uint32_t lo = 0, cnt = 0;
+    if (live && ((blk_ok >> bi) & 1u) && ((blk_ok >> bj) & 1u)) {
+      const uint32_t ki = (uint32_t)(code >> (2 * sd.start[bi])) & ((1u << (2 * sd.klen[bi])) - 1u);
+      const uint32_t kj = (uint32_t)(code >> (2 * sd.start[bj])) & ((1u << (2 * sd.klen[bj])) - 1u);
+      const uint32_t* o = goff + sd.off_base[p] + (ki | (kj << (2 * sd.klen[bi])));
+      lo = o[0];
+      cnt = o[1] - lo;
+    }
+    const uint32_t inc = wave_incl_scan(cnt);
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+    if (T != 0) {
+    s_ex[wv][lane] = inc - cnt;
+    s_lo[wv][lane] = lo;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t* __restrict__ gc = gcode + (size_t)p * n_guides;
+    const uint32_t* __restrict__ gi = gid + (size_t)p * n_guides;
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < T; c0 += WAVE) {
+      const uint32_t c = c0 + lane;
+      if (c < T) {
+        uint32_t l = 0;
+#pragma unroll
+        for (uint32_t step = WAVE / 2; step; step >>= 1) l += (s_ex[wv][l + step] <= c) ? step : 0u;  // the last lane whose candidates start at or before c
+        const uint32_t t = s_lo[wv][l] + (c - s_ex[wv][l]);
+        const uint64_t x = s_code[wv][l] ^ gc[t];
+        const uint64_t m = ((x | (x >> 1)) & 0x5555555555555555ull) | s_nm2[wv][l];
+        const int mm = __popcll(m);
+        if (mm <= max_mm) {
+          // the blocks that agree, lowest first: this table is the pair's first iff they are (bi, bj)
+          int first = -1, second = -1;
+          for (int b = 0; b < sd.nb; ++b)
+            if ((m & sd.pmask2[b]) == 0) { if (first < 0) first = b; else if (second < 0) second = b; }
+          if (first == bi && second == bj) {
+            const unsigned long long o = atomicAdd(n_hits, 1ull);
+            if (o < cap) { OtHit hh; hh.site = i0 + l; hh.guide = gi[t]; hh.mm = (uint32_t)mm; hits[o] = hh; }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    }
+    }
+  }
+}
+void hawk_launch_ot_match_pairs(hipStream_t st, const OtSite* sites, uint64_t n_sites, const OtPairSeeds& sd, const uint32_t* goff,
+                                const uint64_t* gcode, const uint32_t* gid, uint32_t n_guides, int guidelen, int sp0, int max_mm,
+                                OtHit* hits, uint64_t cap, unsigned long long* n_hits) {
+  if (!n_sites || !n_guides) return;
+  hipLaunchKernelGGL(k_ot_match_pairs, dim3((uint32_t)((n_sites + HAWK_BLOCK - 1) / HAWK_BLOCK)), dim3(HAWK_BLOCK), 0, st, sites, n_sites, sd,
+                     goff, gcode, gid, n_guides, guidelen, sp0, max_mm, hits, cap, n_hits);
+}
+
 __global__ __launch_bounds__(256) void k_ot_gather(const OtSite* __restrict__ sites, const OtHit* __restrict__ hits, uint64_t n_hits,
                                                    OtSite* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;

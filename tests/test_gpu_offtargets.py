@@ -25,12 +25,16 @@ def _plant(rng, genome: list, guide: str, pam_seq: str, right: bool, n: int, max
         genome[pos:pos + L] = list(w)
 
 
-@pytest.mark.parametrize("n_guides", [6, 200, 2300])  # 6: all pairs; 200: seeded, one LDS chunk; 2300: three chunks
+@pytest.mark.parametrize("n_guides", [6, 200, 2300, -2300])  # 6: all pairs; 200 / 2300: pair seeds (max_mm + 2 blocks, candidates dealt
+#   evenly over a wave); -2300: the single-block seeds of rounds 1-3 (HAWK_OT_PAIRS=0: guides in three LDS chunks)
 @pytest.mark.parametrize("pam_s,guidelen,right,max_mm,piece", [("NGG", 20, False, 4, 1 << 22), ("TTTV", 23, True, 3, 4096),
                                                               ("TTTV", 23, True, 4, 1 << 22),  # C5 as BASELINE.json states it
                                                               ("NNGRRT", 21, False, 2, 10000), ("NGG", 20, False, 0, 1 << 22),
                                                               ("NGG", 17, False, 6, 1 << 22)])
-def test_offtarget_scan_matches_bruteforce(pam_s, guidelen, right, max_mm, piece, n_guides):
+def test_offtarget_scan_matches_bruteforce(pam_s, guidelen, right, max_mm, piece, n_guides, monkeypatch):
+    if n_guides < 0:
+        monkeypatch.setenv("HAWK_OT_PAIRS", "0")
+        n_guides = -n_guides
     rng = np.random.default_rng(77)
     contigs = {}
     guides = [synth.random_sequence(rng, guidelen) for _ in range(n_guides)]
@@ -136,7 +140,7 @@ def _verify_hits_on_host(contig_arrays, idx, hits, guides, pam_s, guidelen, righ
 
 def test_c5_full_size_properties(monkeypatch):
     """C5 at a size no brute force reaches (3 x 10^8 nt here; bench.py --config c5 runs 3.1 x 10^9): the three match
-    kernels (all pairs, pigeonhole seeds from L2, pigeonhole seeds from LDS) must report the same hit set, every guide
+    kernels (pair seeds; single-block pigeonhole seeds from L2 and from LDS; all pairs) must report the same hit set, every guide
     must find its planted on-target, and every hit must re-verify against the genome bytes on the host."""
     import subprocess, sys, os, json
     code = r"""
@@ -167,11 +171,13 @@ print("RESULT", json.dumps({"n": int(len(order)), "digest": h.hexdigest(), "n_si
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "crispr-hawk_amd"), root)
     res = {}
-    for label, env in (("seeded_lds", {}), ("seeded_global", {"HAWK_OT_SEED_GLOBAL": "1"}), ("all_pairs", {"HAWK_OT_ALLPAIRS": "1"})):
+    for label, env in (("pair_seeds", {}), ("seeded_lds", {"HAWK_OT_PAIRS": "0"}), ("seeded_global", {"HAWK_OT_SEED_GLOBAL": "1"}),
+                       ("all_pairs", {"HAWK_OT_ALLPAIRS": "1"})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         res[label] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][7:])
-    assert res["seeded_lds"]["digest"] == res["seeded_global"]["digest"] == res["all_pairs"]["digest"]
+    assert res["pair_seeds"]["digest"] == res["seeded_lds"]["digest"] == res["seeded_global"]["digest"] == res["all_pairs"]["digest"]
+    print("match_ms", {k: round(v["match_ms"], 2) for k, v in res.items()})
     assert res["seeded_lds"]["n"] >= 100  # ~1 guide in 85 sits behind a TTTV and is its own on-target; the rest are chance near-matches
     # in-process: host re-verification of the default kernel's hits
     rng = np.random.default_rng(1006)
