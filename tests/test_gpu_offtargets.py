@@ -138,24 +138,29 @@ def _verify_hits_on_host(contig_arrays, idx, hits, guides, pam_s, guidelen, righ
         assert mm == int(hits["mm"][i]) <= max_mm
 
 
+C5_CONTIG_NT, C5_GUIDES = 129_166_667, 10_000  # 24 contigs: 3.1 x 10^9 nt
+
+
 def test_c5_full_size_properties(monkeypatch):
-    """C5 at a size no brute force reaches (3 x 10^8 nt here; bench.py --config c5 runs 3.1 x 10^9): the three match
+    """C5 at BASELINE.json's full size - a 3.1 x 10^9-nt genome in 24 contigs, 10^4 guides, TTTV / 23, <= 4 mismatches - which no
+    brute force reaches: the four match
     kernels (pair seeds; single-block pigeonhole seeds from L2 and from LDS; all pairs) must report the same hit set, every guide
     must find its planted on-target, and every hit must re-verify against the genome bytes on the host."""
     import subprocess, sys, os, json
     code = r"""
 import json, sys, hashlib
 import numpy as np
+C5_CONTIG_NT, C5_GUIDES = %d, %d
 sys.path[:0] = [%r, %r]
 from crisprhawk_hip.genome import GenomeIndex
 from crisprhawk_hip.pam import PAM
 rng = np.random.default_rng(1006)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-contigs = {f"chr{i+1}": acgt[rng.integers(0, 4, size=12_500_000, dtype=np.uint8)] for i in range(24)}
+contigs = {f"chr{i+1}": acgt[rng.integers(0, 4, size=C5_CONTIG_NT, dtype=np.uint8)] for i in range(24)}
 grng = np.random.default_rng(1005)
 names = list(contigs)
 guides = []
-while len(guides) < 3000:
+while len(guides) < C5_GUIDES:
     c = contigs[names[int(grng.integers(0, 24))]]
     p = int(grng.integers(0, len(c) - 64))
     guides.append(c[p:p + 23].tobytes().decode())
@@ -169,11 +174,11 @@ for k in ("guide", "row", "q", "strand", "mm", "code", "nmask"):
 print("RESULT", json.dumps({"n": int(len(order)), "digest": h.hexdigest(), "n_sites": int(tm["n_sites"]), "match_ms": tm["match_ms"]}))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = code % (os.path.join(root, "crispr-hawk_amd"), root)
+    code = code % (C5_CONTIG_NT, C5_GUIDES, os.path.join(root, "crispr-hawk_amd"), root)
     res = {}
     for label, env in (("pair_seeds", {}), ("seeded_lds", {"HAWK_OT_PAIRS": "0"}), ("seeded_global", {"HAWK_OT_SEED_GLOBAL": "1"}),
                        ("all_pairs", {"HAWK_OT_ALLPAIRS": "1"})):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1100)
         assert r.returncode == 0, r.stderr[-2000:]
         res[label] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][7:])
     assert res["pair_seeds"]["digest"] == res["seeded_lds"]["digest"] == res["seeded_global"]["digest"] == res["all_pairs"]["digest"]
@@ -182,11 +187,11 @@ print("RESULT", json.dumps({"n": int(len(order)), "digest": h.hexdigest(), "n_si
     # in-process: host re-verification of the default kernel's hits
     rng = np.random.default_rng(1006)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    contigs = {f"chr{i+1}": acgt[rng.integers(0, 4, size=12_500_000, dtype=np.uint8)] for i in range(24)}
+    contigs = {f"chr{i+1}": acgt[rng.integers(0, 4, size=C5_CONTIG_NT, dtype=np.uint8)] for i in range(24)}
     grng = np.random.default_rng(1005)
     names = list(contigs)
     guides, origin = [], []
-    while len(guides) < 3000:
+    while len(guides) < C5_GUIDES:
         ci = int(grng.integers(0, 24))
         c = contigs[names[ci]]
         p = int(grng.integers(0, len(c) - 64))
