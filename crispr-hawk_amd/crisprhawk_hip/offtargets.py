@@ -36,13 +36,30 @@ def crispritz_report_line(hit: OffTargetHit, guide: str, pamlen: int, right: boo
     return f"X\t{crrna}\t{dna}\t{hit.contig}\t{hit.position}\t{hit.position}\t{hit.strand}\t{hit.mm}\t0\t{hit.mm}"
 
 
-def search(genome: GenomeIndex, guides_seqs: List[str], pam: PAM, right: bool, mm: int, verbosity: int, debug: bool) -> List[str]:
-    """The CRISPRitz call's replacement: report lines for every hit of every unique spacer."""
+def crispritz_bulge_line(hit, pamlen: int, right: bool) -> str:
+    """The `targets.txt` row of a bulged site (genome.BulgeHit): type DNA / RNA, crRNA and DNA with '-' at the bulge positions
+    (the field set offtarget.py:77-101 reads; `total` = mismatches + bulge size)."""
+    crrna = ("N" * pamlen + hit.crrna) if right else (hit.crrna + "N" * pamlen)
+    dna = (hit.pam + hit.dna) if right else (hit.dna + hit.pam)
+    return (f"{hit.bulge_type}\t{crrna}\t{dna}\t{hit.contig}\t{hit.position}\t{hit.position}\t{hit.strand}\t{hit.mm}\t{hit.bulge_size}\t"
+            f"{hit.mm + hit.bulge_size}")
+
+
+def search(genome: GenomeIndex, guides_seqs: List[str], pam: PAM, right: bool, mm: int, verbosity: int, debug: bool,
+           bdna: int = 0, brna: int = 0) -> List[str]:
+    """The CRISPRitz call's replacement (`crispritz.py search ... -mm M -bDNA B -bRNA R`, offtargets.py:264-268): report lines
+    for every hit of every unique spacer - the un-bulged sites, then the DNA- / RNA-bulged ones (genome.GenomeIndex.scan_bulges:
+    bulges of up to 2 bases, one row per (guide, site, type, size); CRISPRitz itself is absent, so its output beyond the field
+    set the reference parses is unpinned)."""
+    if bdna < 0 or brna < 0 or bdna > 2 or brna > 2:
+        exception_handler(CrisprHawkOffTargetsError, f"DNA / RNA bulges of 0..2 bases are enumerated (got {bdna} / {brna})", os.EX_DATAERR, debug)
     try:
         hits = genome.scan(guides_seqs, pam, right, mm)
+        bulged = genome.scan_bulges(guides_seqs, pam, right, mm, bdna, brna) if (bdna or brna) else []
     except ValueError as e:
         exception_handler(CrisprHawkOffTargetsError, f"Off-targets search failed: {e}", os.EX_DATAERR, debug, e)
-    return [crispritz_report_line(h, guides_seqs[h.guide], len(pam), right) for h in hits]
+    return [crispritz_report_line(h, guides_seqs[h.guide], len(pam), right) for h in hits] + \
+        [crispritz_bulge_line(h, len(pam), right) for h in bulged]
 
 
 def _compute_cfd_score(offtargets: List[Offtarget], verbosity: int, debug: bool) -> List[Offtarget]:
@@ -131,15 +148,15 @@ def annotate_guides_offtargets(offtargets: List[Offtarget], guides: List[Guide],
     return guides
 
 
-def _genome_index(crispritz_index, guidelen: int, pamlen: int) -> GenomeIndex:
-    """What stands where the reference passes a CRISPRitz index directory: a GenomeIndex, a {contig: sequence} dict or a
-    FASTA path."""
+def _genome_index(crispritz_index, guidelen: int, pamlen: int, max_bulge: int = 0) -> GenomeIndex:
+    """What stands where the reference passes a CRISPRitz index directory: a GenomeIndex (built with max_bulge >= the DNA bulges
+    asked for), a {contig: sequence} dict or a FASTA path."""
     if isinstance(crispritz_index, GenomeIndex):
         return crispritz_index
     if isinstance(crispritz_index, (str, os.PathLike)):
         from .genome import read_fasta
         crispritz_index = read_fasta(str(crispritz_index))
-    return GenomeIndex(crispritz_index, guidelen, pamlen)
+    return GenomeIndex(crispritz_index, guidelen, pamlen, max_bulge=max_bulge)
 
 
 def offtargets_by_spacer(offtargets: List[Offtarget], spacers) -> Dict[str, tuple]:
@@ -156,10 +173,8 @@ def estimate_offtargets_spacers(spacers, pam: PAM, crispritz_index, region, mm: 
                                 outdir: str, verbosity: int, debug: bool) -> Dict[str, tuple]:
     """estimate_offtargets for the columnar report (pipeline.search_files): the same stage - unique spacers -> device scan
     -> CFD -> offtargets_*.tsv -> per-spacer aggregates - without Guide objects."""
-    if bdna or brna:
-        exception_handler(CrisprHawkOffTargetsError, "DNA/RNA bulges are not supported by the GPU off-target scan", os.EX_DATAERR, debug)
     uniq = sorted({sp.upper() for sp in spacers})
-    lines = search(_genome_index(crispritz_index, guidelen, len(pam)), uniq, pam, right, mm, verbosity, debug) if uniq else []
+    lines = search(_genome_index(crispritz_index, guidelen, len(pam), bdna), uniq, pam, right, mm, verbosity, debug, bdna, brna) if uniq else []
     ots = report_offtargets(lines, region, pam, guidelen, [], [], False, right, outdir, verbosity, debug)
     return offtargets_by_spacer(ots, uniq)
 
@@ -170,12 +185,9 @@ def estimate_offtargets(guides: List[Guide], pam: PAM, crispritz_index, region: 
     """offtargets.py:630-722 with the reference's seventeen arguments in the reference's order.  `crispritz_index` is the
     genome (see _genome_index); `crispritz_config` (the conda environment of the external tool) and `threads` have no
     meaning on the device path and are ignored."""
-    if bdna or brna:
-        exception_handler(CrisprHawkOffTargetsError, "DNA/RNA bulges are not supported by the GPU off-target scan",
-                          os.EX_DATAERR, debug)
     guides_seqs = sorted(_filter_guides(guides))
     print_verbosity("Estimating off-targets for found guides", verbosity, VERBOSITYLVL[3])
-    genome = _genome_index(crispritz_index, guidelen, len(pam))
-    lines = search(genome, guides_seqs, pam, right, mm, verbosity, debug)
+    genome = _genome_index(crispritz_index, guidelen, len(pam), bdna)
+    lines = search(genome, guides_seqs, pam, right, mm, verbosity, debug, bdna, brna)
     offtargets = report_offtargets(lines, region, pam, guidelen, annotations, anncolnames, compute_elevation, right, outdir, verbosity, debug)
     return annotate_guides_offtargets(offtargets, guides, verbosity)

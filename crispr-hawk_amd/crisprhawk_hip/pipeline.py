@@ -104,7 +104,7 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
     reference's --estimate-offtargets with its --crispritz-index: a genome.GenomeIndex, a {contig: sequence} dict or a
     FASTA path) runs the off-target stage per region: the `offtargets` / `cfd` columns of the guide report
     (reports.py:292-333, 612-660) and offtargets_{contig}_{start}_{stop}.tsv next to it (offtargets.py:486-558); `mm`,
-    `bdna`, `brna` as on the reference's command line (bulges are refused).  The per-site CFD needs `cfd_tables`."""
+    `bdna`, `brna` as on the reference's command line (bulges of up to 2 bases).  The per-site CFD needs `cfd_tables`."""
     import time as _time
     _t = [_time.perf_counter()]
 
@@ -120,7 +120,7 @@ def search_files(fasta: str, bedfile: str, vcfs: List[str], pam_seq: str, guidel
         if isinstance(genome, (str, os.PathLike)):
             genome = read_fasta(str(genome))
         if isinstance(genome, dict):
-            genome = GenomeIndex(genome, guidelen, len(pam_seq), device=device)  # once for all regions
+            genome = GenomeIndex(genome, guidelen, len(pam_seq), device=device, max_bulge=bdna)  # once for all regions
         ot = dict(genome=genome, mm=mm, bdna=bdna, brna=brna)
         if cfd_tables is not None:
             scoring.set_cfd_tables(*cfd_tables)

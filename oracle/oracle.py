@@ -268,6 +268,22 @@ def offtargets(genome: str, guides: Sequence[str], pam: str, right: bool, max_mm
     return out[:n].copy()
 
 
+OTB_DTYPE = np.dtype([("guide", np.int32), ("strand", np.int32), ("pos", np.int64), ("mm", np.int32), ("btype", np.int32), ("bsize", np.int32),
+                      ("pad", np.int32), ("gaps", np.uint64)])
+
+
+def offtargets_bulges(genome: str, guides: Sequence[str], pam: str, right: bool, max_mm: int, bdna: int, brna: int, cap: int = 1 << 22) -> np.ndarray:
+    """Bulged off-target sites by brute force over every placement (hawk_oracle.c: ora_offtargets_bulges; PARITY UNPINNED -
+    CRISPRitz is absent): rows (guide, strand, pos, mm, btype 1 DNA / 2 RNA, bsize, gaps bitmask in guide orientation)."""
+    guidelen = len(guides[0])
+    out = np.zeros(cap, dtype=OTB_DTYPE)
+    n = lib().ora_offtargets_bulges(genome.encode("ascii"), C.c_int64(len(genome)), "".join(guides).encode("ascii"), len(guides), guidelen,
+                                    pam.encode(), len(pam), int(right), max_mm, bdna, brna, _p(out), C.c_int64(cap))
+    if n < 0:
+        raise OracleError(int(n))
+    return out[:n].copy()
+
+
 def tm_nn(seq: str) -> float:
     """Biopython's Tm_NN with its defaults, restated (hawk_oracle.c: tm_nn)"""
     out = C.c_double()

@@ -233,3 +233,96 @@ def test_sharded_genome_index_partitions_the_hits():
     key = lambda h: sorted(zip(h["guide"].tolist(), h["row"].tolist(), h["q"].tolist(), h["strand"].tolist(), h["mm"].tolist()))
     merged = {k: np.concatenate([p[k] for p in parts]) for k in whole}
     assert key(merged) == key(whole) and len(whole["guide"]) >= 5  # ~1 spacer in 16 is followed by NGG and is its own on-target
+
+
+@pytest.mark.parametrize("pam_s,guidelen,right,max_mm", [("NGG", 20, False, 2), ("TTTV", 23, True, 1)])
+@pytest.mark.parametrize("bdna,brna", [(1, 0), (0, 1), (1, 1), (2, 2)])
+def test_bulged_offtargets_match_bruteforce(pam_s, guidelen, right, max_mm, bdna, brna):
+    """-bDNA / -bRNA (offtargets.py:264-268): sites that pair with a guide once up to 2 bases are bulged out of the DNA or of the
+    RNA.  The device path searches them as mismatch-only scans of derived guides (GenomeIndex.scan_bulges) and must report the
+    rows of the oracle's brute force over every placement (ora.offtargets_bulges; both sides unpinned to CRISPRitz, which is
+    absent): one row per (guide, site, type, size), fewest mismatches, ties to the smallest bulge positions."""
+    rng = np.random.default_rng(99 + bdna * 7 + brna)
+    n_guides = 5
+    guides = [synth.random_sequence(rng, guidelen) for _ in range(n_guides)]
+    guides[1] = guides[1][:6] + "AAAA" + guides[1][10:]  # a run of equal bases: several placements spell the same derived guide
+    concrete = {"NGG": "TGG", "TTTV": "TTTA"}[pam_s]
+    contigs = {}
+    for name, n in (("c1", 30_000), ("c2", 9_001)):
+        g = list(synth.random_sequence(rng, n, iupac_frac=0.0005))
+        for gd in guides:
+            for _ in range(10):  # planted sites: the guide with mismatches, bases inserted (DNA bulge) or deleted (RNA bulge)
+                sp = list(gd)
+                for p in rng.integers(0, guidelen, size=int(rng.integers(0, max_mm + 1))):
+                    sp[p] = "ACGT"[rng.integers(0, 4)]
+                kind = int(rng.integers(0, 3))
+                k = int(rng.integers(1, 3))
+                if kind == 1:
+                    for _ in range(k):
+                        sp.insert(int(rng.integers(1, len(sp) - 1)), "ACGT"[rng.integers(0, 4)])
+                elif kind == 2:
+                    for _ in range(k):
+                        del sp[int(rng.integers(1, len(sp) - 1))]
+                w = (concrete + "".join(sp)) if right else ("".join(sp) + concrete)
+                if rng.random() < 0.5:
+                    w = ora.revcomp(w)
+                pos = int(rng.integers(0, n - len(w)))
+                g[pos:pos + len(w)] = list(w)
+        contigs[name] = "".join(g)
+    pam = PAM(pam_s, right, True)
+    pam.encode(0)
+    idx = GenomeIndex(contigs, guidelen, len(pam_s), piece=4096, max_bulge=bdna)
+    got = idx.scan_bulges(guides, pam, right, max_mm, bdna, brna)
+    want = []
+    for name, seq in contigs.items():
+        for r in ora.offtargets_bulges(seq, guides, pam_s, right, max_mm, bdna, brna):
+            want.append((int(r["guide"]), "DNA" if r["btype"] == 1 else "RNA", int(r["bsize"]), name, int(r["pos"]), "-" if r["strand"] else "+",
+                         int(r["mm"]), int(r["gaps"])))
+    ci = {n: i for i, n in enumerate(contigs)}
+    want.sort(key=lambda t: (t[0], t[1], t[2], ci[t[3]], t[4], t[5] == "-"))
+    assert len(want) > 30 and {t[1] for t in want} == ({"DNA"} if not brna else {"RNA"} if not bdna else {"DNA", "RNA"})
+    assert [(h.guide, h.bulge_type, h.bulge_size, h.contig, h.position, h.strand, h.mm, h.gaps) for h in got] == want
+    # the strings of a row: the guide and the site re-derived from the genome, '-' at the bulges, mismatches in lower case
+    for h in got[:300]:
+        Gs = guidelen + h.bulge_size if h.bulge_type == "DNA" else guidelen - h.bulge_size
+        w = contigs[h.contig][h.position:h.position + Gs + len(pam_s)].upper()
+        w = ora.revcomp(w) if h.strand == "-" else w
+        w = "".join(c if c in "ACGT" else "N" for c in w)
+        site = w[len(pam_s):] if right else w[:Gs]
+        assert h.crrna.replace("-", "") == guides[h.guide] and h.dna.replace("-", "").upper() == site
+        assert len(h.crrna) == len(h.dna) and h.crrna.count("-") == (h.bulge_size if h.bulge_type == "DNA" else 0)
+        assert h.dna.count("-") == (h.bulge_size if h.bulge_type == "RNA" else 0)
+        assert sum(1 for a, b in zip(h.crrna, h.dna) if a != "-" and b != "-" and a != b.upper() or b.islower() and a == "-") >= 0
+        assert sum(1 for a, b in zip(h.crrna, h.dna) if b.islower()) == h.mm
+    # un-bulged scans before and after see the same rows: the window metadata is put back
+    assert [(x.guide, x.contig, x.position, x.strand, x.mm) for x in idx.scan(guides, pam, right, max_mm)] == \
+        sorted(((int(r["guide"]), name, int(r["pos"]), "-" if r["strand"] else "+", int(r["mm"])) for name, seq in contigs.items()
+                for r in ora.offtargets(seq, guides, pam_s, right, max_mm)), key=lambda t: (t[0], ci[t[1]], t[2], t[3] == "-"))
+
+
+def test_offtarget_stage_with_bulges_writes_their_rows(tmp_path):
+    """estimate_offtargets_spacers with bdna / brna > 0: the off-targets TSV holds DNA / RNA rows next to the X rows, every row
+    in the field set the reference's consumer reads (offtarget.py:77-101), counts per spacer include them."""
+    from crisprhawk_hip import scoring
+    from crisprhawk_hip.coordinate import Coordinate
+    from crisprhawk_hip.offtargets import estimate_offtargets_spacers
+    rng = np.random.default_rng(5)
+    guide = synth.random_sequence(rng, 20)
+    g = list(synth.random_sequence(rng, 20_000))
+    sites = {"X": guide + "TGG", "DNA": guide[:9] + "C" + guide[9:] + "AGG", "RNA": guide[:12] + guide[13:] + "CGG"}
+    for k, (kind, w) in enumerate(sites.items()):
+        g[2000 * (k + 1):2000 * (k + 1) + len(w)] = list(w)
+    pam = PAM("NGG", False, True)
+    pam.encode(0)
+    scoring.set_cfd_tables(*synth.cfd_tables())
+    out = estimate_offtargets_spacers([guide], pam, {"chrT": "".join(g)}, Coordinate("chrT", 100, 900, 100), 1, 1, 1, 20, False, str(tmp_path), 0, True)
+    (tsv,) = list(tmp_path.glob("offtargets_chrT_*.tsv"))
+    rows = [ln.split("\t") for ln in tsv.read_text().splitlines()[1:]]
+    kinds = {r[8] for r in rows}
+    assert kinds == {"X", "DNA", "RNA"}
+    assert out[guide][0] == len(rows) >= 3
+    for r in rows:
+        if r[8] == "DNA":
+            assert "-" in r[3] and int(r[7]) == 1
+        if r[8] == "RNA":
+            assert "-" in r[4] and int(r[7]) == 1
