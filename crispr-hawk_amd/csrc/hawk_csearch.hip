@@ -13,11 +13,12 @@
 //       compared with its representative, record by record).  An instance whose windows could meet a row-specific bound
 //       (scan range, row ends) is a cluster of its own; one wholly outside the scan range carries no cluster at all.
 //   per search:  k_cs_templates builds each distinct cluster's rows ONCE, on its representative row, with the string
-//       builder, PAM match, filters and classification of hawk_vsearch.hip (80-byte template rows, strand 0 / strand 1
+//       builder, PAM match, filters and classification of hawk_vsearch.hip (64-byte template rows, strand 0 / strand 1
 //       regions in position order); k_cs_count gives every instance its row count and adds up the job's totals
-//       (candidates, hits: the cluster's own + REF's hits under the shift of the clean stretch in front of it);
-//       after the offset scan k_cs_emit copies template rows into the guide table, a wave per 64 consecutive instances,
-//       patching haplotype row and position.
+//       (candidates, hits: the cluster's own + REF's hits under the shift of the clean stretch in front of it) and adds a wave's
+//       rows up (the offset scan runs over one entry per 64 instances); k_cs_emit_rows then copies template rows into the guide
+//       table - packed 64-byte rows, one linear write stream - a wave per 256 consecutive instances, patching haplotype row
+//       and position.
 // The table holds the same rows as hawk_search on the materialised planes; their order within a haplotype is (cluster,
 // strand, position) instead of (tile, strand, position) - GuideTable.emission_order() sorts either into the reference's.
 // The REF row goes through the plane kernels as before.
