@@ -1005,20 +1005,28 @@ def run_c4(args, R: Ranks):
         records = sum(s.get("records", 0) for s in st)
         instances = sum(s.get("instances", 0) for s in st)
         by_cluster = any(s.get("v_path", 0) == 2 for s in st)
-        emit_ms = sum(s.get("v_emit_ms", 0.0) for s in st)
-        # what the tiles' searches move: rows out + per cluster instance 44 B (count + scan + emit passes) or, per dirty word, the records twice
-        step_bytes = ROW_BYTES * rows + (44 * instances if by_cluster else 2 * REC_BYTES * records)
-        emit_bytes = ROW_BYTES * rows + (20 * instances if by_cluster else REC_BYTES * records)
-        out["roofline"] = {"bound": "hbm", "kernel": ("k_cs_emit" if by_cluster else "k_vsearch<1>") + " (summed over tiles)",
+        # the cluster path times k_cs_emit_rows alone; the per-word path's emit side is k_vsearch<1>
+        emit_ms = sum(s.get("v_emit_rows_ms", 0.0) if s.get("v_path", 0) == 2 else s.get("v_emit_ms", 0.0) for s in st)
+        vrows = sum(s["rows"] for s in st if s.get("v_path", 0) == 2)           # rows of the tiles searched per cluster (REF's few included)
+        # what the tiles' searches move: per cluster path a packed 64-byte row out + 16 B per instance in (k_cs_emit_rows) and
+        # 24 B per instance in the count pass; per dirty word a 74-byte row in columns + the records twice
+        if by_cluster:
+            emit_bytes = PACKED_ROW_BYTES * vrows + (CS_INSTANCE_BYTES + 8.0 / 64) * instances
+            step_bytes = PACKED_ROW_BYTES * vrows + ROW_BYTES * (rows - vrows) + (CS_INSTANCE_BYTES + 24.0) * instances
+        else:
+            emit_bytes = ROW_BYTES * rows + REC_BYTES * records
+            step_bytes = ROW_BYTES * rows + 2 * REC_BYTES * records
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_cs_emit_rows" if by_cluster else "k_vsearch<1>") + " (summed over tiles)",
                            "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9 if emit_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": emit_bytes / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if emit_ms else 0.0, "traffic": None, "launch_ms": emit_ms,
                            "algorithmic_bytes_per_launch": emit_bytes, "records": records, "cluster_instances": instances,
-                           "pricing": "bytes the launches have to move: 74 B per guide row written + " +
-                                      ("20 B per cluster instance read" if by_cluster else "32 B per carried-variant record read"),
+                           "pricing": "bytes the launches have to move: " +
+                                      ("64 B per guide row written (packed row) + 16 B per cluster instance read + 8 B per 64 instances"
+                                       if by_cluster else "74 B per guide row written + 32 B per carried-variant record read"),
                            "step_level": {"algorithmic_bytes": step_bytes, "ms": search_ms,
                                           "frac": step_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if search_ms else None,
-                                          "what": "all search kernels of all tiles: rows written once (74 B) + what the passes read per cluster "
-                                                  "instance / record"},
+                                          "what": "all search kernels of all tiles (the variant-free tiles' plane searches included): rows written "
+                                                  "once + what the passes read per cluster instance / record"},
                            "survey_priced": {"bytes": 0.75 * positions + ROW_BYTES * rows,
                                              "effective_GBps": (0.75 * positions + ROW_BYTES * rows) / (search_ms * 1e-3) / 1e9 if search_ms else None}}
         if R.world == 1 and not args.no_cpu_baseline:

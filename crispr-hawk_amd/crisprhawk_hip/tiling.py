@@ -239,6 +239,7 @@ class TiledRegionSearch:
             stats = {"tile": t, "rows": tab.n_rows, "candidates": tab.n_candidates, "hits": tab.n_hits, "n_hap": ds.n_hap,
                      "search_ms": tab.timing["total_ms"], "scanned_positions": tab.timing["scanned_positions"],
                      "v_count_ms": tab.timing.get("v_count_ms", 0.0), "v_emit_ms": tab.timing.get("v_emit_ms", 0.0),
+                     "v_emit_rows_ms": tab.timing.get("v_emit_rows_ms", 0.0),
                      "records": int(getattr(pt.plan, "n_records", 0)) if pt.plan is not None else 0,
                      "v_path": int(tab.timing.get("v_path", 0)),
                      "instances": (pt.plan.cluster_stats()["instances"] if pt.plan is not None and int(tab.timing.get("v_path", 0)) == 2 else 0)}

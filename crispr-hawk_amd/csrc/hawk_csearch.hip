@@ -89,7 +89,13 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
   uint32_t at = i0;
   for (uint64_t b0 = lo; b0 < hi; b0 += 256) {  // workgroup-uniform trip count
     const uint64_t j = b0 + threadIdx.x;
-    const bool st = j < hi && cl_starts(recs, j, lo);
+    // the record, the one before and the next one's position, asked for at once: nine clusters in ten are a single record, and
+    // those need nothing else
+    const uint64_t jc = j < hi ? j : hi - 1;
+    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + jc);                        // {o, rs, alt_len, alt_off}
+    const uint4 rp = *reinterpret_cast<const uint4*>(recs + (jc > lo ? jc - 1 : jc));
+    const int32_t o_next = recs[jc + 1 < hi ? jc + 1 : jc].o;
+    const bool st = j < hi && (j == lo || (int32_t)r0.x - ((int32_t)rp.x + (int32_t)rp.z) > CL_LINK);
     uint32_t tot;
     const uint32_t ex = block_excl_scan<256 / WAVE>(st ? 1u : 0u, s_w, &tot);
     if (st) {
@@ -98,19 +104,23 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs,
       // that, where REF resumes behind it, and which alt bases it puts there (length + offset into alt_codes) - not the offset
       // alone: the ABI lets a caller pool alt alleles (one shared "A" for every x>A SNV), and the same offset at two loci is not
       // the same variant.
-      const int32_t o_first = recs[j].o;
+      const int32_t o_first = (int32_t)r0.x;
       int32_t pa = 0, rb = 0;
-      if (j > lo) { pa = recs[j - 1].o + (int32_t)recs[j - 1].alt_len; rb = (int32_t)recs[j - 1].rs - pa; }
-      uint64_t e = j, h = cl_mix(0x243F6A8885A308D3ull, (uint64_t)(uint32_t)(o_first + rb));
-      uint32_t n = 0;
-      do {
-        const HxVar r = recs[e];
-        h = cl_mix(h, (uint64_t)r.alt_off | ((uint64_t)r.alt_len << 32));
-        h = cl_mix(h, (uint64_t)r.rs | ((uint64_t)(uint32_t)(r.o - o_first) << 32));
-        ++n; ++e;
-      } while (e < hi && !cl_starts(recs, e, lo) && n < CL_MAXWALK);
+      if (j > lo) { pa = (int32_t)rp.x + (int32_t)rp.z; rb = (int32_t)rp.y - pa; }
+      uint64_t e = j + 1, h = cl_mix(0x243F6A8885A308D3ull, (uint64_t)(uint32_t)(o_first + rb));
+      h = cl_mix(h, (uint64_t)r0.w | ((uint64_t)r0.z << 32));
+      h = cl_mix(h, (uint64_t)r0.y);
+      uint32_t n = 1;
+      if (e < hi && !(o_next - ((int32_t)r0.x + (int32_t)r0.z) > CL_LINK)) {
+        do {
+          const uint4 r = *reinterpret_cast<const uint4*>(recs + e);
+          h = cl_mix(h, (uint64_t)r.w | ((uint64_t)r.z << 32));
+          h = cl_mix(h, (uint64_t)r.y | ((uint64_t)(uint32_t)((int32_t)r.x - o_first) << 32));
+          ++n; ++e;
+        } while (e < hi && !cl_starts(recs, e, lo) && n < CL_MAXWALK);
+      }
       if (e < hi && !cl_starts(recs, e, lo)) atomicOr(status, 1u);  // a chain too long for this path
-      const int32_t o_end = recs[e - 1].o + (int32_t)recs[e - 1].alt_len;
+      const int32_t o_end = n == 1 ? (int32_t)r0.x + (int32_t)r0.z : recs[e - 1].o + (int32_t)recs[e - 1].alt_len;
       // window starts the cluster can touch: [o_first - (L - 1), o_end), L <= 44; the ranges they are tested against
       // (search_guides.py:49-84, 395-420) are [ss - po, se - po) and [PAD, len - L - PAD], po in {0, guidelen}
       const bool outside = o_end <= ss - 44 || o_first - 43 >= se;
@@ -200,26 +210,36 @@ __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64
   inst_slot[i] = s;
   if (__hip_atomic_load(&trep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&trep[s], i);  // (the minimum only falls)
 }
-__global__ __launch_bounds__(256) void k_cl_flag(uint32_t n_inst, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ inst_slot,
-                                                 const uint32_t* __restrict__ trep, uint32_t* __restrict__ flag) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_inst) flag[i] = (cls[i] && inst_slot[i] != CL_NONE && trep[inst_slot[i]] == i) ? 1u : 0u;
+// The representatives - the lowest instance of every distinct cluster - as a bitmap over the instances, set from the TABLE's side:
+// one thread per slot (a few 10^5) instead of one per instance (10^7), then a count per 32-instance word for the scan that numbers them
+__global__ __launch_bounds__(256) void k_cl_mark(uint32_t tsize, const unsigned long long* __restrict__ tkey, const uint32_t* __restrict__ trep,
+                                                 uint32_t* __restrict__ bits) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= tsize || tkey[s] == 0ull) return;
+  const uint32_t i = trep[s];
+  if (i != CL_NONE) atomicOr(&bits[i >> 5], 1u << (i & 31u));
+}
+__global__ __launch_bounds__(256) void k_cl_popc(uint32_t n_words, const uint32_t* __restrict__ bits, uint32_t* __restrict__ cnt) {
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w < n_words) cnt[w] = (uint32_t)__popc(bits[w]);
 }
 struct ClUniq {  // per distinct cluster
   uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* seg; uint32_t* span2;
 };
-// the representatives (lowest instance of every distinct cluster) number the clusters in instance order
-__global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
-                                                   const uint32_t* __restrict__ inst_slot, ClInst ci, const HxVar* __restrict__ recs,
-                                                   const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
-                                                   uint4* __restrict__ slot_desc, ClUniq cu) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_inst || !flag[i]) return;
-  const uint32_t u = (uint32_t)rank[i];
+// the representatives number the clusters in instance order: rank of the instance's bit = clusters in the words before + in its word
+__global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const unsigned long long* __restrict__ tkey, const uint32_t* __restrict__ trep,
+                                                   const uint32_t* __restrict__ bits, const uint64_t* __restrict__ word_rank, ClInst ci,
+                                                   const HxVar* __restrict__ recs, const uint32_t* __restrict__ seg_off,
+                                                   const uint32_t* __restrict__ seg_rel, uint4* __restrict__ slot_desc, ClUniq cu) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= tsize || tkey[s] == 0ull) return;
+  const uint32_t i = trep[s];
+  if (i == CL_NONE) return;
+  const uint32_t u = (uint32_t)word_rank[i >> 5] + (uint32_t)__popc(bits[i >> 5] & ((1u << (i & 31u)) - 1u));
   const uint32_t r = ci.rec[i], n = ci.n[i];
   // what every other instance of the cluster needs to know about its representative, as ONE 16-byte record per table slot (k_cl_uid
   // gathered six arrays through the representative's index before): {cluster number, first record, records | class << 16, REF position of the first allele}
-  slot_desc[inst_slot[i]] = make_uint4(u, r, n | ((uint32_t)ci.cls[i] << 16), (uint32_t)(ci.o[i] + ci.rb[i]));
+  slot_desc[s] = make_uint4(u, r, n | ((uint32_t)ci.cls[i] << 16), (uint32_t)(ci.o[i] + ci.rb[i]));
   const int32_t o_first = recs[r].o, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
   const uint32_t row = ci.row[i];
   cu.rec[u] = r; cu.n[u] = n; cu.row[u] = row; cu.o[u] = o_first;
@@ -233,29 +253,55 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t n_inst, const uint32
   }
   cu.seg[u] = lo;
 }
+// CL_UID_U instances per thread, their loads issued level by level (instance arrays -> representative's descriptor -> both
+// sides' first records): the pass is three dependent round trips per instance and little else
+#define CL_UID_U 4
 __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint32_t* __restrict__ trep,
                                                 const uint4* __restrict__ slot_desc, ClInst ci, const HxVar* __restrict__ recs,
                                                 uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_inst) return;
-  const uint8_t c = ci.cls[i];
-  if (!c) { inst_uid[i] = CL_NONE; return; }
-  const uint32_t s = inst_slot[i];
-  if (s == CL_NONE) { inst_uid[i] = CL_NONE; return; }  // found no slot (k_cl_insert flagged the dictionary)
-  const uint4 d = slot_desc[s];
-  inst_uid[i] = d.x;
-  if (d.y == ci.rec[i]) return;  // the representative itself
-  // exactness: same hash is not same cluster until the variant identities have been compared
-  const uint32_t n = ci.n[i];
-  bool bad = c != 1 || (d.z >> 16) != 1 || (d.z & 0xffffu) != n || (uint32_t)(ci.o[i] + ci.rb[i]) != d.w;  // same REF position of the first allele
-  if (!bad) {
-    const HxVar* a = recs + ci.rec[i];
-    const HxVar* b = recs + d.y;
-    const int32_t oa = a[0].o, ob = b[0].o;
-    for (uint32_t k = 0; k < n; ++k) {  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record, one load per side
-      const uint4 ra = *reinterpret_cast<const uint4*>(a + k), rb = *reinterpret_cast<const uint4*>(b + k);
-      bad = bad || ra.w != rb.w || ra.z != rb.z || ra.y != rb.y || (int32_t)ra.x - oa != (int32_t)rb.x - ob;
+  const uint32_t i0 = blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
+  uint32_t s[CL_UID_U], rec[CL_UID_U], n[CL_UID_U], refp[CL_UID_U];
+  uint8_t c[CL_UID_U];
+  bool in[CL_UID_U], ok[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    const uint32_t i = i0 + u * 256;
+    in[u] = i < n_inst;
+    const uint32_t ic = in[u] ? i : 0u;
+    c[u] = ci.cls[ic]; s[u] = inst_slot[ic]; rec[u] = ci.rec[ic]; n[u] = ci.n[ic];
+    refp[u] = (uint32_t)(ci.o[ic] + ci.rb[ic]);
+  }
+  uint4 d[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    ok[u] = in[u] && c[u] && s[u] != CL_NONE;  // (no slot: k_cl_insert flagged the dictionary)
+    d[u] = slot_desc[ok[u] ? s[u] : 0u];
+    if (!ok[u]) d[u] = make_uint4(CL_NONE, 0u, 0u, 0u);
+  }
+  uint4 ra[CL_UID_U], rb[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record, one load per side
+    ra[u] = *reinterpret_cast<const uint4*>(recs + (ok[u] ? rec[u] : 0u));
+    rb[u] = *reinterpret_cast<const uint4*>(recs + d[u].y);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    if (in[u]) inst_uid[i0 + u * 256] = d[u].x;
+    if (!ok[u] || d[u].y == rec[u]) continue;  // no cluster / the representative itself
+    // exactness: same hash is not same cluster until the variant identities have been compared
+    bool b = c[u] != 1 || (d[u].z >> 16) != 1 || (d[u].z & 0xffffu) != n[u] || refp[u] != d[u].w;  // same REF position of the first allele
+    b = b || ra[u].w != rb[u].w || ra[u].z != rb[u].z || ra[u].y != rb[u].y;
+    if (!b) {
+      const HxVar* pa = recs + rec[u];
+      const HxVar* pb = recs + d[u].y;
+      const int32_t oa = (int32_t)ra[u].x, ob = (int32_t)rb[u].x;
+      for (uint32_t k = 1; k < n[u]; ++k) {
+        const uint4 xa = *reinterpret_cast<const uint4*>(pa + k), xb = *reinterpret_cast<const uint4*>(pb + k);
+        b = b || xa.w != xb.w || xa.z != xb.z || xa.y != xb.y || (int32_t)xa.x - oa != (int32_t)xb.x - ob;
+      }
     }
+    bad = bad || b;
   }
   if (bad) atomicOr(status, 2u);
 }
@@ -292,19 +338,21 @@ void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, con
   if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + 255) / 256), dim3(256), 0, st, n_inst, key, cls,
                                           static_cast<unsigned long long*>(tkey), trep, mask, inst_slot, status, max_probe, fail_bit, n_head);
 }
-void hawk_launch_cl_flag(hipStream_t st, uint32_t n_inst, const uint8_t* cls, const uint32_t* inst_slot, const uint32_t* trep, uint32_t* flag) {
-  hipLaunchKernelGGL(k_cl_flag, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, cls, inst_slot, trep, flag);
+void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tkey, const uint32_t* trep, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
+  hipLaunchKernelGGL(k_cl_mark, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const unsigned long long*>(tkey), trep, bits);
+  hipLaunchKernelGGL(k_cl_popc, dim3((n_words + 255) / 256), dim3(256), 0, st, n_words, bits, cnt);
 }
-void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
-                           const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec,
-                           uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
-  const uint32_t nb = (n_inst + 255) / 256;
+void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tkey, const uint32_t* bits, const uint64_t* word_rank,
+                           const uint32_t* inst_slot, const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb,
+                           uint32_t* rec, uint32_t* n, uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc,
+                           uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid,
+                           uint32_t* status) {
   ClInst ci{o, row, pa, rb, rec, n, key, cls, nullptr};
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
-  hipLaunchKernelGGL(k_cl_assign, dim3(nb), dim3(256), 0, st, n_inst, flag, rank, inst_slot, ci, static_cast<const HxVar*>(recs), seg_off, seg_rel,
-                     static_cast<uint4*>(slot_desc), cu);
-  hipLaunchKernelGGL(k_cl_uid, dim3(nb), dim3(256), 0, st, n_inst, inst_slot, trep, static_cast<const uint4*>(slot_desc), ci, static_cast<const HxVar*>(recs), inst_uid, status);
+  hipLaunchKernelGGL(k_cl_assign, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const unsigned long long*>(tkey), trep, bits, word_rank, ci,
+                     static_cast<const HxVar*>(recs), seg_off, seg_rel, static_cast<uint4*>(slot_desc), cu);
+  hipLaunchKernelGGL(k_cl_uid, dim3((n_inst + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst, inst_slot, trep,
+                     static_cast<const uint4*>(slot_desc), ci, static_cast<const HxVar*>(recs), inst_uid, status);
 }
 
 // ---- per search ------------------------------------------------------------------------------------
@@ -642,47 +690,70 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
 }
 
-// every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it
+// every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it.
+// CS_CNT_U instances per thread, loads issued level by level (instance arrays, then the entries they point at).
+#define CS_CNT_U 4
 __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, const uint4* __restrict__ res,
                                                   const uint32_t* __restrict__ tbase, const unsigned long long* __restrict__ t_count, uint64_t t_cap,
                                                   uint32_t* __restrict__ group_counts, uint32_t* __restrict__ counts, uint32_t* __restrict__ inst_tb,
                                                   unsigned long long* __restrict__ shards) {
   __shared__ uint32_t s_red[256 / WAVE][2];
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i0 = blockIdx.x * (256 * CS_CNT_U) + threadIdx.x;
   const bool ovf = *t_count > t_cap;  // the template rows outgrew their reservation: no table (the host reruns the search)
-  uint32_t cand = 0, hits = 0, rows_i = 0;
-  if (i < cd.n_inst) {
-    const uint32_t u = cd.inst_uid[i];
-    const int32_t paf = cd.inst_pa[i], o = cd.inst_o[i], rbs = cd.inst_rb[i];
-    const int32_t pa = paf & 0x7fffffff;
-    const int32_t pb = o - (p.L - 1);
-    if (pb > pa) {
-      if (paf < 0) {  // inside every range (k_cl_fill): REF's hits of both strands between the run's ends, two 16-byte entries
-        const uint32_t ra = (uint32_t)(pa + rbs), rb2 = (uint32_t)(pb + rbs);
-        const uint4 ea = va.hp[ra >> 5], eb = va.hp[rb2 >> 5];
-        const uint32_t ma = (1u << (ra & 31u)) - 1u, mb = (1u << (rb2 & 31u)) - 1u;
-        const uint32_t hc = (eb.y + (uint32_t)__popc(eb.x & mb)) - (ea.y + (uint32_t)__popc(ea.x & ma)) +
-                            (eb.w + (uint32_t)__popc(eb.z & mb)) - (ea.w + (uint32_t)__popc(ea.z & ma));
-        hits += hc; cand += hc;
-      } else {
-        const VcRanges rg = cs_ranges(hs, p, cd.inst_row[i]);
-        vc_count_run(va, rg, pa, pb, rbs, cand, hits);
-      }
-    }
-    uint32_t c = 0, tb = 0;
-    if (u != CL_NONE) {
-      const uint4 r = res[u];
-      c = r.x + r.y; hits += r.z; cand += r.w;
-      tb = tbase[u];
-    }
-    rows_i = ovf ? 0u : c;
-    counts[i] = rows_i;
-    inst_tb[i] = tb;  // the instance's first template row: the emit pass reads it next to the count instead of going through u
+  uint32_t uid[CS_CNT_U];
+  int32_t paf[CS_CNT_U], o[CS_CNT_U], rbs[CS_CNT_U];
+  bool in[CS_CNT_U];
+#pragma unroll
+  for (int u = 0; u < CS_CNT_U; ++u) {
+    const uint32_t i = i0 + u * 256;
+    in[u] = i < cd.n_inst;
+    const uint32_t ic = in[u] ? i : 0u;
+    uid[u] = cd.inst_uid[ic]; paf[u] = cd.inst_pa[ic]; o[u] = cd.inst_o[ic]; rbs[u] = cd.inst_rb[ic];
   }
-  // what the offset scan runs over: the rows of 64 consecutive instances (one wave here, one wave's contiguous stretch of the table in
-  // the emit pass) - 1.4 x 10^5 entries on C3 instead of 8.8 x 10^6
-  const uint32_t gsum = wave_sum(rows_i);
-  if ((threadIdx.x & (WAVE - 1)) == 0 && blockIdx.x * 256 + threadIdx.x < cd.n_inst) group_counts[(blockIdx.x * 256 + threadIdx.x) / WAVE] = gsum;
+  uint4 ea[CS_CNT_U], eb[CS_CNT_U], r[CS_CNT_U];
+  uint32_t tb[CS_CNT_U];
+#pragma unroll
+  for (int u = 0; u < CS_CNT_U; ++u) {
+    const int32_t pa = paf[u] & 0x7fffffff, pb = o[u] - (p.L - 1);
+    // inside every range (k_cl_fill): REF's hits of both strands between the run's ends, two 16-byte entries
+    const bool inside = in[u] && pb > pa && paf[u] < 0;
+    const uint32_t ra = inside ? (uint32_t)(pa + rbs[u]) : 0u, rb2 = inside ? (uint32_t)(pb + rbs[u]) : 0u;
+    ea[u] = va.hp[ra >> 5]; eb[u] = va.hp[rb2 >> 5];
+    const bool has = in[u] && uid[u] != CL_NONE;
+    r[u] = make_uint4(0u, 0u, 0u, 0u); tb[u] = 0u;
+    if (cd.n_uniq) { r[u] = res[has ? uid[u] : 0u]; tb[u] = tbase[has ? uid[u] : 0u]; }
+    if (!has) { r[u] = make_uint4(0u, 0u, 0u, 0u); tb[u] = 0u; }
+  }
+  uint32_t cand = 0, hits = 0;
+#pragma unroll
+  for (int u = 0; u < CS_CNT_U; ++u) {
+    const uint32_t i = i0 + u * 256;
+    const int32_t pa = paf[u] & 0x7fffffff, pb = o[u] - (p.L - 1);
+    uint32_t rows_i = 0;
+    if (in[u]) {
+      if (pb > pa) {
+        if (paf[u] < 0) {
+          const uint32_t ra = (uint32_t)(pa + rbs[u]), rb2 = (uint32_t)(pb + rbs[u]);
+          const uint32_t ma = (1u << (ra & 31u)) - 1u, mb = (1u << (rb2 & 31u)) - 1u;
+          const uint32_t hc = (eb[u].y + (uint32_t)__popc(eb[u].x & mb)) - (ea[u].y + (uint32_t)__popc(ea[u].x & ma)) +
+                              (eb[u].w + (uint32_t)__popc(eb[u].z & mb)) - (ea[u].w + (uint32_t)__popc(ea[u].z & ma));
+          hits += hc; cand += hc;
+        } else {
+          const VcRanges rg = cs_ranges(hs, p, cd.inst_row[i]);
+          vc_count_run(va, rg, pa, pb, rbs[u], cand, hits);
+        }
+      }
+      hits += r[u].z; cand += r[u].w;
+      rows_i = ovf ? 0u : r[u].x + r[u].y;
+      counts[i] = rows_i;
+      inst_tb[i] = tb[u];  // the instance's first template row: the emit pass reads it next to the count instead of going through the cluster
+    }
+    // what the offset scan runs over: the rows of 64 consecutive instances (one wave here, one wave's contiguous stretch of the table in
+    // the emit pass) - 1.4 x 10^5 entries on C3 instead of 8.8 x 10^6
+    const uint32_t gsum = wave_sum(rows_i);
+    const uint32_t iw = blockIdx.x * (256 * CS_CNT_U) + u * 256 + (threadIdx.x & ~(uint32_t)(WAVE - 1));
+    if ((threadIdx.x & (WAVE - 1)) == 0 && iw < cd.n_inst) group_counts[iw / WAVE] = gsum;
+  }
   const uint32_t a = wave_sum(cand), b = wave_sum(hits);
   if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
   __syncthreads();
@@ -829,7 +900,7 @@ void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va,
                           const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
                           unsigned long long* shards) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 255) / 256), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), tbase, t_count, t_cap,
+  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 256 * CS_CNT_U - 1) / (256 * CS_CNT_U)), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), tbase, t_count, t_cap,
                      group_counts, counts, inst_tb, shards);
 }
 

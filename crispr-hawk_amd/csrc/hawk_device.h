@@ -166,11 +166,12 @@ void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, ui
                             uint32_t* uid2, int32_t* o2, uint32_t* row2, int32_t* pa2, int32_t* rb2);
 void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep,
                            uint32_t mask, uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit);
-void hawk_launch_cl_flag(hipStream_t st, uint32_t n_inst, const uint8_t* cls, const uint32_t* inst_slot, const uint32_t* trep, uint32_t* flag);
-void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, const uint32_t* flag, const uint64_t* rank, const uint32_t* inst_slot,
-                           const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec,
-                           uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status);
+void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tkey, const uint32_t* trep, uint32_t* bits /* zeroed */, uint32_t n_words, uint32_t* cnt);
+void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tkey, const uint32_t* bits, const uint64_t* word_rank,
+                           const uint32_t* inst_slot, const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb,
+                           uint32_t* rec, uint32_t* n, uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc,
+                           uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid,
+                           uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
                               const struct RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status);
 void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const uint32_t* tbase,
