@@ -33,7 +33,7 @@ EXPORTS = [
     "hawk_gt_lists_download", "hawk_gt_lists_indels", "hawk_host_build_segments", "hawk_host_posmap_rev", "hawk_release_cached_memory", "hawk_xplan_create", "hawk_xplan_set_meta", "hawk_xplan_run", "hawk_xplan_view", "hawk_xplan_cluster_stats", "hawk_xplan_cluster_rebuild", "hawk_host_gather_plan", "hawk_xplan_create_gt", "hawk_xplan_rows",
     "hawk_xplan_finish_meta", "hawk_xplan_segments", "hawk_xplan_install_meta", "hawk_host_alloc", "hawk_host_free", "hawk_hapset_rows_equal",
     "hawk_xplan_destroy", "hawk_hapset_set_ref_partner_range", "hawk_xplan_set_ref_partner_range", "hawk_table_collapse_ex", "hawk_table_collapse_export", "hawk_comm_unique_id", "hawk_comm_init",
-    "hawk_comm_destroy", "hawk_comm_last_error", "hawk_comm_allgather_u64", "hawk_comm_gatherv", "hawk_table_gather", "hawk_host_ragged_join", "hawk_host_tsv_write", "hawk_host_vcf_index", "hawk_host_polish_rows", "hawk_host_group_join", "hawk_host_group_samples", "hawk_gbt_predict", "hawk_gt_from_codes",
+    "hawk_comm_destroy", "hawk_comm_last_error", "hawk_comm_allgather_u64", "hawk_comm_gatherv", "hawk_table_gather", "hawk_host_ragged_join", "hawk_host_tsv_write", "hawk_host_vcf_index", "hawk_host_polish_rows", "hawk_host_variant_window", "hawk_host_polish_windows", "hawk_host_group_join", "hawk_host_group_samples", "hawk_gbt_predict", "hawk_gt_from_codes",
 ]
 
 

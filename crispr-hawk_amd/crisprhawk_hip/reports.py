@@ -420,6 +420,22 @@ class Ragged:
         return Ragged(np.concatenate([self.blob, b2]), np.concatenate([self.off, o2[1:] + self.off[-1]]))
 
 
+def _big_bytes(n: int) -> np.ndarray:
+    """n writable bytes.  The carriers' columns of a big report are hundreds of MB that are written once, by many threads: from a
+    fresh allocation in 4 KB pages that is one page fault per 4 KB (C3: 0.05 s of a 0.1 s join) - so large blobs come from an anonymous
+    mapping advised for transparent huge pages (where the kernel has them; a plain mapping otherwise)."""
+    n = max(int(n), 1)
+    if n < (32 << 20):
+        return np.empty(n, dtype=np.uint8)
+    import mmap
+    mm = mmap.mmap(-1, (n + (2 << 20) - 1) & ~((2 << 20) - 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    try:
+        mm.madvise(mmap.MADV_HUGEPAGE)
+    except (AttributeError, OSError, ValueError):
+        pass
+    return np.frombuffer(mm, dtype=np.uint8, count=n)
+
+
 def _ragged_join_raw(item_label: np.ndarray, group_off: np.ndarray, pool: np.ndarray, pool_off: np.ndarray) -> Ragged:
     """Per group: the pool strings its items name, joined by commas (hawk_host_ragged_join), as a Ragged column."""
     import ctypes as C
@@ -437,7 +453,7 @@ def _ragged_join_raw(item_label: np.ndarray, group_off: np.ndarray, pool: np.nda
     n_lab = C.c_uint64(len(pool_off) - 1)
     _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), n_lab, C.c_uint8(44), None,
                                        C.c_uint64(0), p(out_off)), "hawk_host_ragged_join")
-    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    out = _big_bytes(int(out_off[-1]))
     _lib.check(L.hawk_host_ragged_join(p(item), p(goff), C.c_uint64(ng), p(pool), p(pool_off), n_lab, C.c_uint8(44), p(out),
                                        C.c_uint64(len(out)), p(out_off)), "hawk_host_ragged_join")
     return Ragged(out, out_off)
@@ -502,7 +518,7 @@ def _group_join_raw(member_off, member_hap, per_hap: List[List[str]]) -> Ragged:
     L = _host_lib()
     args = (p(moff), p(mh), C.c_uint64(ng), p(hoff), p(flat), C.c_uint64(len(per_hap)), p(pool), p(poff), C.c_uint64(len(vocab)), C.c_uint8(44))
     _lib.check(L.hawk_host_group_join(*args, None, C.c_uint64(0), p(out_off)), "hawk_host_group_join")
-    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    out = _big_bytes(int(out_off[-1]))
     _lib.check(L.hawk_host_group_join(*args, p(out), C.c_uint64(len(out)), p(out_off)), "hawk_host_group_join")
     return Ragged(out, out_off)
 
@@ -548,7 +564,7 @@ def _samples_raw(member_off, member_hap, hap_samples: List[str]) -> Ragged:
     args = (p(moff), p(mh), C.c_uint64(ng), p(hoff), p(flat), C.c_uint64(len(per_hap)), p(sid), p(a1), p(a2), p(ok), C.c_uint64(n_e),
             p(npool), p(noff), C.c_uint64(len(uniq)), p(epool), p(eoff))
     _lib.check(L.hawk_host_group_samples(*args, None, C.c_uint64(0), p(out_off), p(flags)), "hawk_host_group_samples")
-    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    out = _big_bytes(int(out_off[-1]))
     _lib.check(L.hawk_host_group_samples(*args, p(out), C.c_uint64(len(out)), p(out_off), p(flags)), "hawk_host_group_samples")
     col = Ragged(out, out_off)
     odd = np.flatnonzero(flags == 3)  # a group mixing phased entries with others: the reference's own per-group walk
@@ -604,7 +620,8 @@ class HapLabels:
                 continue
             samples.append(h.samples); ids.append(h.id); is_ref.append(h.samples == "REF"); segs.append(h.segments)
             if h.samples != "REF" and h.variants not in ("NA", ""):
-                for v in set(h.variants.split(",")):
+                # (in position order, as the device path lists them: the library's candidate search is a binary search per row)
+                for v in sorted(set(h.variants.split(",")), key=lambda x: (_parse_variant(x)[0], x)):
                     k = vocab.get(v)
                     if k is None:
                         k = vocab[v] = len(vid)
@@ -628,7 +645,9 @@ class HapLabels:
             pos = np.array([p[0] for p in parsed], dtype=np.int64) if parsed else np.zeros(0, np.int64)
             snv = np.array([len(p[1]) == len(p[2]) for p in parsed], dtype=bool) if parsed else np.zeros(0, bool)
             alt0 = np.array([ord(p[2][0]) if (len(p[1]) == len(p[2]) == 1) else 0 for p in parsed], dtype=np.uint8) if parsed else np.zeros(0, np.uint8)
-            afs = [format_af(x) if str(x) != "nan" else "NA" for x in self.af.tolist()]
+            uniq, inv = np.unique(self.af, return_inverse=True)  # (one NaN entry at most: numpy sorts NaN last and merges them)
+            fmt = np.array([format_af(x) if x == x else "NA" for x in uniq.tolist()], dtype=object)
+            afs = fmt[inv.reshape(-1)].tolist() if len(self.af) else []
             self._vt = (pos, snv, alt0, [p[1] for p in parsed], [p[2] for p in parsed], afs)
         return self._vt
 
@@ -645,6 +664,10 @@ def _variant_columns_raw(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabe
     t_pos, t_snv, t_alt0, t_ref, t_alt, t_af = lab.variant_table()
     H = len(lab)
     cnt_h = np.diff(lab.var_off)
+    if lab.seg_csr is not None:  # candidates + the reference's walk for every alt row inside the library
+        done = _variant_columns_native(G, rep_hap, cores, lab)
+        if done is not None:
+            return done
     v_hap = np.repeat(np.arange(H, dtype=np.int64), cnt_h)
     v_var = lab.var_idx
     BIG = np.int64(1) << np.int64(40)
@@ -730,21 +753,110 @@ def _variant_columns_raw(G, rep_hap: np.ndarray, cores: np.ndarray, lab: HapLabe
         pvl = pair_var.tolist()
         for k in slow.tolist():
             g = int(alt_rows[k])
-            parsed = defaultdict(list)
-            for v in set(pvl[s_off[k]:s_off[k + 1]]):
-                parsed[int(t_pos[v])].append((lab.vid[v], t_ref[v], t_alt[v]))
-            s = int(G.strand[g])
-            stored_right = G.right != bool(s)
-            pivot = int(G.pos[g]) if stored_right else int(G.pos[g]) - G.guidelen
-            gen = lab.segments[int(hh[k])].lookup(np.arange(pivot, pivot + L))
-            core = cores[g].tobytes().decode("ascii")
-            variant_id = polish_guide_variants(core, gen, int(G.stop[g]), parsed)
-            vids = variant_id.split(",")
-            afl = [t_af[_vid_index(lab, v)] for v in vids] if variant_id else []
+            v_s, a_s = _polish_row_python(G, lab, g, int(hh[k]), set(pvl[s_off[k]:s_off[k + 1]]), cores)
             vid_lab[g] = af_lab[g] = NA + 1 + len(slow_vid)
-            slow_vid.append(",".join(sorted(set(vids))) if variant_id else "")
-            slow_af.append("NA" if not afl or (len(set(afl)) == 1 and afl[0] == "NA") else ",".join(afl))
+            slow_vid.append(v_s)
+            slow_af.append(a_s)
     return ids.extended(["NA"] + slow_vid).select(vid_lab), afs.extended(["NA"] + slow_af).select(af_lab)
+
+
+def _polish_row_python(G, lab: "HapLabels", g: int, h: int, cand, cores):
+    """(variant_id, af) of group g on haplotype row h by the Python mirror of annotation.polish_guide_variants (it raises where the
+    reference's own assertion fires)"""
+    t_pos, _, _, t_ref, t_alt, t_af = lab.variant_table()
+    L = G.guidelen + G.pamlen
+    parsed = defaultdict(list)
+    for v in cand:
+        parsed[int(t_pos[v])].append((lab.vid[v], t_ref[v], t_alt[v]))
+    s = int(G.strand[g])
+    stored_right = G.right != bool(s)
+    pivot = int(G.pos[g]) if stored_right else int(G.pos[g]) - G.guidelen
+    gen = lab.segments[h].lookup(np.arange(pivot, pivot + L))
+    core = cores[g].tobytes().decode("ascii")
+    variant_id = polish_guide_variants(core, gen, int(G.stop[g]), parsed)
+    vids = variant_id.split(",")
+    afl = [t_af[_vid_index(lab, v)] for v in vids] if variant_id else []
+    return (",".join(sorted(set(vids))) if variant_id else "",
+            "NA" if not afl or (len(set(afl)) == 1 and afl[0] == "NA") else ",".join(afl))
+
+
+def _variant_columns_native(G, rep_hap: np.ndarray, cores: np.ndarray, lab: "HapLabels"):
+    """_variant_columns_raw with the candidate search (annotation.py:246-284) and the walk over the candidates done by the library for
+    every alt row (hawk_host_variant_window + hawk_host_polish_windows): nothing per candidate exists on the Python side.  None when the
+    library cannot take the job (an older build; rows that do not list their variants in position order)."""
+    import ctypes as C
+    from . import _lib
+    try:
+        f_win, f_pol = _host_lib().hawk_host_variant_window, _host_lib().hawk_host_polish_windows
+    except AttributeError:
+        return None
+    ng, L = G.n_groups, G.guidelen + G.pamlen
+    t_pos, _, _, t_ref, t_alt, t_af = lab.variant_table()
+    cnt_h = np.diff(lab.var_off)
+    na = Ragged.from_strings(["NA"])
+    alt_rows = np.flatnonzero(~lab.is_ref[rep_hap] & (cnt_h[rep_hap] > 0))
+    n = len(alt_rows)
+    if n == 0:
+        z = np.zeros(ng, dtype=np.uint32)
+        return na.select(z), na.select(z)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    hp = np.ascontiguousarray(rep_hap[alt_rows], dtype=np.uint32)
+    start = np.ascontiguousarray(np.asarray(G.start, np.int64)[alt_rows])
+    stop = np.ascontiguousarray(np.asarray(G.stop, np.int64)[alt_rows])
+    p_hi = np.maximum(stop, start + L)
+    var_off = np.ascontiguousarray(lab.var_off, dtype=np.uint64)
+    var_idx = np.ascontiguousarray(lab.var_idx, dtype=np.int64)
+    tp = np.ascontiguousarray(t_pos, dtype=np.int64)
+    first = np.zeros(n, dtype=np.uint64)
+    count = np.zeros(n, dtype=np.uint32)
+    rc = f_win(C.c_uint64(n), p(hp), p(start), p(p_hi), p(var_off), p(var_idx), p(tp), C.c_uint64(len(lab)), C.c_uint32(len(tp)), p(first), p(count))
+    if rc == _lib.HAWK_E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "hawk_host_variant_window")
+    c_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(count, out=c_off[1:])
+    strand = np.asarray(G.strand)[alt_rows].astype(bool)
+    pos = np.asarray(G.pos)[alt_rows].astype(np.int64)
+    pivot = np.ascontiguousarray(np.where(np.logical_xor(bool(G.right), strand), pos, pos - G.guidelen), dtype=np.int64)
+    cr = np.ascontiguousarray(cores[alt_rows], dtype=np.uint8)
+    seg_start, seg_rel, seg_gen = lab.seg_csr
+    rpool, roff = _pool(t_ref)
+    apool, aoff = _pool(t_alt)
+    rpool = rpool if len(rpool) else np.zeros(1, np.uint8)
+    apool = apool if len(apool) else np.zeros(1, np.uint8)
+    name_rank = np.argsort(np.argsort(np.array(lab.vid))).astype(np.uint32) if lab.vid else np.zeros(0, np.uint32)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    out_var = np.zeros(max(int(c_off[-1]), 1), dtype=np.uint32)
+    need = np.zeros(n, dtype=np.uint8)
+    _lib.check(f_pol(C.c_uint64(n), C.c_uint32(L), p(cr), p(hp), p(pivot), p(stop), p(first), p(c_off), p(var_idx), C.c_uint64(len(var_idx)),
+                     p(seg_start), p(seg_rel), p(seg_gen), C.c_uint64(len(seg_start) - 1), p(tp), p(rpool), p(roff), p(apool), p(aoff),
+                     C.c_uint32(len(tp)), p(name_rank), p(out_off), p(out_var), p(need)), "hawk_host_polish_windows")
+    shown = out_var[:int(out_off[-1])]
+    # ids in string order; allele frequencies in the ids' order (guide.py:311-328), "NA" when the row shows nothing or every frequency is missing
+    af_names = sorted(set(t_af))
+    af_rank = {s_: k for k, s_ in enumerate(af_names)}
+    af_of_var = np.array([af_rank[x] for x in t_af], dtype=np.int64)
+    ids = _ragged_join_raw(shown, out_off, *_pool(lab.vid))
+    afs = _ragged_join_raw(af_of_var[shown], out_off, *_pool(af_names))
+    n_shown = np.diff(out_off.astype(np.int64))
+    has_af = np.zeros(n, dtype=bool)
+    if len(shown):
+        known = af_of_var[shown] != af_rank.get("NA", -1)
+        has_af = np.bincount(np.repeat(np.arange(n), n_shown), weights=known, minlength=n) > 0
+    NA = n  # rows of the extended pools: the alt rows' own strings, "NA", then the strings of the rows the Python mirror walked
+    vid_lab = np.full(ng, NA, dtype=np.uint32)
+    af_lab = np.full(ng, NA, dtype=np.uint32)
+    vid_lab[alt_rows] = np.arange(n)
+    af_lab[alt_rows] = np.where(has_af, np.arange(n), NA)
+    py_vid: List[str] = []
+    py_af: List[str] = []
+    for k in np.flatnonzero(need).tolist():  # (rows on which the reference's own assertion fires: its Python mirror raises)
+        g = int(alt_rows[k])
+        v_s, a_s = _polish_row_python(G, lab, g, int(hp[k]), set(var_idx[int(first[k]):int(first[k]) + int(count[k])].tolist()), cores)
+        vid_lab[g] = af_lab[g] = NA + 1 + len(py_vid)
+        py_vid.append(v_s)
+        py_af.append(a_s)
+    return ids.extended(["NA"] + py_vid).select(vid_lab), afs.extended(["NA"] + py_af).select(af_lab)
 
 
 def _polish_rows_native(G, lab: "HapLabels", alt_rows, hh, slow, a, cnt, v_var, cores, t_pos, t_ref, t_alt, name_rank):
@@ -912,14 +1024,30 @@ def _report_order(cols: Dict[str, object], gcols: List[str], n: int) -> np.ndarr
     if len(tpos) == 0:
         return order
     rows = order[tpos]
-    run = np.cumsum(~same[tpos])  # tie runs, numbered in output order
-    keys = []
-    for c in reversed(gcols):
+    # One group column after another, in the groupby's priority, and only over the rows the keys so far have not told apart (the
+    # spacer decides nearly all of them; `samples` - kilobytes per row - is hardly ever looked at): every stage contributes an
+    # integer rank, the final order is a lexsort of integers.
+    cur = np.cumsum(~same[tpos]) - 1  # tie runs, numbered in output order
+    ranks = [cur]
+    live = np.arange(len(rows))
+    for c in gcols:
         if c in ("chr", "start", "stop"):
             continue
-        keys.append(_col_take(cols[c], rows))
-    keys.append(run)
-    order[tpos] = rows[np.lexsort(keys)]
+        col = cols[c]
+        if isinstance(col, ConstCol):
+            continue
+        _, inv = np.unique(_col_take(col, rows[live]), return_inverse=True)
+        sub = np.zeros(len(rows), dtype=np.int64)
+        sub[live] = inv.reshape(-1)
+        ranks.append(sub)
+        comp = cur[live] * (int(inv.max()) + 1) + inv.reshape(-1)
+        _, cinv, ccnt = np.unique(comp, return_inverse=True, return_counts=True)
+        cur = cur.copy()
+        cur[live] = cinv.reshape(-1)           # (only compared among rows that were tied before: a dense id within `live` does)
+        live = live[ccnt[cinv.reshape(-1)] > 1]
+        if len(live) == 0:
+            break
+    order[tpos] = rows[np.lexsort(ranks[::-1])]
     return order
 
 
@@ -940,19 +1068,28 @@ def group_columns(G, haplotypes, pam: PAM, contig: str, target: str, scores: Opt
     lab = haplotypes if isinstance(haplotypes, HapLabels) else HapLabels.from_objects(haplotypes)
     if is_ref_hap is None:
         is_ref_hap = lab.is_ref
+    # The two columns that list every carrier of every row are byte gathers inside the library (no GIL held), and the row order needs
+    # none of the text columns: three more threads while this one decodes the spacers and works out the variant columns
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=3)
+    try:
+        c_samples = pool.submit(_samples_raw, member_off, member_hap, lab.samples)
+        c_hapids = pool.submit(_hapids_raw, member_off, member_hap, lab.ids)
+        return _group_columns(G, lab, pam, contig, target, scores, with_cfdon, is_ref_hap, offtargets, names, member_off, member_hap, rep_hap,
+                              pool, c_samples, c_hapids)
+    finally:
+        pool.shutdown(wait=True)
+
+
+def _group_columns(G, lab, pam, contig, target, scores, with_cfdon, is_ref_hap, offtargets, names, member_off, member_hap, rep_hap, pool, c_samples,
+                   c_hapids):
+    ng, L = G.n_groups, G.guidelen + G.pamlen
     # cased + strand cores of the representatives, from the window slices
     sh = np.arange(GUIDESEQPAD, GUIDESEQPAD + L, dtype=np.uint64)
     code = np.zeros((ng, L), dtype=np.uint8)
     for p in range(5):
         code |= (((np.asarray(G.win[p])[:, None] >> sh) & np.uint64(1)).astype(np.uint8) << p)
     cores = _CODE2CHAR[code]
-    # the two columns that list every carrier of every row are byte gathers inside the library (no GIL held): they run on a
-    # second thread while this one works out the variant columns
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        carriers = pool.submit(lambda: (_samples_raw(member_off, member_hap, lab.samples), _hapids_raw(member_off, member_hap, lab.ids)))
-        vid_col, af_col = _variant_columns_raw(G, rep_hap, cores, lab)
-        samples_col, hapids_col = carriers.result()
     # reverse_guides (annotation.py:27-51): strand-1 rows read as their reverse complement, case preserved
     strand = np.asarray(G.strand).astype(np.int64)
     guide = cores.copy()
@@ -980,6 +1117,16 @@ def group_columns(G, haplotypes, pam: PAM, contig: str, target: str, scores: Opt
     uniq, inv = np.unique(gkey, return_inverse=True)
     data["gc_content"] = VocabCol(inv.reshape(-1), [str((int(k) >> 16) / (int(k) & 0xffff) if (int(k) & 0xffff) else 0.0) for k in uniq.tolist()])
     data["origin"] = VocabCol((~is_ref_hap[rep_hap]).astype(np.uint32), ["ref", "alt"], as_object=False)
+    gcols = REPORTCOLS[:5]
+    if pam.cas_system in (SPCAS9, XCAS9):
+        gcols = gcols + REPORTCOLS[6:12] + REPORTCOLS[13:14] + REPORTCOLS[15:17]
+    elif pam.cas_system == CPF1:
+        gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[12:13] + REPORTCOLS[15:17]
+    else:
+        gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[15:17]
+    c_order = pool.submit(_report_order, dict(data), gcols, ng)
+    vid_col, af_col = _variant_columns_raw(G, rep_hap, cores, lab)
+    samples_col, hapids_col, order = c_samples.result(), c_hapids.result(), c_order.result()
     data["samples"] = samples_col
     data["variant_id"] = vid_col
     data["af"] = af_col
@@ -993,14 +1140,6 @@ def group_columns(G, haplotypes, pam: PAM, contig: str, target: str, scores: Opt
         for c, arr in _offtarget_columns(spacers.tolist(), offtargets, pam.cas_system in (SPCAS9, XCAS9)).items():
             data[c] = Ragged.from_strings([str(x) for x in arr.tolist()])
             plain = plain and _plain(arr.tolist())
-    gcols = REPORTCOLS[:5]
-    if pam.cas_system in (SPCAS9, XCAS9):
-        gcols = gcols + REPORTCOLS[6:12] + REPORTCOLS[13:14] + REPORTCOLS[15:17]
-    elif pam.cas_system == CPF1:
-        gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[12:13] + REPORTCOLS[15:17]
-    else:
-        gcols = gcols + REPORTCOLS[6:7] + REPORTCOLS[15:17]
-    order = _report_order(data, gcols, ng)
     return {c: data[c] for c in names}, order, plain
 
 

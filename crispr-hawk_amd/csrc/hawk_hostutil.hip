@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/hawk.h"
@@ -551,6 +552,93 @@ inline bool is_upper(uint8_t c) { return c >= 'A' && c <= 'Z'; }
 inline bool is_lower(uint8_t c) { return c >= 'a' && c <= 'z'; }
 inline uint8_t to_upper(uint8_t c) { return is_lower(c) ? (uint8_t)(c - 32) : c; }
 }  // namespace
+namespace {
+struct PolishTables {
+  uint32_t L;
+  const uint64_t* seg_start; const uint32_t* seg_rel; const int64_t* seg_gen;
+  const int64_t* t_pos; const uint8_t* ref_pool; const uint64_t* ref_off; const uint8_t* alt_pool; const uint64_t* alt_off;
+  const uint32_t* name_rank;
+};
+// one row of annotation.polish_guide_variants: the candidates `cand` (ascending variant indices, no duplicates) the guide g shows,
+// written to w in id order; returns their number, or -1 where the reference's own assertion would fire
+inline int polish_one(const PolishTables& T, const uint8_t* g, uint32_t hap, int64_t pivot, int64_t stop, const uint32_t* cand, uint32_t n_cand,
+                      uint32_t* w) {
+  const uint32_t L = T.L;
+  int64_t gen[64];
+  // genomic position of every guide position: PosSegments.lookup (last segment with rel <= p)
+  const uint64_t s0 = T.seg_start[hap], s1 = T.seg_start[hap + 1];
+  uint64_t j = s0;
+  {
+    uint64_t lo = s0, hi = s1;  // last j in [s0, s1) with seg_rel[j] <= pivot (seg_rel[s0] = 0)
+    const int64_t p0 = pivot < 0 ? 0 : pivot;
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if ((int64_t)T.seg_rel[mid] <= p0) lo = mid; else hi = mid; }
+    j = lo;
+  }
+  for (uint32_t i = 0; i < L; ++i) {
+    const int64_t p = pivot + i;
+    while (j + 1 < s1 && (int64_t)T.seg_rel[j + 1] <= p) ++j;
+    gen[i] = T.seg_gen[j] + (p - (int64_t)T.seg_rel[j]);
+  }
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < L; ++i) {
+    uint32_t offset = 0;
+    for (uint32_t c = 0; c < n_cand; ++c) {
+      const uint32_t v = cand[c];
+      if (T.t_pos[v] != gen[i]) continue;
+      const uint64_t rl = T.ref_off[v + 1] - T.ref_off[v], al = T.alt_off[v + 1] - T.alt_off[v];
+      const uint8_t* alt = T.alt_pool + T.alt_off[v];
+      const bool is_snv = rl == al;
+      if (!is_snv) offset = rl < al ? (uint32_t)(al - rl) : 0u;
+      const uint32_t sl = std::min<uint32_t>(offset + 1, L - i);  // seg = guidepam[i : i + offset + 1]
+      const uint8_t* seg = g + i;
+      bool show = false;
+      if (!is_snv) {  // _check_insertion
+        if (i == 0) {
+          // _find_insertion_stop asserts a lower-case first base and at least one base that is not upper case
+          bool all_up = true;
+          for (uint32_t q = 0; q < sl; ++q) all_up = all_up && is_upper(seg[q]);
+          if (is_upper(seg[0]) || all_up) return -1;
+          uint32_t st = 0;
+          for (uint32_t q = 0; q < sl; ++q) if (is_upper(seg[q])) { st = q; break; }
+          bool ends = st <= al;  // alt.endswith(seg.upper()[:st])
+          for (uint32_t q = 0; q < st && ends; ++q) ends = alt[al - st + q] == to_upper(seg[q]);
+          show = ends;
+        }
+        if (!show && gen[i] == stop && sl <= al) {  // alt.startswith(seg.upper())
+          bool starts = true;
+          for (uint32_t q = 0; q < sl && starts; ++q) starts = alt[q] == to_upper(seg[q]);
+          show = starts;
+        }
+      }
+      if (!show) {  // seg.islower() and seg.upper() == alt
+        bool low = true;
+        for (uint32_t q = 0; q < sl; ++q) low = low && is_lower(seg[q]);
+        if (low && sl == al) {
+          bool eq = true;
+          for (uint32_t q = 0; q < sl && eq; ++q) eq = alt[q] == to_upper(seg[q]);
+          show = eq;
+        }
+      }
+      if (show) {
+        bool dup = false;
+        for (uint32_t q = 0; q < m; ++q) dup = dup || w[q] == v;
+        if (!dup) w[m++] = v;
+      }
+    }
+  }
+  std::sort(w, w + m, [&](uint32_t x, uint32_t y) { return T.name_rank[x] < T.name_rank[y]; });
+  return (int)m;
+}
+// out_var[off[k] ..) -> out_var[out_off[k] ..), in place (rows only move towards the front)
+inline void polish_compact(uint64_t n, const uint64_t* off, const std::vector<uint32_t>& cnt, uint64_t* out_off, uint32_t* out_var) {
+  out_off[0] = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t src = off[k], dst = out_off[k];
+    if (dst != src) memmove(out_var + dst, out_var + src, (size_t)cnt[k] * 4);
+    out_off[k + 1] = dst + cnt[k];
+  }
+}
+}  // namespace
 int hawk_host_polish_rows(uint64_t n, uint32_t L, const uint8_t* cores, const uint32_t* hap, const int64_t* pivot, const int64_t* stop,
                           const uint64_t* cand_off, const uint32_t* cand_var, const uint64_t* seg_start, const uint32_t* seg_rel,
                           const int64_t* seg_gen, uint64_t n_haps, const int64_t* t_pos, const uint8_t* ref_pool, const uint64_t* ref_off,
@@ -562,86 +650,87 @@ int hawk_host_polish_rows(uint64_t n, uint32_t L, const uint8_t* cores, const ui
     return HAWK_E_INVALID;
   for (uint64_t k = 0; k < n; ++k) if (hap[k] >= n_haps || cand_off[k + 1] < cand_off[k]) return HAWK_E_INVALID;
   for (uint64_t i = 0; i < cand_off[n]; ++i) if (cand_var[i] >= n_var) return HAWK_E_INVALID;
+  const PolishTables T{L, seg_start, seg_rel, seg_gen, t_pos, ref_pool, ref_off, alt_pool, alt_off, name_rank};
   std::vector<uint32_t> cnt(n, 0);
   par_groups(n, [&](uint64_t k0, uint64_t k1) {
-    int64_t gen[64];
     for (uint64_t k = k0; k < k1; ++k) {
-      need_python[k] = 0;
-      const uint8_t* g = cores + k * L;
-      // genomic position of every guide position: PosSegments.lookup (last segment with rel <= p)
-      const uint64_t s0 = seg_start[hap[k]], s1 = seg_start[hap[k] + 1];
-      uint64_t j = s0;
-      {
-        uint64_t lo = s0, hi = s1;  // last j in [s0, s1) with seg_rel[j] <= pivot (seg_rel[s0] = 0)
-        const int64_t p0 = pivot[k] < 0 ? 0 : pivot[k];
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if ((int64_t)seg_rel[mid] <= p0) lo = mid; else hi = mid; }
-        j = lo;
-      }
-      for (uint32_t i = 0; i < L; ++i) {
-        const int64_t p = pivot[k] + i;
-        while (j + 1 < s1 && (int64_t)seg_rel[j + 1] <= p) ++j;
-        gen[i] = seg_gen[j] + (p - (int64_t)seg_rel[j]);
-      }
-      uint32_t* w = out_var + cand_off[k];
-      uint32_t m = 0;
-      for (uint32_t i = 0; i < L && !need_python[k]; ++i) {
-        uint32_t offset = 0;
-        for (uint64_t c = cand_off[k]; c < cand_off[k + 1]; ++c) {
-          const uint32_t v = cand_var[c];
-          if (t_pos[v] != gen[i]) continue;
-          const uint64_t rl = ref_off[v + 1] - ref_off[v], al = alt_off[v + 1] - alt_off[v];
-          const uint8_t* alt = alt_pool + alt_off[v];
-          const bool is_snv = rl == al;
-          if (!is_snv) offset = rl < al ? (uint32_t)(al - rl) : 0u;
-          const uint32_t sl = std::min<uint32_t>(offset + 1, L - i);  // seg = guidepam[i : i + offset + 1]
-          const uint8_t* seg = g + i;
-          bool show = false;
-          if (!is_snv) {  // _check_insertion
-            if (i == 0) {
-              // _find_insertion_stop asserts a lower-case first base and at least one base that is not upper case
-              bool all_up = true;
-              for (uint32_t q = 0; q < sl; ++q) all_up = all_up && is_upper(seg[q]);
-              if (is_upper(seg[0]) || all_up) { need_python[k] = 1; break; }
-              uint32_t st = 0;
-              for (uint32_t q = 0; q < sl; ++q) if (is_upper(seg[q])) { st = q; break; }
-              bool ends = st <= al;  // alt.endswith(seg.upper()[:st])
-              for (uint32_t q = 0; q < st && ends; ++q) ends = alt[al - st + q] == to_upper(seg[q]);
-              show = ends;
-            }
-            if (!show && gen[i] == stop[k] && sl <= al) {  // alt.startswith(seg.upper())
-              bool starts = true;
-              for (uint32_t q = 0; q < sl && starts; ++q) starts = alt[q] == to_upper(seg[q]);
-              show = starts;
-            }
-          }
-          if (!show) {  // seg.islower() and seg.upper() == alt
-            bool low = true;
-            for (uint32_t q = 0; q < sl; ++q) low = low && is_lower(seg[q]);
-            if (low && sl == al) {
-              bool eq = true;
-              for (uint32_t q = 0; q < sl && eq; ++q) eq = alt[q] == to_upper(seg[q]);
-              show = eq;
-            }
-          }
-          if (show) {
-            bool dup = false;
-            for (uint32_t q = 0; q < m; ++q) dup = dup || w[q] == v;
-            if (!dup) w[m++] = v;
-          }
-        }
-      }
-      if (need_python[k]) m = 0;
-      std::sort(w, w + m, [&](uint32_t a, uint32_t b) { return name_rank[a] < name_rank[b]; });
-      cnt[k] = m;
+      const int m = polish_one(T, cores + k * L, hap[k], pivot[k], stop[k], cand_var + cand_off[k], (uint32_t)(cand_off[k + 1] - cand_off[k]),
+                               out_var + cand_off[k]);
+      need_python[k] = m < 0;
+      cnt[k] = m < 0 ? 0u : (uint32_t)m;
     }
   });
-  // compact: out_var[out_off[k] ..) in place (rows only move towards the front)
-  out_off[0] = 0;
-  for (uint64_t k = 0; k < n; ++k) {
-    const uint64_t src = cand_off[k], dst = out_off[k];
-    if (dst != src) memmove(out_var + dst, out_var + src, (size_t)cnt[k] * 4);
-    out_off[k + 1] = dst + cnt[k];
-  }
+  polish_compact(n, cand_off, cnt, out_off, out_var);
+  return HAWK_OK;
+}
+
+int hawk_host_variant_window(uint64_t n, const uint32_t* hap, const int64_t* p_lo, const int64_t* p_hi, const uint64_t* var_off,
+                             const int64_t* var_idx, const int64_t* t_pos, uint64_t n_haps, uint32_t n_var, uint64_t* first, uint32_t* count) {
+  if (!n) return HAWK_OK;
+  if (!hap || !p_lo || !p_hi || !var_off || !var_idx || !t_pos || !first || !count) return HAWK_E_INVALID;
+  std::atomic<int> bad{0};
+  par_groups(n_haps, [&](uint64_t h0, uint64_t h1) {  // every row's list: valid indices, ascending positions
+    for (uint64_t h = h0; h < h1 && !bad.load(std::memory_order_relaxed); ++h) {
+      if (var_off[h + 1] < var_off[h]) { bad = 1; break; }
+      int64_t prev = INT64_MIN;
+      for (uint64_t k = var_off[h]; k < var_off[h + 1]; ++k) {
+        const int64_t v = var_idx[k];
+        if (v < 0 || v >= (int64_t)n_var) { bad = 1; break; }
+        if (t_pos[v] < prev) { bad = 2; break; }
+        prev = t_pos[v];
+      }
+    }
+  });
+  if (bad.load() == 1) return HAWK_E_INVALID;
+  if (bad.load() == 2) return HAWK_E_UNSUPPORTED;  // (the caller sorts, or takes its own route)
+  for (uint64_t k = 0; k < n; ++k) if (hap[k] >= n_haps) return HAWK_E_INVALID;
+  par_groups(n, [&](uint64_t k0, uint64_t k1) {
+    for (uint64_t k = k0; k < k1; ++k) {
+      const uint64_t b0 = var_off[hap[k]], b1 = var_off[hap[k] + 1];
+      uint64_t lo = b0, hi = b1;  // first entry with position >= p_lo
+      while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (t_pos[var_idx[mid]] < p_lo[k]) lo = mid + 1; else hi = mid; }
+      const uint64_t a = lo;
+      hi = b1;                    // first entry with position > p_hi
+      while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (t_pos[var_idx[mid]] <= p_hi[k]) lo = mid + 1; else hi = mid; }
+      first[k] = a;
+      count[k] = (uint32_t)(lo - a);
+    }
+  });
+  return HAWK_OK;
+}
+
+int hawk_host_polish_windows(uint64_t n, uint32_t L, const uint8_t* cores, const uint32_t* hap, const int64_t* pivot, const int64_t* stop,
+                             const uint64_t* first, const uint64_t* cand_off, const int64_t* var_idx, uint64_t n_idx, const uint64_t* seg_start,
+                             const uint32_t* seg_rel, const int64_t* seg_gen, uint64_t n_haps, const int64_t* t_pos, const uint8_t* ref_pool,
+                             const uint64_t* ref_off, const uint8_t* alt_pool, const uint64_t* alt_off, uint32_t n_var, const uint32_t* name_rank,
+                             uint64_t* out_off, uint32_t* out_var, uint8_t* need_python) {
+  if (!n) { if (out_off) out_off[0] = 0; return HAWK_OK; }
+  if (!cores || !hap || !pivot || !stop || !first || !cand_off || !var_idx || !seg_start || !seg_rel || !seg_gen || !t_pos || !ref_off || !alt_off ||
+      !name_rank || !out_off || !out_var || !need_python || !L || L > 64)
+    return HAWK_E_INVALID;
+  for (uint64_t k = 0; k < n; ++k)
+    if (hap[k] >= n_haps || cand_off[k + 1] < cand_off[k] || first[k] + (cand_off[k + 1] - cand_off[k]) > n_idx) return HAWK_E_INVALID;
+  const PolishTables T{L, seg_start, seg_rel, seg_gen, t_pos, ref_pool, ref_off, alt_pool, alt_off, name_rank};
+  std::vector<uint32_t> cnt(n, 0);
+  std::atomic<int> bad{0};
+  par_groups(n, [&](uint64_t k0, uint64_t k1) {
+    std::vector<uint32_t> cand;
+    for (uint64_t k = k0; k < k1; ++k) {
+      const uint64_t nc = cand_off[k + 1] - cand_off[k];
+      cand.resize(nc);
+      for (uint64_t c = 0; c < nc; ++c) {
+        const int64_t v = var_idx[first[k] + c];
+        if (v < 0 || v >= (int64_t)n_var) { bad = 1; cand[c] = 0; } else cand[c] = (uint32_t)v;
+      }
+      std::sort(cand.begin(), cand.end());
+      const uint32_t nu = (uint32_t)(std::unique(cand.begin(), cand.end()) - cand.begin());
+      const int m = polish_one(T, cores + k * L, hap[k], pivot[k], stop[k], cand.data(), nu, out_var + cand_off[k]);
+      need_python[k] = m < 0;
+      cnt[k] = m < 0 ? 0u : (uint32_t)m;
+    }
+  });
+  if (bad.load()) return HAWK_E_INVALID;
+  polish_compact(n, cand_off, cnt, out_off, out_var);
   return HAWK_OK;
 }
 

@@ -303,6 +303,20 @@ int hawk_host_polish_rows(uint64_t n, uint32_t L, const uint8_t* cores, const ui
                           const uint8_t* alt_pool, const uint64_t* alt_off, uint32_t n_var, const uint32_t* name_rank, uint64_t* out_off,
                           uint32_t* out_var, uint8_t* need_python);
 
+/* The same for EVERY alt row of a report, candidates found here as well (annotation.py:246-284: the variants of the guide's haplotype
+ * whose adjusted position lies in [start, max(stop, start + L)]).  Haplotype row h lists its variants - indices into the variant
+ * table - at var_idx[var_off[h] .. var_off[h + 1]), ascending by position.  hawk_host_variant_window: per row k the window
+ * [first[k], first[k] + count[k]) of its haplotype's list with p_lo[k] <= position <= p_hi[k]  (HAWK_E_UNSUPPORTED when a list is not in
+ * position order: the caller keeps its own route).  hawk_host_polish_windows: hawk_host_polish_rows with row k's candidates read from
+ * var_idx[first[k] ..), cand_off[k + 1] - cand_off[k] of them (sorted and made unique here); out_var has capacity cand_off[n]. */
+int hawk_host_variant_window(uint64_t n, const uint32_t* hap, const int64_t* p_lo, const int64_t* p_hi, const uint64_t* var_off,
+                             const int64_t* var_idx, const int64_t* t_pos, uint64_t n_haps, uint32_t n_var, uint64_t* first, uint32_t* count);
+int hawk_host_polish_windows(uint64_t n, uint32_t L, const uint8_t* cores, const uint32_t* hap, const int64_t* pivot, const int64_t* stop,
+                             const uint64_t* first, const uint64_t* cand_off, const int64_t* var_idx, uint64_t n_idx, const uint64_t* seg_start,
+                             const uint32_t* seg_rel, const int64_t* seg_gen, uint64_t n_haps, const int64_t* t_pos, const uint8_t* ref_pool,
+                             const uint64_t* ref_off, const uint8_t* alt_pool, const uint64_t* alt_off, uint32_t n_var, const uint32_t* name_rank,
+                             uint64_t* out_off, uint32_t* out_var, uint8_t* need_python);
+
 /* The line index of a VCF text held in (mapped) memory - replaces the streaming index pass of readers.VCF (variant.py:622-708: the
  * reference opens the file through pysam / tabix): per line its start, POS (-1 header or empty line, -2 malformed record), where
  * the sample columns begin (0: fewer than nine tabs) and the length of its CHROM field; line_start has n_lines + 1 entries.  The

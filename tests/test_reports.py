@@ -67,23 +67,33 @@ def test_report_from_oracle_rows_matches_reference_tsv(case):
     G = reports.ReportGroups.from_report_input(inp)
     df2 = reports.report_from_groups(G, labels, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     assert reports.to_tsv(df2) == fx["report_tsv"]
-    # rows with an indel among their candidate variants: the library's polish helper (position maps as flat arrays) and the
-    # Python mirror of annotation.polish_guide_variants must name the same variants
+    # variant_id / af three ways: candidates + walk inside the library for every alt row (hawk_host_variant_window + _polish_windows),
+    # the numpy route with the library walking only the rows with an indel among their candidates (hawk_host_polish_rows), and the
+    # Python mirror of annotation.polish_guide_variants - the same variants named
     lab = reports.HapLabels.from_objects(labels)
     assert lab.seg_csr is not None
-    calls = []
-    orig = reports._polish_rows_native
-    reports._polish_rows_native = lambda *a, **k: (calls.append(len(a[4])), orig(*a, **k))[1]
+    calls = {"all": 0, "indel": []}
+    orig_all, orig_rows = reports._variant_columns_native, reports._polish_rows_native
+
+    def counted_all(*a, **k):
+        r = orig_all(*a, **k)
+        calls["all"] += r is not None
+        return r
+    reports._variant_columns_native = counted_all
+    reports._polish_rows_native = lambda *a, **k: (calls["indel"].append(len(a[4])), orig_rows(*a, **k))[1]
     try:
         native = reports.group_columns(G, lab, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
+        assert calls["all"] == (1 if len(lab.var_idx) else 0) and not calls["indel"]
+        reports._variant_columns_native = lambda *a, **k: None
+        native_rows = reports.group_columns(G, lab, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     finally:
-        reports._polish_rows_native = orig
+        reports._variant_columns_native, reports._polish_rows_native = orig_all, orig_rows
     lab.seg_csr = None
     mirror = reports.group_columns(G, lab, _pam(fx), fx["contig"], fx["target"], with_cfdon=fx["cfd"])
     for c in ("variant_id", "af"):
-        assert native[0][c].strings() == mirror[0][c].strings(), c
+        assert native[0][c].strings() == mirror[0][c].strings() == native_rows[0][c].strings(), c
     if case == "indel_dense":
-        assert calls and calls[0] > 50  # the helper really had rows to walk
+        assert calls["indel"] and calls["indel"][0] > 50  # the helper really had rows to walk
     # ... and the columns written by the library's TSV writer are the reference's text
     import tempfile
     with tempfile.TemporaryDirectory() as d:

@@ -59,3 +59,4 @@ for rep in range(3):
 os.unlink(out)
 if pr:
     pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+    pstats.Stats(pr).sort_stats("cumtime").print_stats("reports.py|workload.py", 30)
