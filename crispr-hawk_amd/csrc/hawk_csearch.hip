@@ -186,29 +186,53 @@ __global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_
   pm.uid2[d] = pm.uid[i]; pm.o2[d] = pm.o[i]; pm.row2[d] = row; pm.pa2[d] = pm.pa[i]; pm.rb2[d] = pm.rb[i];
 }
 
+// CL_INS_U instances per thread: their first looks at the table are in flight together (the pass is gathers into a few MB and
+// nothing else).  The looks are ordinary cached loads: a stale answer only sends the instance on to the atomic, which tells the truth.
+#define CL_INS_U 4
 __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
-                                                   unsigned long long* __restrict__ tkey, uint32_t* __restrict__ trep, uint32_t mask,
+                                                   unsigned long long* tkey, uint32_t* trep, uint32_t mask,
                                                    uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status, uint32_t max_probe, uint32_t fail_bit,
                                                    uint32_t i_first) {
-  const uint32_t i = i_first + blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_inst) return;
-  if (!cls[i]) { inst_slot[i] = CL_NONE; return; }
-  const unsigned long long k = key[i];
-  uint32_t s = (uint32_t)(k >> 17) & mask;
-  bool placed = false;
-  // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
-  // for the distinct clusters expected gives up after max_probe slots and the host repeats the insert with the full size)
-  for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
-    // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
-    // atomic on it would queue them all at one address (a stale read only sends the instance to the CAS, which answers with the truth)
-    unsigned long long cur = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == 0ull) cur = atomicCAS(&tkey[s], 0ull, k);
-    if (cur == 0ull || cur == k) { placed = true; break; }
-    s = (s + 1u) & mask;
+  const uint32_t i0 = i_first + blockIdx.x * (256 * CL_INS_U) + threadIdx.x;
+  unsigned long long k[CL_INS_U], cur[CL_INS_U];
+  uint32_t s[CL_INS_U], rep[CL_INS_U];
+  bool on[CL_INS_U];
+#pragma unroll
+  for (int u = 0; u < CL_INS_U; ++u) {
+    const uint32_t i = i0 + u * 256;
+    const uint32_t ic = i < n_inst ? i : 0u;
+    on[u] = i < n_inst && cls[ic] != 0;
+    k[u] = key[ic];
+    if (i < n_inst && !on[u]) inst_slot[i] = CL_NONE;
   }
-  if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, fail_bit); return; }  // full-size table: cannot happen; the dictionary is then not used
-  inst_slot[i] = s;
-  if (__hip_atomic_load(&trep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&trep[s], i);  // (the minimum only falls)
+#pragma unroll
+  for (int u = 0; u < CL_INS_U; ++u) {
+    s[u] = (uint32_t)(k[u] >> 17) & mask;
+    cur[u] = tkey[s[u]]; rep[u] = trep[s[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < CL_INS_U; ++u) {
+    if (!on[u]) continue;
+    const uint32_t i = i0 + u * 256;
+    unsigned long long c = cur[u];
+    uint32_t sl = s[u];
+    bool placed = false, first = true;
+    // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
+    // for the distinct clusters expected gives up after max_probe slots and the host repeats the insert with the full size)
+    for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
+      // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
+      // atomic on it would queue them all at one address
+      if (!first) c = tkey[sl];
+      if (c == 0ull) c = atomicCAS(&tkey[sl], 0ull, k[u]);  // (a slot never changes hands once taken: any other value seen is final)
+      if (c == 0ull || c == k[u]) { placed = true; break; }
+      sl = (sl + 1u) & mask;
+      first = false;
+    }
+    if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, fail_bit); continue; }  // full-size table: cannot happen; the dictionary is then not used
+    inst_slot[i] = sl;
+    const uint32_t seen = (first && rep[u] != CL_NONE) ? rep[u] : __hip_atomic_load(&trep[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen > i) atomicMin(&trep[sl], i);  // (the minimum only falls: a stale, higher value only costs the atomic)
+  }
 }
 // The representatives - the lowest instance of every distinct cluster - as a bitmap over the instances, set from the TABLE's side:
 // one thread per slot (a few 10^5) instead of one per instance (10^7), then a count per 32-instance word for the scan that numbers them
@@ -333,9 +357,9 @@ void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, ui
 void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep,
                            uint32_t mask, uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
   n_head = n_head < n_inst ? n_head : n_inst;
-  if (n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_head + 255) / 256), dim3(256), 0, st, n_head, key, cls, static_cast<unsigned long long*>(tkey), trep, mask,
+  if (n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_head + 256 * CL_INS_U - 1) / (256 * CL_INS_U)), dim3(256), 0, st, n_head, key, cls, static_cast<unsigned long long*>(tkey), trep, mask,
                                  inst_slot, status, max_probe, fail_bit, 0u);
-  if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + 255) / 256), dim3(256), 0, st, n_inst, key, cls,
+  if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + 256 * CL_INS_U - 1) / (256 * CL_INS_U)), dim3(256), 0, st, n_inst, key, cls,
                                           static_cast<unsigned long long*>(tkey), trep, mask, inst_slot, status, max_probe, fail_bit, n_head);
 }
 void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tkey, const uint32_t* trep, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
@@ -388,8 +412,8 @@ __device__ __forceinline__ int64_t posmap_hint(const HapSetDev& hs, uint32_t k0,
 // at tbase[u] (strand 0 in position order, then strand 1), packed: a workgroup adds up its clusters' rows and takes its
 // stretch of the template array with one atomic.
 __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, GuideParams gp, RefInfo ri,
-                                                      uint4* __restrict__ res, uint32_t* __restrict__ tbase, CsRow* __restrict__ trows,
-                                                      unsigned long long* __restrict__ t_count, uint64_t t_cap, int* status) {
+                                                      uint4* __restrict__ res, uint4* __restrict__ res2, uint32_t* __restrict__ tbase,
+                                                      CsRow* __restrict__ trows, unsigned long long* __restrict__ t_count, uint64_t t_cap, int* status) {
   __shared__ double s_cfd[336];
   __shared__ uint32_t s_w[256 / WAVE];
   __shared__ unsigned long long s_base;
@@ -417,6 +441,18 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   const int32_t qb = o_end < haplen ? o_end : haplen;
   const int nwords = qb > qa ? (qb - qa + 31) / 32 : 0;
   const VcRanges rg = cs_ranges(hs, p, h);
+  // REF's PAM hits (both strands) in front of where the cluster's own window starts begin, and in front of where REF resumes behind
+  // its last allele: the clean run between two clusters of a row then has  before(this cluster) - behind(the one in front)  hits,
+  // whichever row carries the two (k_cs_count) - REF coordinates, so part of the cluster's identity
+  auto hits_before = [&](int64_t x) -> uint32_t {
+    const int64_t xm = (int64_t)va.ref_S * 32;
+    const uint32_t xc = (uint32_t)(x < 0 ? 0 : (x > xm ? xm : x));
+    const uint4 e = va.hp[xc >> 5];
+    const uint32_t m = (1u << (xc & 31u)) - 1u;
+    return e.y + (uint32_t)__popc(e.x & m) + e.w + (uint32_t)__popc(e.z & m);
+  };
+  const int32_t rb_front = back ? (int32_t)sv[0].rs - (sv[0].o + (int32_t)sv[0].alt_len) : 0;
+  const uint32_t h_front = hits_before((int64_t)o_first + rb_front - (L - 1)), h_behind = hits_before((int64_t)recs[r0 + nc - 1].rs);
   const int poF = p.right ? 0 : p.guidelen, poR = p.right ? p.guidelen : 0;
   const uint32_t mlo = L >= 32 ? 0xffffffffu : ((1u << L) - 1u), mhi = L <= 32 ? 0u : ((1u << (L - 32)) - 1u);
   const int W = L + 2 * HAWK_PAD;
@@ -594,7 +630,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   const uint64_t tb = s_base + gex;
   if (tb + want > 0xffffffffull) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
   if (!one_round) {
-    if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
+    if (leader) { res[u] = make_uint4(n0, n1, hits, cand); res2[u] = make_uint4((uint32_t)tb, h_front, h_behind, 0u); tbase[u] = (uint32_t)tb; }
     if (!live || n0 + n1 == 0) return;  // no barrier below
     uint32_t b0 = 0, b1 = 0, h2 = 0, c2 = 0;
 #pragma unroll 1
@@ -687,75 +723,76 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
     if (sd == 0) n0 = ns; else n1 = ns;
     done += ns;
   }
-  if (leader) { res[u] = make_uint4(n0, n1, hits, cand); tbase[u] = (uint32_t)tb; }
+  if (leader) { res[u] = make_uint4(n0, n1, hits, cand); res2[u] = make_uint4((uint32_t)tb, h_front, h_behind, 0u); tbase[u] = (uint32_t)tb; }
 }
 
-// every instance: rows = those of its cluster; the job's totals get the cluster's own hits and the clean run in front of it.
-// CS_CNT_U instances per thread, loads issued level by level (instance arrays, then the entries they point at).
+// every instance: rows = those of its cluster; the job's totals get the cluster's own hits and those of the clean run in front of it -
+// REF's hits before this cluster minus REF's hits behind the cluster in front (res2 of the two, the neighbour's through the lane
+// below): two 16-byte gathers per instance.  CS_CNT_U instances per thread, loads issued level by level.
 #define CS_CNT_U 4
 __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, const uint4* __restrict__ res,
-                                                  const uint32_t* __restrict__ tbase, const unsigned long long* __restrict__ t_count, uint64_t t_cap,
+                                                  const uint4* __restrict__ res2, const unsigned long long* __restrict__ t_count, uint64_t t_cap,
                                                   uint32_t* __restrict__ group_counts, uint32_t* __restrict__ counts, uint32_t* __restrict__ inst_tb,
                                                   unsigned long long* __restrict__ shards) {
   __shared__ uint32_t s_red[256 / WAVE][2];
   const uint32_t i0 = blockIdx.x * (256 * CS_CNT_U) + threadIdx.x;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
   const bool ovf = *t_count > t_cap;  // the template rows outgrew their reservation: no table (the host reruns the search)
-  uint32_t uid[CS_CNT_U];
-  int32_t paf[CS_CNT_U], o[CS_CNT_U], rbs[CS_CNT_U];
+  uint32_t uid[CS_CNT_U], below[CS_CNT_U];
+  int32_t paf[CS_CNT_U];
   bool in[CS_CNT_U];
 #pragma unroll
   for (int u = 0; u < CS_CNT_U; ++u) {
     const uint32_t i = i0 + u * 256;
     in[u] = i < cd.n_inst;
     const uint32_t ic = in[u] ? i : 0u;
-    uid[u] = cd.inst_uid[ic]; paf[u] = cd.inst_pa[ic]; o[u] = cd.inst_o[ic]; rbs[u] = cd.inst_rb[ic];
+    uid[u] = cd.inst_uid[ic]; paf[u] = cd.inst_pa[ic];
+    below[u] = CL_NONE;
+    if (lane == 0 && in[u] && i > 0) below[u] = cd.inst_uid[i - 1];  // (the other lanes' neighbour is the lane below)
   }
-  uint4 ea[CS_CNT_U], eb[CS_CNT_U], r[CS_CNT_U];
-  uint32_t tb[CS_CNT_U];
+  uint4 r[CS_CNT_U], r2[CS_CNT_U];
+  uint32_t behind0[CS_CNT_U];
 #pragma unroll
   for (int u = 0; u < CS_CNT_U; ++u) {
-    const int32_t pa = paf[u] & 0x7fffffff, pb = o[u] - (p.L - 1);
-    // inside every range (k_cl_fill): REF's hits of both strands between the run's ends, two 16-byte entries
-    const bool inside = in[u] && pb > pa && paf[u] < 0;
-    const uint32_t ra = inside ? (uint32_t)(pa + rbs[u]) : 0u, rb2 = inside ? (uint32_t)(pb + rbs[u]) : 0u;
-    ea[u] = va.hp[ra >> 5]; eb[u] = va.hp[rb2 >> 5];
     const bool has = in[u] && uid[u] != CL_NONE;
-    r[u] = make_uint4(0u, 0u, 0u, 0u); tb[u] = 0u;
-    if (cd.n_uniq) { r[u] = res[has ? uid[u] : 0u]; tb[u] = tbase[has ? uid[u] : 0u]; }
-    if (!has) { r[u] = make_uint4(0u, 0u, 0u, 0u); tb[u] = 0u; }
+    r[u] = make_uint4(0u, 0u, 0u, 0u); r2[u] = r[u]; behind0[u] = 0u;
+    if (cd.n_uniq) {
+      r[u] = res[has ? uid[u] : 0u]; r2[u] = res2[has ? uid[u] : 0u];
+      if (lane == 0 && below[u] != CL_NONE) behind0[u] = res2[below[u]].z;
+    }
+    if (!has) { r[u] = make_uint4(0u, 0u, 0u, 0u); r2[u] = r[u]; }
   }
   uint32_t cand = 0, hits = 0;
 #pragma unroll
   for (int u = 0; u < CS_CNT_U; ++u) {
     const uint32_t i = i0 + u * 256;
-    const int32_t pa = paf[u] & 0x7fffffff, pb = o[u] - (p.L - 1);
+    uint32_t behind = (uint32_t)__shfl_up((int)r2[u].z, 1);
+    if (lane == 0) behind = behind0[u];
     uint32_t rows_i = 0;
     if (in[u]) {
-      if (pb > pa) {
-        if (paf[u] < 0) {
-          const uint32_t ra = (uint32_t)(pa + rbs[u]), rb2 = (uint32_t)(pb + rbs[u]);
-          const uint32_t ma = (1u << (ra & 31u)) - 1u, mb = (1u << (rb2 & 31u)) - 1u;
-          const uint32_t hc = (eb[u].y + (uint32_t)__popc(eb[u].x & mb)) - (ea[u].y + (uint32_t)__popc(ea[u].x & ma)) +
-                              (eb[u].w + (uint32_t)__popc(eb[u].z & mb)) - (ea[u].w + (uint32_t)__popc(ea[u].z & ma));
-          hits += hc; cand += hc;
-        } else {
+      if (paf[u] < 0) {  // the run in front lies inside every range (k_cl_fill): it has a cluster at either end, and those know
+        const uint32_t hc = r2[u].y - behind;
+        hits += hc; cand += hc;
+      } else {
+        const int32_t pa = paf[u], pb = cd.inst_o[i] - (p.L - 1);
+        if (pb > pa) {
           const VcRanges rg = cs_ranges(hs, p, cd.inst_row[i]);
-          vc_count_run(va, rg, pa, pb, rbs[u], cand, hits);
+          vc_count_run(va, rg, pa, pb, cd.inst_rb[i], cand, hits);
         }
       }
       hits += r[u].z; cand += r[u].w;
       rows_i = ovf ? 0u : r[u].x + r[u].y;
       counts[i] = rows_i;
-      inst_tb[i] = tb[u];  // the instance's first template row: the emit pass reads it next to the count instead of going through the cluster
+      inst_tb[i] = r2[u].x;  // the instance's first template row: the emit pass reads it next to the count instead of going through the cluster
     }
     // what the offset scan runs over: the rows of 64 consecutive instances (one wave here, one wave's contiguous stretch of the table in
     // the emit pass) - 1.4 x 10^5 entries on C3 instead of 8.8 x 10^6
     const uint32_t gsum = wave_sum(rows_i);
     const uint32_t iw = blockIdx.x * (256 * CS_CNT_U) + u * 256 + (threadIdx.x & ~(uint32_t)(WAVE - 1));
-    if ((threadIdx.x & (WAVE - 1)) == 0 && iw < cd.n_inst) group_counts[iw / WAVE] = gsum;
+    if (lane == 0 && iw < cd.n_inst) group_counts[iw / WAVE] = gsum;
   }
   const uint32_t a = wave_sum(cand), b = wave_sum(hits);
-  if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
+  if (lane == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t t0 = 0, t1 = 0;
@@ -890,17 +927,19 @@ void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const uint32_t* 
 }
 
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const GuideParams& gp,
-                              const RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status) {
+                              const RefInfo& ri, void* res, void* res2, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap,
+                              int* status) {
   if (!cd.n_uniq) return;
   const uint32_t nb = (uint32_t)(((uint64_t)cd.n_uniq * CS_G + 255) / 256);
-  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), tbase, static_cast<CsRow*>(trows),
+  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), static_cast<uint4*>(res2), tbase,
+                     static_cast<CsRow*>(trows),
                      t_count, t_cap, status);
 }
-void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const uint32_t* tbase,
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const void* res2,
                           const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
                           unsigned long long* shards) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 256 * CS_CNT_U - 1) / (256 * CS_CNT_U)), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), tbase, t_count, t_cap,
+  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 256 * CS_CNT_U - 1) / (256 * CS_CNT_U)), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), static_cast<const uint4*>(res2), t_count, t_cap,
                      group_counts, counts, inst_tb, shards);
 }
 

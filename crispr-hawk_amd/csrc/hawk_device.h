@@ -173,8 +173,9 @@ void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, cons
                            uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid,
                            uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
-                              const struct RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status);
-void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const uint32_t* tbase,
+                              const struct RefInfo& ri, void* res, void* res2, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap,
+                              int* status);
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const void* res2,
                           const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
                           unsigned long long* shards);
 void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const uint32_t* counts, const uint32_t* inst_tb, const void* trows, const uint64_t* offsets,
