@@ -160,7 +160,7 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
     const char* e0 = getenv("HAWK_CLUSTER_ROWS0");  // tests: a first reservation small enough to overflow
     const uint64_t first = e0 ? strtoull(e0, nullptr, 10) : 16ull * cl.n_uniq + 65536;
     tcap = std::max<uint64_t>(std::min<uint64_t>(cl.slots, std::max<uint64_t>(hs->cs_tcap, first)), 1);
-    // (cs_res: {rows per strand, hits, candidates} of every distinct cluster, then {first template row, REF's hits before / behind it})
+    // (cs_res, 32 bytes per distinct cluster: {rows per strand, hits, candidates} {first template row, REF's hits before / behind it})
     if ((rc = hs->cs_res.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 32)) || (rc = hs->cs_tbase.reserve((size_t)std::max<uint32_t>(cl.n_uniq, 1) * 4)) ||
         (rc = hs->cs_trows.reserve((size_t)tcap * hawk_cs_row_bytes())) || (rc = hs->cs_itb.reserve((size_t)std::max<uint32_t>(cl.n_inst, 1) * 4)) ||
         (rc = hs->cs_icnt.reserve((size_t)std::max<uint32_t>(cl.n_inst, 1) * 4)))
@@ -170,10 +170,9 @@ static int hawk_search_once(hawk_hapset* hs, const hawk_search_params* p, hawk_t
   uint32_t* const d_counts_v = hs->counts.as<uint32_t>() + plane_tiles;
   auto view_count = [&]() {
     if (by_cluster) {
-      void* const res2 = static_cast<char*>(hs->cs_res.p) + (size_t)std::max<uint32_t>(cd.n_uniq, 1) * 16;
-      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, res2, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, d_tcount, tcap, d_status);
+      hawk_launch_cs_templates(ctx->stream, d, va, cd, sp, gp, ri, hs->cs_res.p, hs->cs_tbase.as<uint32_t>(), hs->cs_trows.p, d_tcount, tcap, d_status);
       (void)hipEventRecord(ctx->ev[8], ctx->stream);
-      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, res2, d_tcount, tcap, d_counts_v, hs->cs_icnt.as<uint32_t>(),
+      hawk_launch_cs_count(ctx->stream, d, va, cd, sp, hs->cs_res.p, d_tcount, tcap, d_counts_v, hs->cs_icnt.as<uint32_t>(),
                            hs->cs_itb.as<uint32_t>(), d_shards);
     } else {
       hawk_launch_vsearch(ctx->stream, 0, d, va, sp, gp, ri, hs->d_tile_meta, hs->counts.as<uint32_t>(), hs->vcnt0.as<uint32_t>(), d_shards, nullptr,

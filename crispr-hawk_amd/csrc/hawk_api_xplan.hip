@@ -310,11 +310,12 @@ static int xplan_build_dict(hawk_xplan* x) {
   }
   TEMPCHK(tmp, &d_bkt, (size_t)n_inst * 2);
   TEMPCHK(tmp, &d_cnt_br, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_first_rb, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_base_br, ((size_t)n * n_bkt + 1) * 8);
-  uint32_t *d_rec, *d_n, *d_slot, *d_bits, *d_wcnt, *d_trep;
-  void* d_slot_uid;  // 16 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
+  uint32_t *d_rec, *d_n, *d_slot, *d_bits, *d_wcnt;
+  void* d_slot_uid;  // 32 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
+  void* d_tab;       // the table itself: 16-byte slots {key, ~lowest instance}
   uint64_t *d_key, *d_rank;
   uint8_t* d_cls;
-  unsigned long long *d_tkey, *d_partial, *d_shards;
+  unsigned long long *d_partial, *d_shards;
   ScanTotals* d_tot;
   // the hash table of distinct clusters: at least two slots per instance would always do, but on a shared panel the distinct
   // clusters are a small fraction of the instances and clearing 12 bytes x 2^25 slots costs as much as a kernel of this build
@@ -333,19 +334,17 @@ static int xplan_build_dict(hawk_xplan* x) {
   TEMPCHK(tmp, &d_key, (size_t)n_inst * 8);
   TEMPCHK(tmp, &d_rank, ((size_t)n_words + 1) * 8);
   TEMPCHK(tmp, &d_cls, (size_t)n_inst);
-  TEMPCHK(tmp, &d_tkey, (size_t)tsize * 8);
-  TEMPCHK(tmp, &d_trep, (size_t)tsize * 4);
+  TEMPCHK(tmp, &d_tab, (size_t)tsize * hawk_cl_slot_bytes());
   TEMPCHK(tmp, &d_partial, ((size_t)std::max<uint64_t>(n_inst, (uint64_t)n * n_bkt) / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
-  HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsmall * 8, st));
-  HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsmall * 4, st));
+  HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsmall * hawk_cl_slot_bytes(), st));
   HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
   HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
   hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
                       t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls, d_bkt, bshift, n_bkt, d_cnt_br, d_first_rb, d_status);
-  hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tkey, d_trep, tsmall - 1, d_slot, d_status, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u);
-  hawk_launch_cl_mark(st, tsmall, d_tkey, d_trep, d_bits, n_words, d_wcnt);
+  hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tab, tsmall - 1, d_slot, d_status, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u);
+  hawk_launch_cl_mark(st, tsmall, d_tab, d_bits, n_words, d_wcnt);
   hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
   ScanTotals tot;
   uint32_t st_now = 0;
@@ -358,20 +357,19 @@ static int xplan_build_dict(hawk_xplan* x) {
     tused = tsize;
     st_now &= ~8u;
     HIPCHK(hipMemcpyAsync(d_status, &st_now, 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(d_tkey, 0, (size_t)tsize * 8, st));
-    HIPCHK(hipMemsetAsync(d_trep, 0xff, (size_t)tsize * 4, st));
+    HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsize * hawk_cl_slot_bytes(), st));
     HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
     HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
     HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
-    hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tkey, d_trep, tsize - 1, d_slot, d_status, 0xffffffffu, 2u);
-    hawk_launch_cl_mark(st, tsize, d_tkey, d_trep, d_bits, n_words, d_wcnt);
+    hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tab, tsize - 1, d_slot, d_status, 0xffffffffu, 2u);
+    hawk_launch_cl_mark(st, tsize, d_tab, d_bits, n_words, d_wcnt);
     hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
     HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
   }
   const uint32_t n_uniq = (uint32_t)tot.n_keep;
-  TEMPCHK(tmp, &d_slot_uid, (size_t)tused * 16);
+  TEMPCHK(tmp, &d_slot_uid, (size_t)tused * 32);
   cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.last_uniq = n_uniq;
   if (n_uniq) {
     uint32_t* d_span2;
@@ -381,7 +379,7 @@ static int xplan_build_dict(hawk_xplan* x) {
       return rc;
     uint64_t* d_slot64;
     TEMPCHK(tmp, &d_slot64, ((size_t)n_uniq + 1) * 8);
-    hawk_launch_cl_assign(st, n_inst, tused, d_tkey, d_bits, d_rank, d_slot, d_trep, x->recs.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls,
+    hawk_launch_cl_assign(st, n_inst, tused, d_tab, d_bits, d_rank, d_slot, x->recs.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls,
                           x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), d_slot_uid, cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
                           cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, t_uid, d_status);
     hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, d_slot64, d_tot + 1);

@@ -186,16 +186,20 @@ __global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_
   pm.uid2[d] = pm.uid[i]; pm.o2[d] = pm.o[i]; pm.row2[d] = row; pm.pa2[d] = pm.pa[i]; pm.rb2[d] = pm.rb[i];
 }
 
-// CL_INS_U instances per thread: their first looks at the table are in flight together (the pass is gathers into a few MB and
-// nothing else).  The looks are ordinary cached loads: a stale answer only sends the instance on to the atomic, which tells the truth.
+// The table of distinct clusters: 16-byte slots {hash key (0: free), ~(lowest instance seen), -} - key and representative in ONE
+// 64-byte request to L2 (the pass is bound by the number of such requests, not by bytes; two arrays were two requests per look).
+struct __attribute__((aligned(16))) ClSlot { unsigned long long key; uint32_t nrep; uint32_t pad; };  // nrep = ~instance: 0 = none, atomicMax lowers the instance
+static_assert(sizeof(ClSlot) == 16, "table slot layout");
+// CL_INS_U instances per thread: their first looks at the table are in flight together.  The looks are ordinary cached loads: a
+// stale answer only sends the instance on to the atomic, which tells the truth.
 #define CL_INS_U 4
 __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
-                                                   unsigned long long* tkey, uint32_t* trep, uint32_t mask,
-                                                   uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status, uint32_t max_probe, uint32_t fail_bit,
-                                                   uint32_t i_first) {
+                                                   ClSlot* tab, uint32_t mask, uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status,
+                                                   uint32_t max_probe, uint32_t fail_bit, uint32_t i_first) {
   const uint32_t i0 = i_first + blockIdx.x * (256 * CL_INS_U) + threadIdx.x;
-  unsigned long long k[CL_INS_U], cur[CL_INS_U];
-  uint32_t s[CL_INS_U], rep[CL_INS_U];
+  unsigned long long k[CL_INS_U];
+  uint4 look[CL_INS_U];
+  uint32_t s[CL_INS_U];
   bool on[CL_INS_U];
 #pragma unroll
   for (int u = 0; u < CL_INS_U; ++u) {
@@ -208,40 +212,40 @@ __global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64
 #pragma unroll
   for (int u = 0; u < CL_INS_U; ++u) {
     s[u] = (uint32_t)(k[u] >> 17) & mask;
-    cur[u] = tkey[s[u]]; rep[u] = trep[s[u]];
+    look[u] = *reinterpret_cast<const uint4*>(tab + s[u]);
   }
 #pragma unroll
   for (int u = 0; u < CL_INS_U; ++u) {
     if (!on[u]) continue;
     const uint32_t i = i0 + u * 256;
-    unsigned long long c = cur[u];
+    unsigned long long c = (unsigned long long)look[u].x | ((unsigned long long)look[u].y << 32);
+    uint32_t nrep = look[u].z;
     uint32_t sl = s[u];
-    bool placed = false, first = true;
+    bool placed = false;
     // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
     // for the distinct clusters expected gives up after max_probe slots and the host repeats the insert with the full size)
     for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
       // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
       // atomic on it would queue them all at one address
-      if (!first) c = tkey[sl];
-      if (c == 0ull) c = atomicCAS(&tkey[sl], 0ull, k[u]);  // (a slot never changes hands once taken: any other value seen is final)
+      if (probe) { const uint4 e = *reinterpret_cast<const uint4*>(tab + sl); c = (unsigned long long)e.x | ((unsigned long long)e.y << 32); nrep = e.z; }
+      if (c == 0ull) { c = atomicCAS(&tab[sl].key, 0ull, k[u]); nrep = 0u; }  // (a slot never changes hands once taken: any other value seen is final)
       if (c == 0ull || c == k[u]) { placed = true; break; }
       sl = (sl + 1u) & mask;
-      first = false;
     }
     if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, fail_bit); continue; }  // full-size table: cannot happen; the dictionary is then not used
     inst_slot[i] = sl;
-    const uint32_t seen = (first && rep[u] != CL_NONE) ? rep[u] : __hip_atomic_load(&trep[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen > i) atomicMin(&trep[sl], i);  // (the minimum only falls: a stale, higher value only costs the atomic)
+    if (nrep < ~i) atomicMax(&tab[sl].nrep, ~i);  // (the lowest instance only falls: a stale look only costs the atomic)
   }
 }
 // The representatives - the lowest instance of every distinct cluster - as a bitmap over the instances, set from the TABLE's side:
 // one thread per slot (a few 10^5) instead of one per instance (10^7), then a count per 32-instance word for the scan that numbers them
-__global__ __launch_bounds__(256) void k_cl_mark(uint32_t tsize, const unsigned long long* __restrict__ tkey, const uint32_t* __restrict__ trep,
-                                                 uint32_t* __restrict__ bits) {
+__global__ __launch_bounds__(256) void k_cl_mark(uint32_t tsize, const ClSlot* __restrict__ tab, uint32_t* __restrict__ bits) {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= tsize || tkey[s] == 0ull) return;
-  const uint32_t i = trep[s];
-  if (i != CL_NONE) atomicOr(&bits[i >> 5], 1u << (i & 31u));
+  if (s >= tsize) return;
+  const uint4 e = *reinterpret_cast<const uint4*>(tab + s);
+  if ((e.x | e.y) == 0u || e.z == 0u) return;
+  const uint32_t i = ~e.z;
+  atomicOr(&bits[i >> 5], 1u << (i & 31u));
 }
 __global__ __launch_bounds__(256) void k_cl_popc(uint32_t n_words, const uint32_t* __restrict__ bits, uint32_t* __restrict__ cnt) {
   const uint32_t w = blockIdx.x * 256 + threadIdx.x;
@@ -251,20 +255,24 @@ struct ClUniq {  // per distinct cluster
   uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* seg; uint32_t* span2;
 };
 // the representatives number the clusters in instance order: rank of the instance's bit = clusters in the words before + in its word
-__global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const unsigned long long* __restrict__ tkey, const uint32_t* __restrict__ trep,
-                                                   const uint32_t* __restrict__ bits, const uint64_t* __restrict__ word_rank, ClInst ci,
-                                                   const HxVar* __restrict__ recs, const uint32_t* __restrict__ seg_off,
-                                                   const uint32_t* __restrict__ seg_rel, uint4* __restrict__ slot_desc, ClUniq cu) {
+__global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const ClSlot* __restrict__ tab, const uint32_t* __restrict__ bits,
+                                                   const uint64_t* __restrict__ word_rank, ClInst ci, const HxVar* __restrict__ recs,
+                                                   const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
+                                                   uint4* __restrict__ slot_desc, ClUniq cu) {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= tsize || tkey[s] == 0ull) return;
-  const uint32_t i = trep[s];
-  if (i == CL_NONE) return;
+  if (s >= tsize) return;
+  const uint4 e = *reinterpret_cast<const uint4*>(tab + s);
+  if ((e.x | e.y) == 0u || e.z == 0u) return;
+  const uint32_t i = ~e.z;
   const uint32_t u = (uint32_t)word_rank[i >> 5] + (uint32_t)__popc(bits[i >> 5] & ((1u << (i & 31u)) - 1u));
   const uint32_t r = ci.rec[i], n = ci.n[i];
-  // what every other instance of the cluster needs to know about its representative, as ONE 16-byte record per table slot (k_cl_uid
-  // gathered six arrays through the representative's index before): {cluster number, first record, records | class << 16, REF position of the first allele}
-  slot_desc[s] = make_uint4(u, r, n | ((uint32_t)ci.cls[i] << 16), (uint32_t)(ci.o[i] + ci.rb[i]));
-  const int32_t o_first = recs[r].o, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
+  // what every other instance of the cluster needs to know about its representative, as ONE 32-byte record per table slot - one
+  // request to L2: {cluster number, first record, records | class << 16, REF position of the first allele} {the first record's
+  // rs, alt_len, alt_off, -} (nine clusters in ten are that one record: k_cl_uid then never touches the representative's records)
+  const uint4 r0 = *reinterpret_cast<const uint4*>(recs + r);
+  slot_desc[2 * (size_t)s] = make_uint4(u, r, n | ((uint32_t)ci.cls[i] << 16), (uint32_t)(ci.o[i] + ci.rb[i]));
+  slot_desc[2 * (size_t)s + 1] = make_uint4(r0.y, r0.z, r0.w, 0u);
+  const int32_t o_first = (int32_t)r0.x, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
   const uint32_t row = ci.row[i];
   cu.rec[u] = r; cu.n[u] = n; cu.row[u] = row; cu.o[u] = o_first;
   cu.span2[u] = 2u * ((uint32_t)(o_end - o_first) + CL_LINK);  // rows the cluster can have: window starts [o_first - L + 1, o_end) x 2 strands
@@ -280,9 +288,8 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const unsigne
 // CL_UID_U instances per thread, their loads issued level by level (instance arrays -> representative's descriptor -> both
 // sides' first records): the pass is three dependent round trips per instance and little else
 #define CL_UID_U 4
-__global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint32_t* __restrict__ trep,
-                                                const uint4* __restrict__ slot_desc, ClInst ci, const HxVar* __restrict__ recs,
-                                                uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint4* __restrict__ slot_desc, ClInst ci,
+                                                const HxVar* __restrict__ recs, uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
   const uint32_t i0 = blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
   uint32_t s[CL_UID_U], rec[CL_UID_U], n[CL_UID_U], refp[CL_UID_U];
   uint8_t c[CL_UID_U];
@@ -295,18 +302,14 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
     c[u] = ci.cls[ic]; s[u] = inst_slot[ic]; rec[u] = ci.rec[ic]; n[u] = ci.n[ic];
     refp[u] = (uint32_t)(ci.o[ic] + ci.rb[ic]);
   }
-  uint4 d[CL_UID_U];
+  uint4 d[CL_UID_U], d1[CL_UID_U], ra[CL_UID_U];
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
     ok[u] = in[u] && c[u] && s[u] != CL_NONE;  // (no slot: k_cl_insert flagged the dictionary)
-    d[u] = slot_desc[ok[u] ? s[u] : 0u];
+    const size_t sd = ok[u] ? 2 * (size_t)s[u] : 0;
+    d[u] = slot_desc[sd]; d1[u] = slot_desc[sd + 1];
+    ra[u] = *reinterpret_cast<const uint4*>(recs + (ok[u] ? rec[u] : 0u));  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record
     if (!ok[u]) d[u] = make_uint4(CL_NONE, 0u, 0u, 0u);
-  }
-  uint4 ra[CL_UID_U], rb[CL_UID_U];
-#pragma unroll
-  for (int u = 0; u < CL_UID_U; ++u) {  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record, one load per side
-    ra[u] = *reinterpret_cast<const uint4*>(recs + (ok[u] ? rec[u] : 0u));
-    rb[u] = *reinterpret_cast<const uint4*>(recs + d[u].y);
   }
   bool bad = false;
 #pragma unroll
@@ -315,11 +318,11 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
     if (!ok[u] || d[u].y == rec[u]) continue;  // no cluster / the representative itself
     // exactness: same hash is not same cluster until the variant identities have been compared
     bool b = c[u] != 1 || (d[u].z >> 16) != 1 || (d[u].z & 0xffffu) != n[u] || refp[u] != d[u].w;  // same REF position of the first allele
-    b = b || ra[u].w != rb[u].w || ra[u].z != rb[u].z || ra[u].y != rb[u].y;
-    if (!b) {
+    b = b || ra[u].y != d1[u].x || ra[u].z != d1[u].y || ra[u].w != d1[u].z;
+    if (!b && n[u] > 1) {
       const HxVar* pa = recs + rec[u];
       const HxVar* pb = recs + d[u].y;
-      const int32_t oa = (int32_t)ra[u].x, ob = (int32_t)rb[u].x;
+      const int32_t oa = (int32_t)ra[u].x, ob = pb[0].o;
       for (uint32_t k = 1; k < n[u]; ++k) {
         const uint4 xa = *reinterpret_cast<const uint4*>(pa + k), xb = *reinterpret_cast<const uint4*>(pb + k);
         b = b || xa.w != xb.w || xa.z != xb.z || xa.y != xb.y || (int32_t)xa.x - oa != (int32_t)xb.x - ob;
@@ -354,28 +357,29 @@ void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, ui
 // then all lower `trep` - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's size).  After
 // the head launch (<= `n_head` instances: a few dozen rows) every common cluster's key and its lowest instance are in the table,
 // so the rest only look.
-void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep,
-                           uint32_t mask, uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
+void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tab, uint32_t mask,
+                           uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
   n_head = n_head < n_inst ? n_head : n_inst;
-  if (n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_head + 256 * CL_INS_U - 1) / (256 * CL_INS_U)), dim3(256), 0, st, n_head, key, cls, static_cast<unsigned long long*>(tkey), trep, mask,
-                                 inst_slot, status, max_probe, fail_bit, 0u);
-  if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + 256 * CL_INS_U - 1) / (256 * CL_INS_U)), dim3(256), 0, st, n_inst, key, cls,
-                                          static_cast<unsigned long long*>(tkey), trep, mask, inst_slot, status, max_probe, fail_bit, n_head);
+  const uint32_t per = 256 * CL_INS_U;
+  if (n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_head + per - 1) / per), dim3(256), 0, st, n_head, key, cls, static_cast<ClSlot*>(tab), mask, inst_slot,
+                                 status, max_probe, fail_bit, 0u);
+  if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + per - 1) / per), dim3(256), 0, st, n_inst, key, cls, static_cast<ClSlot*>(tab),
+                                          mask, inst_slot, status, max_probe, fail_bit, n_head);
 }
-void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tkey, const uint32_t* trep, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
-  hipLaunchKernelGGL(k_cl_mark, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const unsigned long long*>(tkey), trep, bits);
+size_t hawk_cl_slot_bytes() { return sizeof(ClSlot); }
+void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
+  hipLaunchKernelGGL(k_cl_mark, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits);
   hipLaunchKernelGGL(k_cl_popc, dim3((n_words + 255) / 256), dim3(256), 0, st, n_words, bits, cnt);
 }
-void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tkey, const uint32_t* bits, const uint64_t* word_rank,
-                           const uint32_t* inst_slot, const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb,
-                           uint32_t* rec, uint32_t* n, uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc,
-                           uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid,
-                           uint32_t* status) {
+void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tab, const uint32_t* bits, const uint64_t* word_rank,
+                           const uint32_t* inst_slot, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
+                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec, uint32_t* u_n,
+                           uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
   ClInst ci{o, row, pa, rb, rec, n, key, cls, nullptr};
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
-  hipLaunchKernelGGL(k_cl_assign, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const unsigned long long*>(tkey), trep, bits, word_rank, ci,
+  hipLaunchKernelGGL(k_cl_assign, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits, word_rank, ci,
                      static_cast<const HxVar*>(recs), seg_off, seg_rel, static_cast<uint4*>(slot_desc), cu);
-  hipLaunchKernelGGL(k_cl_uid, dim3((n_inst + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst, inst_slot, trep,
+  hipLaunchKernelGGL(k_cl_uid, dim3((n_inst + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst, inst_slot,
                      static_cast<const uint4*>(slot_desc), ci, static_cast<const HxVar*>(recs), inst_uid, status);
 }
 
@@ -408,12 +412,12 @@ __device__ __forceinline__ int64_t posmap_hint(const HapSetDev& hs, uint32_t k0,
 }
 
 // Every distinct cluster's rows, once: a group of CS_G lanes per cluster, each lane one word of 32 window starts per round.
-// res[u] = {rows of strand 0, rows of strand 1, PAM hits, candidates} of the cluster's own window starts; its template rows sit
+// res[2u] = {rows of strand 0, rows of strand 1, PAM hits, candidates} of the cluster's own window starts, res[2u + 1] = {first template
+// row, REF's hits before the cluster, REF's hits behind it, -} (32 bytes: one request to L2 from k_cs_count); its template rows sit
 // at tbase[u] (strand 0 in position order, then strand 1), packed: a workgroup adds up its clusters' rows and takes its
 // stretch of the template array with one atomic.
 __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, GuideParams gp, RefInfo ri,
-                                                      uint4* __restrict__ res, uint4* __restrict__ res2, uint32_t* __restrict__ tbase,
-                                                      CsRow* __restrict__ trows, unsigned long long* __restrict__ t_count, uint64_t t_cap, int* status) {
+                                                      uint4* __restrict__ res, uint32_t* __restrict__ tbase, CsRow* __restrict__ trows, unsigned long long* __restrict__ t_count, uint64_t t_cap, int* status) {
   __shared__ double s_cfd[336];
   __shared__ uint32_t s_w[256 / WAVE];
   __shared__ unsigned long long s_base;
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   const uint64_t tb = s_base + gex;
   if (tb + want > 0xffffffffull) atomicExch(status, -7 /* HAWK_E_UNSUPPORTED: template rows beyond 32-bit indices */);
   if (!one_round) {
-    if (leader) { res[u] = make_uint4(n0, n1, hits, cand); res2[u] = make_uint4((uint32_t)tb, h_front, h_behind, 0u); tbase[u] = (uint32_t)tb; }
+    if (leader) { res[2 * u] = make_uint4(n0, n1, hits, cand); res[2 * u + 1] = make_uint4((uint32_t)tb, h_front, h_behind, 0u); tbase[u] = (uint32_t)tb; }
     if (!live || n0 + n1 == 0) return;  // no barrier below
     uint32_t b0 = 0, b1 = 0, h2 = 0, c2 = 0;
 #pragma unroll 1
@@ -723,15 +727,15 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
     if (sd == 0) n0 = ns; else n1 = ns;
     done += ns;
   }
-  if (leader) { res[u] = make_uint4(n0, n1, hits, cand); res2[u] = make_uint4((uint32_t)tb, h_front, h_behind, 0u); tbase[u] = (uint32_t)tb; }
+  if (leader) { res[2 * u] = make_uint4(n0, n1, hits, cand); res[2 * u + 1] = make_uint4((uint32_t)tb, h_front, h_behind, 0u); tbase[u] = (uint32_t)tb; }
 }
 
 // every instance: rows = those of its cluster; the job's totals get the cluster's own hits and those of the clean run in front of it -
-// REF's hits before this cluster minus REF's hits behind the cluster in front (res2 of the two, the neighbour's through the lane
+// REF's hits before this cluster minus REF's hits behind the cluster in front (second half of the two entries, the neighbour's through the lane
 // below): two 16-byte gathers per instance.  CS_CNT_U instances per thread, loads issued level by level.
 #define CS_CNT_U 4
 __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDict cd, ScanParams p, const uint4* __restrict__ res,
-                                                  const uint4* __restrict__ res2, const unsigned long long* __restrict__ t_count, uint64_t t_cap,
+                                                  const unsigned long long* __restrict__ t_count, uint64_t t_cap,
                                                   uint32_t* __restrict__ group_counts, uint32_t* __restrict__ counts, uint32_t* __restrict__ inst_tb,
                                                   unsigned long long* __restrict__ shards) {
   __shared__ uint32_t s_red[256 / WAVE][2];
@@ -757,8 +761,9 @@ __global__ __launch_bounds__(256) void k_cs_count(HapSetDev hs, VcArgs va, ClDic
     const bool has = in[u] && uid[u] != CL_NONE;
     r[u] = make_uint4(0u, 0u, 0u, 0u); r2[u] = r[u]; behind0[u] = 0u;
     if (cd.n_uniq) {
-      r[u] = res[has ? uid[u] : 0u]; r2[u] = res2[has ? uid[u] : 0u];
-      if (lane == 0 && below[u] != CL_NONE) behind0[u] = res2[below[u]].z;
+      const uint32_t us = has ? uid[u] : 0u;
+      r[u] = res[2 * us]; r2[u] = res[2 * us + 1];
+      if (lane == 0 && below[u] != CL_NONE) behind0[u] = res[2 * below[u] + 1].z;
     }
     if (!has) { r[u] = make_uint4(0u, 0u, 0u, 0u); r2[u] = r[u]; }
   }
@@ -927,19 +932,17 @@ void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const uint32_t* 
 }
 
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const GuideParams& gp,
-                              const RefInfo& ri, void* res, void* res2, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap,
-                              int* status) {
+                              const RefInfo& ri, void* res, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap, int* status) {
   if (!cd.n_uniq) return;
   const uint32_t nb = (uint32_t)(((uint64_t)cd.n_uniq * CS_G + 255) / 256);
-  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), static_cast<uint4*>(res2), tbase,
-                     static_cast<CsRow*>(trows),
+  hipLaunchKernelGGL(k_cs_templates, dim3(nb), dim3(256), 0, st, hs, va, cd, p, gp, ri, static_cast<uint4*>(res), tbase, static_cast<CsRow*>(trows),
                      t_count, t_cap, status);
 }
-void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const void* res2,
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
                           const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
                           unsigned long long* shards) {
   if (!cd.n_inst) return;
-  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 256 * CS_CNT_U - 1) / (256 * CS_CNT_U)), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), static_cast<const uint4*>(res2), t_count, t_cap,
+  hipLaunchKernelGGL(k_cs_count, dim3((cd.n_inst + 256 * CS_CNT_U - 1) / (256 * CS_CNT_U)), dim3(256), 0, st, hs, va, cd, p, static_cast<const uint4*>(res), t_count, t_cap,
                      group_counts, counts, inst_tb, shards);
 }
 
@@ -998,7 +1001,7 @@ void hawk_launch_rows_unpack(hipStream_t st, const uint4* rows, uint64_t n, int6
 // its copies (start, stop, strand, REF-or-not, the windows)
 __global__ __launch_bounds__(256) void k_cc_ucnt(const uint4* __restrict__ res, uint32_t nu, uint32_t* __restrict__ cnt) {
   const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-  if (u < nu) { const uint4 r = res[u]; cnt[u] = r.x + r.y; }
+  if (u < nu) { const uint4 r = res[2 * u]; cnt[u] = r.x + r.y; }
 }
 // mini row r0 + moff[u] + k is row k of distinct cluster u: template row tbase[u] + k
 __global__ __launch_bounds__(256) void k_cc_mini(GuideCols c, uint64_t r0, const CsRow* __restrict__ trows, uint64_t t_rows,
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_cs_gid(ClDict cd, const uint4* __restri
   uint32_t cnt = 0, tb = 0;
   if (i < cd.n_inst) {
     const uint32_t u = cd.inst_uid[i];
-    if (u != CL_NONE) { const uint4 r = res[u]; cnt = r.x + r.y; tb = (uint32_t)moff[u]; }
+    if (u != CL_NONE) { const uint4 r = res[2 * u]; cnt = r.x + r.y; tb = (uint32_t)moff[u]; }
   }
   const uint32_t inc = wave_incl_scan(cnt);
   const uint32_t Wt = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);

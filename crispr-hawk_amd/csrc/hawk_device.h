@@ -164,18 +164,19 @@ void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_of
 void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* bkt, const uint64_t* base_br,
                             const uint32_t* first_rb, const uint32_t* uid, const int32_t* o, const uint32_t* row, const int32_t* pa, const int32_t* rb,
                             uint32_t* uid2, int32_t* o2, uint32_t* row2, int32_t* pa2, int32_t* rb2);
-void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tkey, uint32_t* trep,
-                           uint32_t mask, uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit);
-void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tkey, const uint32_t* trep, uint32_t* bits /* zeroed */, uint32_t n_words, uint32_t* cnt);
-void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tkey, const uint32_t* bits, const uint64_t* word_rank,
-                           const uint32_t* inst_slot, const uint32_t* trep, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb,
-                           uint32_t* rec, uint32_t* n, uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc,
+size_t hawk_cl_slot_bytes();  // a slot of the table of distinct clusters: {key, ~lowest instance}
+void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tab /* zeroed */, uint32_t mask,
+                           uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit);
+void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits /* zeroed */, uint32_t n_words, uint32_t* cnt);
+void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tab, const uint32_t* bits, const uint64_t* word_rank,
+                           const uint32_t* inst_slot, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
+                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc /* 32 B per slot */,
                            uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid,
                            uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
-                              const struct RefInfo& ri, void* res, void* res2, uint32_t* tbase, void* trows, unsigned long long* t_count, uint64_t t_cap,
-                              int* status);
-void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res, const void* res2,
+                              const struct RefInfo& ri, void* res /* 32 B per distinct cluster */, uint32_t* tbase, void* trows,
+                              unsigned long long* t_count, uint64_t t_cap, int* status);
+void hawk_launch_cs_count(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const void* res,
                           const unsigned long long* t_count, uint64_t t_cap, uint32_t* group_counts, uint32_t* counts, uint32_t* inst_tb,
                           unsigned long long* shards);
 void hawk_launch_cs_emit_rows(hipStream_t st, const ClDict& cd, const uint32_t* counts, const uint32_t* inst_tb, const void* trows, const uint64_t* offsets,

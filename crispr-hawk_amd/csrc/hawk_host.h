@@ -118,7 +118,7 @@ struct hawk_hapset {
   DevBuf vcnt0;               // per tile: rows of strand 0 (k_vsearch<0> -> k_vsearch<1>)
   DevBuf refhp;               // REF's PAM hits + prefix counts per strand (k_ref_hits), keyed like refbits
   uint64_t cs_tcap = 0;       // template rows a search of this view may need (raised to the plan's bound after an overflow)
-  DevBuf cs_res, cs_tbase, cs_trows, cs_itb, cs_icnt;  // per distinct cluster {rows per strand, hits, candidates}, first template row; template rows; per instance its first template row
+  DevBuf cs_res, cs_tbase, cs_trows, cs_itb, cs_icnt;  // per distinct cluster 32 B {rows per strand, hits, candidates} {first template row, REF hits before / behind}, first template row; template rows; per instance its first template row
   DevBuf cmini[8], cm_gid;   // hawk_table_collapse of such a table: REF's rows + the template rows as a table of their own, their groups  // the cluster search of a view: per distinct cluster {rows per strand, hits, candidates}, first template row; template rows
   DevBuf colsA[8];
   DevBuf rowsA;               // packed rows of a cluster-searched table (colsA then stages REF's rows only)
