@@ -26,7 +26,7 @@ void hawk_xplan_destroy(hawk_xplan* x) {
   (void)hipStreamSynchronize(x->ctx->stream);
   for (auto& p : x->ref_plane) hawk_pool_free(p);
   for (auto& b : x->ref5) b.release();
-  DevBuf* bufs[] = {&x->recs, &x->tiles, &x->codes, &x->off, &x->hlen, &x->hash,
+  DevBuf* bufs[] = {&x->recs, &x->heads, &x->tiles, &x->codes, &x->off, &x->hlen, &x->hash,
                     &x->m_is_ref, &x->m_ss, &x->m_se, &x->m_seg_off, &x->m_seg_rel, &x->m_seg_gen, &x->m_tile,
                     &x->cl.inst_uid, &x->cl.inst_o, &x->cl.inst_row, &x->cl.inst_pa, &x->cl.inst_rb, &x->cl.u_rec, &x->cl.u_n, &x->cl.u_row,
                     &x->cl.u_o, &x->cl.u_seg};
@@ -69,6 +69,7 @@ static int xplan_build(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
   if (!rc && !d_idx) rc = t_idx.reserve(nc * 4);
   if (!rc && !d_idx) rc = t_o.reserve(nc * 4);
   if (!rc) rc = x->recs.reserve(nc * hawk_hx_record_bytes());
+  if (!rc) rc = x->heads.reserve(nc * 16);
   if (!rc) rc = x->tiles.reserve(nwg * hawk_hx_tile_bytes());
   if (!rc) rc = x->codes.reserve(std::max<size_t>(alt_codes_len, 1));
   if (!rc) rc = x->off.reserve((size_t)(n_hap + 1) * 8);
@@ -111,6 +112,7 @@ static int xplan_build(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
     hawk_launch_hx_prepare(st, x->off.as<uint64_t>(), d_idx ? d_idx : t_idx.as<uint32_t>(), d_o ? d_o : t_o.as<int32_t>(), ncar, t_r0.as<uint32_t>(),
                            t_span.as<uint32_t>(), t_ao.as<uint32_t>(), t_al.as<uint32_t>(), t_am.p, x->hlen.as<uint32_t>(), n_hap, x->S,
                            x->recs.p, x->tiles.p);
+    hawk_launch_hx_heads(st, x->recs.p, ncar, x->heads.p);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -273,79 +275,73 @@ static int xplan_build_dict(hawk_xplan* x) {
   const uint32_t n = x->n_hap;
   if (x->ncar == 0 || x->ncar >= (1ull << 32) - 2 || n < 2) { cl.status = 4; return HAWK_OK; }
   PoolScope tmp;
-  uint32_t *d_cnt, *d_off, *d_status;
-  TEMPCHK(tmp, &d_cnt, (size_t)n * 4);
-  TEMPCHK(tmp, &d_off, (size_t)(n + 1) * 4);
+  // the rows' records in chunks (hawk_csearch.hip): chunks per row -> their offsets and rows, then the instances every chunk opens
+  const uint32_t ch_bound = hawk_cl_chunk_bound(x->ncar, n);
+  uint32_t *d_ch_off, *d_ch_row, *d_cnt, *d_base, *d_status;
+  TEMPCHK(tmp, &d_ch_off, (size_t)(n + 1) * 4);
+  TEMPCHK(tmp, &d_ch_row, (size_t)ch_bound * 4);
+  TEMPCHK(tmp, &d_cnt, (size_t)ch_bound * 4);
+  TEMPCHK(tmp, &d_base, (size_t)(ch_bound + 1) * 4);
   TEMPCHK(tmp, &d_status, 64);
   HIPCHK(hipMemsetAsync(d_status, 0, 64, st));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ch_bound * 4, st));  // (chunks beyond the last one open nothing)
   HIPCHK(hipEventRecord(ctx->ev[8], st));
-  hawk_launch_cl_count(st, x->recs.p, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_cnt);
-  hawk_launch_scan_u32(st, d_cnt, n, d_off);
-  uint32_t n_inst = 0, n_head = 0;  // n_head: the instances of the first 48 rows (hawk_launch_cl_insert)
-  HIPCHK(hipMemcpyAsync(&n_inst, d_off + n, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&n_head, d_off + std::min<uint32_t>(n, 49), 4, hipMemcpyDeviceToHost, st));
+  hawk_launch_cl_chunks(st, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row);
+  // (the number of chunks is only known on the device - rows that scan nothing have none: the count pass and its scan run over the bound)
+  hawk_launch_cl_count(st, x->heads.p, x->off.as<uint64_t>(), d_ch_off, d_ch_row, n, ch_bound, d_cnt);
+  hawk_launch_scan_u32(st, d_cnt, ch_bound, d_base);
+  uint32_t n_chunks = 0, n_head = 0, n_inst = 0;  // n_head: the chunks of the first 48 rows (hawk_launch_cl_fill)
+  HIPCHK(hipMemcpyAsync(&n_chunks, d_ch_off + n, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&n_head, d_ch_off + std::min<uint32_t>(n, 49), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&n_inst, d_base + ch_bound, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (n_chunks > ch_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: chunk count beyond its bound"); return HAWK_E_HIP; }
   if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
   int rc;
   if ((rc = cl.inst_uid.reserve((size_t)n_inst * 4)) || (rc = cl.inst_o.reserve((size_t)n_inst * 4)) || (rc = cl.inst_row.reserve((size_t)n_inst * 4)) ||
       (rc = cl.inst_pa.reserve((size_t)n_inst * 4)) || (rc = cl.inst_rb.reserve((size_t)n_inst * 4)))
     return rc;
-  // built in (row, position) order, then laid out stretch by stretch of REF (k_cl_permute)
-  // HAWK_CLUSTER_ORDER=stretch lays the instances out stretch by stretch of REF (32 kb each: the template rows a search copies
-  // then stay in L2) at the price of a table that is no longer haplotype-major; the default keeps (row, position) order
-  uint32_t bshift = 31;
-  { const char* eo = getenv("HAWK_CLUSTER_ORDER"); if (eo && eo[0] == 's') { bshift = 15; while (((x->ref_len >> bshift) + 1) > 1024) ++bshift; } }
-  const uint32_t n_bkt = (x->ref_len >> bshift) + 1;
-  uint32_t *t_uid, *t_row, *d_cnt_br, *d_first_rb;
-  int32_t *t_o, *t_pa, *t_rb;
-  uint16_t* d_bkt;
-  uint64_t* d_base_br;
-  const bool in_place = n_bkt == 1;  // one stretch: the order the instances are built in is the order they stay in
-  if (in_place) {
-    t_uid = cl.inst_uid.as<uint32_t>(); t_row = cl.inst_row.as<uint32_t>(); t_o = cl.inst_o.as<int32_t>();
-    t_pa = cl.inst_pa.as<int32_t>(); t_rb = cl.inst_rb.as<int32_t>();
-  } else {
-    TEMPCHK(tmp, &t_uid, (size_t)n_inst * 4); TEMPCHK(tmp, &t_row, (size_t)n_inst * 4); TEMPCHK(tmp, &t_o, (size_t)n_inst * 4);
-    TEMPCHK(tmp, &t_pa, (size_t)n_inst * 4); TEMPCHK(tmp, &t_rb, (size_t)n_inst * 4);
-  }
-  TEMPCHK(tmp, &d_bkt, (size_t)n_inst * 2);
-  TEMPCHK(tmp, &d_cnt_br, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_first_rb, (size_t)n * n_bkt * 4); TEMPCHK(tmp, &d_base_br, ((size_t)n * n_bkt + 1) * 8);
+  uint32_t* const t_uid = cl.inst_uid.as<uint32_t>();   // the instances stay in the order they are built in: (row, position)
+  uint32_t* const t_row = cl.inst_row.as<uint32_t>();
+  int32_t* const t_o = cl.inst_o.as<int32_t>();
+  int32_t* const t_pa = cl.inst_pa.as<int32_t>();
+  int32_t* const t_rb = cl.inst_rb.as<int32_t>();
   uint32_t *d_rec, *d_n, *d_slot, *d_bits, *d_wcnt;
   void* d_slot_uid;  // 32 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
   void* d_tab;       // the table itself: 16-byte slots {key, ~lowest instance}
-  uint64_t *d_key, *d_rank;
-  uint8_t* d_cls;
+  uint64_t* d_rank;
   unsigned long long *d_partial, *d_shards;
   ScanTotals* d_tot;
   // the hash table of distinct clusters: at least two slots per instance would always do, but on a shared panel the distinct
-  // clusters are a small fraction of the instances and clearing 12 bytes x 2^25 slots costs as much as a kernel of this build
-  // (C3: 0.08 ms) - so the first attempt takes four slots per distinct cluster EXPECTED (the last build's count, else an eighth
-  // of the instances), gives up after 64 probes (status bit 8), and the insert is repeated with the full size
+  // clusters are a small fraction of the instances and clearing 16 bytes x 2^25 slots costs as much as a kernel of this build
+  // - so the first attempt takes four slots per distinct cluster EXPECTED (the last build's count, else half
+  // of the instances), gives up after 64 probes (status bit 8), and the pass is repeated with the full size
   uint32_t tsize = 1024;
   while (tsize < 2u * n_inst && tsize < (1u << 31)) tsize <<= 1;
   uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
   { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 4 : (uint64_t)n_inst / 2; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
+  const uint32_t n_words = (n_inst + 31) / 32;  // the representatives as a bitmap over the instances
   TEMPCHK(tmp, &d_rec, (size_t)n_inst * 4);
   TEMPCHK(tmp, &d_n, (size_t)n_inst * 4);
   TEMPCHK(tmp, &d_slot, (size_t)n_inst * 4);
-  const uint32_t n_words = (n_inst + 31) / 32;  // the representatives as a bitmap over the instances
   TEMPCHK(tmp, &d_bits, (size_t)n_words * 4);
   TEMPCHK(tmp, &d_wcnt, (size_t)n_words * 4);
-  TEMPCHK(tmp, &d_key, (size_t)n_inst * 8);
   TEMPCHK(tmp, &d_rank, ((size_t)n_words + 1) * 8);
-  TEMPCHK(tmp, &d_cls, (size_t)n_inst);
   TEMPCHK(tmp, &d_tab, (size_t)tsize * hawk_cl_slot_bytes());
-  TEMPCHK(tmp, &d_partial, ((size_t)std::max<uint64_t>(n_inst, (uint64_t)n * n_bkt) / 1024 + 2) * 8);
+  TEMPCHK(tmp, &d_partial, ((size_t)n_inst / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
-  HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsmall * hawk_cl_slot_bytes(), st));
-  HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
-  HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
-  hawk_launch_cl_fill(st, x->recs.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_off,
-                      t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls, d_bkt, bshift, n_bkt, d_cnt_br, d_first_rb, d_status);
-  hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tab, tsmall - 1, d_slot, d_status, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u);
-  hawk_launch_cl_mark(st, tsmall, d_tab, d_bits, n_words, d_wcnt);
-  hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
+  auto cut_and_insert = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit) -> int {
+    HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
+    HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
+    HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
+    hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), d_ch_off, d_ch_row,
+                        n_chunks, n_head, d_base, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot, d_status, d_tab, tsz - 1, max_probe, fail_bit);
+    hawk_launch_cl_mark(st, tsz, d_tab, d_bits, n_words, d_wcnt);
+    hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
+    return HAWK_OK;
+  };
+  if ((rc = cut_and_insert(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u))) return rc;
   ScanTotals tot;
   uint32_t st_now = 0;
   HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
@@ -357,13 +353,8 @@ static int xplan_build_dict(hawk_xplan* x) {
     tused = tsize;
     st_now &= ~8u;
     HIPCHK(hipMemcpyAsync(d_status, &st_now, 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsize * hawk_cl_slot_bytes(), st));
-    HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
     HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
-    HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
-    hawk_launch_cl_insert(st, n_inst, n_head, d_key, d_cls, d_tab, tsize - 1, d_slot, d_status, 0xffffffffu, 2u);
-    hawk_launch_cl_mark(st, tsize, d_tab, d_bits, n_words, d_wcnt);
-    hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
+    if ((rc = cut_and_insert(tsize, 0xffffffffu, 2u))) return rc;
     HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -379,7 +370,7 @@ static int xplan_build_dict(hawk_xplan* x) {
       return rc;
     uint64_t* d_slot64;
     TEMPCHK(tmp, &d_slot64, ((size_t)n_uniq + 1) * 8);
-    hawk_launch_cl_assign(st, n_inst, tused, d_tab, d_bits, d_rank, d_slot, x->recs.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_key, d_cls,
+    hawk_launch_cl_assign(st, n_inst, tused, d_tab, d_bits, d_rank, x->heads.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot,
                           x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), d_slot_uid, cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
                           cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, t_uid, d_status);
     hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, d_slot64, d_tot + 1);
@@ -387,11 +378,6 @@ static int xplan_build_dict(hawk_xplan* x) {
   } else {
     HIPCHK(hipMemsetAsync(t_uid, 0xff, (size_t)n_inst * 4, st));
     tot.n_keep = 0;
-  }
-  if (!in_place) {
-    hawk_launch_mscan(st, d_cnt_br, (uint64_t)n * n_bkt, d_partial, d_shards, d_base_br, d_tot);
-    hawk_launch_cl_permute(st, n_inst, n, n_bkt, d_bkt, d_base_br, d_first_rb, t_uid, t_o, t_row, t_pa, t_rb, cl.inst_uid.as<uint32_t>(),
-                           cl.inst_o.as<int32_t>(), cl.inst_row.as<uint32_t>(), cl.inst_pa.as<int32_t>(), cl.inst_rb.as<int32_t>());
   }
   uint32_t status = 0;
   HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));

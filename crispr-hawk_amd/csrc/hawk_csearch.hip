@@ -40,28 +40,83 @@ __device__ __forceinline__ uint64_t cl_mix(uint64_t h, uint64_t v) {
   h = (h ^ v) * 0x9E3779B97F4A7C15ull;
   return h ^ (h >> 29);
 }
-__device__ __forceinline__ bool cl_starts(const HxVar* __restrict__ recs, uint64_t j, uint64_t lo) {
+// What the dictionary passes read of a record: its first 16 bytes.  The plan keeps them a second time as an array of their own
+// (hawk_launch_hx_heads, at plan creation): the three passes over every record are HBM-bound, and a 32-byte record fetched for
+// 16 of its bytes is twice the traffic.
+struct __attribute__((aligned(16))) HxHead { int32_t o; uint32_t rs; uint32_t alt_len; uint32_t alt_off; };
+static_assert(sizeof(HxHead) == 16, "record head layout");
+__global__ __launch_bounds__(256) void k_hx_heads(const HxVar* __restrict__ recs, uint64_t n, uint4* __restrict__ heads) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) heads[j] = *reinterpret_cast<const uint4*>(recs + j);
+}
+void hawk_launch_hx_heads(hipStream_t st, const void* recs, uint64_t n, void* heads) {
+  if (n) hipLaunchKernelGGL(k_hx_heads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const HxVar*>(recs), n, static_cast<uint4*>(heads));
+}
+__device__ __forceinline__ bool cl_starts(const HxHead* __restrict__ recs, uint64_t j, uint64_t lo) {
   if (j == lo) return true;
   const int32_t prev_end = recs[j - 1].o + (int32_t)recs[j - 1].alt_len;
   return recs[j].o - prev_end > CL_LINK;
 }
 
 // ---- dictionary -----------------------------------------------------------------------------------
-// instances per row: its clusters + one closing instance (the clean run behind the last cluster); REF and rows that scan
-// nothing (collapsed onto another row) have none
-__global__ __launch_bounds__(256) void k_cl_count(const HxVar* __restrict__ recs, const uint64_t* __restrict__ hv_off,
-                                                  const uint8_t* __restrict__ is_ref, const int32_t* __restrict__ ss,
-                                                  const int32_t* __restrict__ se, uint32_t* __restrict__ cnt) {
+// The rows' records are walked in CHUNKS of CL_CHUNK consecutive records of one row (a row of C3 has two): one workgroup per chunk
+// in the two passes over the records, so that the grid is ten thousand equal pieces of work and not five thousand loops.
+// Instances per row: its clusters + one closing instance (the clean run behind the last cluster); REF and rows that scan nothing
+// (collapsed onto another row) have none - and no chunk.
+#define CL_ROW_U 4                  // records per thread in the two passes over the records: their loads are in flight together
+#define CL_CHUNK (256 * CL_ROW_U)
+// rows -> chunks, one workgroup: chunks per row, their offsets (ch_off[n_rows + 1]) and every chunk's row
+__global__ __launch_bounds__(1024) void k_cl_chunks(const uint64_t* __restrict__ hv_off, const uint8_t* __restrict__ is_ref, const int32_t* __restrict__ ss,
+                                                    const int32_t* __restrict__ se, uint32_t n_rows, uint32_t* __restrict__ ch_off,
+                                                    uint32_t* __restrict__ ch_row) {
+  __shared__ uint32_t s_w[1024 / WAVE];
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 1024) {
+    const uint32_t row = r0 + threadIdx.x;
+    uint32_t nch = 0;
+    if (row < n_rows) {
+      const uint64_t len = hv_off[row + 1] - hv_off[row];
+      const bool dead = is_ref[row] || se[row] <= ss[row];
+      nch = dead ? 0u : (len ? (uint32_t)((len + CL_CHUNK - 1) / CL_CHUNK) : 1u);
+    }
+    uint32_t tot;
+    const uint32_t ex = carry + block_excl_scan<1024 / WAVE>(nch, s_w, &tot);
+    if (row < n_rows) {
+      ch_off[row] = ex;
+      for (uint32_t c = 0; c < nch; ++c) ch_row[ex + c] = row;
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) ch_off[n_rows] = carry;
+}
+// cluster starts of chunk b (+ the closing instance in a row's last chunk)
+__global__ __launch_bounds__(256) void k_cl_count(const HxHead* __restrict__ recs, const uint64_t* __restrict__ hv_off, const uint32_t* __restrict__ ch_off,
+                                                  const uint32_t* __restrict__ ch_row, uint32_t n_rows, uint32_t* __restrict__ cnt) {
   __shared__ uint32_t s_w[256 / WAVE];
-  const uint32_t row = blockIdx.x;
+  const uint32_t b = blockIdx.x;
+  if (b >= ch_off[n_rows]) return;  // (launched over the bound on the chunks: their number is only known on the device; workgroup-uniform)
+  const uint32_t row = ch_row[b];
   const uint64_t lo = hv_off[row], hi = hv_off[row + 1];
-  const bool dead = is_ref[row] || se[row] <= ss[row];
+  const uint64_t b0 = lo + (uint64_t)(b - ch_off[row]) * CL_CHUNK;
   uint32_t c = 0;
-  if (!dead)
-    for (uint64_t j = lo + threadIdx.x; j < hi; j += 256) c += cl_starts(recs, j, lo) ? 1u : 0u;
+  if (hi > lo) {
+    uint4 r0[CL_ROW_U], rp[CL_ROW_U];
+#pragma unroll
+    for (int u = 0; u < CL_ROW_U; ++u) {
+      const uint64_t j = b0 + u * 256 + threadIdx.x;
+      const uint64_t jc = j < hi ? j : hi - 1;
+      r0[u] = *reinterpret_cast<const uint4*>(recs + jc);
+      rp[u] = *reinterpret_cast<const uint4*>(recs + (jc > lo ? jc - 1 : jc));
+    }
+#pragma unroll
+    for (int u = 0; u < CL_ROW_U; ++u) {
+      const uint64_t j = b0 + u * 256 + threadIdx.x;
+      c += (j < hi && (j == lo || (int32_t)r0[u].x - ((int32_t)rp[u].x + (int32_t)rp[u].z) > CL_LINK)) ? 1u : 0u;
+    }
+  }
   uint32_t tot;
   (void)block_excl_scan<256 / WAVE>(c, s_w, &tot);
-  if (threadIdx.x == 0) cnt[row] = dead ? 0u : tot + 1u;
+  if (threadIdx.x == 0) cnt[b] = tot + (b + 1 == ch_off[row + 1] ? 1u : 0u);
 }
 
 struct ClInst {  // per instance (k_cl_fill)
@@ -70,173 +125,165 @@ struct ClInst {  // per instance (k_cl_fill)
   int32_t* pa;     // where the clean run in front of the instance starts: end of the previous record's allele, 0 at the row's start
   int32_t* rb;     // REF shift of that run
   uint32_t* rec;   // first record of the cluster (index over all rows)
-  uint32_t* n;     // its records
-  uint64_t* key;   // hash of the variant identities (+ the row, for a cluster that must stay the row's own)
-  uint8_t* cls;    // 0: no cluster (closing instance, or cluster wholly outside the scan range), 1: shareable, 2: the row's own
-  uint16_t* bkt;   // which stretch of REF the instance lies in (REF position >> bshift): the order the searches walk the instances in
+  uint32_t* n;     // its records | class << 16 - 0: no cluster (closing instance, or cluster wholly outside the scan range), 1: shareable,
+                   // 2: the row's own
+  uint32_t* slot;  // its slot in the table of distinct clusters (CL_NONE: no cluster)
 };
+// The table of distinct clusters: 16-byte slots {hash key (0: free), ~(lowest instance seen), -} - key and representative in ONE
+// 64-byte request to L2 (the looks are bound by the number of such requests, not by bytes; two arrays were two requests per look).
+struct __attribute__((aligned(16))) ClSlot { unsigned long long key; uint32_t nrep; uint32_t pad; };  // nrep = ~instance: 0 = none, atomicMax lowers the instance
+static_assert(sizeof(ClSlot) == 16, "table slot layout");
+size_t hawk_cl_slot_bytes() { return sizeof(ClSlot); }
 
-__global__ __launch_bounds__(256) void k_cl_fill(const HxVar* __restrict__ recs, const uint64_t* __restrict__ hv_off,
+// Cuts chunks [b_first, ...) of the rows into instances AND enters every instance into the table of distinct clusters (hash of the
+// variant identities -> slot; the slot's lowest instance becomes the cluster's representative).  One kernel for both: cutting streams
+// the records and the instance arrays through HBM, the table looks are gathers into a few MB of L2 - different resources.
+__global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs, const uint64_t* __restrict__ hv_off,
                                                  const uint32_t* __restrict__ hap_len, const int32_t* __restrict__ ss_,
-                                                 const int32_t* __restrict__ se_, const uint32_t* __restrict__ inst_off, ClInst ci,
-                                                 uint32_t bshift, uint32_t n_bkt, uint32_t* __restrict__ status) {
-  __shared__ uint32_t s_w[256 / WAVE];
-  const uint32_t row = blockIdx.x;
-  const uint32_t i0 = inst_off[row], i1 = inst_off[row + 1];
-  if (i0 == i1) return;  // workgroup-uniform
+                                                 const int32_t* __restrict__ se_, const uint32_t* __restrict__ ch_off,
+                                                 const uint32_t* __restrict__ ch_row, const uint32_t* __restrict__ inst_base, ClInst ci,
+                                                 uint32_t* __restrict__ status, ClSlot* tab, uint32_t mask, uint32_t max_probe, uint32_t fail_bit,
+                                                 uint32_t b_first) {
+  __shared__ uint32_t s_c[256 / WAVE][CL_ROW_U];  // cluster starts per wave and record slice
+  const uint32_t b = b_first + blockIdx.x, row = ch_row[b];
   const uint64_t lo = hv_off[row], hi = hv_off[row + 1];
+  const uint64_t b0 = lo + (uint64_t)(b - ch_off[row]) * CL_CHUNK;
   const int32_t ss = ss_[row], se = se_[row], hl = (int32_t)hap_len[row];
-  uint32_t at = i0;
-  for (uint64_t b0 = lo; b0 < hi; b0 += 256) {  // workgroup-uniform trip count
-    const uint64_t j = b0 + threadIdx.x;
-    // the record, the one before and the next one's position, asked for at once: nine clusters in ten are a single record, and
-    // those need nothing else
-    const uint64_t jc = j < hi ? j : hi - 1;
-    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + jc);                        // {o, rs, alt_len, alt_off}
-    const uint4 rp = *reinterpret_cast<const uint4*>(recs + (jc > lo ? jc - 1 : jc));
-    const int32_t o_next = recs[jc + 1 < hi ? jc + 1 : jc].o;
-    const bool st = j < hi && (j == lo || (int32_t)r0.x - ((int32_t)rp.x + (int32_t)rp.z) > CL_LINK);
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan<256 / WAVE>(st ? 1u : 0u, s_w, &tot);
-    if (st) {
-      const uint32_t i = at + ex;
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const uint32_t at = inst_base[b];
+  uint32_t round_tot = 0;
+  if (hi > lo) {
+    // CL_ROW_U slices of 256 consecutive records: every thread's record and the one before it, asked for at once.  The records BEHIND
+    // it - a cluster's second and third - are the records of the lanes above (nine clusters in ten are one record, ninety-nine in a
+    // hundred at most three): no dependent load until a cluster is longer than that or crosses the wave's end.
+    uint4 r0[CL_ROW_U], rp[CL_ROW_U];
+    bool st[CL_ROW_U];
+    unsigned long long bal[CL_ROW_U];
+#pragma unroll
+    for (int u = 0; u < CL_ROW_U; ++u) {
+      const uint64_t j = b0 + u * 256 + threadIdx.x;
+      const uint64_t jc = j < hi ? j : hi - 1;
+      r0[u] = *reinterpret_cast<const uint4*>(recs + jc);                        // {o, rs, alt_len, alt_off}
+      rp[u] = *reinterpret_cast<const uint4*>(recs + (jc > lo ? jc - 1 : jc));
+    }
+#pragma unroll
+    for (int u = 0; u < CL_ROW_U; ++u) {
+      const uint64_t j = b0 + u * 256 + threadIdx.x;
+      st[u] = j < hi && (j == lo || (int32_t)r0[u].x - ((int32_t)rp[u].x + (int32_t)rp[u].z) > CL_LINK);
+      bal[u] = __ballot(st[u]);
+      if (lane == 0) s_c[wv][u] = (uint32_t)__popcll(bal[u]);
+    }
+    __syncthreads();
+    uint32_t pre[CL_ROW_U];  // starts of the slices / waves in front of this wave's part of slice u (slice-major = record order)
+#pragma unroll
+    for (int u = 0; u < CL_ROW_U; ++u) {
+      pre[u] = round_tot;
+#pragma unroll
+      for (int w = 0; w < 256 / WAVE; ++w) {
+        const uint32_t x = s_c[w][u];
+        if (w < (int)wv) pre[u] += x;
+        round_tot += x;
+      }
+    }
+    unsigned long long key[CL_ROW_U];
+    uint32_t idx[CL_ROW_U];
+    bool on[CL_ROW_U];
+    auto cut = [&](const int u) __attribute__((always_inline)) {  // (called once per slice with a constant: the slices' registers stay registers)
+      // the records of lanes + 1, + 2 (every lane takes part in the exchange)
+      const uint4 nx1 = make_uint4((uint32_t)__shfl_down((int)r0[u].x, 1), (uint32_t)__shfl_down((int)r0[u].y, 1),
+                                   (uint32_t)__shfl_down((int)r0[u].z, 1), (uint32_t)__shfl_down((int)r0[u].w, 1));
+      const uint4 nx2 = make_uint4((uint32_t)__shfl_down((int)r0[u].x, 2), (uint32_t)__shfl_down((int)r0[u].y, 2),
+                                   (uint32_t)__shfl_down((int)r0[u].z, 2), (uint32_t)__shfl_down((int)r0[u].w, 2));
+      on[u] = false; key[u] = 0; idx[u] = 0;
+      if (!st[u]) return;
+      const uint64_t j = b0 + u * 256 + threadIdx.x;
+      const uint32_t i = at + pre[u] + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
       // A cluster's identity is WHERE in REF its first allele starts and, record by record, where the allele lies relative to
       // that, where REF resumes behind it, and which alt bases it puts there (length + offset into alt_codes) - not the offset
       // alone: the ABI lets a caller pool alt alleles (one shared "A" for every x>A SNV), and the same offset at two loci is not
       // the same variant.
-      const int32_t o_first = (int32_t)r0.x;
+      const int32_t o_first = (int32_t)r0[u].x;
       int32_t pa = 0, rb = 0;
-      if (j > lo) { pa = (int32_t)rp.x + (int32_t)rp.z; rb = (int32_t)rp.y - pa; }
+      if (j > lo) { pa = (int32_t)rp[u].x + (int32_t)rp[u].z; rb = (int32_t)rp[u].y - pa; }
       uint64_t e = j + 1, h = cl_mix(0x243F6A8885A308D3ull, (uint64_t)(uint32_t)(o_first + rb));
-      h = cl_mix(h, (uint64_t)r0.w | ((uint64_t)r0.z << 32));
-      h = cl_mix(h, (uint64_t)r0.y);
+      h = cl_mix(h, (uint64_t)r0[u].w | ((uint64_t)r0[u].z << 32));
+      h = cl_mix(h, (uint64_t)r0[u].y);
       uint32_t n = 1;
-      if (e < hi && !(o_next - ((int32_t)r0.x + (int32_t)r0.z) > CL_LINK)) {
-        do {
-          const uint4 r = *reinterpret_cast<const uint4*>(recs + e);
-          h = cl_mix(h, (uint64_t)r.w | ((uint64_t)r.z << 32));
-          h = cl_mix(h, (uint64_t)r.y | ((uint64_t)(uint32_t)((int32_t)r.x - o_first) << 32));
-          ++n; ++e;
-        } while (e < hi && !cl_starts(recs, e, lo) && n < CL_MAXWALK);
+      int32_t o_end = (int32_t)r0[u].x + (int32_t)r0[u].z;  // end of the cluster's last allele so far
+      bool open = e < hi;                                    // the record at e may still belong to the cluster
+      while (open) {
+        const uint32_t ahead = (uint32_t)(e - j);
+        uint4 r;
+        if (ahead == 1 && lane + 1 < WAVE) r = nx1;
+        else if (ahead == 2 && lane + 2 < WAVE) r = nx2;
+        else r = *reinterpret_cast<const uint4*>(recs + e);
+        if ((int32_t)r.x - o_end > CL_LINK) break;           // it starts the next cluster
+        if (n >= CL_MAXWALK) { atomicOr(status, 1u); break; }  // a chain too long for this path
+        h = cl_mix(h, (uint64_t)r.w | ((uint64_t)r.z << 32));
+        h = cl_mix(h, (uint64_t)r.y | ((uint64_t)(uint32_t)((int32_t)r.x - o_first) << 32));
+        o_end = (int32_t)r.x + (int32_t)r.z;
+        ++n; ++e;
+        open = e < hi;
       }
-      if (e < hi && !cl_starts(recs, e, lo)) atomicOr(status, 1u);  // a chain too long for this path
-      const int32_t o_end = n == 1 ? (int32_t)r0.x + (int32_t)r0.z : recs[e - 1].o + (int32_t)recs[e - 1].alt_len;
       // window starts the cluster can touch: [o_first - (L - 1), o_end), L <= 44; the ranges they are tested against
       // (search_guides.py:49-84, 395-420) are [ss - po, se - po) and [PAD, len - L - PAD], po in {0, guidelen}
       const bool outside = o_end <= ss - 44 || o_first - 43 >= se;
       const bool interior = o_first - 43 >= (ss > HAWK_PAD ? ss : HAWK_PAD) && o_first >= 64 && o_end <= se - 44 &&
                             o_end <= hl - 44 - HAWK_PAD + 1 && o_end + 128 <= hl;
-      uint64_t key = h;
-      uint8_t cls = 1;
-      if (outside) { cls = 0; key = 0; }
-      else if (!interior) { cls = 2; key = cl_mix(h ^ 0xA4093822299F31D0ull, (uint64_t)row + 1u); }
-      if (cls && key == 0) key = 1;
+      uint64_t k = h;
+      uint32_t cls = 1;
+      if (outside) { cls = 0; k = 0; }
+      else if (!interior) { cls = 2; k = cl_mix(h ^ 0xA4093822299F31D0ull, (uint64_t)row + 1u); }
+      if (cls && k == 0) k = 1;
       // the clean run in front, [pa, o_first - (L - 1)), lies inside every range of both strands for every geometry: its count
       // then needs neither the row nor its bounds (bit 31 of pa)
       const bool run_inside = pa >= (ss > HAWK_PAD ? ss : HAWK_PAD) && o_first <= se - 44 && o_first <= hl - 44 - HAWK_PAD + 1;
       ci.o[i] = o_first; ci.row[i] = row; ci.pa[i] = pa | (run_inside ? (int32_t)0x80000000 : 0); ci.rb[i] = rb;
-      ci.rec[i] = (uint32_t)j; ci.n[i] = n; ci.key[i] = key; ci.cls[i] = cls;
-      const uint32_t b = (uint32_t)(o_first + rb > 0 ? o_first + rb : 0) >> bshift;  // REF position of the first allele
-      ci.bkt[i] = (uint16_t)(b < n_bkt ? b : n_bkt - 1);
+      ci.rec[i] = (uint32_t)j; ci.n[i] = n | (cls << 16);
+      if (!cls) ci.slot[i] = CL_NONE;
+      on[u] = cls != 0; key[u] = k; idx[u] = i;
+    };
+    static_assert(CL_ROW_U == 4, "one call per slice");
+    cut(0); cut(1); cut(2); cut(3);
+    // ... and into the table: the round's looks in flight together.  The looks are ordinary cached loads: a stale answer only sends
+    // the instance on to the atomic, which tells the truth.
+    uint4 look[CL_ROW_U];
+    uint32_t sl0[CL_ROW_U];
+#pragma unroll
+    for (int u = 0; u < CL_ROW_U; ++u) {
+      sl0[u] = (uint32_t)(key[u] >> 17) & mask;
+      look[u] = *reinterpret_cast<const uint4*>(tab + sl0[u]);
     }
-    at += tot;
+    auto enter = [&](const int u) __attribute__((always_inline)) {
+      if (!on[u]) return;
+      const uint32_t i = idx[u];
+      unsigned long long c = (unsigned long long)look[u].x | ((unsigned long long)look[u].y << 32);
+      uint32_t nrep = look[u].z, sl = sl0[u];
+      bool placed = false;
+      // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
+      // for the distinct clusters expected gives up after max_probe slots and the host repeats the pass with the full size)
+      for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
+        // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
+        // atomic on it would queue them all at one address
+        if (probe) { const uint4 e2 = *reinterpret_cast<const uint4*>(tab + sl); c = (unsigned long long)e2.x | ((unsigned long long)e2.y << 32); nrep = e2.z; }
+        if (c == 0ull) { c = atomicCAS(&tab[sl].key, 0ull, key[u]); nrep = 0u; }  // (a slot never changes hands once taken: any other value seen is final)
+        if (c == 0ull || c == key[u]) { placed = true; break; }
+        sl = (sl + 1u) & mask;
+      }
+      if (!placed) { ci.slot[i] = CL_NONE; atomicOr(status, fail_bit); return; }  // full-size table: cannot happen; the dictionary is then not used
+      ci.slot[i] = sl;
+      if (nrep < ~i) atomicMax(&tab[sl].nrep, ~i);  // (the lowest instance only falls: a stale look only costs the atomic)
+    };
+    enter(0); enter(1); enter(2); enter(3);
   }
-  if (threadIdx.x == 0) {  // the closing instance
-    const uint32_t i = i1 - 1;
+  if (threadIdx.x == 0 && b + 1 == ch_off[row + 1]) {  // the row's last chunk: the closing instance
+    const uint32_t i = at + round_tot;
     int32_t pa = 0, rb = 0;
     if (hi > lo) { pa = recs[hi - 1].o + (int32_t)recs[hi - 1].alt_len; rb = (int32_t)recs[hi - 1].rs - pa; }
-    ci.o[i] = CL_FAR; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb; ci.rec[i] = 0; ci.n[i] = 0; ci.key[i] = 0; ci.cls[i] = 0;
-    const uint32_t b = (uint32_t)(pa + rb > 0 ? pa + rb : 0) >> bshift;
-    ci.bkt[i] = (uint16_t)(b < n_bkt ? b : n_bkt - 1);
+    ci.o[i] = CL_FAR; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb; ci.rec[i] = 0; ci.n[i] = 0; ci.slot[i] = CL_NONE;
   }
 }
 
-// Optionally (HAWK_CLUSTER_ORDER=stretch) the instances are laid out stretch by stretch of REF (bucket-major: all rows'
-// instances of the first 32 kb, then of the next ...) rather than row by row: the workgroups in flight at any time then copy the
-// template rows of ONE stretch's clusters, a few hundred KB that stay in every XCD's L2 (the emit pass fetches 0.18 instead of
-// 1.45 GB from HBM).  Within a stretch the order is (row, position), so a wave's 64 instances still write one contiguous
-// piece of the table - but the table is then not haplotype-major, so the default is one stretch: the order they were built in.
-#define CL_MAXBKT 1024
-__global__ __launch_bounds__(256) void k_cl_bucket(const uint32_t* __restrict__ inst_off, const uint16_t* __restrict__ bkt, uint32_t n_rows,
-                                                   uint32_t n_bkt, uint32_t* __restrict__ cnt_br, uint32_t* __restrict__ first_rb) {
-  __shared__ uint32_t s_cnt[CL_MAXBKT], s_first[CL_MAXBKT];
-  const uint32_t row = blockIdx.x;
-  for (uint32_t b = threadIdx.x; b < n_bkt; b += 256) { s_cnt[b] = 0; s_first[b] = 0xffffffffu; }
-  __syncthreads();
-  const uint32_t i0 = inst_off[row], i1 = inst_off[row + 1];
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const uint32_t b = bkt[i];
-    atomicAdd(&s_cnt[b], 1u);
-    atomicMin(&s_first[b], i);
-  }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < n_bkt; b += 256) {
-    cnt_br[(size_t)b * n_rows + row] = s_cnt[b];
-    first_rb[(size_t)row * n_bkt + b] = s_first[b];
-  }
-}
-struct ClPerm { const uint32_t* uid; const int32_t* o; const uint32_t* row; const int32_t* pa; const int32_t* rb;
-                uint32_t* uid2; int32_t* o2; uint32_t* row2; int32_t* pa2; int32_t* rb2; };
-__global__ __launch_bounds__(256) void k_cl_permute(uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* __restrict__ bkt,
-                                                    const uint64_t* __restrict__ base_br, const uint32_t* __restrict__ first_rb, ClPerm pm) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_inst) return;
-  const uint32_t b = bkt[i], row = pm.row[i];
-  const uint64_t d = base_br[(size_t)b * n_rows + row] + (i - first_rb[(size_t)row * n_bkt + b]);
-  pm.uid2[d] = pm.uid[i]; pm.o2[d] = pm.o[i]; pm.row2[d] = row; pm.pa2[d] = pm.pa[i]; pm.rb2[d] = pm.rb[i];
-}
-
-// The table of distinct clusters: 16-byte slots {hash key (0: free), ~(lowest instance seen), -} - key and representative in ONE
-// 64-byte request to L2 (the pass is bound by the number of such requests, not by bytes; two arrays were two requests per look).
-struct __attribute__((aligned(16))) ClSlot { unsigned long long key; uint32_t nrep; uint32_t pad; };  // nrep = ~instance: 0 = none, atomicMax lowers the instance
-static_assert(sizeof(ClSlot) == 16, "table slot layout");
-// CL_INS_U instances per thread: their first looks at the table are in flight together.  The looks are ordinary cached loads: a
-// stale answer only sends the instance on to the atomic, which tells the truth.
-#define CL_INS_U 4
-__global__ __launch_bounds__(256) void k_cl_insert(uint32_t n_inst, const uint64_t* __restrict__ key, const uint8_t* __restrict__ cls,
-                                                   ClSlot* tab, uint32_t mask, uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ status,
-                                                   uint32_t max_probe, uint32_t fail_bit, uint32_t i_first) {
-  const uint32_t i0 = i_first + blockIdx.x * (256 * CL_INS_U) + threadIdx.x;
-  unsigned long long k[CL_INS_U];
-  uint4 look[CL_INS_U];
-  uint32_t s[CL_INS_U];
-  bool on[CL_INS_U];
-#pragma unroll
-  for (int u = 0; u < CL_INS_U; ++u) {
-    const uint32_t i = i0 + u * 256;
-    const uint32_t ic = i < n_inst ? i : 0u;
-    on[u] = i < n_inst && cls[ic] != 0;
-    k[u] = key[ic];
-    if (i < n_inst && !on[u]) inst_slot[i] = CL_NONE;
-  }
-#pragma unroll
-  for (int u = 0; u < CL_INS_U; ++u) {
-    s[u] = (uint32_t)(k[u] >> 17) & mask;
-    look[u] = *reinterpret_cast<const uint4*>(tab + s[u]);
-  }
-#pragma unroll
-  for (int u = 0; u < CL_INS_U; ++u) {
-    if (!on[u]) continue;
-    const uint32_t i = i0 + u * 256;
-    unsigned long long c = (unsigned long long)look[u].x | ((unsigned long long)look[u].y << 32);
-    uint32_t nrep = look[u].z;
-    uint32_t sl = s[u];
-    bool placed = false;
-    // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
-    // for the distinct clusters expected gives up after max_probe slots and the host repeats the insert with the full size)
-    for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
-      // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
-      // atomic on it would queue them all at one address
-      if (probe) { const uint4 e = *reinterpret_cast<const uint4*>(tab + sl); c = (unsigned long long)e.x | ((unsigned long long)e.y << 32); nrep = e.z; }
-      if (c == 0ull) { c = atomicCAS(&tab[sl].key, 0ull, k[u]); nrep = 0u; }  // (a slot never changes hands once taken: any other value seen is final)
-      if (c == 0ull || c == k[u]) { placed = true; break; }
-      sl = (sl + 1u) & mask;
-    }
-    if (!placed) { inst_slot[i] = CL_NONE; atomicOr(status, fail_bit); continue; }  // full-size table: cannot happen; the dictionary is then not used
-    inst_slot[i] = sl;
-    if (nrep < ~i) atomicMax(&tab[sl].nrep, ~i);  // (the lowest instance only falls: a stale look only costs the atomic)
-  }
-}
 // The representatives - the lowest instance of every distinct cluster - as a bitmap over the instances, set from the TABLE's side:
 // one thread per slot (a few 10^5) instead of one per instance (10^7), then a count per 32-instance word for the scan that numbers them
 __global__ __launch_bounds__(256) void k_cl_mark(uint32_t tsize, const ClSlot* __restrict__ tab, uint32_t* __restrict__ bits) {
@@ -256,7 +303,7 @@ struct ClUniq {  // per distinct cluster
 };
 // the representatives number the clusters in instance order: rank of the instance's bit = clusters in the words before + in its word
 __global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const ClSlot* __restrict__ tab, const uint32_t* __restrict__ bits,
-                                                   const uint64_t* __restrict__ word_rank, ClInst ci, const HxVar* __restrict__ recs,
+                                                   const uint64_t* __restrict__ word_rank, ClInst ci, const HxHead* __restrict__ recs,
                                                    const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
                                                    uint4* __restrict__ slot_desc, ClUniq cu) {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;
@@ -265,12 +312,12 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const ClSlot*
   if ((e.x | e.y) == 0u || e.z == 0u) return;
   const uint32_t i = ~e.z;
   const uint32_t u = (uint32_t)word_rank[i >> 5] + (uint32_t)__popc(bits[i >> 5] & ((1u << (i & 31u)) - 1u));
-  const uint32_t r = ci.rec[i], n = ci.n[i];
+  const uint32_t r = ci.rec[i], ncls = ci.n[i], n = ncls & 0xffffu;
   // what every other instance of the cluster needs to know about its representative, as ONE 32-byte record per table slot - one
   // request to L2: {cluster number, first record, records | class << 16, REF position of the first allele} {the first record's
   // rs, alt_len, alt_off, -} (nine clusters in ten are that one record: k_cl_uid then never touches the representative's records)
   const uint4 r0 = *reinterpret_cast<const uint4*>(recs + r);
-  slot_desc[2 * (size_t)s] = make_uint4(u, r, n | ((uint32_t)ci.cls[i] << 16), (uint32_t)(ci.o[i] + ci.rb[i]));
+  slot_desc[2 * (size_t)s] = make_uint4(u, r, ncls, (uint32_t)(ci.o[i] + ci.rb[i]));
   slot_desc[2 * (size_t)s + 1] = make_uint4(r0.y, r0.z, r0.w, 0u);
   const int32_t o_first = (int32_t)r0.x, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
   const uint32_t row = ci.row[i];
@@ -288,27 +335,26 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const ClSlot*
 // CL_UID_U instances per thread, their loads issued level by level (instance arrays -> representative's descriptor -> both
 // sides' first records): the pass is three dependent round trips per instance and little else
 #define CL_UID_U 4
-__global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t* __restrict__ inst_slot, const uint4* __restrict__ slot_desc, ClInst ci,
-                                                const HxVar* __restrict__ recs, uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint4* __restrict__ slot_desc, ClInst ci, const HxHead* __restrict__ recs,
+                                                uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
   const uint32_t i0 = blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
-  uint32_t s[CL_UID_U], rec[CL_UID_U], n[CL_UID_U], refp[CL_UID_U];
-  uint8_t c[CL_UID_U];
+  uint32_t s[CL_UID_U], rec[CL_UID_U], ncls[CL_UID_U], refp[CL_UID_U];
   bool in[CL_UID_U], ok[CL_UID_U];
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
     const uint32_t i = i0 + u * 256;
     in[u] = i < n_inst;
     const uint32_t ic = in[u] ? i : 0u;
-    c[u] = ci.cls[ic]; s[u] = inst_slot[ic]; rec[u] = ci.rec[ic]; n[u] = ci.n[ic];
+    s[u] = ci.slot[ic]; rec[u] = ci.rec[ic]; ncls[u] = ci.n[ic];
     refp[u] = (uint32_t)(ci.o[ic] + ci.rb[ic]);
   }
   uint4 d[CL_UID_U], d1[CL_UID_U], ra[CL_UID_U];
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
-    ok[u] = in[u] && c[u] && s[u] != CL_NONE;  // (no slot: k_cl_insert flagged the dictionary)
+    ok[u] = in[u] && (ncls[u] >> 16) && s[u] != CL_NONE;  // (no slot: the table filled up and the pass flagged the dictionary)
     const size_t sd = ok[u] ? 2 * (size_t)s[u] : 0;
     d[u] = slot_desc[sd]; d1[u] = slot_desc[sd + 1];
-    ra[u] = *reinterpret_cast<const uint4*>(recs + (ok[u] ? rec[u] : 0u));  // {o, rs, alt_len, alt_off}: the first 16 bytes of a record
+    ra[u] = *reinterpret_cast<const uint4*>(recs + (ok[u] ? rec[u] : 0u));  // {o, rs, alt_len, alt_off}
     if (!ok[u]) d[u] = make_uint4(CL_NONE, 0u, 0u, 0u);
   }
   bool bad = false;
@@ -316,14 +362,16 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
   for (int u = 0; u < CL_UID_U; ++u) {
     if (in[u]) inst_uid[i0 + u * 256] = d[u].x;
     if (!ok[u] || d[u].y == rec[u]) continue;  // no cluster / the representative itself
-    // exactness: same hash is not same cluster until the variant identities have been compared
-    bool b = c[u] != 1 || (d[u].z >> 16) != 1 || (d[u].z & 0xffffu) != n[u] || refp[u] != d[u].w;  // same REF position of the first allele
+    // exactness: same hash is not same cluster until the variant identities have been compared - both shareable, as many records,
+    // the same REF position of the first allele, then record by record
+    bool b = ncls[u] != d[u].z || (ncls[u] >> 16) != 1 || refp[u] != d[u].w;
     b = b || ra[u].y != d1[u].x || ra[u].z != d1[u].y || ra[u].w != d1[u].z;
-    if (!b && n[u] > 1) {
-      const HxVar* pa = recs + rec[u];
-      const HxVar* pb = recs + d[u].y;
+    const uint32_t n = ncls[u] & 0xffffu;
+    if (!b && n > 1) {
+      const HxHead* pa = recs + rec[u];
+      const HxHead* pb = recs + d[u].y;
       const int32_t oa = (int32_t)ra[u].x, ob = pb[0].o;
-      for (uint32_t k = 1; k < n[u]; ++k) {
+      for (uint32_t k = 1; k < n; ++k) {
         const uint4 xa = *reinterpret_cast<const uint4*>(pa + k), xb = *reinterpret_cast<const uint4*>(pb + k);
         b = b || xa.w != xb.w || xa.z != xb.z || xa.y != xb.y || (int32_t)xa.x - oa != (int32_t)xb.x - ob;
       }
@@ -333,54 +381,47 @@ __global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint32_t*
   if (bad) atomicOr(status, 2u);
 }
 
-void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint8_t* is_ref, const int32_t* ss, const int32_t* se,
-                          uint32_t n_rows, uint32_t* cnt) {
-  hipLaunchKernelGGL(k_cl_count, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, is_ref, ss, se, cnt);
+// rows -> chunks: ch_off[n_rows + 1] (chunks in front of every row) and the chunks' rows; ch_row has room for n_records / CL_CHUNK + n_rows entries
+uint32_t hawk_cl_chunk_bound(uint64_t n_records, uint32_t n_rows) { return (uint32_t)(n_records / CL_CHUNK) + n_rows; }
+void hawk_launch_cl_chunks(hipStream_t st, const uint64_t* hv_off, const uint8_t* is_ref, const int32_t* ss, const int32_t* se, uint32_t n_rows,
+                           uint32_t* ch_off, uint32_t* ch_row) {
+  hipLaunchKernelGGL(k_cl_chunks, dim3(1), dim3(1024), 0, st, hv_off, is_ref, ss, se, n_rows, ch_off, ch_row);
 }
+void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_rows,
+                          uint32_t ch_bound, uint32_t* cnt /* zeroed */) {
+  if (ch_bound) hipLaunchKernelGGL(k_cl_count, dim3(ch_bound), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, ch_off, ch_row, n_rows, cnt);
+}
+// Two launches: the chunks of the first rows, then the rest.  A common cluster - a frequent SNV without a neighbour - has thousands
+// of instances, half of which are in flight at once in a single launch: they all find its slot empty, all try the CAS, then all
+// lower the representative - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's size).  After
+// the head launch (a few dozen rows) every common cluster's key and its lowest instance are in the table, so the rest only look.
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
-                         uint32_t n_rows, const uint32_t* inst_off, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                         uint64_t* key, uint8_t* cls, uint16_t* bkt, uint32_t bshift, uint32_t n_bkt, uint32_t* cnt_br, uint32_t* first_rb,
-                         uint32_t* status) {
-  ClInst ci{o, row, pa, rb, rec, n, key, cls, bkt};
-  hipLaunchKernelGGL(k_cl_fill, dim3(n_rows), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_off, hap_len, ss, se, inst_off, ci, bshift, n_bkt,
-                     status);
-  if (n_bkt > 1) hipLaunchKernelGGL(k_cl_bucket, dim3(n_rows), dim3(256), 0, st, inst_off, bkt, n_rows, n_bkt, cnt_br, first_rb);
+                         const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_chunks, uint32_t n_head, const uint32_t* inst_base, int32_t* o,
+                         uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot, uint32_t* status, void* tab, uint32_t mask,
+                         uint32_t max_probe, uint32_t fail_bit) {
+  ClInst ci{o, row, pa, rb, rec, n, slot};
+  n_head = n_head < n_chunks ? n_head : n_chunks;
+  if (n_head)
+    hipLaunchKernelGGL(k_cl_fill, dim3(n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row, inst_base, ci,
+                       status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, 0u);
+  if (n_chunks > n_head)
+    hipLaunchKernelGGL(k_cl_fill, dim3(n_chunks - n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row,
+                       inst_base, ci, status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, n_head);
 }
-void hawk_launch_cl_permute(hipStream_t st, uint32_t n_inst, uint32_t n_rows, uint32_t n_bkt, const uint16_t* bkt, const uint64_t* base_br,
-                            const uint32_t* first_rb, const uint32_t* uid, const int32_t* o, const uint32_t* row, const int32_t* pa, const int32_t* rb,
-                            uint32_t* uid2, int32_t* o2, uint32_t* row2, int32_t* pa2, int32_t* rb2) {
-  ClPerm pm{uid, o, row, pa, rb, uid2, o2, row2, pa2, rb2};
-  hipLaunchKernelGGL(k_cl_permute, dim3((n_inst + 255) / 256), dim3(256), 0, st, n_inst, n_rows, n_bkt, bkt, base_br, first_rb, pm);
-}
-// Two launches: the instances of the first rows, then the rest.  A common cluster - a frequent SNV without a neighbour - has
-// thousands of instances, half of which are in flight at once in a single launch: they all find its slot empty, all try the CAS,
-// then all lower `trep` - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's size).  After
-// the head launch (<= `n_head` instances: a few dozen rows) every common cluster's key and its lowest instance are in the table,
-// so the rest only look.
-void hawk_launch_cl_insert(hipStream_t st, uint32_t n_inst, uint32_t n_head, const uint64_t* key, const uint8_t* cls, void* tab, uint32_t mask,
-                           uint32_t* inst_slot, uint32_t* status, uint32_t max_probe, uint32_t fail_bit) {
-  n_head = n_head < n_inst ? n_head : n_inst;
-  const uint32_t per = 256 * CL_INS_U;
-  if (n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_head + per - 1) / per), dim3(256), 0, st, n_head, key, cls, static_cast<ClSlot*>(tab), mask, inst_slot,
-                                 status, max_probe, fail_bit, 0u);
-  if (n_inst > n_head) hipLaunchKernelGGL(k_cl_insert, dim3((n_inst - n_head + per - 1) / per), dim3(256), 0, st, n_inst, key, cls, static_cast<ClSlot*>(tab),
-                                          mask, inst_slot, status, max_probe, fail_bit, n_head);
-}
-size_t hawk_cl_slot_bytes() { return sizeof(ClSlot); }
 void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
   hipLaunchKernelGGL(k_cl_mark, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits);
   hipLaunchKernelGGL(k_cl_popc, dim3((n_words + 255) / 256), dim3(256), 0, st, n_words, bits, cnt);
 }
 void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tab, const uint32_t* bits, const uint64_t* word_rank,
-                           const uint32_t* inst_slot, const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n,
-                           uint64_t* key, uint8_t* cls, const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec, uint32_t* u_n,
-                           uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
-  ClInst ci{o, row, pa, rb, rec, n, key, cls, nullptr};
+                           const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot,
+                           const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row,
+                           int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
+  ClInst ci{o, row, pa, rb, rec, n, slot};
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
   hipLaunchKernelGGL(k_cl_assign, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits, word_rank, ci,
-                     static_cast<const HxVar*>(recs), seg_off, seg_rel, static_cast<uint4*>(slot_desc), cu);
-  hipLaunchKernelGGL(k_cl_uid, dim3((n_inst + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst, inst_slot,
-                     static_cast<const uint4*>(slot_desc), ci, static_cast<const HxVar*>(recs), inst_uid, status);
+                     static_cast<const HxHead*>(recs), seg_off, seg_rel, static_cast<uint4*>(slot_desc), cu);
+  hipLaunchKernelGGL(k_cl_uid, dim3((n_inst + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst, static_cast<const uint4*>(slot_desc), ci,
+                     static_cast<const HxHead*>(recs), inst_uid, status);
 }
 
 // ---- per search ------------------------------------------------------------------------------------

@@ -138,6 +138,7 @@ struct hawk_xplan {
   uint32_t ref_S;
   DevBuf ref5[HAWK_PLANES];  // the same planes (+ an all-zero V plane) at the ROWS' stride S: row 0 of a view (hawk_xplan_view)
   DevBuf recs, tiles, codes, off, hlen, hash;  // 32 B per carried variant, 16 B per (row, tile): hawk_expand.hip
+  DevBuf heads;                               // the records' first 16 bytes {o, rs, alt_len, alt_off} once more: what the dictionary passes stream
   // metadata of the produced rows (hawk_xplan_set_meta)
   bool has_meta;
   std::vector<int32_t> scan_start, scan_stop;

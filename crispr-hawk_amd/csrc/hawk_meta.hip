@@ -66,16 +66,23 @@ __global__ __launch_bounds__(256) void k_seg_count(const uint64_t* __restrict__ 
   if (threadIdx.x == 0) seg_cnt[r] = s_sum + 1u;  // + the identity segment every row starts with
 }
 
-// exclusive scan of n u32 counts into n + 1 u32 offsets, one workgroup (n = rows of a plan)
+// exclusive scan of n u32 counts into n + 1 u32 offsets, one workgroup (n = rows of a plan, chunks of its records): four
+// consecutive counts per thread and round
 __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ off) {
   __shared__ uint32_t s_w[1024 / WAVE];
   uint32_t carry = 0;
-  for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
-    const uint32_t i = b0 + threadIdx.x;
-    const uint32_t c = i < n ? cnt[i] : 0u;
+  for (uint32_t b0 = 0; b0 < n; b0 += 4096) {
+    const uint32_t i = b0 + threadIdx.x * 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = i + k < n ? cnt[i + k] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan<1024 / WAVE>(c, s_w, &tot);
-    if (i < n) off[i] = carry + ex;
+    uint32_t ex = carry + block_excl_scan<1024 / WAVE>(c[0] + c[1] + c[2] + c[3], s_w, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < n) off[i + k] = ex;
+      ex += c[k];
+    }
     carry += tot;
   }
   if (threadIdx.x == 0) off[n] = carry;
