@@ -290,16 +290,15 @@ static int xplan_build_dict(hawk_xplan* x) {
   // (the number of chunks is only known on the device - rows that scan nothing have none: the count pass and its scan run over the bound)
   hawk_launch_cl_count(st, x->heads.p, x->off.as<uint64_t>(), d_ch_off, d_ch_row, n, ch_bound, d_cnt);
   hawk_launch_scan_u32(st, d_cnt, ch_bound, d_base);
-  uint32_t n_chunks = 0, n_head = 0, n_inst = 0;  // n_head: the chunks of the first 48 rows (hawk_launch_cl_fill)
-  HIPCHK(hipMemcpyAsync(&n_chunks, d_ch_off + n, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&n_head, d_ch_off + std::min<uint32_t>(n, 49), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&n_inst, d_base + ch_bound, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (n_chunks > ch_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: chunk count beyond its bound"); return HAWK_E_HIP; }
-  if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
+  // No read-back here: an instance starts at a record or closes a row, so records + rows bounds their number - the instance arrays,
+  // the bitmap and the grids of the passes below are sized by the bound, the passes read the true count on the device, and the
+  // host learns it together with the number of distinct clusters
+  const uint32_t inst_bound = (uint32_t)x->ncar + n;
+  const uint32_t* const d_n_inst = d_base + ch_bound;
   int rc;
-  if ((rc = cl.inst_uid.reserve((size_t)n_inst * 4)) || (rc = cl.inst_o.reserve((size_t)n_inst * 4)) || (rc = cl.inst_row.reserve((size_t)n_inst * 4)) ||
-      (rc = cl.inst_pa.reserve((size_t)n_inst * 4)) || (rc = cl.inst_rb.reserve((size_t)n_inst * 4)))
+  if ((rc = cl.inst_uid.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_o.reserve((size_t)inst_bound * 4)) ||
+      (rc = cl.inst_row.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_pa.reserve((size_t)inst_bound * 4)) ||
+      (rc = cl.inst_rb.reserve((size_t)inst_bound * 4)))
     return rc;
   uint32_t* const t_uid = cl.inst_uid.as<uint32_t>();   // the instances stay in the order they are built in: (row, position)
   uint32_t* const t_row = cl.inst_row.as<uint32_t>();
@@ -317,37 +316,40 @@ static int xplan_build_dict(hawk_xplan* x) {
   // - so the first attempt takes four slots per distinct cluster EXPECTED (the last build's count, else half
   // of the instances), gives up after 64 probes (status bit 8), and the pass is repeated with the full size
   uint32_t tsize = 1024;
-  while (tsize < 2u * n_inst && tsize < (1u << 31)) tsize <<= 1;
+  while (tsize < 2u * inst_bound && tsize < (1u << 31)) tsize <<= 1;
   uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
-  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 4 : (uint64_t)n_inst / 2; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
-  const uint32_t n_words = (n_inst + 31) / 32;  // the representatives as a bitmap over the instances
-  TEMPCHK(tmp, &d_rec, (size_t)n_inst * 4);
-  TEMPCHK(tmp, &d_n, (size_t)n_inst * 4);
-  TEMPCHK(tmp, &d_slot, (size_t)n_inst * 4);
+  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 4 : (uint64_t)inst_bound / 2; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
+  const uint32_t n_words = (inst_bound + 31) / 32;  // the representatives as a bitmap over the instances
+  TEMPCHK(tmp, &d_rec, (size_t)inst_bound * 4);
+  TEMPCHK(tmp, &d_n, (size_t)inst_bound * 4);
+  TEMPCHK(tmp, &d_slot, (size_t)inst_bound * 4);
   TEMPCHK(tmp, &d_bits, (size_t)n_words * 4);
   TEMPCHK(tmp, &d_wcnt, (size_t)n_words * 4);
   TEMPCHK(tmp, &d_rank, ((size_t)n_words + 1) * 8);
   TEMPCHK(tmp, &d_tab, (size_t)tsize * hawk_cl_slot_bytes());
-  TEMPCHK(tmp, &d_partial, ((size_t)n_inst / 1024 + 2) * 8);
+  TEMPCHK(tmp, &d_partial, ((size_t)inst_bound / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
   auto cut_and_insert = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit) -> int {
     HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
     HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
     HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
-    hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), d_ch_off, d_ch_row,
-                        n_chunks, n_head, d_base, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot, d_status, d_tab, tsz - 1, max_probe, fail_bit);
+    hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row,
+                        ch_bound, d_base, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot, d_status, d_tab, tsz - 1, max_probe, fail_bit);
     hawk_launch_cl_mark(st, tsz, d_tab, d_bits, n_words, d_wcnt);
     hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
     return HAWK_OK;
   };
   if ((rc = cut_and_insert(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u))) return rc;
   ScanTotals tot;
-  uint32_t st_now = 0;
+  uint32_t st_now = 0, n_inst = 0;
+  HIPCHK(hipMemcpyAsync(&n_inst, d_n_inst, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&st_now, d_status, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
+  if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
+  if (n_inst > inst_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: instance count beyond its bound"); return HAWK_E_HIP; }
   uint32_t tused = tsmall;
   if (st_now & 8u) {  // the small table filled up: once more with two slots per instance
     tused = tsize;
@@ -370,7 +372,7 @@ static int xplan_build_dict(hawk_xplan* x) {
       return rc;
     uint64_t* d_slot64;
     TEMPCHK(tmp, &d_slot64, ((size_t)n_uniq + 1) * 8);
-    hawk_launch_cl_assign(st, n_inst, tused, d_tab, d_bits, d_rank, x->heads.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot,
+    hawk_launch_cl_assign(st, n_inst, d_n_inst, tused, d_tab, d_bits, d_rank, x->heads.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot,
                           x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), d_slot_uid, cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
                           cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, t_uid, d_status);
     hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, d_slot64, d_tot + 1);

@@ -143,9 +143,11 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
                                                  const int32_t* __restrict__ se_, const uint32_t* __restrict__ ch_off,
                                                  const uint32_t* __restrict__ ch_row, const uint32_t* __restrict__ inst_base, ClInst ci,
                                                  uint32_t* __restrict__ status, ClSlot* tab, uint32_t mask, uint32_t max_probe, uint32_t fail_bit,
-                                                 uint32_t b_first) {
+                                                 uint32_t b_first, uint32_t n_rows) {
   __shared__ uint32_t s_c[256 / WAVE][CL_ROW_U];  // cluster starts per wave and record slice
-  const uint32_t b = b_first + blockIdx.x, row = ch_row[b];
+  const uint32_t b = b_first + blockIdx.x;
+  if (b >= ch_off[n_rows]) return;  // (launched over the bound on the chunks; workgroup-uniform)
+  const uint32_t row = ch_row[b];
   const uint64_t lo = hv_off[row], hi = hv_off[row + 1];
   const uint64_t b0 = lo + (uint64_t)(b - ch_off[row]) * CL_CHUNK;
   const int32_t ss = ss_[row], se = se_[row], hl = (int32_t)hap_len[row];
@@ -335,8 +337,10 @@ __global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const ClSlot*
 // CL_UID_U instances per thread, their loads issued level by level (instance arrays -> representative's descriptor -> both
 // sides' first records): the pass is three dependent round trips per instance and little else
 #define CL_UID_U 4
-__global__ __launch_bounds__(256) void k_cl_uid(uint32_t n_inst, const uint4* __restrict__ slot_desc, ClInst ci, const HxHead* __restrict__ recs,
-                                                uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_cl_uid(const uint32_t* __restrict__ n_inst_dev, const uint4* __restrict__ slot_desc, ClInst ci,
+                                                const HxHead* __restrict__ recs, uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
+  const uint32_t n_inst = *n_inst_dev;  // (launched over the bound on the instances)
+  if (blockIdx.x * (256 * CL_UID_U) >= n_inst) return;
   const uint32_t i0 = blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
   uint32_t s[CL_UID_U], rec[CL_UID_U], ncls[CL_UID_U], refp[CL_UID_U];
   bool in[CL_UID_U], ok[CL_UID_U];
@@ -391,28 +395,31 @@ void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_o
                           uint32_t ch_bound, uint32_t* cnt /* zeroed */) {
   if (ch_bound) hipLaunchKernelGGL(k_cl_count, dim3(ch_bound), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, ch_off, ch_row, n_rows, cnt);
 }
-// Two launches: the chunks of the first rows, then the rest.  A common cluster - a frequent SNV without a neighbour - has thousands
-// of instances, half of which are in flight at once in a single launch: they all find its slot empty, all try the CAS, then all
-// lower the representative - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's size).  After
-// the head launch (a few dozen rows) every common cluster's key and its lowest instance are in the table, so the rest only look.
+// Two launches: the first chunks (a few dozen rows), then the rest.  A common cluster - a frequent SNV without a neighbour - has
+// thousands of instances, half of which are in flight at once in a single launch: they all find its slot empty, all try the CAS,
+// then all lower the representative - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's
+// size).  After the head launch every common cluster's key and its lowest instance are in the table, so the rest only look.
+// Both launches run over the BOUND on the chunks (their number is on the device only; surplus workgroups leave at once).
+#define CL_HEAD_CHUNKS 96
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
-                         const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_chunks, uint32_t n_head, const uint32_t* inst_base, int32_t* o,
+                         uint32_t n_rows, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t ch_bound, const uint32_t* inst_base, int32_t* o,
                          uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot, uint32_t* status, void* tab, uint32_t mask,
                          uint32_t max_probe, uint32_t fail_bit) {
   ClInst ci{o, row, pa, rb, rec, n, slot};
-  n_head = n_head < n_chunks ? n_head : n_chunks;
+  const uint32_t n_head = ch_bound < CL_HEAD_CHUNKS ? ch_bound : CL_HEAD_CHUNKS;
   if (n_head)
     hipLaunchKernelGGL(k_cl_fill, dim3(n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row, inst_base, ci,
-                       status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, 0u);
-  if (n_chunks > n_head)
-    hipLaunchKernelGGL(k_cl_fill, dim3(n_chunks - n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row,
-                       inst_base, ci, status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, n_head);
+                       status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, 0u, n_rows);
+  if (ch_bound > n_head)
+    hipLaunchKernelGGL(k_cl_fill, dim3(ch_bound - n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row,
+                       inst_base, ci, status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, n_head, n_rows);
 }
 void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
   hipLaunchKernelGGL(k_cl_mark, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits);
   hipLaunchKernelGGL(k_cl_popc, dim3((n_words + 255) / 256), dim3(256), 0, st, n_words, bits, cnt);
 }
-void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tab, const uint32_t* bits, const uint64_t* word_rank,
+void hawk_launch_cl_assign(hipStream_t st, uint32_t inst_bound, const uint32_t* n_inst_dev, uint32_t tsize, const void* tab, const uint32_t* bits,
+                           const uint64_t* word_rank,
                            const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot,
                            const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row,
                            int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
@@ -420,7 +427,7 @@ void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, cons
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
   hipLaunchKernelGGL(k_cl_assign, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits, word_rank, ci,
                      static_cast<const HxHead*>(recs), seg_off, seg_rel, static_cast<uint4*>(slot_desc), cu);
-  hipLaunchKernelGGL(k_cl_uid, dim3((n_inst + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst, static_cast<const uint4*>(slot_desc), ci,
+  hipLaunchKernelGGL(k_cl_uid, dim3((inst_bound + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst_dev, static_cast<const uint4*>(slot_desc), ci,
                      static_cast<const HxHead*>(recs), inst_uid, status);
 }
 

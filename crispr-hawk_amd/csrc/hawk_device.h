@@ -163,12 +163,13 @@ void hawk_launch_cl_chunks(hipStream_t st, const uint64_t* hv_off, const uint8_t
 void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_rows,
                           uint32_t ch_bound, uint32_t* cnt /* zeroed */);
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
-                         const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_chunks, uint32_t n_head, const uint32_t* inst_base, int32_t* o,
+                         uint32_t n_rows, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t ch_bound, const uint32_t* inst_base, int32_t* o,
                          uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot, uint32_t* status, void* tab /* zeroed */,
                          uint32_t mask, uint32_t max_probe, uint32_t fail_bit);  // cuts the chunks AND fills the table
 size_t hawk_cl_slot_bytes();  // a slot of the table of distinct clusters: {key, ~lowest instance}
 void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits /* zeroed */, uint32_t n_words, uint32_t* cnt);
-void hawk_launch_cl_assign(hipStream_t st, uint32_t n_inst, uint32_t tsize, const void* tab, const uint32_t* bits, const uint64_t* word_rank,
+void hawk_launch_cl_assign(hipStream_t st, uint32_t inst_bound, const uint32_t* n_inst_dev, uint32_t tsize, const void* tab, const uint32_t* bits,
+                           const uint64_t* word_rank,
                            const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot,
                            const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc /* 32 B per slot */, uint32_t* u_rec, uint32_t* u_n,
                            uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status);
