@@ -306,7 +306,6 @@ static int xplan_build_dict(hawk_xplan* x) {
   int32_t* const t_pa = cl.inst_pa.as<int32_t>();
   int32_t* const t_rb = cl.inst_rb.as<int32_t>();
   uint32_t *d_rec, *d_n, *d_slot, *d_bits, *d_wcnt;
-  void* d_slot_uid;  // 32 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
   void* d_tab;       // the table itself: 16-byte slots {key, ~lowest instance}
   uint64_t* d_rank;
   unsigned long long *d_partial, *d_shards;
@@ -330,64 +329,58 @@ static int xplan_build_dict(hawk_xplan* x) {
   TEMPCHK(tmp, &d_partial, ((size_t)inst_bound / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
   TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
-  auto cut_and_insert = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit) -> int {
+  // One pass = cut + insert, number the distinct clusters, describe them, give every instance its cluster and verify it - queued
+  // without a read-back in between: what the host would size by the number of distinct clusters is sized by its bound (the table's
+  // slots, or the instances if fewer).  The host reads the counts once, at the end, and repeats the pass if the small table gave up.
+  ScanTotals tot[2];
+  uint32_t status = 0, n_inst = 0, tused = 0;
+  auto pass = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit) -> int {
+    const uint32_t u_bound = std::min<uint32_t>(tsz, inst_bound);
+    uint32_t* d_span2;
+    uint64_t* d_slot64;
+    void* d_slot_uid;  // 32 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
+    TEMPCHK(tmp, &d_slot_uid, (size_t)tsz * 32);
+    TEMPCHK(tmp, &d_span2, (size_t)u_bound * 4);
+    TEMPCHK(tmp, &d_slot64, ((size_t)u_bound + 1) * 8);
+    int rc2;
+    if ((rc2 = cl.u_rec.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_n.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_row.reserve((size_t)u_bound * 4)) ||
+        (rc2 = cl.u_o.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_seg.reserve((size_t)u_bound * 4)))
+      return rc2;
     HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
     HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
     HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
+    HIPCHK(hipMemsetAsync(d_span2, 0, (size_t)u_bound * 4, st));
+    HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals) * 2, st));
     hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row,
                         ch_bound, d_base, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot, d_status, d_tab, tsz - 1, max_probe, fail_bit);
     hawk_launch_cl_mark(st, tsz, d_tab, d_bits, n_words, d_wcnt);
     hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
-    return HAWK_OK;
-  };
-  if ((rc = cut_and_insert(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u))) return rc;
-  ScanTotals tot;
-  uint32_t st_now = 0, n_inst = 0;
-  HIPCHK(hipMemcpyAsync(&n_inst, d_n_inst, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&st_now, d_status, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipGetLastError());
-  if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
-  if (n_inst > inst_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: instance count beyond its bound"); return HAWK_E_HIP; }
-  uint32_t tused = tsmall;
-  if (st_now & 8u) {  // the small table filled up: once more with two slots per instance
-    tused = tsize;
-    st_now &= ~8u;
-    HIPCHK(hipMemcpyAsync(d_status, &st_now, 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
-    if ((rc = cut_and_insert(tsize, 0xffffffffu, 2u))) return rc;
-    HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-  }
-  const uint32_t n_uniq = (uint32_t)tot.n_keep;
-  TEMPCHK(tmp, &d_slot_uid, (size_t)tused * 32);
-  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.last_uniq = n_uniq;
-  if (n_uniq) {
-    uint32_t* d_span2;
-    TEMPCHK(tmp, &d_span2, (size_t)n_uniq * 4);
-    if ((rc = cl.u_rec.reserve((size_t)n_uniq * 4)) || (rc = cl.u_n.reserve((size_t)n_uniq * 4)) || (rc = cl.u_row.reserve((size_t)n_uniq * 4)) ||
-        (rc = cl.u_o.reserve((size_t)n_uniq * 4)) || (rc = cl.u_seg.reserve((size_t)n_uniq * 4)))
-      return rc;
-    uint64_t* d_slot64;
-    TEMPCHK(tmp, &d_slot64, ((size_t)n_uniq + 1) * 8);
-    hawk_launch_cl_assign(st, n_inst, d_n_inst, tused, d_tab, d_bits, d_rank, x->heads.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot,
+    hawk_launch_cl_assign(st, inst_bound, d_n_inst, tsz, d_tab, d_bits, d_rank, x->heads.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot,
                           x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), d_slot_uid, cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
                           cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, t_uid, d_status);
-    hawk_launch_mscan(st, d_span2, n_uniq, d_partial, d_shards, d_slot64, d_tot + 1);
-    HIPCHK(hipMemcpyAsync(&tot, d_tot + 1, sizeof(tot), hipMemcpyDeviceToHost, st));
-  } else {
-    HIPCHK(hipMemsetAsync(t_uid, 0xff, (size_t)n_inst * 4, st));
-    tot.n_keep = 0;
+    hawk_launch_mscan(st, d_span2, u_bound, d_partial, d_shards, d_slot64, d_tot + 1);  // (zeros behind the last distinct cluster)
+    HIPCHK(hipMemcpyAsync(&n_inst, d_n_inst, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof(ScanTotals) * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(ctx->ev[9], st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    tused = tsz;
+    return HAWK_OK;
+  };
+  if ((rc = pass(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u))) return rc;
+  if (status & 8u) {  // the small table filled up: once more with two slots per instance
+    status &= ~8u;
+    HIPCHK(hipMemcpyAsync(d_status, &status, 4, hipMemcpyHostToDevice, st));
+    if ((rc = pass(tsize, 0xffffffffu, 2u))) return rc;
   }
-  uint32_t status = 0;
-  HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(ctx->ev[9], st));
-  HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipGetLastError());
+  (void)tused;
+  if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
+  if (n_inst > inst_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: instance count beyond its bound"); return HAWK_E_HIP; }
+  const uint32_t n_uniq = (uint32_t)tot[0].n_keep;
+  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.last_uniq = n_uniq;
   (void)hipEventElapsedTime(&cl.build_ms, ctx->ev[8], ctx->ev[9]);
-  cl.slots = tot.n_keep;
+  cl.slots = n_uniq ? tot[1].n_keep : 0;
   cl.status = status;
   // worth it when clusters are shared (the template rows are extra traffic otherwise) and the templates fit a sane budget
   // (HAWK_CLUSTER_MAX_SLOTS template rows, default 2^27 = 10 GB; HAWK_CLUSTER_MIN_SHARE instances per distinct cluster, default 3:
