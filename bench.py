@@ -248,7 +248,7 @@ def csearch_roofline(rows, ref_rows, positions, hits, L, scored, cl, templates_m
     if traffic_key and os.path.exists(PROFILE_TRAFFIC_R4):
         tk = [v for k, v in json.load(open(PROFILE_TRAFFIC_R4)).get(traffic_key, {}).items() if k.startswith("k_cs_emit_rows")]
         traffic = tk[0]["fetch_bytes"] + tk[0]["write_bytes"] if tk else None
-    count_moved = 24.0 * cl["instances"]  # cluster id, run start, position, REF shift in; row count + first template row out
+    count_moved = 16.0 * cl["instances"]  # cluster id + run start in, row count + first template row out (the clusters' 32-byte entries come out of L2)
     return {"bound": "hbm", "kernel": "k_cs_emit_rows", "achieved": gbps(emit_moved, emit_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbps(emit_moved, emit_ms) / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": emit_ms,
             "algorithmic_bytes_per_launch": emit_moved,
@@ -261,7 +261,7 @@ def csearch_roofline(rows, ref_rows, positions, hits, L, scored, cl, templates_m
                               "k_cs_count": {"launch_ms": count_ms, "instances": cl["instances"], "moved_bytes": count_moved,
                                              "frac": gbps(count_moved, count_ms) / HBM_PEAK_GBS}},
             "step_level": {"algorithmic_bytes": step_alg, "what": "SURVEY 8(d) K2 + K3 + K4 over every haplotype position / hit / row, every unit priced once",
-                           "moved_bytes": PACKED_ROW_BYTES * vrows + ROW_BYTES * ref_rows + (CS_INSTANCE_BYTES + 24.0) * cl["instances"]}}
+                           "moved_bytes": PACKED_ROW_BYTES * vrows + ROW_BYTES * ref_rows + (CS_INSTANCE_BYTES + 16.0) * cl["instances"]}}
 
 
 def tab_ref_rows(reg, pam, args, mm, pt, device):
@@ -1009,10 +1009,10 @@ def run_c4(args, R: Ranks):
         emit_ms = sum(s.get("v_emit_rows_ms", 0.0) if s.get("v_path", 0) == 2 else s.get("v_emit_ms", 0.0) for s in st)
         vrows = sum(s["rows"] for s in st if s.get("v_path", 0) == 2)           # rows of the tiles searched per cluster (REF's few included)
         # what the tiles' searches move: per cluster path a packed 64-byte row out + 16 B per instance in (k_cs_emit_rows) and
-        # 24 B per instance in the count pass; per dirty word a 74-byte row in columns + the records twice
+        # 16 B per instance in the count pass; per dirty word a 74-byte row in columns + the records twice
         if by_cluster:
             emit_bytes = PACKED_ROW_BYTES * vrows + (CS_INSTANCE_BYTES + 8.0 / 64) * instances
-            step_bytes = PACKED_ROW_BYTES * vrows + ROW_BYTES * (rows - vrows) + (CS_INSTANCE_BYTES + 24.0) * instances
+            step_bytes = PACKED_ROW_BYTES * vrows + ROW_BYTES * (rows - vrows) + (CS_INSTANCE_BYTES + 16.0) * instances
         else:
             emit_bytes = ROW_BYTES * rows + REC_BYTES * records
             step_bytes = ROW_BYTES * rows + 2 * REC_BYTES * records
