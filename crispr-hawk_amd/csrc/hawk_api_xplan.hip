@@ -112,7 +112,7 @@ static int xplan_build(hawk_hapset* ref_set, uint32_t n_var, const uint32_t* v_r
     hawk_launch_hx_prepare(st, x->off.as<uint64_t>(), d_idx ? d_idx : t_idx.as<uint32_t>(), d_o ? d_o : t_o.as<int32_t>(), ncar, t_r0.as<uint32_t>(),
                            t_span.as<uint32_t>(), t_ao.as<uint32_t>(), t_al.as<uint32_t>(), t_am.p, x->hlen.as<uint32_t>(), n_hap, x->S,
                            x->recs.p, x->tiles.p);
-    hawk_launch_hx_heads(st, x->recs.p, ncar, x->heads.p);
+    hawk_launch_hx_heads(st, x->recs.p, d_idx ? d_idx : t_idx.as<uint32_t>(), ncar, x->heads.p);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -269,32 +269,38 @@ int hawk_xplan_run(hawk_xplan* x, hawk_hapset** out, uint64_t* hash_out, float* 
 static int xplan_build_dict(hawk_xplan* x) {
   auto& cl = x->cl;
   if (cl.built) return HAWK_OK;
-  cl.built = true; cl.usable = false; cl.status = 0; cl.n_inst = cl.n_uniq = 0; cl.slots = 0; cl.build_ms = 0.f;
+  cl.built = true; cl.usable = false; cl.status = 0; cl.n_inst = cl.n_uniq = cl.n_real = 0; cl.slots = 0; cl.build_ms = 0.f;
   hawk_ctx* ctx = x->ctx;
   hipStream_t st = ctx->stream;
   const uint32_t n = x->n_hap;
   if (x->ncar == 0 || x->ncar >= (1ull << 32) - 2 || n < 2) { cl.status = 4; return HAWK_OK; }
   PoolScope tmp;
   // the rows' records in chunks (hawk_csearch.hip): chunks per row -> their offsets and rows, then the instances every chunk opens
+  // and how many of them go on the list of the clusters that are more than their variant
+  const uint32_t n_var = x->n_var;
   const uint32_t ch_bound = hawk_cl_chunk_bound(x->ncar, n);
-  uint32_t *d_ch_off, *d_ch_row, *d_cnt, *d_base, *d_status;
+  uint32_t *d_ch_off, *d_ch_row, *d_cnt, *d_lcnt, *d_base, *d_lbase, *d_status;
   TEMPCHK(tmp, &d_ch_off, (size_t)(n + 1) * 4);
   TEMPCHK(tmp, &d_ch_row, (size_t)ch_bound * 4);
-  TEMPCHK(tmp, &d_cnt, (size_t)ch_bound * 4);
+  TEMPCHK(tmp, &d_cnt, (size_t)ch_bound * 4 * 2);
+  d_lcnt = d_cnt + ch_bound;
   TEMPCHK(tmp, &d_base, (size_t)(ch_bound + 1) * 4);
+  TEMPCHK(tmp, &d_lbase, (size_t)(ch_bound + 1) * 4);
   TEMPCHK(tmp, &d_status, 64);
   HIPCHK(hipMemsetAsync(d_status, 0, 64, st));
-  HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ch_bound * 4, st));  // (chunks beyond the last one open nothing)
+  HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ch_bound * 4 * 2, st));  // (chunks beyond the last one open nothing)
   HIPCHK(hipEventRecord(ctx->ev[8], st));
   hawk_launch_cl_chunks(st, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row);
   // (the number of chunks is only known on the device - rows that scan nothing have none: the count pass and its scan run over the bound)
-  hawk_launch_cl_count(st, x->heads.p, x->off.as<uint64_t>(), d_ch_off, d_ch_row, n, ch_bound, d_cnt);
-  hawk_launch_scan_u32(st, d_cnt, ch_bound, d_base);
+  hawk_launch_cl_count(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), d_ch_off, d_ch_row, n,
+                       n_var, ch_bound, d_cnt, d_lcnt);
+  hawk_launch_scan2_u32(st, d_cnt, d_lcnt, ch_bound, d_base, d_lbase);
   // No read-back here: an instance starts at a record or closes a row, so records + rows bounds their number - the instance arrays,
-  // the bitmap and the grids of the passes below are sized by the bound, the passes read the true count on the device, and the
-  // host learns it together with the number of distinct clusters
+  // the list and the grids of the passes below are sized by the bound, the passes read the true counts on the device, and the host
+  // learns them together with the number of distinct clusters
   const uint32_t inst_bound = (uint32_t)x->ncar + n;
   const uint32_t* const d_n_inst = d_base + ch_bound;
+  const uint32_t* const d_n_list = d_lbase + ch_bound;
   int rc;
   if ((rc = cl.inst_uid.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_o.reserve((size_t)inst_bound * 4)) ||
       (rc = cl.inst_row.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_pa.reserve((size_t)inst_bound * 4)) ||
@@ -305,41 +311,38 @@ static int xplan_build_dict(hawk_xplan* x) {
   int32_t* const t_o = cl.inst_o.as<int32_t>();
   int32_t* const t_pa = cl.inst_pa.as<int32_t>();
   int32_t* const t_rb = cl.inst_rb.as<int32_t>();
-  uint32_t *d_rec, *d_n, *d_slot, *d_bits, *d_wcnt;
-  void* d_tab;       // the table itself: 16-byte slots {key, ~lowest instance}
-  uint64_t* d_rank;
+  const uint32_t bm_words = n_var / 32 + 1;
+  uint32_t *d_counters, *d_claim, *d_state;
+  void *d_tab, *d_list, *d_vdesc;  // the table of the listed instances' clusters, the list, the variants' describers: hawk_csearch.hip
   unsigned long long *d_partial, *d_shards;
   ScanTotals* d_tot;
-  // the hash table of distinct clusters: at least two slots per instance would always do, but on a shared panel the distinct
-  // clusters are a small fraction of the instances and clearing 16 bytes x 2^25 slots costs as much as a kernel of this build
-  // - so the first attempt takes four slots per distinct cluster EXPECTED (the last build's count, else half
-  // of the instances), gives up after 64 probes (status bit 8), and the pass is repeated with the full size
+  // The table: at least two slots per listed instance would always do, but the distinct clusters are a small fraction of the instances
+  // and clearing 32 bytes x 2^25 slots costs more than every kernel of this build - so the first attempt takes two slots per
+  // distinct cluster EXPECTED (the last build's count, else an eighth of the instances), gives up after 64 probes (status bit 8),
+  // and the pass is repeated with the full size
   uint32_t tsize = 1024;
-  while (tsize < 2u * inst_bound && tsize < (1u << 31)) tsize <<= 1;
+  while (tsize < 2u * inst_bound && tsize < (1u << 30)) tsize <<= 1;
   uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
-  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 4 : (uint64_t)inst_bound / 2; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
-  const uint32_t n_words = (inst_bound + 31) / 32;  // the representatives as a bitmap over the instances
-  TEMPCHK(tmp, &d_rec, (size_t)inst_bound * 4);
-  TEMPCHK(tmp, &d_n, (size_t)inst_bound * 4);
-  TEMPCHK(tmp, &d_slot, (size_t)inst_bound * 4);
-  TEMPCHK(tmp, &d_bits, (size_t)n_words * 4);
-  TEMPCHK(tmp, &d_wcnt, (size_t)n_words * 4);
-  TEMPCHK(tmp, &d_rank, ((size_t)n_words + 1) * 8);
+  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 2 : (uint64_t)inst_bound / 8; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
+  TEMPCHK(tmp, &d_counters, 64);
+  TEMPCHK(tmp, &d_claim, (size_t)bm_words * 4);
+  TEMPCHK(tmp, &d_vdesc, (size_t)std::max<uint32_t>(n_var, 1) * 8);
+  TEMPCHK(tmp, &d_list, (size_t)inst_bound * hawk_cl_listed_bytes());
+  TEMPCHK(tmp, &d_state, (size_t)inst_bound * 4);
   TEMPCHK(tmp, &d_tab, (size_t)tsize * hawk_cl_slot_bytes());
-  TEMPCHK(tmp, &d_partial, ((size_t)inst_bound / 1024 + 2) * 8);
+  TEMPCHK(tmp, &d_partial, (((size_t)n_var + std::min<uint32_t>(tsize, inst_bound)) / 1024 + 2) * 8);
   TEMPCHK(tmp, &d_shards, 512 * 8);
-  TEMPCHK(tmp, &d_tot, sizeof(ScanTotals) * 2);
-  // One pass = cut + insert, number the distinct clusters, describe them, give every instance its cluster and verify it - queued
-  // without a read-back in between: what the host would size by the number of distinct clusters is sized by its bound (the table's
-  // slots, or the instances if fewer).  The host reads the counts once, at the end, and repeats the pass if the small table gave up.
-  ScanTotals tot[2];
-  uint32_t status = 0, n_inst = 0, tused = 0;
+  TEMPCHK(tmp, &d_tot, sizeof(ScanTotals));
+  // One pass = cut the rows (a one-record shareable instance is its variant; the rest goes on the list), the listed instances through
+  // the table, the distinct clusters' descriptions, the listed instances that share a cluster - queued without a read-back in
+  // between: what the host would size by a count is sized by its bound (the variants + the table's slots, or + the instances if
+  // fewer).  The host reads the counts once, at the end, and repeats the pass if the small table gave up.
+  ScanTotals tot;
+  uint32_t status = 0, n_inst = 0, n_uniq = 0, n_real = 0, cnt2[2] = {0, 0};
   auto pass = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit) -> int {
-    const uint32_t u_bound = std::min<uint32_t>(tsz, inst_bound);
+    const uint32_t u_bound = n_var + std::min<uint32_t>(tsz, inst_bound);  // the variants, then what the table can hold
     uint32_t* d_span2;
     uint64_t* d_slot64;
-    void* d_slot_uid;  // 32 bytes per table slot: the representative's descriptor (k_cl_assign -> k_cl_uid)
-    TEMPCHK(tmp, &d_slot_uid, (size_t)tsz * 32);
     TEMPCHK(tmp, &d_span2, (size_t)u_bound * 4);
     TEMPCHK(tmp, &d_slot64, ((size_t)u_bound + 1) * 8);
     int rc2;
@@ -348,24 +351,26 @@ static int xplan_build_dict(hawk_xplan* x) {
       return rc2;
     HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
     HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
-    HIPCHK(hipMemsetAsync(d_bits, 0, (size_t)n_words * 4, st));
+    HIPCHK(hipMemsetAsync(d_counters, 0, 64, st));
+    HIPCHK(hipMemsetAsync(d_claim, 0, (size_t)bm_words * 4, st));
+    HIPCHK(hipMemsetAsync(d_vdesc, 0, (size_t)std::max<uint32_t>(n_var, 1) * 8, st));  // (a variant nobody describes stays a hole)
     HIPCHK(hipMemsetAsync(d_span2, 0, (size_t)u_bound * 4, st));
-    HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals) * 2, st));
+    HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
     hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row,
-                        ch_bound, d_base, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot, d_status, d_tab, tsz - 1, max_probe, fail_bit);
-    hawk_launch_cl_mark(st, tsz, d_tab, d_bits, n_words, d_wcnt);
-    hawk_launch_mscan(st, d_wcnt, n_words, d_partial, d_shards, d_rank, d_tot);
-    hawk_launch_cl_assign(st, inst_bound, d_n_inst, tsz, d_tab, d_bits, d_rank, x->heads.p, t_o, t_row, t_pa, t_rb, d_rec, d_n, d_slot,
-                          x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), d_slot_uid, cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
-                          cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, t_uid, d_status);
-    hawk_launch_mscan(st, d_span2, u_bound, d_partial, d_shards, d_slot64, d_tot + 1);  // (zeros behind the last distinct cluster)
+                        ch_bound, d_base, d_lbase, t_o, t_row, t_pa, t_rb, t_uid, d_vdesc, d_claim, n_var, d_list, d_status);
+    hawk_launch_cl_finish(st, inst_bound, d_n_list, d_counters, n_var, u_bound, d_tab, tsz - 1, max_probe, fail_bit, d_list, d_state, d_vdesc, x->heads.p,
+                          t_uid, x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
+                          cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, d_status);
+    hawk_launch_mscan(st, d_span2, u_bound, d_partial, d_shards, d_slot64, d_tot);  // (zeros behind the last distinct cluster)
     HIPCHK(hipMemcpyAsync(&n_inst, d_n_inst, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof(ScanTotals) * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(cnt2, d_counters, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(ScanTotals), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(ctx->ev[9], st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
-    tused = tsz;
+    n_uniq = std::min<uint32_t>(n_var + cnt2[0], u_bound);  // the range of the numbers
+    n_real = cnt2[0] + cnt2[1];
     return HAWK_OK;
   };
   if ((rc = pass(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u))) return rc;
@@ -374,13 +379,11 @@ static int xplan_build_dict(hawk_xplan* x) {
     HIPCHK(hipMemcpyAsync(d_status, &status, 4, hipMemcpyHostToDevice, st));
     if ((rc = pass(tsize, 0xffffffffu, 2u))) return rc;
   }
-  (void)tused;
   if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
   if (n_inst > inst_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: instance count beyond its bound"); return HAWK_E_HIP; }
-  const uint32_t n_uniq = (uint32_t)tot[0].n_keep;
-  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.last_uniq = n_uniq;
+  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.n_real = n_real; cl.last_uniq = cnt2[0];
   (void)hipEventElapsedTime(&cl.build_ms, ctx->ev[8], ctx->ev[9]);
-  cl.slots = n_uniq ? tot[1].n_keep : 0;
+  cl.slots = n_uniq ? tot.n_keep : 0;
   cl.status = status;
   // worth it when clusters are shared (the template rows are extra traffic otherwise) and the templates fit a sane budget
   // (HAWK_CLUSTER_MAX_SLOTS template rows, default 2^27 = 10 GB; HAWK_CLUSTER_MIN_SHARE instances per distinct cluster, default 3:
@@ -389,7 +392,7 @@ static int xplan_build_dict(hawk_xplan* x) {
   const char* e2 = getenv("HAWK_CLUSTER_MIN_SHARE");
   const uint64_t max_slots = e1 ? strtoull(e1, nullptr, 10) : (1ull << 27);
   const double min_share = e2 ? atof(e2) : 3.0;
-  if (!status && (cl.slots > max_slots || (double)n_inst < min_share * (double)std::max<uint32_t>(n_uniq, 1))) cl.status = 4;
+  if (!status && (cl.slots > max_slots || (double)n_inst < min_share * (double)std::max<uint32_t>(n_real, 1))) cl.status = 4;
   cl.usable = cl.status == 0;
   return HAWK_OK;
 }
@@ -399,7 +402,7 @@ int hawk_xplan_cluster_stats(const hawk_xplan* x, uint32_t* usable, uint32_t* n_
   if (!x) return HAWK_E_INVALID;
   if (usable) *usable = x->cl.built && x->cl.usable ? 1u : 0u;
   if (n_instances) *n_instances = x->cl.n_inst;
-  if (n_distinct) *n_distinct = x->cl.n_uniq;
+  if (n_distinct) *n_distinct = x->cl.n_real;
   if (template_slots) *template_slots = x->cl.slots;
   if (build_ms) *build_ms = x->cl.build_ms;
   if (status) *status = x->cl.built ? x->cl.status : 0xffffffffu;

@@ -40,17 +40,21 @@ __device__ __forceinline__ uint64_t cl_mix(uint64_t h, uint64_t v) {
   h = (h ^ v) * 0x9E3779B97F4A7C15ull;
   return h ^ (h >> 29);
 }
-// What the dictionary passes read of a record: its first 16 bytes.  The plan keeps them a second time as an array of their own
-// (hawk_launch_hx_heads, at plan creation): the three passes over every record are HBM-bound, and a 32-byte record fetched for
-// 16 of its bytes is twice the traffic.
-struct __attribute__((aligned(16))) HxHead { int32_t o; uint32_t rs; uint32_t alt_len; uint32_t alt_off; };
+// What the dictionary passes read of a record: {o, rs, alt_len} and WHICH variant it is (its index in the plan's variant table, from
+// which hawk_expand.hip took rs, alt_len and the alt bases - so two records of one variant are the same allele at the same place in
+// REF, by construction).  The plan keeps these 16 bytes as an array of their own (hawk_launch_hx_heads, at plan creation): the
+// passes over every record are HBM-bound, and a 32-byte record fetched for half its bytes is twice the traffic.
+struct __attribute__((aligned(16))) HxHead { int32_t o; uint32_t rs; uint32_t alt_len; uint32_t var; };
 static_assert(sizeof(HxHead) == 16, "record head layout");
-__global__ __launch_bounds__(256) void k_hx_heads(const HxVar* __restrict__ recs, uint64_t n, uint4* __restrict__ heads) {
+__global__ __launch_bounds__(256) void k_hx_heads(const HxVar* __restrict__ recs, const uint32_t* __restrict__ hv_idx, uint64_t n, uint4* __restrict__ heads) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j < n) heads[j] = *reinterpret_cast<const uint4*>(recs + j);
+  if (j >= n) return;
+  const uint4 r = *reinterpret_cast<const uint4*>(recs + j);
+  heads[j] = make_uint4(r.x, r.y, r.z, hv_idx[j]);
 }
-void hawk_launch_hx_heads(hipStream_t st, const void* recs, uint64_t n, void* heads) {
-  if (n) hipLaunchKernelGGL(k_hx_heads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const HxVar*>(recs), n, static_cast<uint4*>(heads));
+void hawk_launch_hx_heads(hipStream_t st, const void* recs, const uint32_t* hv_idx, uint64_t n, void* heads) {
+  if (n) hipLaunchKernelGGL(k_hx_heads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const HxVar*>(recs), hv_idx, n,
+                            static_cast<uint4*>(heads));
 }
 __device__ __forceinline__ bool cl_starts(const HxHead* __restrict__ recs, uint64_t j, uint64_t lo) {
   if (j == lo) return true;
@@ -89,16 +93,102 @@ __global__ __launch_bounds__(1024) void k_cl_chunks(const uint64_t* __restrict__
   }
   if (threadIdx.x == 0) ch_off[n_rows] = carry;
 }
-// cluster starts of chunk b (+ the closing instance in a row's last chunk)
-__global__ __launch_bounds__(256) void k_cl_count(const HxHead* __restrict__ recs, const uint64_t* __restrict__ hv_off, const uint32_t* __restrict__ ch_off,
-                                                  const uint32_t* __restrict__ ch_row, uint32_t n_rows, uint32_t* __restrict__ cnt) {
+struct ClInst {  // per instance (k_cl_fill)
+  int32_t* o;      // row position of the cluster's first allele (closing instance: CL_FAR)
+  uint32_t* row;
+  int32_t* pa;     // where the clean run in front of the instance starts: end of the previous record's allele, 0 at the row's start
+  int32_t* rb;     // REF shift of that run
+  uint32_t* uid;   // its distinct cluster (CL_NONE: none)
+};
+struct ClUniq {  // per distinct cluster: first record, records, row and row position of the instance that describes it; k_cl_describe adds the rest
+  uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* seg; uint32_t* span2;
+};
+#define CL_PENDING 0x80000000u
+// Nine clusters in ten are ONE record of a shareable instance: such a cluster IS its variant, and its number is the variant's
+// index - no table, no comparison.  Which instance describes it does not matter: every such instance whose variant the first rows
+// have not described yet writes {its record, its row} - ONE aligned 64-bit store, so whichever write lands last is whole.
+// Every other instance with a cluster - several records, or windows that could meet a bound of its row - is put on a LIST by the
+// cutting pass (its place known without an atomic: the counting pass counts those too) and goes through a hash table of 32-byte
+// slots in passes of their own over that list: {hash key (0: free), cluster number + 1 (0: not yet numbered), records | class << 16
+// of the instance that opened the slot} {REF position of its first allele, that record's rs, alt_len, variant}; these are
+// numbered behind the variants, in the order they are met (the order carries no meaning: every table a search writes is in
+// instance order).
+// Why this shape: the passes are bound by the NUMBER of requests to L2 (a 4-byte gather costs what a 64-byte line costs: ~1.3 x 10^11
+// requests/s at best) and by same-address atomics (~10 ns each, whoever waits for them) - not by bytes and not by arithmetic.
+struct __attribute__((aligned(32))) ClSlot { unsigned long long key; uint32_t up1; uint32_t ncls; uint32_t id[4]; };
+static_assert(sizeof(ClSlot) == 32, "table slot layout");
+size_t hawk_cl_slot_bytes() { return sizeof(ClSlot); }
+struct __attribute__((aligned(32))) ClListed {  // a listed instance: all the table passes need of it
+  uint32_t inst, key_lo, key_hi, rec, ncls, refp, row; int32_t o_first;
+};
+static_assert(sizeof(ClListed) == 32, "list entry layout");
+size_t hawk_cl_listed_bytes() { return sizeof(ClListed); }
+
+// One cluster start: the walk over its records and what follows from it.  r0 / rp: the record at j and the one before it; nx1 / nx2:
+// the records of lanes + 1, + 2 (a cluster's second and third record are the records of the lanes above - nine clusters in ten are
+// one record, ninety-nine in a hundred at most three: no dependent load until a cluster is longer or crosses the wave's end).
+struct ClCut { int32_t o_first, o_end, pa, rb; uint32_t n, cls; unsigned long long key; bool run_inside, too_long; };
+__device__ __forceinline__ ClCut cl_cut(const HxHead* __restrict__ recs, uint64_t lo, uint64_t hi, uint64_t j, const uint4& r0, const uint4& rp,
+                                         const uint4& nx1, const uint4& nx2, uint32_t lane, int32_t ss, int32_t se, int32_t hl, uint32_t row) {
+  ClCut c;
+  // A cluster's identity is WHERE in REF its first allele starts and, record by record, which variant it is (and so which allele,
+  // where it lies and where REF resumes behind it) and where it lies relative to the first - hashed here, compared record by
+  // record before two instances share a cluster (k_cl_uid).
+  c.o_first = (int32_t)r0.x; c.pa = 0; c.rb = 0; c.too_long = false;
+  if (j > lo) { c.pa = (int32_t)rp.x + (int32_t)rp.z; c.rb = (int32_t)rp.y - c.pa; }
+  uint64_t e = j + 1, h = cl_mix(0x243F6A8885A308D3ull, (uint64_t)(uint32_t)(c.o_first + c.rb));
+  h = cl_mix(h, (uint64_t)r0.w | ((uint64_t)r0.z << 32));
+  h = cl_mix(h, (uint64_t)r0.y);
+  c.n = 1;
+  c.o_end = (int32_t)r0.x + (int32_t)r0.z;  // end of the cluster's last allele so far
+  bool open = e < hi;                        // the record at e may still belong to the cluster
+  while (open) {
+    const uint32_t ahead = (uint32_t)(e - j);
+    uint4 r;
+    if (ahead == 1 && lane + 1 < WAVE) r = nx1;
+    else if (ahead == 2 && lane + 2 < WAVE) r = nx2;
+    else r = *reinterpret_cast<const uint4*>(recs + e);
+    if ((int32_t)r.x - c.o_end > CL_LINK) break;      // it starts the next cluster
+    if (c.n >= CL_MAXWALK) { c.too_long = true; break; }  // a chain too long for this path
+    h = cl_mix(h, (uint64_t)r.w | ((uint64_t)r.z << 32));
+    h = cl_mix(h, (uint64_t)r.y | ((uint64_t)(uint32_t)((int32_t)r.x - c.o_first) << 32));
+    c.o_end = (int32_t)r.x + (int32_t)r.z;
+    ++c.n; ++e;
+    open = e < hi;
+  }
+  // window starts the cluster can touch: [o_first - (L - 1), o_end), L <= 44; the ranges they are tested against
+  // (search_guides.py:49-84, 395-420) are [ss - po, se - po) and [PAD, len - L - PAD], po in {0, guidelen}
+  const bool outside = c.o_end <= ss - 44 || c.o_first - 43 >= se;
+  const bool interior = c.o_first - 43 >= (ss > HAWK_PAD ? ss : HAWK_PAD) && c.o_first >= 64 && c.o_end <= se - 44 &&
+                        c.o_end <= hl - 44 - HAWK_PAD + 1 && c.o_end + 128 <= hl;
+  c.key = h; c.cls = 1;
+  if (outside) { c.cls = 0; c.key = 0; }
+  else if (!interior) { c.cls = 2; c.key = cl_mix(h ^ 0xA4093822299F31D0ull, (uint64_t)row + 1u); }
+  if (c.cls && c.key == 0) c.key = 1;
+  // the clean run in front, [pa, o_first - (L - 1)), lies inside every range of both strands for every geometry: its count
+  // then needs neither the row nor its bounds (bit 31 of the instance's pa)
+  c.run_inside = c.pa >= (ss > HAWK_PAD ? ss : HAWK_PAD) && c.o_first <= se - 44 && c.o_first <= hl - 44 - HAWK_PAD + 1;
+  return c;
+}
+__device__ __forceinline__ uint4 shfl_down4(const uint4& v, int d) {
+  return make_uint4((uint32_t)__shfl_down((int)v.x, d), (uint32_t)__shfl_down((int)v.y, d), (uint32_t)__shfl_down((int)v.z, d),
+                    (uint32_t)__shfl_down((int)v.w, d));
+}
+
+// chunk b: the instances it opens (its cluster starts + the closing instance in a row's last chunk) and how many of them go on the list
+__global__ __launch_bounds__(256) void k_cl_count(const HxHead* __restrict__ recs, const uint64_t* __restrict__ hv_off, const uint32_t* __restrict__ hap_len,
+                                                  const int32_t* __restrict__ ss_, const int32_t* __restrict__ se_, const uint32_t* __restrict__ ch_off,
+                                                  const uint32_t* __restrict__ ch_row, uint32_t n_rows, uint32_t n_var, uint32_t* __restrict__ cnt,
+                                                  uint32_t* __restrict__ lcnt) {
   __shared__ uint32_t s_w[256 / WAVE];
   const uint32_t b = blockIdx.x;
   if (b >= ch_off[n_rows]) return;  // (launched over the bound on the chunks: their number is only known on the device; workgroup-uniform)
   const uint32_t row = ch_row[b];
   const uint64_t lo = hv_off[row], hi = hv_off[row + 1];
   const uint64_t b0 = lo + (uint64_t)(b - ch_off[row]) * CL_CHUNK;
-  uint32_t c = 0;
+  const int32_t ss = ss_[row], se = se_[row], hl = (int32_t)hap_len[row];
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  uint32_t c = 0;  // starts | listed << 16
   if (hi > lo) {
     uint4 r0[CL_ROW_U], rp[CL_ROW_U];
 #pragma unroll
@@ -108,43 +198,38 @@ __global__ __launch_bounds__(256) void k_cl_count(const HxHead* __restrict__ rec
       r0[u] = *reinterpret_cast<const uint4*>(recs + jc);
       rp[u] = *reinterpret_cast<const uint4*>(recs + (jc > lo ? jc - 1 : jc));
     }
-#pragma unroll
-    for (int u = 0; u < CL_ROW_U; ++u) {
+    auto one = [&](const int u) __attribute__((always_inline)) {
+      const uint4 nx1 = shfl_down4(r0[u], 1), nx2 = shfl_down4(r0[u], 2);  // (every lane takes part in the exchange)
       const uint64_t j = b0 + u * 256 + threadIdx.x;
-      c += (j < hi && (j == lo || (int32_t)r0[u].x - ((int32_t)rp[u].x + (int32_t)rp[u].z) > CL_LINK)) ? 1u : 0u;
-    }
+      if (!(j < hi && (j == lo || (int32_t)r0[u].x - ((int32_t)rp[u].x + (int32_t)rp[u].z) > CL_LINK))) return;
+      const ClCut k = cl_cut(recs, lo, hi, j, r0[u], rp[u], nx1, nx2, lane, ss, se, hl, row);
+      const bool simple = k.n == 1 && k.cls == 1 && r0[u].w < n_var;
+      c += 1u + ((k.cls != 0 && !simple) ? 0x10000u : 0u);
+    };
+    static_assert(CL_ROW_U == 4, "one call per slice");
+    one(0); one(1); one(2); one(3);
   }
   uint32_t tot;
   (void)block_excl_scan<256 / WAVE>(c, s_w, &tot);
-  if (threadIdx.x == 0) cnt[b] = tot + (b + 1 == ch_off[row + 1] ? 1u : 0u);
+  if (threadIdx.x == 0) { cnt[b] = (tot & 0xffffu) + (b + 1 == ch_off[row + 1] ? 1u : 0u); lcnt[b] = tot >> 16; }
 }
 
-struct ClInst {  // per instance (k_cl_fill)
-  int32_t* o;      // row position of the cluster's first allele (closing instance: CL_FAR)
-  uint32_t* row;
-  int32_t* pa;     // where the clean run in front of the instance starts: end of the previous record's allele, 0 at the row's start
-  int32_t* rb;     // REF shift of that run
-  uint32_t* rec;   // first record of the cluster (index over all rows)
-  uint32_t* n;     // its records | class << 16 - 0: no cluster (closing instance, or cluster wholly outside the scan range), 1: shareable,
-                   // 2: the row's own
-  uint32_t* slot;  // its slot in the table of distinct clusters (CL_NONE: no cluster)
-};
-// The table of distinct clusters: 16-byte slots {hash key (0: free), ~(lowest instance seen), -} - key and representative in ONE
-// 64-byte request to L2 (the looks are bound by the number of such requests, not by bytes; two arrays were two requests per look).
-struct __attribute__((aligned(16))) ClSlot { unsigned long long key; uint32_t nrep; uint32_t pad; };  // nrep = ~instance: 0 = none, atomicMax lowers the instance
-static_assert(sizeof(ClSlot) == 16, "table slot layout");
-size_t hawk_cl_slot_bytes() { return sizeof(ClSlot); }
-
-// Cuts chunks [b_first, ...) of the rows into instances AND enters every instance into the table of distinct clusters (hash of the
-// variant identities -> slot; the slot's lowest instance becomes the cluster's representative).  One kernel for both: cutting streams
-// the records and the instance arrays through HBM, the table looks are gathers into a few MB of L2 - different resources.
+// Cuts chunks [b_first, ...) of the rows into instances.  A one-record shareable instance IS its variant (uid = the variant's index);
+// any other instance with a cluster goes on the list for k_cl_enter / k_cl_uid.  No atomic that anybody waits for:
+// places in the instance arrays and on the list come from the counting pass; the variants the FIRST rows describe set a bit, and
+// the later launch reads those bits through LDS (a chunk's records are consecutive variants-in-a-row, ascending: one window of
+// the bitmap, C3: all 4 KB of it, loaded once per workgroup) and describes what they left.
+#define CL_BM_WORDS 4096  // the window's LDS words (16 KB); a chunk that spans more variants asks the bitmap in HBM directly
 __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs, const uint64_t* __restrict__ hv_off,
                                                  const uint32_t* __restrict__ hap_len, const int32_t* __restrict__ ss_,
                                                  const int32_t* __restrict__ se_, const uint32_t* __restrict__ ch_off,
-                                                 const uint32_t* __restrict__ ch_row, const uint32_t* __restrict__ inst_base, ClInst ci,
-                                                 uint32_t* __restrict__ status, ClSlot* tab, uint32_t mask, uint32_t max_probe, uint32_t fail_bit,
-                                                 uint32_t b_first, uint32_t n_rows) {
+                                                 const uint32_t* __restrict__ ch_row, const uint32_t* __restrict__ inst_base,
+                                                 const uint32_t* __restrict__ list_base, ClInst ci, unsigned long long* __restrict__ var_desc,
+                                                 uint32_t* claim_bits, uint32_t n_var, ClListed* __restrict__ cx_list, uint32_t* __restrict__ status,
+                                                 uint32_t b_first, uint32_t n_rows, uint32_t head) {
   __shared__ uint32_t s_c[256 / WAVE][CL_ROW_U];  // cluster starts per wave and record slice
+  __shared__ uint32_t s_l[256 / WAVE][CL_ROW_U];  // ... and how many of them are listed
+  __shared__ uint32_t s_bm[CL_BM_WORDS];
   const uint32_t b = b_first + blockIdx.x;
   if (b >= ch_off[n_rows]) return;  // (launched over the bound on the chunks; workgroup-uniform)
   const uint32_t row = ch_row[b];
@@ -152,12 +237,16 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
   const uint64_t b0 = lo + (uint64_t)(b - ch_off[row]) * CL_CHUNK;
   const int32_t ss = ss_[row], se = se_[row], hl = (int32_t)hap_len[row];
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  const uint32_t at = inst_base[b];
+  const uint32_t at = inst_base[b], lat = list_base[b];
   uint32_t round_tot = 0;
   if (hi > lo) {
-    // CL_ROW_U slices of 256 consecutive records: every thread's record and the one before it, asked for at once.  The records BEHIND
-    // it - a cluster's second and third - are the records of the lanes above (nine clusters in ten are one record, ninety-nine in a
-    // hundred at most three): no dependent load until a cluster is longer than that or crosses the wave's end.
+    // the chunk's window of the variants' bitmap (the head launch writes the bitmap and reads nothing of it)
+    const uint64_t b1 = b0 + CL_CHUNK < hi ? b0 + CL_CHUNK : hi;
+    const uint32_t v_lo = recs[b0].var, v_hi = recs[b1 - 1].var;
+    const uint32_t w_lo = v_lo >> 5, n_w = v_hi >= v_lo && v_hi < n_var ? (v_hi >> 5) - w_lo + 1u : 0u;
+    const bool bm_lds = !head && n_w != 0u && n_w <= CL_BM_WORDS;  // workgroup-uniform
+    if (bm_lds) for (uint32_t w = threadIdx.x; w < n_w; w += 256) s_bm[w] = claim_bits[w_lo + w];
+    // CL_ROW_U slices of 256 consecutive records: every thread's record and the one before it, asked for at once
     uint4 r0[CL_ROW_U], rp[CL_ROW_U];
     bool st[CL_ROW_U];
     unsigned long long bal[CL_ROW_U];
@@ -165,7 +254,7 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
     for (int u = 0; u < CL_ROW_U; ++u) {
       const uint64_t j = b0 + u * 256 + threadIdx.x;
       const uint64_t jc = j < hi ? j : hi - 1;
-      r0[u] = *reinterpret_cast<const uint4*>(recs + jc);                        // {o, rs, alt_len, alt_off}
+      r0[u] = *reinterpret_cast<const uint4*>(recs + jc);                        // {o, rs, alt_len, variant}
       rp[u] = *reinterpret_cast<const uint4*>(recs + (jc > lo ? jc - 1 : jc));
     }
 #pragma unroll
@@ -175,7 +264,7 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
       bal[u] = __ballot(st[u]);
       if (lane == 0) s_c[wv][u] = (uint32_t)__popcll(bal[u]);
     }
-    __syncthreads();
+    __syncthreads();  // (also publishes the bitmap window)
     uint32_t pre[CL_ROW_U];  // starts of the slices / waves in front of this wave's part of slice u (slice-major = record order)
 #pragma unroll
     for (int u = 0; u < CL_ROW_U; ++u) {
@@ -187,193 +276,241 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
         round_tot += x;
       }
     }
-    unsigned long long key[CL_ROW_U];
-    uint32_t idx[CL_ROW_U];
-    bool on[CL_ROW_U];
+    uint4 ea[CL_ROW_U], eb[CL_ROW_U];  // the list entries of this thread's starts, if they are listed
+    bool listed[CL_ROW_U];
+    unsigned long long lbal[CL_ROW_U];
     auto cut = [&](const int u) __attribute__((always_inline)) {  // (called once per slice with a constant: the slices' registers stay registers)
-      // the records of lanes + 1, + 2 (every lane takes part in the exchange)
-      const uint4 nx1 = make_uint4((uint32_t)__shfl_down((int)r0[u].x, 1), (uint32_t)__shfl_down((int)r0[u].y, 1),
-                                   (uint32_t)__shfl_down((int)r0[u].z, 1), (uint32_t)__shfl_down((int)r0[u].w, 1));
-      const uint4 nx2 = make_uint4((uint32_t)__shfl_down((int)r0[u].x, 2), (uint32_t)__shfl_down((int)r0[u].y, 2),
-                                   (uint32_t)__shfl_down((int)r0[u].z, 2), (uint32_t)__shfl_down((int)r0[u].w, 2));
-      on[u] = false; key[u] = 0; idx[u] = 0;
-      if (!st[u]) return;
-      const uint64_t j = b0 + u * 256 + threadIdx.x;
-      const uint32_t i = at + pre[u] + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
-      // A cluster's identity is WHERE in REF its first allele starts and, record by record, where the allele lies relative to
-      // that, where REF resumes behind it, and which alt bases it puts there (length + offset into alt_codes) - not the offset
-      // alone: the ABI lets a caller pool alt alleles (one shared "A" for every x>A SNV), and the same offset at two loci is not
-      // the same variant.
-      const int32_t o_first = (int32_t)r0[u].x;
-      int32_t pa = 0, rb = 0;
-      if (j > lo) { pa = (int32_t)rp[u].x + (int32_t)rp[u].z; rb = (int32_t)rp[u].y - pa; }
-      uint64_t e = j + 1, h = cl_mix(0x243F6A8885A308D3ull, (uint64_t)(uint32_t)(o_first + rb));
-      h = cl_mix(h, (uint64_t)r0[u].w | ((uint64_t)r0[u].z << 32));
-      h = cl_mix(h, (uint64_t)r0[u].y);
-      uint32_t n = 1;
-      int32_t o_end = (int32_t)r0[u].x + (int32_t)r0[u].z;  // end of the cluster's last allele so far
-      bool open = e < hi;                                    // the record at e may still belong to the cluster
-      while (open) {
-        const uint32_t ahead = (uint32_t)(e - j);
-        uint4 r;
-        if (ahead == 1 && lane + 1 < WAVE) r = nx1;
-        else if (ahead == 2 && lane + 2 < WAVE) r = nx2;
-        else r = *reinterpret_cast<const uint4*>(recs + e);
-        if ((int32_t)r.x - o_end > CL_LINK) break;           // it starts the next cluster
-        if (n >= CL_MAXWALK) { atomicOr(status, 1u); break; }  // a chain too long for this path
-        h = cl_mix(h, (uint64_t)r.w | ((uint64_t)r.z << 32));
-        h = cl_mix(h, (uint64_t)r.y | ((uint64_t)(uint32_t)((int32_t)r.x - o_first) << 32));
-        o_end = (int32_t)r.x + (int32_t)r.z;
-        ++n; ++e;
-        open = e < hi;
+      const uint4 nx1 = shfl_down4(r0[u], 1), nx2 = shfl_down4(r0[u], 2);  // (every lane takes part in the exchange)
+      listed[u] = false;
+      ea[u] = make_uint4(0u, 0u, 0u, 0u); eb[u] = ea[u];
+      if (st[u]) {
+        const uint64_t j = b0 + u * 256 + threadIdx.x;
+        const uint32_t i = at + pre[u] + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
+        const ClCut k = cl_cut(recs, lo, hi, j, r0[u], rp[u], nx1, nx2, lane, ss, se, hl, row);
+        if (k.too_long) atomicOr(status, 1u);
+        ci.o[i] = k.o_first; ci.row[i] = row; ci.pa[i] = k.pa | (k.run_inside ? (int32_t)0x80000000 : 0); ci.rb[i] = k.rb;
+        const uint32_t v = r0[u].w;
+        const bool simple = k.n == 1 && k.cls == 1 && v < n_var;  // the cluster is its variant
+        if (!k.cls) ci.uid[i] = CL_NONE;
+        if (simple) {
+          ci.uid[i] = v;
+          const uint32_t bit = 1u << (v & 31u);
+          const unsigned long long desc = (unsigned long long)(uint32_t)j | ((unsigned long long)row << 32);  // (row >= 1: never 0)
+          if (head) {  // the first rows describe what they carry and say so
+            var_desc[v] = desc;
+            (void)__hip_atomic_fetch_or(&claim_bits[v >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if (!((bm_lds ? s_bm[(v >> 5) - w_lo] : claim_bits[v >> 5]) & bit)) {
+            var_desc[v] = desc;  // whichever of these lands last is whole: one aligned 64-bit store
+          }
+        }
+        listed[u] = k.cls != 0 && !simple;
+        ea[u] = make_uint4(i, (uint32_t)k.key, (uint32_t)(k.key >> 32), (uint32_t)j);
+        eb[u] = make_uint4(k.n | (k.cls << 16), (uint32_t)(k.o_first + k.rb), row, (uint32_t)k.o_first);
       }
-      // window starts the cluster can touch: [o_first - (L - 1), o_end), L <= 44; the ranges they are tested against
-      // (search_guides.py:49-84, 395-420) are [ss - po, se - po) and [PAD, len - L - PAD], po in {0, guidelen}
-      const bool outside = o_end <= ss - 44 || o_first - 43 >= se;
-      const bool interior = o_first - 43 >= (ss > HAWK_PAD ? ss : HAWK_PAD) && o_first >= 64 && o_end <= se - 44 &&
-                            o_end <= hl - 44 - HAWK_PAD + 1 && o_end + 128 <= hl;
-      uint64_t k = h;
-      uint32_t cls = 1;
-      if (outside) { cls = 0; k = 0; }
-      else if (!interior) { cls = 2; k = cl_mix(h ^ 0xA4093822299F31D0ull, (uint64_t)row + 1u); }
-      if (cls && k == 0) k = 1;
-      // the clean run in front, [pa, o_first - (L - 1)), lies inside every range of both strands for every geometry: its count
-      // then needs neither the row nor its bounds (bit 31 of pa)
-      const bool run_inside = pa >= (ss > HAWK_PAD ? ss : HAWK_PAD) && o_first <= se - 44 && o_first <= hl - 44 - HAWK_PAD + 1;
-      ci.o[i] = o_first; ci.row[i] = row; ci.pa[i] = pa | (run_inside ? (int32_t)0x80000000 : 0); ci.rb[i] = rb;
-      ci.rec[i] = (uint32_t)j; ci.n[i] = n | (cls << 16);
-      if (!cls) ci.slot[i] = CL_NONE;
-      on[u] = cls != 0; key[u] = k; idx[u] = i;
+      lbal[u] = __ballot(listed[u]);
+      if (lane == 0) s_l[wv][u] = (uint32_t)__popcll(lbal[u]);
     };
     static_assert(CL_ROW_U == 4, "one call per slice");
     cut(0); cut(1); cut(2); cut(3);
-    // ... and into the table: the round's looks in flight together.  The looks are ordinary cached loads: a stale answer only sends
-    // the instance on to the atomic, which tells the truth.
-    uint4 look[CL_ROW_U];
-    uint32_t sl0[CL_ROW_U];
+    __syncthreads();
+    uint32_t lpre = lat;  // places on the list: slice-major, like the instances
 #pragma unroll
     for (int u = 0; u < CL_ROW_U; ++u) {
-      sl0[u] = (uint32_t)(key[u] >> 17) & mask;
-      look[u] = *reinterpret_cast<const uint4*>(tab + sl0[u]);
-    }
-    auto enter = [&](const int u) __attribute__((always_inline)) {
-      if (!on[u]) return;
-      const uint32_t i = idx[u];
-      unsigned long long c = (unsigned long long)look[u].x | ((unsigned long long)look[u].y << 32);
-      uint32_t nrep = look[u].z, sl = sl0[u];
-      bool placed = false;
-      // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
-      // for the distinct clusters expected gives up after max_probe slots and the host repeats the pass with the full size)
-      for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
-        // a plain look first: a common cluster's slot holds its key long before most of its thousands of instances arrive, and an
-        // atomic on it would queue them all at one address
-        if (probe) { const uint4 e2 = *reinterpret_cast<const uint4*>(tab + sl); c = (unsigned long long)e2.x | ((unsigned long long)e2.y << 32); nrep = e2.z; }
-        if (c == 0ull) { c = atomicCAS(&tab[sl].key, 0ull, key[u]); nrep = 0u; }  // (a slot never changes hands once taken: any other value seen is final)
-        if (c == 0ull || c == key[u]) { placed = true; break; }
-        sl = (sl + 1u) & mask;
+      uint32_t mine = lpre;
+#pragma unroll
+      for (int w = 0; w < 256 / WAVE; ++w) {
+        const uint32_t x = s_l[w][u];
+        if (w < (int)wv) mine += x;
+        lpre += x;
       }
-      if (!placed) { ci.slot[i] = CL_NONE; atomicOr(status, fail_bit); return; }  // full-size table: cannot happen; the dictionary is then not used
-      ci.slot[i] = sl;
-      if (nrep < ~i) atomicMax(&tab[sl].nrep, ~i);  // (the lowest instance only falls: a stale look only costs the atomic)
-    };
-    enter(0); enter(1); enter(2); enter(3);
+      if (listed[u]) {
+        uint4* dst = reinterpret_cast<uint4*>(cx_list + mine + (uint32_t)__popcll(lbal[u] & ((1ull << lane) - 1ull)));
+        dst[0] = ea[u]; dst[1] = eb[u];
+      }
+    }
   }
   if (threadIdx.x == 0 && b + 1 == ch_off[row + 1]) {  // the row's last chunk: the closing instance
     const uint32_t i = at + round_tot;
     int32_t pa = 0, rb = 0;
     if (hi > lo) { pa = recs[hi - 1].o + (int32_t)recs[hi - 1].alt_len; rb = (int32_t)recs[hi - 1].rs - pa; }
-    ci.o[i] = CL_FAR; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb; ci.rec[i] = 0; ci.n[i] = 0; ci.slot[i] = CL_NONE;
+    ci.o[i] = CL_FAR; ci.row[i] = row; ci.pa[i] = pa; ci.rb[i] = rb; ci.uid[i] = CL_NONE;
   }
 }
 
-// The representatives - the lowest instance of every distinct cluster - as a bitmap over the instances, set from the TABLE's side:
-// one thread per slot (a few 10^5) instead of one per instance (10^7), then a count per 32-instance word for the scan that numbers them
-__global__ __launch_bounds__(256) void k_cl_mark(uint32_t tsize, const ClSlot* __restrict__ tab, uint32_t* __restrict__ bits) {
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= tsize) return;
-  const uint4 e = *reinterpret_cast<const uint4*>(tab + s);
-  if ((e.x | e.y) == 0u || e.z == 0u) return;
-  const uint32_t i = ~e.z;
-  atomicOr(&bits[i >> 5], 1u << (i & 31u));
-}
-__global__ __launch_bounds__(256) void k_cl_popc(uint32_t n_words, const uint32_t* __restrict__ bits, uint32_t* __restrict__ cnt) {
-  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
-  if (w < n_words) cnt[w] = (uint32_t)__popc(bits[w]);
-}
-struct ClUniq {  // per distinct cluster
-  uint32_t* rec; uint32_t* n; uint32_t* row; int32_t* o; uint32_t* seg; uint32_t* span2;
-};
-// the representatives number the clusters in instance order: rank of the instance's bit = clusters in the words before + in its word
-__global__ __launch_bounds__(256) void k_cl_assign(uint32_t tsize, const ClSlot* __restrict__ tab, const uint32_t* __restrict__ bits,
-                                                   const uint64_t* __restrict__ word_rank, ClInst ci, const HxHead* __restrict__ recs,
-                                                   const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
-                                                   uint4* __restrict__ slot_desc, ClUniq cu) {
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= tsize) return;
-  const uint4 e = *reinterpret_cast<const uint4*>(tab + s);
-  if ((e.x | e.y) == 0u || e.z == 0u) return;
-  const uint32_t i = ~e.z;
-  const uint32_t u = (uint32_t)word_rank[i >> 5] + (uint32_t)__popc(bits[i >> 5] & ((1u << (i & 31u)) - 1u));
-  const uint32_t r = ci.rec[i], ncls = ci.n[i], n = ncls & 0xffffu;
-  // what every other instance of the cluster needs to know about its representative, as ONE 32-byte record per table slot - one
-  // request to L2: {cluster number, first record, records | class << 16, REF position of the first allele} {the first record's
-  // rs, alt_len, alt_off, -} (nine clusters in ten are that one record: k_cl_uid then never touches the representative's records)
-  const uint4 r0 = *reinterpret_cast<const uint4*>(recs + r);
-  slot_desc[2 * (size_t)s] = make_uint4(u, r, ncls, (uint32_t)(ci.o[i] + ci.rb[i]));
-  slot_desc[2 * (size_t)s + 1] = make_uint4(r0.y, r0.z, r0.w, 0u);
-  const int32_t o_first = (int32_t)r0.x, o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
-  const uint32_t row = ci.row[i];
-  cu.rec[u] = r; cu.n[u] = n; cu.row[u] = row; cu.o[u] = o_first;
-  cu.span2[u] = 2u * ((uint32_t)(o_end - o_first) + CL_LINK);  // rows the cluster can have: window starts [o_first - L + 1, o_end) x 2 strands
-  // the position-map segment in force CL_LINK + PAD positions in front of the cluster: every position a search asks for lies behind it
-  const uint32_t rel = o_first > CL_LINK + HAWK_PAD ? (uint32_t)(o_first - CL_LINK - HAWK_PAD) : 0u;
-  uint32_t lo = seg_off[row], hi = seg_off[row + 1];
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (seg_rel[mid] <= rel) lo = mid; else hi = mid;
-  }
-  cu.seg[u] = lo;
-}
-// CL_UID_U instances per thread, their loads issued level by level (instance arrays -> representative's descriptor -> both
-// sides' first records): the pass is three dependent round trips per instance and little else
+// The listed instances into the table, CL_UID_U per thread (their looks in flight together; an ordinary cached load first: a stale
+// answer only sends the instance on to the atomic, which tells the truth).  The instance that takes a free slot opens a new distinct
+// cluster: it draws the next number behind the variants (one atomic per WORKGROUP), describes the cluster and fills in the slot; one
+// that finds its key there notes CL_PENDING | slot for k_cl_uid.
 #define CL_UID_U 4
-__global__ __launch_bounds__(256) void k_cl_uid(const uint32_t* __restrict__ n_inst_dev, const uint4* __restrict__ slot_desc, ClInst ci,
-                                                const HxHead* __restrict__ recs, uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ status) {
-  const uint32_t n_inst = *n_inst_dev;  // (launched over the bound on the instances)
-  if (blockIdx.x * (256 * CL_UID_U) >= n_inst) return;
-  const uint32_t i0 = blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
-  uint32_t s[CL_UID_U], rec[CL_UID_U], ncls[CL_UID_U], refp[CL_UID_U];
-  bool in[CL_UID_U], ok[CL_UID_U];
+__global__ __launch_bounds__(256) void k_cl_enter(const ClListed* __restrict__ cx_list, const uint32_t* __restrict__ n_list_dev, uint32_t t_first,
+                                                  uint32_t t_end, ClSlot* tab, uint32_t mask, uint32_t max_probe, uint32_t fail_bit,
+                                                  uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ cx_state, ClUniq cu,
+                                                  const HxHead* __restrict__ recs, uint32_t* n_table, uint32_t n_var, uint32_t u_cap,
+                                                  uint32_t* __restrict__ status) {
+  __shared__ uint32_t s_n[256 / WAVE][CL_UID_U];
+  __shared__ uint32_t s_base;
+  const uint32_t n_list = *n_list_dev < t_end ? *n_list_dev : t_end;  // (launched over the bound on the list)
+  const uint32_t t0 = t_first + blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
+  if (t_first + blockIdx.x * (256 * CL_UID_U) >= n_list) return;  // workgroup-uniform
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  uint4 ent[CL_UID_U], lk[CL_UID_U];
+  uint32_t sl[CL_UID_U];
+  bool on[CL_UID_U], won[CL_UID_U];
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
-    const uint32_t i = i0 + u * 256;
-    in[u] = i < n_inst;
-    const uint32_t ic = in[u] ? i : 0u;
-    s[u] = ci.slot[ic]; rec[u] = ci.rec[ic]; ncls[u] = ci.n[ic];
-    refp[u] = (uint32_t)(ci.o[ic] + ci.rb[ic]);
+    const uint32_t t = t0 + u * 256;
+    on[u] = t < n_list;
+    ent[u] = *reinterpret_cast<const uint4*>(cx_list + (on[u] ? t : t_first));  // {instance, key, first record}
   }
-  uint4 d[CL_UID_U], d1[CL_UID_U], ra[CL_UID_U];
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
-    ok[u] = in[u] && (ncls[u] >> 16) && s[u] != CL_NONE;  // (no slot: the table filled up and the pass flagged the dictionary)
-    const size_t sd = ok[u] ? 2 * (size_t)s[u] : 0;
-    d[u] = slot_desc[sd]; d1[u] = slot_desc[sd + 1];
-    ra[u] = *reinterpret_cast<const uint4*>(recs + (ok[u] ? rec[u] : 0u));  // {o, rs, alt_len, alt_off}
-    if (!ok[u]) d[u] = make_uint4(CL_NONE, 0u, 0u, 0u);
+    const unsigned long long k = (unsigned long long)ent[u].y | ((unsigned long long)ent[u].z << 32);
+    sl[u] = (uint32_t)(k >> 17) & mask;
+    lk[u] = *reinterpret_cast<const uint4*>(tab + sl[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    won[u] = false;
+    if (!on[u]) continue;
+    const unsigned long long k = (unsigned long long)ent[u].y | ((unsigned long long)ent[u].z << 32);
+    uint4 e0 = lk[u];
+    uint32_t s = sl[u];
+    bool placed = false;
+    // (the full-size table has >= 2 slots per instance: a free slot is met long before the bound; a first attempt with a table sized
+    // for the distinct clusters expected gives up after max_probe slots and the host repeats the passes with the full size)
+    for (uint32_t probe = 0; probe <= mask && probe < max_probe; ++probe) {
+      if (probe) e0 = *reinterpret_cast<const uint4*>(tab + s);
+      unsigned long long c = (unsigned long long)e0.x | ((unsigned long long)e0.y << 32);
+      if (c == 0ull) {  // (a slot never changes hands once taken: any other value seen is final)
+        c = atomicCAS(&tab[s].key, 0ull, k);
+        won[u] = c == 0ull;
+      }
+      if (c == 0ull || c == k) { placed = true; break; }
+      s = (s + 1u) & mask;
+    }
+    sl[u] = s;
+    const uint32_t t = t0 + u * 256;
+    if (!placed) { won[u] = false; cx_state[t] = CL_NONE; inst_uid[ent[u].x] = CL_NONE; atomicOr(status, fail_bit); continue; }  // full-size table: cannot happen
+    cx_state[t] = won[u] ? CL_NONE : (CL_PENDING | s);
+  }
+  // the new distinct clusters of this workgroup draw their numbers with one atomic
+  unsigned long long wb[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) { wb[u] = __ballot(won[u]); if (lane == 0) s_n[wv][u] = (uint32_t)__popcll(wb[u]); }
+  __syncthreads();
+  uint32_t tot = 0, mine[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    mine[u] = tot;
+#pragma unroll
+    for (int w = 0; w < 256 / WAVE; ++w) { const uint32_t x = s_n[w][u]; if (w < (int)wv) mine[u] += x; tot += x; }
+  }
+  if (!tot) return;  // workgroup-uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(n_table, tot);
+  __syncthreads();
+  const uint32_t base = n_var + s_base;
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    if (!won[u]) continue;
+    const uint32_t un = base + mine[u] + (uint32_t)__popcll(wb[u] & ((1ull << lane) - 1ull));
+    const uint32_t i = ent[u].x;
+    if (un >= u_cap) { inst_uid[i] = CL_NONE; atomicOr(status, fail_bit); continue; }  // (more distinct clusters than slots: cannot happen)
+    const uint4 e1 = reinterpret_cast<const uint4*>(cx_list + (t0 + u * 256))[1];  // {records | class, REF position, row, row position}
+    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + ent[u].w);
+    ClSlot* e = tab + sl[u];
+    *reinterpret_cast<uint4*>(e->id) = make_uint4(e1.y, r0.y, r0.z, r0.w);
+    *reinterpret_cast<uint2*>(&e->up1) = make_uint2(un + 1u, e1.x);
+    inst_uid[i] = un;
+    cu.rec[un] = ent[u].w; cu.n[un] = e1.x & 0xffffu; cu.row[un] = e1.z; cu.o[un] = (int32_t)e1.w;
+  }
+}
+
+// what a search needs of every distinct cluster: for a variant's cluster the description unpacked from the one word its describer
+// left (a variant that is nowhere a cluster of its own stays a hole: u_n = 0); for all of them the template rows they can have and
+// the position-map segment their searches start from
+__global__ __launch_bounds__(256) void k_cl_describe(const uint32_t* __restrict__ n_table_dev, uint32_t n_var, uint32_t u_cap,
+                                                     const unsigned long long* __restrict__ var_desc, ClUniq cu, const HxHead* __restrict__ recs,
+                                                     const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
+                                                     uint32_t* __restrict__ n_variant_clusters) {
+  const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t nu = n_var + *n_table_dev < u_cap ? n_var + *n_table_dev : u_cap;  // (launched over the bound on the distinct clusters)
+  bool variant_cluster = false;
+  if (u < nu) {
+    uint32_t n, r, row;
+    int32_t o_first;
+    if (u < n_var) {
+      const unsigned long long d = var_desc[u];
+      variant_cluster = d != 0ull;
+      r = (uint32_t)d; row = (uint32_t)(d >> 32); n = variant_cluster ? 1u : 0u;
+      o_first = variant_cluster ? recs[r].o : 0;
+      cu.rec[u] = r; cu.n[u] = n; cu.row[u] = row; cu.o[u] = o_first;
+    } else {
+      n = cu.n[u]; r = cu.rec[u]; row = cu.row[u]; o_first = cu.o[u];
+    }
+    if (n == 0) { cu.span2[u] = 0; cu.seg[u] = 0; }
+    else {
+      const int32_t o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
+      cu.span2[u] = 2u * ((uint32_t)(o_end - o_first) + CL_LINK);  // rows the cluster can have: window starts [o_first - L + 1, o_end) x 2 strands
+      // the position-map segment in force CL_LINK + PAD positions in front of the cluster: every position a search asks for lies behind it
+      const uint32_t rel = o_first > CL_LINK + HAWK_PAD ? (uint32_t)(o_first - CL_LINK - HAWK_PAD) : 0u;
+      uint32_t lo = seg_off[row], hi = seg_off[row + 1];
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (seg_rel[mid] <= rel) lo = mid; else hi = mid;
+      }
+      cu.seg[u] = lo;
+    }
+  }
+  const unsigned long long vb = __ballot(variant_cluster);  // (statistics: how many variants are clusters of their own)
+  if ((threadIdx.x & (WAVE - 1)) == 0 && vb) atomicAdd(n_variant_clusters, (uint32_t)__popcll(vb));
+}
+// The listed instances that found their hash in the table: number from the slot, identity compared record by record with the instance
+// that opened the cluster (exactness: same hash is not same cluster until then).  Loads level by level.
+__global__ __launch_bounds__(256) void k_cl_uid(const ClListed* __restrict__ cx_list, const uint32_t* __restrict__ n_list_dev, uint32_t t_end,
+                                                const uint32_t* __restrict__ cx_state, const ClSlot* __restrict__ tab, uint32_t* __restrict__ inst_uid,
+                                                ClUniq cu, const HxHead* __restrict__ recs, uint32_t* __restrict__ status) {
+  const uint32_t n_list = *n_list_dev < t_end ? *n_list_dev : t_end;  // (launched over the bound on the list)
+  if (blockIdx.x * (256 * CL_UID_U) >= n_list) return;
+  const uint32_t t0 = blockIdx.x * (256 * CL_UID_U) + threadIdx.x;
+  uint32_t v[CL_UID_U];
+  bool pend[CL_UID_U];
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    const uint32_t t = t0 + u * 256;
+    v[u] = t < n_list ? cx_state[t] : CL_NONE;
+    pend[u] = v[u] != CL_NONE && (v[u] & CL_PENDING);
+    any = any || pend[u];
+  }
+  if (!__any(any)) return;
+  uint4 e0[CL_UID_U], e1[CL_UID_U], la[CL_UID_U], lb[CL_UID_U], ra[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    const uint4* e = reinterpret_cast<const uint4*>(tab + (pend[u] ? (v[u] & ~CL_PENDING) : 0u));
+    e0[u] = e[0]; e1[u] = e[1];
+    const uint4* l = reinterpret_cast<const uint4*>(cx_list + (pend[u] ? t0 + u * 256 : 0u));
+    la[u] = l[0]; lb[u] = l[1];  // {instance, key, first record} {records | class, REF position, row, row position}
+  }
+  uint32_t rrec[CL_UID_U];
+#pragma unroll
+  for (int u = 0; u < CL_UID_U; ++u) {
+    ra[u] = *reinterpret_cast<const uint4*>(recs + (pend[u] ? la[u].w : 0u));  // {o, rs, alt_len, variant}
+    rrec[u] = (pend[u] && e0[u].z != 0u && (lb[u].x & 0xffffu) > 1u) ? cu.rec[e0[u].z - 1u] : 0u;
   }
   bool bad = false;
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
-    if (in[u]) inst_uid[i0 + u * 256] = d[u].x;
-    if (!ok[u] || d[u].y == rec[u]) continue;  // no cluster / the representative itself
-    // exactness: same hash is not same cluster until the variant identities have been compared - both shareable, as many records,
-    // the same REF position of the first allele, then record by record
-    bool b = ncls[u] != d[u].z || (ncls[u] >> 16) != 1 || refp[u] != d[u].w;
-    b = b || ra[u].y != d1[u].x || ra[u].z != d1[u].y || ra[u].w != d1[u].z;
-    const uint32_t n = ncls[u] & 0xffffu;
+    if (!pend[u]) continue;
+    const uint32_t i = la[u].x, ncls = lb[u].x;
+    if (e0[u].z == 0u) { inst_uid[i] = CL_NONE; bad = true; continue; }  // (a taken slot without a number: cannot happen)
+    inst_uid[i] = e0[u].z - 1u;
+    // both shareable, as many records, the same REF position of the first allele, then record by record
+    bool b = ncls != e0[u].w || (ncls >> 16) != 1 || lb[u].y != e1[u].x;
+    b = b || ra[u].y != e1[u].y || ra[u].z != e1[u].z || ra[u].w != e1[u].w;
+    const uint32_t n = ncls & 0xffffu;
     if (!b && n > 1) {
-      const HxHead* pa = recs + rec[u];
-      const HxHead* pb = recs + d[u].y;
+      const HxHead* pa = recs + la[u].w;
+      const HxHead* pb = recs + rrec[u];
       const int32_t oa = (int32_t)ra[u].x, ob = pb[0].o;
       for (uint32_t k = 1; k < n; ++k) {
         const uint4 xa = *reinterpret_cast<const uint4*>(pa + k), xb = *reinterpret_cast<const uint4*>(pb + k);
@@ -391,44 +528,55 @@ void hawk_launch_cl_chunks(hipStream_t st, const uint64_t* hv_off, const uint8_t
                            uint32_t* ch_off, uint32_t* ch_row) {
   hipLaunchKernelGGL(k_cl_chunks, dim3(1), dim3(1024), 0, st, hv_off, is_ref, ss, se, n_rows, ch_off, ch_row);
 }
-void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_rows,
-                          uint32_t ch_bound, uint32_t* cnt /* zeroed */) {
-  if (ch_bound) hipLaunchKernelGGL(k_cl_count, dim3(ch_bound), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, ch_off, ch_row, n_rows, cnt);
+void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
+                          const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_rows, uint32_t n_var, uint32_t ch_bound, uint32_t* cnt /* zeroed */,
+                          uint32_t* lcnt /* zeroed */) {
+  if (ch_bound)
+    hipLaunchKernelGGL(k_cl_count, dim3(ch_bound), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row, n_rows,
+                       n_var, cnt, lcnt);
 }
-// Two launches: the first chunks (a few dozen rows), then the rest.  A common cluster - a frequent SNV without a neighbour - has
-// thousands of instances, half of which are in flight at once in a single launch: they all find its slot empty, all try the CAS,
-// then all lower the representative - thousands of device-scope atomics queued at one address (60-90 us, whatever the panel's
-// size).  After the head launch every common cluster's key and its lowest instance are in the table, so the rest only look.
-// Both launches run over the BOUND on the chunks (their number is on the device only; surplus workgroups leave at once).
+// Two launches: the first chunks (a few dozen rows), then the rest - and likewise the head of the list, then the rest.  A common
+// cluster has thousands of instances, half of which are in flight at once in a single launch: in the table passes they all find
+// their slot empty and all go to the atomic - thousands of device-scope atomics queued at one address (60-90 us, whatever the
+// panel's size); in the cutting pass they would all describe the cluster.  After the head launch every common cluster is there.
+// The launches run over BOUNDS (the numbers of chunks and of listed instances are on the device only; surplus workgroups leave at once).
 #define CL_HEAD_CHUNKS 96
+#define CL_HEAD_LISTED 16384
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
-                         uint32_t n_rows, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t ch_bound, const uint32_t* inst_base, int32_t* o,
-                         uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot, uint32_t* status, void* tab, uint32_t mask,
-                         uint32_t max_probe, uint32_t fail_bit) {
-  ClInst ci{o, row, pa, rb, rec, n, slot};
+                         uint32_t n_rows, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t ch_bound, const uint32_t* inst_base,
+                         const uint32_t* list_base, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* inst_uid, void* var_desc,
+                         uint32_t* claim_bits, uint32_t n_var, void* cx_list, uint32_t* status) {
+  ClInst ci{o, row, pa, rb, inst_uid};
   const uint32_t n_head = ch_bound < CL_HEAD_CHUNKS ? ch_bound : CL_HEAD_CHUNKS;
   if (n_head)
-    hipLaunchKernelGGL(k_cl_fill, dim3(n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row, inst_base, ci,
-                       status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, 0u, n_rows);
+    hipLaunchKernelGGL(k_cl_fill, dim3(n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row, inst_base,
+                       list_base, ci, static_cast<unsigned long long*>(var_desc), claim_bits, n_var, static_cast<ClListed*>(cx_list), status, 0u, n_rows, 1u);
   if (ch_bound > n_head)
     hipLaunchKernelGGL(k_cl_fill, dim3(ch_bound - n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row,
-                       inst_base, ci, status, static_cast<ClSlot*>(tab), mask, max_probe, fail_bit, n_head, n_rows);
+                       inst_base, list_base, ci, static_cast<unsigned long long*>(var_desc), claim_bits, n_var, static_cast<ClListed*>(cx_list), status,
+                       n_head, n_rows, 0u);
 }
-void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits, uint32_t n_words, uint32_t* cnt) {
-  hipLaunchKernelGGL(k_cl_mark, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits);
-  hipLaunchKernelGGL(k_cl_popc, dim3((n_words + 255) / 256), dim3(256), 0, st, n_words, bits, cnt);
-}
-void hawk_launch_cl_assign(hipStream_t st, uint32_t inst_bound, const uint32_t* n_inst_dev, uint32_t tsize, const void* tab, const uint32_t* bits,
-                           const uint64_t* word_rank,
-                           const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot,
-                           const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row,
-                           int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status) {
-  ClInst ci{o, row, pa, rb, rec, n, slot};
+// after the cutting pass: the listed instances through the table, the distinct clusters' descriptions, then the listed instances
+// that share a cluster.  counters: [0] the table's distinct clusters, [1] the variants that are clusters of their own (zeroed).
+void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* n_list_dev, uint32_t* counters, uint32_t n_var, uint32_t u_cap, void* tab,
+                           uint32_t mask, uint32_t max_probe, uint32_t fail_bit, const void* cx_list, uint32_t* cx_state, const void* var_desc,
+                           const void* recs, uint32_t* inst_uid, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* u_rec, uint32_t* u_n,
+                           uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* status) {
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
-  hipLaunchKernelGGL(k_cl_assign, dim3((tsize + 255) / 256), dim3(256), 0, st, tsize, static_cast<const ClSlot*>(tab), bits, word_rank, ci,
-                     static_cast<const HxHead*>(recs), seg_off, seg_rel, static_cast<uint4*>(slot_desc), cu);
-  hipLaunchKernelGGL(k_cl_uid, dim3((inst_bound + 256 * CL_UID_U - 1) / (256 * CL_UID_U)), dim3(256), 0, st, n_inst_dev, static_cast<const uint4*>(slot_desc), ci,
-                     static_cast<const HxHead*>(recs), inst_uid, status);
+  const uint32_t per = 256 * CL_UID_U;
+  const uint32_t head = list_bound < CL_HEAD_LISTED ? list_bound : CL_HEAD_LISTED;
+  const ClListed* list = static_cast<const ClListed*>(cx_list);
+  if (head)
+    hipLaunchKernelGGL(k_cl_enter, dim3((head + per - 1) / per), dim3(256), 0, st, list, n_list_dev, 0u, head, static_cast<ClSlot*>(tab), mask, max_probe,
+                       fail_bit, inst_uid, cx_state, cu, static_cast<const HxHead*>(recs), counters, n_var, u_cap, status);
+  if (list_bound > head)
+    hipLaunchKernelGGL(k_cl_enter, dim3((list_bound - head + per - 1) / per), dim3(256), 0, st, list, n_list_dev, head, list_bound, static_cast<ClSlot*>(tab),
+                       mask, max_probe, fail_bit, inst_uid, cx_state, cu, static_cast<const HxHead*>(recs), counters, n_var, u_cap, status);
+  hipLaunchKernelGGL(k_cl_describe, dim3((u_cap + 255) / 256), dim3(256), 0, st, counters, n_var, u_cap, static_cast<const unsigned long long*>(var_desc), cu,
+                     static_cast<const HxHead*>(recs), seg_off, seg_rel, counters + 1);
+  if (list_bound)
+    hipLaunchKernelGGL(k_cl_uid, dim3((list_bound + per - 1) / per), dim3(256), 0, st, list, n_list_dev, list_bound, cx_state, static_cast<const ClSlot*>(tab),
+                       inst_uid, cu, static_cast<const HxHead*>(recs), status);
 }
 
 // ---- per search ------------------------------------------------------------------------------------
@@ -476,19 +624,22 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   if (gp.score_cfdon) for (uint32_t i = tid; i < 336; i += 256) s_cfd[i] = gp.cfd_mm[i];
   __syncthreads();
   const uint32_t gl = tid & (CS_G - 1);
-  uint32_t u = (blockIdx.x * 256 + tid) / CS_G;
-  const bool live = u < cd.n_uniq;
-  if (!live) u = cd.n_uniq - 1;  // lanes of a surplus group redo the last cluster and write nothing
+  const uint32_t u = (blockIdx.x * 256 + tid) / CS_G;
+  // the numbers of the distinct clusters have holes (a variant that is nowhere a cluster of its own: u_n = 0); their groups and the
+  // surplus groups of the last workgroup go through the motions on record 0 of row 0 with no window start, and write nothing
+  const uint32_t nc_u = u < cd.n_uniq ? cd.u_n[u] : 0u;
+  const bool live = nc_u != 0u;
+  const bool hole = u < cd.n_uniq && !live;
   const HxVar* __restrict__ recs = static_cast<const HxVar*>(va.recs_);
-  const uint32_t h = cd.u_row[u], r0 = cd.u_rec[u], nc = cd.u_n[u];
-  const uint32_t seg0 = cd.u_seg[u], seg_end = hs.seg_off[h + 1];
+  const uint32_t h = live ? cd.u_row[u] : 0u, r0 = live ? cd.u_rec[u] : 0u, nc = live ? nc_u : 1u;
+  const uint32_t seg0 = live ? cd.u_seg[u] : hs.seg_off[0], seg_end = hs.seg_off[h + 1];
   const uint32_t back = (uint64_t)r0 > va.hv_off[h] ? 1u : 0u;  // the record in front of the cluster sets the REF shift it starts from
   const HxVar* __restrict__ sv = recs + r0 - back;
   const int nrec = (int)(nc + back);
   const int L = p.L;
   const int32_t haplen = (int32_t)hs.hap_len[h];
-  const int32_t o_first = cd.u_o[u];
-  const int32_t o_end = recs[r0 + nc - 1].o + (int32_t)recs[r0 + nc - 1].alt_len;
+  const int32_t o_first = live ? cd.u_o[u] : 0;
+  const int32_t o_end = live ? recs[r0 + nc - 1].o + (int32_t)recs[r0 + nc - 1].alt_len : 0;
   const int32_t qa = o_first - (L - 1) > 0 ? o_first - (L - 1) : 0;
   const int32_t qb = o_end < haplen ? o_end : haplen;
   const int nwords = qb > qa ? (qb - qa + 31) / 32 : 0;
@@ -673,6 +824,7 @@ __global__ __launch_bounds__(256) void k_cs_templates(HapSetDev hs, VcArgs va, C
   hits = group_incl_scan(hits, gl); cand = group_incl_scan(cand, gl);  // the group's totals in its last lane
   // ---- the workgroup's stretch of the template array: rows of the long clusters, kept starts (>= rows) of the others
   const bool leader = live && gl == CS_G - 1;
+  if (hole && gl == CS_G - 1) { res[2 * u] = make_uint4(0u, 0u, 0u, 0u); res[2 * u + 1] = make_uint4(0u, 0u, 0u, 0u); tbase[u] = 0u; }
   const uint32_t want = one_round ? TF + TR : n0 + n1;
   uint32_t btot;
   const uint32_t bex = block_excl_scan<256 / WAVE>(leader ? want : 0u, s_w, &btot);  // its barriers publish the groups' LDS entries

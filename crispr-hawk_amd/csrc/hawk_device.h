@@ -155,24 +155,26 @@ struct ClDict {
 };
 size_t hawk_cs_row_bytes();
 void hawk_launch_scan_u32(hipStream_t st, const uint32_t* cnt, uint32_t n, uint32_t* off);  // exclusive scan into n + 1 offsets, one workgroup
-void hawk_launch_hx_heads(hipStream_t st, const void* recs, uint64_t n, void* heads);  // the records' first 16 bytes, as an array of their own
+void hawk_launch_scan2_u32(hipStream_t st, const uint32_t* cnt_a, const uint32_t* cnt_b, uint32_t n, uint32_t* off_a, uint32_t* off_b);  // two arrays, one launch
+void hawk_launch_hx_heads(hipStream_t st, const void* recs, const uint32_t* hv_idx, uint64_t n, void* heads);  // {o, rs, alt_len, variant} per record
 // (the hawk_launch_cl_* passes take the HEADS as `recs`)
 uint32_t hawk_cl_chunk_bound(uint64_t n_records, uint32_t n_rows);  // room for ch_row / the chunks' counts
 void hawk_launch_cl_chunks(hipStream_t st, const uint64_t* hv_off, const uint8_t* is_ref, const int32_t* ss, const int32_t* se, uint32_t n_rows,
                            uint32_t* ch_off, uint32_t* ch_row);
-void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_rows,
-                          uint32_t ch_bound, uint32_t* cnt /* zeroed */);
+void hawk_launch_cl_count(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
+                          const uint32_t* ch_off, const uint32_t* ch_row, uint32_t n_rows, uint32_t n_var, uint32_t ch_bound, uint32_t* cnt /* zeroed */,
+                          uint32_t* lcnt /* zeroed */);  // per chunk: the instances it opens, and how many of them go on the list
 void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_off, const uint32_t* hap_len, const int32_t* ss, const int32_t* se,
-                         uint32_t n_rows, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t ch_bound, const uint32_t* inst_base, int32_t* o,
-                         uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot, uint32_t* status, void* tab /* zeroed */,
-                         uint32_t mask, uint32_t max_probe, uint32_t fail_bit);  // cuts the chunks AND fills the table
-size_t hawk_cl_slot_bytes();  // a slot of the table of distinct clusters: {key, ~lowest instance}
-void hawk_launch_cl_mark(hipStream_t st, uint32_t tsize, const void* tab, uint32_t* bits /* zeroed */, uint32_t n_words, uint32_t* cnt);
-void hawk_launch_cl_assign(hipStream_t st, uint32_t inst_bound, const uint32_t* n_inst_dev, uint32_t tsize, const void* tab, const uint32_t* bits,
-                           const uint64_t* word_rank,
-                           const void* recs, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* rec, uint32_t* n, uint32_t* slot,
-                           const uint32_t* seg_off, const uint32_t* seg_rel, void* slot_desc /* 32 B per slot */, uint32_t* u_rec, uint32_t* u_n,
-                           uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* inst_uid, uint32_t* status);
+                         uint32_t n_rows, const uint32_t* ch_off, const uint32_t* ch_row, uint32_t ch_bound, const uint32_t* inst_base,
+                         const uint32_t* list_base, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* inst_uid,
+                         void* var_desc /* 8 B per variant, zeroed */, uint32_t* claim_bits /* n_var bits, zeroed */, uint32_t n_var,
+                         void* cx_list /* hawk_cl_listed_bytes() per listed instance */, uint32_t* status);
+size_t hawk_cl_slot_bytes();    // a slot of the table of the listed instances' clusters
+size_t hawk_cl_listed_bytes();  // a list entry
+void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* n_list_dev, uint32_t* counters /* 2, zeroed */, uint32_t n_var, uint32_t u_cap,
+                           void* tab /* zeroed */, uint32_t mask, uint32_t max_probe, uint32_t fail_bit, const void* cx_list, uint32_t* cx_state,
+                           const void* var_desc, const void* recs, uint32_t* inst_uid, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* u_rec,
+                           uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
                               const struct RefInfo& ri, void* res /* 32 B per distinct cluster */, uint32_t* tbase, void* trows,
                               unsigned long long* t_count, uint64_t t_cap, int* status);

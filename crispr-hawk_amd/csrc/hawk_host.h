@@ -154,7 +154,8 @@ struct hawk_xplan {
   // the cluster dictionary (hawk_csearch.hip), built by the first hawk_xplan_view after the metadata is set
   struct {
     bool built = false, usable = false;
-    uint32_t n_inst = 0, n_uniq = 0;
+    uint32_t n_inst = 0, n_uniq = 0;  // n_uniq: the RANGE of the distinct clusters' numbers (variants first - with holes - then the table's)
+    uint32_t n_real = 0;              // how many distinct clusters there are
     uint32_t last_uniq = 0;  // distinct clusters of the previous build (sizes the first hash table of the next)
     uint64_t slots = 0;     // bound on the template rows of a search: window starts x 2 strands over all distinct clusters
     uint32_t status = 0;    // why it is not usable: 1 a chain of > 4096 records, 2 hash collision, 4 too large / too little sharing

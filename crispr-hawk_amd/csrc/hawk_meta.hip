@@ -88,6 +88,29 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t* __restrict__ 
   if (threadIdx.x == 0) off[n] = carry;
 }
 
+// the same for two count arrays at once (one launch: the dictionary's chunks open instances AND put some of them on a list)
+__global__ __launch_bounds__(1024) void k_scan2_u32(const uint32_t* __restrict__ cnt_a, const uint32_t* __restrict__ cnt_b, uint32_t n,
+                                                    uint32_t* __restrict__ off_a, uint32_t* __restrict__ off_b) {
+  __shared__ uint32_t s_w[1024 / WAVE];
+  uint32_t carry_a = 0, carry_b = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += 4096) {
+    const uint32_t i = b0 + threadIdx.x * 4;
+    uint32_t a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = i + k < n ? cnt_a[i + k] : 0u; b[k] = i + k < n ? cnt_b[i + k] : 0u; }
+    uint32_t tot_a, tot_b;
+    uint32_t ea = carry_a + block_excl_scan<1024 / WAVE>(a[0] + a[1] + a[2] + a[3], s_w, &tot_a);
+    uint32_t eb = carry_b + block_excl_scan<1024 / WAVE>(b[0] + b[1] + b[2] + b[3], s_w, &tot_b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < n) { off_a[i + k] = ea; off_b[i + k] = eb; }
+      ea += a[k]; eb += b[k];
+    }
+    carry_a += tot_a; carry_b += tot_b;
+  }
+  if (threadIdx.x == 0) { off_a[n] = carry_a; off_b[n] = carry_b; }
+}
+
 __global__ __launch_bounds__(256) void k_seg_fill(const uint64_t* __restrict__ ioff, const uint32_t* __restrict__ indel,
                                                   const uint32_t* __restrict__ hv_idx, const int32_t* __restrict__ hv_o,
                                                   const int32_t* __restrict__ v_r0, const int32_t* __restrict__ v_chain,
@@ -182,6 +205,9 @@ void hawk_launch_segments(hipStream_t st, const uint64_t* ioff, const uint32_t* 
   } else {
     hipLaunchKernelGGL(k_seg_fill, dim3(n_rows), dim3(256), 0, st, ioff, indel, hv_idx, hv_o, v_r0, v_chain, hap_len, startp, seg_off, seg_rel, seg_gen);
   }
+}
+void hawk_launch_scan2_u32(hipStream_t st, const uint32_t* cnt_a, const uint32_t* cnt_b, uint32_t n, uint32_t* off_a, uint32_t* off_b) {
+  hipLaunchKernelGGL(k_scan2_u32, dim3(1), dim3(1024), 0, st, cnt_a, cnt_b, n, off_a, off_b);
 }
 void hawk_launch_scan_u32(hipStream_t st, const uint32_t* cnt, uint32_t n, uint32_t* off) {
   hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, cnt, n, off);
