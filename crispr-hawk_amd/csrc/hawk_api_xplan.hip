@@ -275,32 +275,49 @@ static int xplan_build_dict(hawk_xplan* x) {
   const uint32_t n = x->n_hap;
   if (x->ncar == 0 || x->ncar >= (1ull << 32) - 2 || n < 2) { cl.status = 4; return HAWK_OK; }
   PoolScope tmp;
-  // the rows' records in chunks (hawk_csearch.hip): chunks per row -> their offsets and rows, then the instances every chunk opens
-  // and how many of them go on the list of the clusters that are more than their variant
+  // Sizes first - nothing below waits for a count from the device.  An instance starts at a record or closes a row, so records + rows
+  // bounds their number: the instance arrays, the list and the grids of the passes are sized by the bound, the passes read the true
+  // counts on the device, and the host learns them together with the number of distinct clusters, once, at the end.
   const uint32_t n_var = x->n_var;
-  const uint32_t ch_bound = hawk_cl_chunk_bound(x->ncar, n);
-  uint32_t *d_ch_off, *d_ch_row, *d_cnt, *d_lcnt, *d_base, *d_lbase, *d_status;
+  const uint32_t ch_bound = hawk_cl_chunk_bound(x->ncar, n);  // the rows' records in chunks (hawk_csearch.hip)
+  const uint32_t inst_bound = (uint32_t)x->ncar + n;
+  const uint32_t bm_words = n_var / 32 + 1;
+  // The table of the clusters that are more than their variant: at least two slots per listed instance would always do, but the
+  // distinct clusters are a small fraction of the instances and clearing 32 bytes x 2^25 slots costs more than every kernel of this
+  // build - so the first attempt takes two slots per distinct cluster EXPECTED (the last build's count, else an eighth of the
+  // instances), gives up after 64 probes (status bit 8), and the pass is repeated with the full size
+  uint32_t tsize = 1024;
+  while (tsize < 2u * inst_bound && tsize < (1u << 30)) tsize <<= 1;
+  uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
+  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 2 : (uint64_t)inst_bound / 8; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
+  const uint32_t u_bound0 = n_var + std::min<uint32_t>(tsmall, inst_bound);  // cluster numbers of the first attempt: the variants, then what its table can hold
+  // everything that starts from zero, in ONE block cleared by ONE memset: status, counters, scan totals and shards, the chunks' counts,
+  // the variants' bitmap and describers, the clusters' template-row bounds, the first attempt's table
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t z_status = 0, z_counters = 256, z_tot = 512, z_shards = 768, z_cnt = z_shards + up(512 * 8),
+               z_claim = z_cnt + up((size_t)ch_bound * 8), z_vdesc = z_claim + up((size_t)bm_words * 4),
+               z_span2 = z_vdesc + up((size_t)std::max<uint32_t>(n_var, 1) * 8), z_tab = z_span2 + up((size_t)u_bound0 * 4),
+               z_end = z_tab + (size_t)tsmall * hawk_cl_slot_bytes();
+  char* d_zero;
+  TEMPCHK(tmp, &d_zero, z_end);
+  uint32_t* const d_status = reinterpret_cast<uint32_t*>(d_zero + z_status);
+  uint32_t* const d_counters = reinterpret_cast<uint32_t*>(d_zero + z_counters);
+  ScanTotals* const d_tot = reinterpret_cast<ScanTotals*>(d_zero + z_tot);
+  unsigned long long* const d_shards = reinterpret_cast<unsigned long long*>(d_zero + z_shards);
+  uint32_t* const d_cnt = reinterpret_cast<uint32_t*>(d_zero + z_cnt);
+  uint32_t* const d_lcnt = d_cnt + ch_bound;
+  uint32_t* const d_claim = reinterpret_cast<uint32_t*>(d_zero + z_claim);
+  void* const d_vdesc = d_zero + z_vdesc;
+  uint32_t *d_ch_off, *d_ch_row, *d_base, *d_lbase, *d_state;
+  void* d_list;
+  unsigned long long* d_partial;
   TEMPCHK(tmp, &d_ch_off, (size_t)(n + 1) * 4);
   TEMPCHK(tmp, &d_ch_row, (size_t)ch_bound * 4);
-  TEMPCHK(tmp, &d_cnt, (size_t)ch_bound * 4 * 2);
-  d_lcnt = d_cnt + ch_bound;
   TEMPCHK(tmp, &d_base, (size_t)(ch_bound + 1) * 4);
   TEMPCHK(tmp, &d_lbase, (size_t)(ch_bound + 1) * 4);
-  TEMPCHK(tmp, &d_status, 64);
-  HIPCHK(hipMemsetAsync(d_status, 0, 64, st));
-  HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ch_bound * 4 * 2, st));  // (chunks beyond the last one open nothing)
-  HIPCHK(hipEventRecord(ctx->ev[8], st));
-  hawk_launch_cl_chunks(st, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row);
-  // (the number of chunks is only known on the device - rows that scan nothing have none: the count pass and its scan run over the bound)
-  hawk_launch_cl_count(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), d_ch_off, d_ch_row, n,
-                       n_var, ch_bound, d_cnt, d_lcnt);
-  hawk_launch_scan2_u32(st, d_cnt, d_lcnt, ch_bound, d_base, d_lbase);
-  // No read-back here: an instance starts at a record or closes a row, so records + rows bounds their number - the instance arrays,
-  // the list and the grids of the passes below are sized by the bound, the passes read the true counts on the device, and the host
-  // learns them together with the number of distinct clusters
-  const uint32_t inst_bound = (uint32_t)x->ncar + n;
-  const uint32_t* const d_n_inst = d_base + ch_bound;
-  const uint32_t* const d_n_list = d_lbase + ch_bound;
+  TEMPCHK(tmp, &d_list, (size_t)inst_bound * hawk_cl_listed_bytes());
+  TEMPCHK(tmp, &d_state, (size_t)inst_bound * 4);
+  TEMPCHK(tmp, &d_partial, (((size_t)n_var + std::min<uint32_t>(tsize, inst_bound)) / 1024 + 2) * 8);
   int rc;
   if ((rc = cl.inst_uid.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_o.reserve((size_t)inst_bound * 4)) ||
       (rc = cl.inst_row.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_pa.reserve((size_t)inst_bound * 4)) ||
@@ -311,51 +328,40 @@ static int xplan_build_dict(hawk_xplan* x) {
   int32_t* const t_o = cl.inst_o.as<int32_t>();
   int32_t* const t_pa = cl.inst_pa.as<int32_t>();
   int32_t* const t_rb = cl.inst_rb.as<int32_t>();
-  const uint32_t bm_words = n_var / 32 + 1;
-  uint32_t *d_counters, *d_claim, *d_state;
-  void *d_tab, *d_list, *d_vdesc;  // the table of the listed instances' clusters, the list, the variants' describers: hawk_csearch.hip
-  unsigned long long *d_partial, *d_shards;
-  ScanTotals* d_tot;
-  // The table: at least two slots per listed instance would always do, but the distinct clusters are a small fraction of the instances
-  // and clearing 32 bytes x 2^25 slots costs more than every kernel of this build - so the first attempt takes two slots per
-  // distinct cluster EXPECTED (the last build's count, else an eighth of the instances), gives up after 64 probes (status bit 8),
-  // and the pass is repeated with the full size
-  uint32_t tsize = 1024;
-  while (tsize < 2u * inst_bound && tsize < (1u << 30)) tsize <<= 1;
-  uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
-  { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 2 : (uint64_t)inst_bound / 8; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
-  TEMPCHK(tmp, &d_counters, 64);
-  TEMPCHK(tmp, &d_claim, (size_t)bm_words * 4);
-  TEMPCHK(tmp, &d_vdesc, (size_t)std::max<uint32_t>(n_var, 1) * 8);
-  TEMPCHK(tmp, &d_list, (size_t)inst_bound * hawk_cl_listed_bytes());
-  TEMPCHK(tmp, &d_state, (size_t)inst_bound * 4);
-  TEMPCHK(tmp, &d_tab, (size_t)tsize * hawk_cl_slot_bytes());
-  TEMPCHK(tmp, &d_partial, (((size_t)n_var + std::min<uint32_t>(tsize, inst_bound)) / 1024 + 2) * 8);
-  TEMPCHK(tmp, &d_shards, 512 * 8);
-  TEMPCHK(tmp, &d_tot, sizeof(ScanTotals));
+  HIPCHK(hipEventRecord(ctx->ev[8], st));
+  HIPCHK(hipMemsetAsync(d_zero, 0, z_end, st));
+  // chunks per row -> their offsets and rows, then the instances every chunk opens and how many of them go on the list of the
+  // clusters that are more than their variant (the number of chunks is only known on the device - rows that scan nothing have
+  // none: the count pass and its scan run over the bound; chunks beyond the last one open nothing)
+  hawk_launch_cl_chunks(st, x->off.as<uint64_t>(), x->m_is_ref.as<uint8_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row);
+  hawk_launch_cl_count(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), d_ch_off, d_ch_row, n,
+                       n_var, ch_bound, d_cnt, d_lcnt);
+  hawk_launch_scan2_u32(st, d_cnt, d_lcnt, ch_bound, d_base, d_lbase);
+  const uint32_t* const d_n_inst = d_base + ch_bound;
+  const uint32_t* const d_n_list = d_lbase + ch_bound;
   // One pass = cut the rows (a one-record shareable instance is its variant; the rest goes on the list), the listed instances through
   // the table, the distinct clusters' descriptions, the listed instances that share a cluster - queued without a read-back in
-  // between: what the host would size by a count is sized by its bound (the variants + the table's slots, or + the instances if
-  // fewer).  The host reads the counts once, at the end, and repeats the pass if the small table gave up.
+  // between.  The host reads the counts once, at the end, and repeats the pass if the small table gave up.
   ScanTotals tot;
   uint32_t status = 0, n_inst = 0, n_uniq = 0, n_real = 0, cnt2[2] = {0, 0};
-  auto pass = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit) -> int {
+  auto pass = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit, bool first) -> int {
     const uint32_t u_bound = n_var + std::min<uint32_t>(tsz, inst_bound);  // the variants, then what the table can hold
-    uint32_t* d_span2;
+    uint32_t* d_span2 = reinterpret_cast<uint32_t*>(d_zero + z_span2);
+    void* d_tab = d_zero + z_tab;
     uint64_t* d_slot64;
-    TEMPCHK(tmp, &d_span2, (size_t)u_bound * 4);
+    if (!first) {  // the repeat: its own, larger table and bounds; everything cleared again
+      TEMPCHK(tmp, &d_span2, (size_t)u_bound * 4);
+      TEMPCHK(tmp, &d_tab, (size_t)tsz * hawk_cl_slot_bytes());
+      HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
+      HIPCHK(hipMemsetAsync(d_span2, 0, (size_t)u_bound * 4, st));
+      HIPCHK(hipMemsetAsync(d_zero + z_counters, 0, z_cnt - z_counters, st));               // counters, totals, shards
+      HIPCHK(hipMemsetAsync(d_zero + z_claim, 0, z_span2 - z_claim, st));                   // the variants' bitmap and describers
+    }
     TEMPCHK(tmp, &d_slot64, ((size_t)u_bound + 1) * 8);
     int rc2;
     if ((rc2 = cl.u_rec.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_n.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_row.reserve((size_t)u_bound * 4)) ||
         (rc2 = cl.u_o.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_seg.reserve((size_t)u_bound * 4)))
       return rc2;
-    HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
-    HIPCHK(hipMemsetAsync(d_shards, 0, 512 * 8, st));
-    HIPCHK(hipMemsetAsync(d_counters, 0, 64, st));
-    HIPCHK(hipMemsetAsync(d_claim, 0, (size_t)bm_words * 4, st));
-    HIPCHK(hipMemsetAsync(d_vdesc, 0, (size_t)std::max<uint32_t>(n_var, 1) * 8, st));  // (a variant nobody describes stays a hole)
-    HIPCHK(hipMemsetAsync(d_span2, 0, (size_t)u_bound * 4, st));
-    HIPCHK(hipMemsetAsync(d_tot, 0, sizeof(ScanTotals), st));
     hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row,
                         ch_bound, d_base, d_lbase, t_o, t_row, t_pa, t_rb, t_uid, d_vdesc, d_claim, n_var, d_list, d_status);
     hawk_launch_cl_finish(st, inst_bound, d_n_list, d_counters, n_var, u_bound, d_tab, tsz - 1, max_probe, fail_bit, d_list, d_state, d_vdesc, x->heads.p,
@@ -373,11 +379,11 @@ static int xplan_build_dict(hawk_xplan* x) {
     n_real = cnt2[0] + cnt2[1];
     return HAWK_OK;
   };
-  if ((rc = pass(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u))) return rc;
+  if ((rc = pass(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u, true))) return rc;
   if (status & 8u) {  // the small table filled up: once more with two slots per instance
     status &= ~8u;
     HIPCHK(hipMemcpyAsync(d_status, &status, 4, hipMemcpyHostToDevice, st));
-    if ((rc = pass(tsize, 0xffffffffu, 2u))) return rc;
+    if ((rc = pass(tsize, 0xffffffffu, 2u, false))) return rc;
   }
   if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
   if (n_inst > inst_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: instance count beyond its bound"); return HAWK_E_HIP; }

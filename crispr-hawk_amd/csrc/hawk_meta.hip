@@ -88,25 +88,37 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t* __restrict__ 
   if (threadIdx.x == 0) off[n] = carry;
 }
 
-// the same for two count arrays at once (one launch: the dictionary's chunks open instances AND put some of them on a list)
+// the same for two count arrays at once (one launch: the dictionary's chunks open instances AND put some of them on a list);
+// eight consecutive counts of either array per thread and round
 __global__ __launch_bounds__(1024) void k_scan2_u32(const uint32_t* __restrict__ cnt_a, const uint32_t* __restrict__ cnt_b, uint32_t n,
                                                     uint32_t* __restrict__ off_a, uint32_t* __restrict__ off_b) {
-  __shared__ uint32_t s_w[1024 / WAVE];
+  __shared__ uint32_t s_w[2][1024 / WAVE];
   uint32_t carry_a = 0, carry_b = 0;
-  for (uint32_t b0 = 0; b0 < n; b0 += 4096) {
-    const uint32_t i = b0 + threadIdx.x * 4;
-    uint32_t a[4], b[4];
+  for (uint32_t b0 = 0; b0 < n; b0 += 8192) {
+    const uint32_t i = b0 + threadIdx.x * 8;
+    uint32_t a[8], b[8], sa = 0, sb = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = i + k < n ? cnt_a[i + k] : 0u; b[k] = i + k < n ? cnt_b[i + k] : 0u; }
-    uint32_t tot_a, tot_b;
-    uint32_t ea = carry_a + block_excl_scan<1024 / WAVE>(a[0] + a[1] + a[2] + a[3], s_w, &tot_a);
-    uint32_t eb = carry_b + block_excl_scan<1024 / WAVE>(b[0] + b[1] + b[2] + b[3], s_w, &tot_b);
+    for (int k = 0; k < 8; ++k) { a[k] = i + k < n ? cnt_a[i + k] : 0u; b[k] = i + k < n ? cnt_b[i + k] : 0u; sa += a[k]; sb += b[k]; }
+    // both scans share their two barriers
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const uint32_t ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
+    if (lane == WAVE - 1) { s_w[0][wv] = ia; s_w[1][wv] = ib; }
+    __syncthreads();
+    uint32_t pa = 0, pb = 0, ta = 0, tb = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int w = 0; w < 1024 / WAVE; ++w) {
+      const uint32_t xa = s_w[0][w], xb = s_w[1][w];
+      if (w < wv) { pa += xa; pb += xb; }
+      ta += xa; tb += xb;
+    }
+    __syncthreads();
+    uint32_t ea = carry_a + pa + ia - sa, eb = carry_b + pb + ib - sb;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
       if (i + k < n) { off_a[i + k] = ea; off_b[i + k] = eb; }
       ea += a[k]; eb += b[k];
     }
-    carry_a += tot_a; carry_b += tot_b;
+    carry_a += ta; carry_b += tb;
   }
   if (threadIdx.x == 0) { off_a[n] = carry_a; off_b[n] = carry_b; }
 }
