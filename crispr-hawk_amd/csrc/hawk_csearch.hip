@@ -8,10 +8,13 @@
 // with no neighbour - yields the same rows in every one of them, shifted by the copies' upstream indels.  On the C3 panel
 // 8.8 x 10^6 cluster instances are 7.3 x 10^4 distinct clusters.
 //
-//   dictionary (once per plan; hawk_xplan_view):  k_cl_count / k_cl_fill cut every row into cluster instances and hash
-//       their variant identities, k_cl_insert / k_cl_assign / k_cl_uid number the distinct ones (exactly: every instance is
-//       compared with its representative, record by record).  An instance whose windows could meet a row-specific bound
-//       (scan range, row ends) is a cluster of its own; one wholly outside the scan range carries no cluster at all.
+//   dictionary (once per plan; hawk_xplan_view):  k_cl_chunks / k_cl_count / k_cl_fill cut every row's records into cluster instances.
+//       An instance of ONE record whose windows can meet no bound of its row IS its variant: its distinct cluster is the variant's
+//       index in the plan's table - nothing to look up, nothing to compare.  Every other instance with a cluster goes on a list and
+//       through a hash table of the variant identities (k_cl_enter), and is compared record by record with the instance that
+//       opened its cluster (k_cl_uid: exactly - same hash is not same cluster until then); those clusters are numbered behind the
+//       variants.  An instance whose windows could meet a row-specific bound (scan range, row ends) is a cluster of its own; one
+//       wholly outside the scan range carries no cluster at all.
 //   per search:  k_cs_templates builds each distinct cluster's rows ONCE, on its representative row, with the string
 //       builder, PAM match, filters and classification of hawk_vsearch.hip (64-byte template rows, strand 0 / strand 1
 //       regions in position order); k_cs_count gives every instance its row count and adds up the job's totals

@@ -262,6 +262,58 @@ def test_cluster_dictionary_with_a_shared_alt_pool(monkeypatch):
     _same_table(reg, "TTTV", 23, True, cfd=False)
 
 
+def test_cluster_dictionary_numbers_with_holes():
+    """A one-record shareable cluster is numbered by its variant's index; a variant that only ever travels with a neighbour within
+    64 positions is nowhere a cluster of its own - its number stays a hole the search skips - and the pair is one cluster of the
+    table.  Linked pairs (every carrier of the first SNV carries the second, 20 nt away), isolated SNVs and a few pairs that are
+    split in some samples: same table as the oracle, and the distinct count the host works out."""
+    rng = np.random.default_rng(8801)
+    reg = synth.make_region(8802, "chrH", 60_000, 2_000, 56_000)
+    n_samples = 12
+    reg.samples = [f"S{i:04d}" for i in range(n_samples)]
+    seq = reg.contig_seq.upper()
+    sites, pos = [], 3_000
+    for k in range(60):
+        kind = k % 3  # 0: isolated SNV, 1: a linked pair, 2: a pair split in a few copies
+        gt = (rng.random((n_samples, 2)) < 0.35).astype(np.uint8)
+        if not gt.any():
+            gt[0, 0] = 1
+
+        def snv(p):
+            ref = seq[p - 1]
+            return ref, "ACGT"[("ACGT".index(ref) + 1) % 4]
+        r, a = snv(pos)
+        sites.append(synth.VariantSite(pos, r, a, float(gt.mean()), gt.copy()))
+        if kind:
+            g2 = gt.copy()
+            if kind == 2:
+                g2[rng.integers(0, n_samples), rng.integers(0, 2)] ^= 1
+                if not g2.any():
+                    g2 = gt.copy()
+            r2, a2 = snv(pos + 20)
+            sites.append(synth.VariantSite(pos + 20, r2, a2, float(g2.mean()), g2))
+        pos += 800
+    reg.variants = sites
+    ds, info, _ms, kept = expand_on_device(reg, 3, keep_plan=True)
+    ds.plan.view()
+    st = ds.plan.cluster_stats()
+    vpos = np.array([v.pos for v in reg.variants], dtype=np.int64)
+    distinct = set()
+    for inf in info:
+        idx = np.sort(np.asarray(inf.variant_idx, dtype=np.int64))
+        if len(idx):
+            for part in np.split(idx, np.flatnonzero(np.diff(vpos[idx]) > 64) + 1):
+                distinct.add(tuple(part.tolist()))
+    assert st["usable"] and st["status"] == 0 and st["distinct"] == len(distinct)
+    assert any(len(d) == 2 for d in distinct) and any(len(d) == 1 for d in distinct)
+    alone = {d[0] for d in distinct if len(d) == 1}
+    assert len(alone) < len(reg.variants)  # some variants are never a cluster of their own: holes
+    ds.plan.close()
+    ds.close()
+    _same_table(reg, "NGG", 20, False, oracle=True)
+    _same_table(reg, "TTTV", 23, True, cfd=False)
+
+
 def test_cluster_dictionary_outgrows_its_first_hash_table():
     """The dictionary's first hash table is sized for the distinct clusters EXPECTED (an eighth of the instances); a panel of
     private variants - every cluster its own - fills it, the insert gives up and is repeated with two slots per instance."""
