@@ -291,10 +291,10 @@ static int xplan_build_dict(hawk_xplan* x) {
   uint32_t tsmall = std::min<uint32_t>(1u << 16, tsize);
   { const uint64_t expect = cl.last_uniq ? (uint64_t)cl.last_uniq * 2 : (uint64_t)inst_bound / 8; while (tsmall < expect && tsmall < tsize) tsmall <<= 1; }
   const uint32_t u_bound0 = n_var + std::min<uint32_t>(tsmall, inst_bound);  // cluster numbers of the first attempt: the variants, then what its table can hold
-  // everything that starts from zero, in ONE block cleared by ONE memset: status, counters, scan totals and shards, the chunks' counts,
-  // the variants' bitmap and describers, the clusters' template-row bounds, the first attempt's table
+  // everything that starts from zero, in ONE block cleared by ONE memset: status, counters, the chunks' counts, the variants' bitmap
+  // and describers, the clusters' template-row bounds, the first attempt's table
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t z_status = 0, z_counters = 256, z_tot = 512, z_shards = 768, z_cnt = z_shards + up(512 * 8),
+  const size_t z_status = 0, z_counters = 256, z_results = 512, z_cnt = 768,
                z_claim = z_cnt + up((size_t)ch_bound * 8), z_vdesc = z_claim + up((size_t)bm_words * 4),
                z_span2 = z_vdesc + up((size_t)std::max<uint32_t>(n_var, 1) * 8), z_tab = z_span2 + up((size_t)u_bound0 * 4),
                z_end = z_tab + (size_t)tsmall * hawk_cl_slot_bytes();
@@ -302,22 +302,19 @@ static int xplan_build_dict(hawk_xplan* x) {
   TEMPCHK(tmp, &d_zero, z_end);
   uint32_t* const d_status = reinterpret_cast<uint32_t*>(d_zero + z_status);
   uint32_t* const d_counters = reinterpret_cast<uint32_t*>(d_zero + z_counters);
-  ScanTotals* const d_tot = reinterpret_cast<ScanTotals*>(d_zero + z_tot);
-  unsigned long long* const d_shards = reinterpret_cast<unsigned long long*>(d_zero + z_shards);
+  unsigned long long* const d_results = reinterpret_cast<unsigned long long*>(d_zero + z_results);
   uint32_t* const d_cnt = reinterpret_cast<uint32_t*>(d_zero + z_cnt);
   uint32_t* const d_lcnt = d_cnt + ch_bound;
   uint32_t* const d_claim = reinterpret_cast<uint32_t*>(d_zero + z_claim);
   void* const d_vdesc = d_zero + z_vdesc;
   uint32_t *d_ch_off, *d_ch_row, *d_base, *d_lbase, *d_state;
   void* d_list;
-  unsigned long long* d_partial;
   TEMPCHK(tmp, &d_ch_off, (size_t)(n + 1) * 4);
   TEMPCHK(tmp, &d_ch_row, (size_t)ch_bound * 4);
   TEMPCHK(tmp, &d_base, (size_t)(ch_bound + 1) * 4);
   TEMPCHK(tmp, &d_lbase, (size_t)(ch_bound + 1) * 4);
   TEMPCHK(tmp, &d_list, (size_t)inst_bound * hawk_cl_listed_bytes());
   TEMPCHK(tmp, &d_state, (size_t)inst_bound * 4);
-  TEMPCHK(tmp, &d_partial, (((size_t)n_var + std::min<uint32_t>(tsize, inst_bound)) / 1024 + 2) * 8);
   int rc;
   if ((rc = cl.inst_uid.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_o.reserve((size_t)inst_bound * 4)) ||
       (rc = cl.inst_row.reserve((size_t)inst_bound * 4)) || (rc = cl.inst_pa.reserve((size_t)inst_bound * 4)) ||
@@ -342,41 +339,36 @@ static int xplan_build_dict(hawk_xplan* x) {
   // One pass = cut the rows (a one-record shareable instance is its variant; the rest goes on the list), the listed instances through
   // the table, the distinct clusters' descriptions, the listed instances that share a cluster - queued without a read-back in
   // between.  The host reads the counts once, at the end, and repeats the pass if the small table gave up.
-  ScanTotals tot;
-  uint32_t status = 0, n_inst = 0, n_uniq = 0, n_real = 0, cnt2[2] = {0, 0};
+  unsigned long long res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t status = 0, n_inst = 0, n_uniq = 0, n_real = 0;
   auto pass = [&](uint32_t tsz, uint32_t max_probe, uint32_t fail_bit, bool first) -> int {
     const uint32_t u_bound = n_var + std::min<uint32_t>(tsz, inst_bound);  // the variants, then what the table can hold
     uint32_t* d_span2 = reinterpret_cast<uint32_t*>(d_zero + z_span2);
     void* d_tab = d_zero + z_tab;
-    uint64_t* d_slot64;
     if (!first) {  // the repeat: its own, larger table and bounds; everything cleared again
       TEMPCHK(tmp, &d_span2, (size_t)u_bound * 4);
       TEMPCHK(tmp, &d_tab, (size_t)tsz * hawk_cl_slot_bytes());
       HIPCHK(hipMemsetAsync(d_tab, 0, (size_t)tsz * hawk_cl_slot_bytes(), st));
       HIPCHK(hipMemsetAsync(d_span2, 0, (size_t)u_bound * 4, st));
-      HIPCHK(hipMemsetAsync(d_zero + z_counters, 0, z_cnt - z_counters, st));               // counters, totals, shards
+      HIPCHK(hipMemsetAsync(d_zero + z_counters, 0, z_cnt - z_counters, st));               // counters, results
       HIPCHK(hipMemsetAsync(d_zero + z_claim, 0, z_span2 - z_claim, st));                   // the variants' bitmap and describers
     }
-    TEMPCHK(tmp, &d_slot64, ((size_t)u_bound + 1) * 8);
     int rc2;
     if ((rc2 = cl.u_rec.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_n.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_row.reserve((size_t)u_bound * 4)) ||
         (rc2 = cl.u_o.reserve((size_t)u_bound * 4)) || (rc2 = cl.u_seg.reserve((size_t)u_bound * 4)))
       return rc2;
     hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row,
                         ch_bound, d_base, d_lbase, t_o, t_row, t_pa, t_rb, t_uid, d_vdesc, d_claim, n_var, d_list, d_status);
-    hawk_launch_cl_finish(st, inst_bound, d_n_list, d_counters, n_var, u_bound, d_tab, tsz - 1, max_probe, fail_bit, d_list, d_state, d_vdesc, x->heads.p,
+    hawk_launch_cl_finish(st, inst_bound, d_n_inst, d_n_list, d_counters, d_results, n_var, u_bound, d_tab, tsz - 1, max_probe, fail_bit, d_list, d_state, d_vdesc, x->heads.p,
                           t_uid, x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
                           cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, d_status);
-    hawk_launch_mscan(st, d_span2, u_bound, d_partial, d_shards, d_slot64, d_tot);  // (zeros behind the last distinct cluster)
-    HIPCHK(hipMemcpyAsync(&n_inst, d_n_inst, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(cnt2, d_counters, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&tot, d_tot, sizeof(ScanTotals), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(res, d_results, 64, hipMemcpyDeviceToHost, st));  // {instances, the table's clusters, the variants that are clusters, template rows, status}
     HIPCHK(hipEventRecord(ctx->ev[9], st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
-    n_uniq = std::min<uint32_t>(n_var + cnt2[0], u_bound);  // the range of the numbers
-    n_real = cnt2[0] + cnt2[1];
+    n_inst = (uint32_t)res[0]; status = (uint32_t)res[4];
+    n_uniq = std::min<uint32_t>(n_var + (uint32_t)res[1], u_bound);  // the range of the numbers
+    n_real = (uint32_t)(res[1] + res[2]);
     return HAWK_OK;
   };
   if ((rc = pass(tsmall, tsmall < tsize ? 64u : 0xffffffffu, tsmall < tsize ? 8u : 2u, true))) return rc;
@@ -387,9 +379,9 @@ static int xplan_build_dict(hawk_xplan* x) {
   }
   if (n_inst == 0) { cl.status = 4; return HAWK_OK; }
   if (n_inst > inst_bound) { snprintf(hawk_hip_err_buf(), 256, "hawk_xplan_view: instance count beyond its bound"); return HAWK_E_HIP; }
-  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.n_real = n_real; cl.last_uniq = cnt2[0];
+  cl.n_inst = n_inst; cl.n_uniq = n_uniq; cl.n_real = n_real; cl.last_uniq = (uint32_t)res[1];
   (void)hipEventElapsedTime(&cl.build_ms, ctx->ev[8], ctx->ev[9]);
-  cl.slots = n_uniq ? tot.n_keep : 0;
+  cl.slots = n_uniq ? res[3] : 0;
   cl.status = status;
   // worth it when clusters are shared (the template rows are extra traffic otherwise) and the templates fit a sane budget
   // (HAWK_CLUSTER_MAX_SLOTS template rows, default 2^27 = 10 GB; HAWK_CLUSTER_MIN_SHARE instances per distinct cluster, default 3:

@@ -434,8 +434,9 @@ __global__ __launch_bounds__(256) void k_cl_enter(const ClListed* __restrict__ c
 __global__ __launch_bounds__(256) void k_cl_describe(const uint32_t* __restrict__ n_table_dev, uint32_t n_var, uint32_t u_cap,
                                                      const unsigned long long* __restrict__ var_desc, ClUniq cu, const HxHead* __restrict__ recs,
                                                      const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_rel,
-                                                     uint32_t* __restrict__ n_variant_clusters) {
+                                                     uint32_t* __restrict__ n_variant_clusters, unsigned long long* __restrict__ slots_total) {
   const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+  uint32_t span_u = 0;
   const uint32_t nu = n_var + *n_table_dev < u_cap ? n_var + *n_table_dev : u_cap;  // (launched over the bound on the distinct clusters)
   bool variant_cluster = false;
   if (u < nu) {
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(256) void k_cl_describe(const uint32_t* __restrict_
     if (n == 0) { cu.span2[u] = 0; cu.seg[u] = 0; }
     else {
       const int32_t o_end = recs[r + n - 1].o + (int32_t)recs[r + n - 1].alt_len;
-      cu.span2[u] = 2u * ((uint32_t)(o_end - o_first) + CL_LINK);  // rows the cluster can have: window starts [o_first - L + 1, o_end) x 2 strands
+      span_u = 2u * ((uint32_t)(o_end - o_first) + CL_LINK);  // rows the cluster can have: window starts [o_first - L + 1, o_end) x 2 strands
+      cu.span2[u] = span_u;
       // the position-map segment in force CL_LINK + PAD positions in front of the cluster: every position a search asks for lies behind it
       const uint32_t rel = o_first > CL_LINK + HAWK_PAD ? (uint32_t)(o_first - CL_LINK - HAWK_PAD) : 0u;
       uint32_t lo = seg_off[row], hi = seg_off[row + 1];
@@ -466,6 +468,14 @@ __global__ __launch_bounds__(256) void k_cl_describe(const uint32_t* __restrict_
   }
   const unsigned long long vb = __ballot(variant_cluster);  // (statistics: how many variants are clusters of their own)
   if ((threadIdx.x & (WAVE - 1)) == 0 && vb) atomicAdd(n_variant_clusters, (uint32_t)__popcll(vb));
+  // the template rows a search may need at most: the sum of the clusters' bounds (nobody waits for these atomics)
+  const uint32_t ssum = wave_sum(span_u);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && ssum) atomicAdd(slots_total, (unsigned long long)ssum);
+}
+// what the host wants to know of a finished build, as one block (one copy instead of four)
+__global__ void k_cl_results(const uint32_t* __restrict__ n_inst, const uint32_t* __restrict__ counters, const unsigned long long* __restrict__ slots_total,
+                             const uint32_t* __restrict__ status, unsigned long long* __restrict__ out) {
+  out[0] = *n_inst; out[1] = counters[0]; out[2] = counters[1]; out[3] = *slots_total; out[4] = *status;
 }
 // The listed instances that found their hash in the table: number from the slot, identity compared record by record with the instance
 // that opened the cluster (exactness: same hash is not same cluster until then).  Loads level by level.
@@ -550,7 +560,9 @@ void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_of
                          const uint32_t* list_base, int32_t* o, uint32_t* row, int32_t* pa, int32_t* rb, uint32_t* inst_uid, void* var_desc,
                          uint32_t* claim_bits, uint32_t n_var, void* cx_list, uint32_t* status) {
   ClInst ci{o, row, pa, rb, inst_uid};
-  const uint32_t n_head = ch_bound < CL_HEAD_CHUNKS ? ch_bound : CL_HEAD_CHUNKS;
+  // (a small job - a stretch of a region on one of several GPUs - has no crowd to keep away from one address, and two launches
+  // of pure latency to save: everything in the second launch, where every instance whose variant nobody described writes it)
+  const uint32_t n_head = ch_bound < 16 * CL_HEAD_CHUNKS ? 0u : CL_HEAD_CHUNKS;
   if (n_head)
     hipLaunchKernelGGL(k_cl_fill, dim3(n_head), dim3(256), 0, st, static_cast<const HxHead*>(recs), hv_off, hap_len, ss, se, ch_off, ch_row, inst_base,
                        list_base, ci, static_cast<unsigned long long*>(var_desc), claim_bits, n_var, static_cast<ClListed*>(cx_list), status, 0u, n_rows, 1u);
@@ -560,14 +572,16 @@ void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_of
                        n_head, n_rows, 0u);
 }
 // after the cutting pass: the listed instances through the table, the distinct clusters' descriptions, then the listed instances
-// that share a cluster.  counters: [0] the table's distinct clusters, [1] the variants that are clusters of their own (zeroed).
-void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* n_list_dev, uint32_t* counters, uint32_t n_var, uint32_t u_cap, void* tab,
+// that share a cluster.  counters: [0] the table's distinct clusters, [1] the variants that are clusters of their own, [4..5] the
+// template rows a search may need at most (zeroed); results: {instances, [0], [1], template rows, status} for the host, 64 bytes.
+void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* n_inst_dev, const uint32_t* n_list_dev, uint32_t* counters,
+                           unsigned long long* results, uint32_t n_var, uint32_t u_cap, void* tab,
                            uint32_t mask, uint32_t max_probe, uint32_t fail_bit, const void* cx_list, uint32_t* cx_state, const void* var_desc,
                            const void* recs, uint32_t* inst_uid, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* u_rec, uint32_t* u_n,
                            uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* status) {
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
   const uint32_t per = 256 * CL_UID_U;
-  const uint32_t head = list_bound < CL_HEAD_LISTED ? list_bound : CL_HEAD_LISTED;
+  const uint32_t head = list_bound < 16 * CL_HEAD_LISTED ? 0u : CL_HEAD_LISTED;
   const ClListed* list = static_cast<const ClListed*>(cx_list);
   if (head)
     hipLaunchKernelGGL(k_cl_enter, dim3((head + per - 1) / per), dim3(256), 0, st, list, n_list_dev, 0u, head, static_cast<ClSlot*>(tab), mask, max_probe,
@@ -576,10 +590,11 @@ void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* 
     hipLaunchKernelGGL(k_cl_enter, dim3((list_bound - head + per - 1) / per), dim3(256), 0, st, list, n_list_dev, head, list_bound, static_cast<ClSlot*>(tab),
                        mask, max_probe, fail_bit, inst_uid, cx_state, cu, static_cast<const HxHead*>(recs), counters, n_var, u_cap, status);
   hipLaunchKernelGGL(k_cl_describe, dim3((u_cap + 255) / 256), dim3(256), 0, st, counters, n_var, u_cap, static_cast<const unsigned long long*>(var_desc), cu,
-                     static_cast<const HxHead*>(recs), seg_off, seg_rel, counters + 1);
+                     static_cast<const HxHead*>(recs), seg_off, seg_rel, counters + 1, reinterpret_cast<unsigned long long*>(counters + 4));
   if (list_bound)
     hipLaunchKernelGGL(k_cl_uid, dim3((list_bound + per - 1) / per), dim3(256), 0, st, list, n_list_dev, list_bound, cx_state, static_cast<const ClSlot*>(tab),
                        inst_uid, cu, static_cast<const HxHead*>(recs), status);
+  hipLaunchKernelGGL(k_cl_results, dim3(1), dim3(1), 0, st, n_inst_dev, counters, reinterpret_cast<const unsigned long long*>(counters + 4), status, results);
 }
 
 // ---- per search ------------------------------------------------------------------------------------
