@@ -313,3 +313,45 @@ def test_report_order_resolves_ties_like_the_full_lexsort():
     # rows that agree in every key may come in either order: compare the keys along the two permutations
     for k in keys:
         assert np.array_equal(k[got], k[want])
+
+
+def test_variant_window_equals_searchsorted():
+    """hawk_host_variant_window (every alt row's window of its haplotype's position-ordered variant list) against numpy's
+    searchsorted over (haplotype, position) keys: random lists with empty rows, repeated positions and windows that miss;
+    a list out of position order is refused (the caller keeps its numpy route)."""
+    import ctypes as C
+    from crisprhawk_hip import _lib
+    L = reports._host_lib()
+    rng = np.random.default_rng(11)
+    n_var, n_hap, n = 400, 37, 3000
+    t_pos = np.sort(rng.integers(1000, 9000, n_var)).astype(np.int64)
+    lists = [np.sort(rng.choice(n_var, size=int(k), replace=False)) if k else np.zeros(0, np.int64) for k in rng.integers(0, 60, n_hap)]
+    var_off = np.concatenate(([0], np.cumsum([len(x) for x in lists]))).astype(np.uint64)
+    var_idx = np.ascontiguousarray(np.concatenate(lists), dtype=np.int64)
+    hap = rng.integers(0, n_hap, n).astype(np.uint32)
+    lo = rng.integers(900, 9100, n).astype(np.int64)
+    hi = lo + rng.integers(0, 40, n)
+    first, count = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.hawk_host_variant_window(C.c_uint64(n), p(hap), p(lo), p(hi), p(var_off), p(var_idx), p(t_pos), C.c_uint64(n_hap), C.c_uint32(n_var),
+                                    p(first), p(count))
+    assert rc == _lib.HAWK_OK
+    big = np.int64(1) << np.int64(40)
+    key = np.repeat(np.arange(n_hap, dtype=np.int64), np.diff(var_off.astype(np.int64))) * big + t_pos[var_idx]
+    a = np.searchsorted(key, hap.astype(np.int64) * big + lo, side="left")
+    b = np.searchsorted(key, hap.astype(np.int64) * big + hi, side="right")
+    assert np.array_equal(first.astype(np.int64)[b > a], a[b > a]) and np.array_equal(count.astype(np.int64), b - a)
+    assert (count > 0).sum() > 100 and (count == 0).sum() > 100
+    bad = var_idx.copy()
+    h = int(np.argmax(np.diff(var_off.astype(np.int64)) > 3))
+    s0 = int(var_off[h])
+    bad[s0], bad[s0 + 2] = bad[s0 + 2], bad[s0]
+    if t_pos[bad[s0]] != t_pos[bad[s0 + 2]]:
+        rc = L.hawk_host_variant_window(C.c_uint64(n), p(hap), p(lo), p(hi), p(var_off), p(bad), p(t_pos), C.c_uint64(n_hap), C.c_uint32(n_var),
+                                        p(first), p(count))
+        assert rc == _lib.HAWK_E_UNSUPPORTED
+    bad = var_idx.copy()
+    bad[5] = n_var
+    rc = L.hawk_host_variant_window(C.c_uint64(n), p(hap), p(lo), p(hi), p(var_off), p(bad), p(t_pos), C.c_uint64(n_hap), C.c_uint32(n_var),
+                                    p(first), p(count))
+    assert rc == _lib.HAWK_E_INVALID
