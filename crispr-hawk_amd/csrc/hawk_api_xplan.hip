@@ -360,7 +360,7 @@ static int xplan_build_dict(hawk_xplan* x) {
     hawk_launch_cl_fill(st, x->heads.p, x->off.as<uint64_t>(), x->hlen.as<uint32_t>(), x->m_ss.as<int32_t>(), x->m_se.as<int32_t>(), n, d_ch_off, d_ch_row,
                         ch_bound, d_base, d_lbase, t_o, t_row, t_pa, t_rb, t_uid, d_vdesc, d_claim, n_var, d_list, d_status);
     hawk_launch_cl_finish(st, inst_bound, d_n_inst, d_n_list, d_counters, d_results, n_var, u_bound, d_tab, tsz - 1, max_probe, fail_bit, d_list, d_state, d_vdesc, x->heads.p,
-                          t_uid, x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
+                          t_uid, t_row, x->m_seg_off.as<uint32_t>(), x->m_seg_rel.as<uint32_t>(), cl.u_rec.as<uint32_t>(), cl.u_n.as<uint32_t>(),
                           cl.u_row.as<uint32_t>(), cl.u_o.as<int32_t>(), cl.u_seg.as<uint32_t>(), d_span2, d_status);
     HIPCHK(hipMemcpyAsync(res, d_results, 64, hipMemcpyDeviceToHost, st));  // {instances, the table's clusters, the variants that are clusters, template rows, status}
     HIPCHK(hipEventRecord(ctx->ev[9], st));

@@ -112,17 +112,17 @@ struct ClUniq {  // per distinct cluster: first record, records, row and row pos
 // have not described yet writes {its record, its row} - ONE aligned 64-bit store, so whichever write lands last is whole.
 // Every other instance with a cluster - several records, or windows that could meet a bound of its row - is put on a LIST by the
 // cutting pass (its place known without an atomic: the counting pass counts those too) and goes through a hash table of 32-byte
-// slots in passes of their own over that list: {hash key (0: free), cluster number + 1 (0: not yet numbered), records | class << 16
-// of the instance that opened the slot} {REF position of its first allele, that record's rs, alt_len, variant}; these are
-// numbered behind the variants, in the order they are met (the order carries no meaning: every table a search writes is in
-// instance order).
+// slots in passes of their own over that list: {hash key (0: free), -} for the pass that enters them, {cluster number + 1 (0: not yet
+// numbered), records | class << 16 of the instance that opened the slot, REF position of its first allele, its first variant} -
+// ONE 16-byte piece, one request - for the pass that compares; these are numbered behind the variants, in the order they are met
+// (the order carries no meaning: every table a search writes is in instance order).
 // Why this shape: the passes are bound by the NUMBER of requests to L2 (a 4-byte gather costs what a 64-byte line costs: ~1.3 x 10^11
 // requests/s at best) and by same-address atomics (~10 ns each, whoever waits for them) - not by bytes and not by arithmetic.
-struct __attribute__((aligned(32))) ClSlot { unsigned long long key; uint32_t up1; uint32_t ncls; uint32_t id[4]; };
+struct __attribute__((aligned(32))) ClSlot { unsigned long long key; unsigned long long pad; uint32_t up1, ncls, refp, var; };
 static_assert(sizeof(ClSlot) == 32, "table slot layout");
 size_t hawk_cl_slot_bytes() { return sizeof(ClSlot); }
 struct __attribute__((aligned(32))) ClListed {  // a listed instance: all the table passes need of it
-  uint32_t inst, key_lo, key_hi, rec, ncls, refp, row; int32_t o_first;
+  uint32_t inst, key_lo, key_hi, rec, ncls, refp; int32_t o_first; uint32_t var;
 };
 static_assert(sizeof(ClListed) == 32, "list entry layout");
 size_t hawk_cl_listed_bytes() { return sizeof(ClListed); }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
         }
         listed[u] = k.cls != 0 && !simple;
         ea[u] = make_uint4(i, (uint32_t)k.key, (uint32_t)(k.key >> 32), (uint32_t)j);
-        eb[u] = make_uint4(k.n | (k.cls << 16), (uint32_t)(k.o_first + k.rb), row, (uint32_t)k.o_first);
+        eb[u] = make_uint4(k.n | (k.cls << 16), (uint32_t)(k.o_first + k.rb), (uint32_t)k.o_first, v);
       }
       lbal[u] = __ballot(listed[u]);
       if (lane == 0) s_l[wv][u] = (uint32_t)__popcll(lbal[u]);
@@ -347,9 +347,8 @@ __global__ __launch_bounds__(256) void k_cl_fill(const HxHead* __restrict__ recs
 #define CL_UID_U 4
 __global__ __launch_bounds__(256) void k_cl_enter(const ClListed* __restrict__ cx_list, const uint32_t* __restrict__ n_list_dev, uint32_t t_first,
                                                   uint32_t t_end, ClSlot* tab, uint32_t mask, uint32_t max_probe, uint32_t fail_bit,
-                                                  uint32_t* __restrict__ inst_uid, uint32_t* __restrict__ cx_state, ClUniq cu,
-                                                  const HxHead* __restrict__ recs, uint32_t* n_table, uint32_t n_var, uint32_t u_cap,
-                                                  uint32_t* __restrict__ status) {
+                                                  uint32_t* __restrict__ inst_uid, const uint32_t* __restrict__ inst_row, uint32_t* __restrict__ cx_state,
+                                                  ClUniq cu, uint32_t* n_table, uint32_t n_var, uint32_t u_cap, uint32_t* __restrict__ status) {
   __shared__ uint32_t s_n[256 / WAVE][CL_UID_U];
   __shared__ uint32_t s_base;
   const uint32_t n_list = *n_list_dev < t_end ? *n_list_dev : t_end;  // (launched over the bound on the list)
@@ -418,13 +417,10 @@ __global__ __launch_bounds__(256) void k_cl_enter(const ClListed* __restrict__ c
     const uint32_t un = base + mine[u] + (uint32_t)__popcll(wb[u] & ((1ull << lane) - 1ull));
     const uint32_t i = ent[u].x;
     if (un >= u_cap) { inst_uid[i] = CL_NONE; atomicOr(status, fail_bit); continue; }  // (more distinct clusters than slots: cannot happen)
-    const uint4 e1 = reinterpret_cast<const uint4*>(cx_list + (t0 + u * 256))[1];  // {records | class, REF position, row, row position}
-    const uint4 r0 = *reinterpret_cast<const uint4*>(recs + ent[u].w);
-    ClSlot* e = tab + sl[u];
-    *reinterpret_cast<uint4*>(e->id) = make_uint4(e1.y, r0.y, r0.z, r0.w);
-    *reinterpret_cast<uint2*>(&e->up1) = make_uint2(un + 1u, e1.x);
+    const uint4 e1 = reinterpret_cast<const uint4*>(cx_list + (t0 + u * 256))[1];  // {records | class, REF position, row position, first variant}
+    *reinterpret_cast<uint4*>(&tab[sl[u]].up1) = make_uint4(un + 1u, e1.x, e1.y, e1.w);
     inst_uid[i] = un;
-    cu.rec[un] = ent[u].w; cu.n[un] = e1.x & 0xffffu; cu.row[un] = e1.z; cu.o[un] = (int32_t)e1.w;
+    cu.rec[un] = ent[u].w; cu.n[un] = e1.x & 0xffffu; cu.row[un] = inst_row[i]; cu.o[un] = (int32_t)e1.z;
   }
 }
 
@@ -466,11 +462,20 @@ __global__ __launch_bounds__(256) void k_cl_describe(const uint32_t* __restrict_
       cu.seg[u] = lo;
     }
   }
-  const unsigned long long vb = __ballot(variant_cluster);  // (statistics: how many variants are clusters of their own)
-  if ((threadIdx.x & (WAVE - 1)) == 0 && vb) atomicAdd(n_variant_clusters, (uint32_t)__popcll(vb));
-  // the template rows a search may need at most: the sum of the clusters' bounds (nobody waits for these atomics)
+  // how many variants are clusters of their own (statistics), and the template rows a search may need at most - the sum of the
+  // clusters' bounds: one atomic each per WORKGROUP (same-address atomics are served one after the other, ~10 ns each)
+  __shared__ uint32_t s_red[256 / WAVE][2];
+  const unsigned long long vb = __ballot(variant_cluster);
   const uint32_t ssum = wave_sum(span_u);
-  if ((threadIdx.x & (WAVE - 1)) == 0 && ssum) atomicAdd(slots_total, (unsigned long long)ssum);
+  if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = (uint32_t)__popcll(vb); s_red[threadIdx.x / WAVE][1] = ssum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int w = 0; w < 256 / WAVE; ++w) { a += s_red[w][0]; b += s_red[w][1]; }
+    if (a) atomicAdd(n_variant_clusters, a);
+    if (b) atomicAdd(slots_total, (unsigned long long)b);
+  }
 }
 // what the host wants to know of a finished build, as one block (one copy instead of four)
 __global__ void k_cl_results(const uint32_t* __restrict__ n_inst, const uint32_t* __restrict__ counters, const unsigned long long* __restrict__ slots_total,
@@ -496,35 +501,31 @@ __global__ __launch_bounds__(256) void k_cl_uid(const ClListed* __restrict__ cx_
     any = any || pend[u];
   }
   if (!__any(any)) return;
-  uint4 e0[CL_UID_U], e1[CL_UID_U], la[CL_UID_U], lb[CL_UID_U], ra[CL_UID_U];
+  uint4 e1[CL_UID_U], la[CL_UID_U], lb[CL_UID_U];
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
-    const uint4* e = reinterpret_cast<const uint4*>(tab + (pend[u] ? (v[u] & ~CL_PENDING) : 0u));
-    e0[u] = e[0]; e1[u] = e[1];
+    e1[u] = reinterpret_cast<const uint4*>(tab + (pend[u] ? (v[u] & ~CL_PENDING) : 0u))[1];  // {number + 1, records | class, REF position, first variant}
     const uint4* l = reinterpret_cast<const uint4*>(cx_list + (pend[u] ? t0 + u * 256 : 0u));
-    la[u] = l[0]; lb[u] = l[1];  // {instance, key, first record} {records | class, REF position, row, row position}
+    la[u] = l[0]; lb[u] = l[1];  // {instance, key, first record} {records | class, REF position, row position, first variant}
   }
   uint32_t rrec[CL_UID_U];
 #pragma unroll
-  for (int u = 0; u < CL_UID_U; ++u) {
-    ra[u] = *reinterpret_cast<const uint4*>(recs + (pend[u] ? la[u].w : 0u));  // {o, rs, alt_len, variant}
-    rrec[u] = (pend[u] && e0[u].z != 0u && (lb[u].x & 0xffffu) > 1u) ? cu.rec[e0[u].z - 1u] : 0u;
-  }
+  for (int u = 0; u < CL_UID_U; ++u) rrec[u] = (pend[u] && e1[u].x != 0u && (lb[u].x & 0xffffu) > 1u) ? cu.rec[e1[u].x - 1u] : 0u;
   bool bad = false;
 #pragma unroll
   for (int u = 0; u < CL_UID_U; ++u) {
     if (!pend[u]) continue;
     const uint32_t i = la[u].x, ncls = lb[u].x;
-    if (e0[u].z == 0u) { inst_uid[i] = CL_NONE; bad = true; continue; }  // (a taken slot without a number: cannot happen)
-    inst_uid[i] = e0[u].z - 1u;
-    // both shareable, as many records, the same REF position of the first allele, then record by record
-    bool b = ncls != e0[u].w || (ncls >> 16) != 1 || lb[u].y != e1[u].x;
-    b = b || ra[u].y != e1[u].y || ra[u].z != e1[u].z || ra[u].w != e1[u].w;
+    if (e1[u].x == 0u) { inst_uid[i] = CL_NONE; bad = true; continue; }  // (a taken slot without a number: cannot happen)
+    inst_uid[i] = e1[u].x - 1u;
+    // both shareable, as many records, the same REF position of the first allele and the same first variant (its allele, place and
+    // REF resume follow), then record by record
+    bool b = ncls != e1[u].y || (ncls >> 16) != 1 || lb[u].y != e1[u].z || lb[u].w != e1[u].w;
     const uint32_t n = ncls & 0xffffu;
     if (!b && n > 1) {
       const HxHead* pa = recs + la[u].w;
       const HxHead* pb = recs + rrec[u];
-      const int32_t oa = (int32_t)ra[u].x, ob = pb[0].o;
+      const int32_t oa = (int32_t)lb[u].z, ob = pb[0].o;
       for (uint32_t k = 1; k < n; ++k) {
         const uint4 xa = *reinterpret_cast<const uint4*>(pa + k), xb = *reinterpret_cast<const uint4*>(pb + k);
         b = b || xa.w != xb.w || xa.z != xb.z || xa.y != xb.y || (int32_t)xa.x - oa != (int32_t)xb.x - ob;
@@ -577,18 +578,18 @@ void hawk_launch_cl_fill(hipStream_t st, const void* recs, const uint64_t* hv_of
 void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* n_inst_dev, const uint32_t* n_list_dev, uint32_t* counters,
                            unsigned long long* results, uint32_t n_var, uint32_t u_cap, void* tab,
                            uint32_t mask, uint32_t max_probe, uint32_t fail_bit, const void* cx_list, uint32_t* cx_state, const void* var_desc,
-                           const void* recs, uint32_t* inst_uid, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* u_rec, uint32_t* u_n,
-                           uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* status) {
+                           const void* recs, uint32_t* inst_uid, const uint32_t* inst_row, const uint32_t* seg_off, const uint32_t* seg_rel,
+                           uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* status) {
   ClUniq cu{u_rec, u_n, u_row, u_o, u_seg, u_span2};
   const uint32_t per = 256 * CL_UID_U;
   const uint32_t head = list_bound < 16 * CL_HEAD_LISTED ? 0u : CL_HEAD_LISTED;
   const ClListed* list = static_cast<const ClListed*>(cx_list);
   if (head)
     hipLaunchKernelGGL(k_cl_enter, dim3((head + per - 1) / per), dim3(256), 0, st, list, n_list_dev, 0u, head, static_cast<ClSlot*>(tab), mask, max_probe,
-                       fail_bit, inst_uid, cx_state, cu, static_cast<const HxHead*>(recs), counters, n_var, u_cap, status);
+                       fail_bit, inst_uid, inst_row, cx_state, cu, counters, n_var, u_cap, status);
   if (list_bound > head)
     hipLaunchKernelGGL(k_cl_enter, dim3((list_bound - head + per - 1) / per), dim3(256), 0, st, list, n_list_dev, head, list_bound, static_cast<ClSlot*>(tab),
-                       mask, max_probe, fail_bit, inst_uid, cx_state, cu, static_cast<const HxHead*>(recs), counters, n_var, u_cap, status);
+                       mask, max_probe, fail_bit, inst_uid, inst_row, cx_state, cu, counters, n_var, u_cap, status);
   hipLaunchKernelGGL(k_cl_describe, dim3((u_cap + 255) / 256), dim3(256), 0, st, counters, n_var, u_cap, static_cast<const unsigned long long*>(var_desc), cu,
                      static_cast<const HxHead*>(recs), seg_off, seg_rel, counters + 1, reinterpret_cast<unsigned long long*>(counters + 4));
   if (list_bound)

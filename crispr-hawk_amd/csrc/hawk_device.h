@@ -174,8 +174,9 @@ size_t hawk_cl_listed_bytes();  // a list entry
 void hawk_launch_cl_finish(hipStream_t st, uint32_t list_bound, const uint32_t* n_inst_dev, const uint32_t* n_list_dev, uint32_t* counters /* 8, zeroed */,
                            unsigned long long* results /* 8: instances, table clusters, variant clusters, template rows, status */, uint32_t n_var, uint32_t u_cap,
                            void* tab /* zeroed */, uint32_t mask, uint32_t max_probe, uint32_t fail_bit, const void* cx_list, uint32_t* cx_state,
-                           const void* var_desc, const void* recs, uint32_t* inst_uid, const uint32_t* seg_off, const uint32_t* seg_rel, uint32_t* u_rec,
-                           uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2, uint32_t* status);
+                           const void* var_desc, const void* recs, uint32_t* inst_uid, const uint32_t* inst_row, const uint32_t* seg_off,
+                           const uint32_t* seg_rel, uint32_t* u_rec, uint32_t* u_n, uint32_t* u_row, int32_t* u_o, uint32_t* u_seg, uint32_t* u_span2,
+                           uint32_t* status);
 void hawk_launch_cs_templates(hipStream_t st, const HapSetDev& hs, const VcArgs& va, const ClDict& cd, const ScanParams& p, const struct GuideParams& gp,
                               const struct RefInfo& ri, void* res /* 32 B per distinct cluster */, uint32_t* tbase, void* trows,
                               unsigned long long* t_count, uint64_t t_cap, int* status);
