@@ -295,7 +295,7 @@ static int xplan_build_dict(hawk_xplan* x) {
   // and describers, the clusters' template-row bounds, the first attempt's table
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t z_status = 0, z_counters = 256, z_results = 512, z_cnt = 768,
-               z_claim = z_cnt + up((size_t)ch_bound * 8), z_vdesc = z_claim + up((size_t)bm_words * 4),
+               z_claim = z_cnt + up(((size_t)ch_bound + 4) * 8), z_vdesc = z_claim + up((size_t)bm_words * 4),
                z_span2 = z_vdesc + up((size_t)std::max<uint32_t>(n_var, 1) * 8), z_tab = z_span2 + up((size_t)u_bound0 * 4),
                z_end = z_tab + (size_t)tsmall * hawk_cl_slot_bytes();
   char* d_zero;
@@ -304,7 +304,7 @@ static int xplan_build_dict(hawk_xplan* x) {
   uint32_t* const d_counters = reinterpret_cast<uint32_t*>(d_zero + z_counters);
   unsigned long long* const d_results = reinterpret_cast<unsigned long long*>(d_zero + z_results);
   uint32_t* const d_cnt = reinterpret_cast<uint32_t*>(d_zero + z_cnt);
-  uint32_t* const d_lcnt = d_cnt + ch_bound;
+  uint32_t* const d_lcnt = d_cnt + ((ch_bound + 3) & ~3u);  // (16-byte aligned: k_scan2_u32 loads four counts at a time)
   uint32_t* const d_claim = reinterpret_cast<uint32_t*>(d_zero + z_claim);
   void* const d_vdesc = d_zero + z_vdesc;
   uint32_t *d_ch_off, *d_ch_row, *d_base, *d_lbase, *d_state;

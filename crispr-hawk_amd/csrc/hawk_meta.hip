@@ -88,19 +88,32 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t* __restrict__ 
   if (threadIdx.x == 0) off[n] = carry;
 }
 
-// the same for two count arrays at once (one launch: the dictionary's chunks open instances AND put some of them on a list);
-// eight consecutive counts of either array per thread and round
+// the same for two count arrays at once (one launch: the dictionary's chunks open instances AND put some of them on a list).
+// A thread takes sixteen CONSECUTIVE counts of either array (four 16-byte loads each, all in flight at once), scans them in
+// registers, and the workgroup scans the threads' sums once per 16384 counts: a scan of 1.5 x 10^4 counts is latency and nothing
+// else, so it is one round trip and one pair of barriers instead of fifteen.  Arrays and offsets 16-byte aligned, as the pool's are.
 __global__ __launch_bounds__(1024) void k_scan2_u32(const uint32_t* __restrict__ cnt_a, const uint32_t* __restrict__ cnt_b, uint32_t n,
                                                     uint32_t* __restrict__ off_a, uint32_t* __restrict__ off_b) {
   __shared__ uint32_t s_w[2][1024 / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   uint32_t carry_a = 0, carry_b = 0;
-  for (uint32_t b0 = 0; b0 < n; b0 += 8192) {
-    const uint32_t i = b0 + threadIdx.x * 8;
-    uint32_t a[8], b[8], sa = 0, sb = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += 16 * 1024) {
+    const uint32_t i0 = b0 + threadIdx.x * 16;
+    uint32_t a[16], b[16];
+    if (i0 + 16 <= n) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { a[k] = i + k < n ? cnt_a[i + k] : 0u; b[k] = i + k < n ? cnt_b[i + k] : 0u; sa += a[k]; sb += b[k]; }
-    // both scans share their two barriers
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+      for (int q = 0; q < 4; ++q) {
+        const uint4 va = reinterpret_cast<const uint4*>(cnt_a + i0)[q], vb = reinterpret_cast<const uint4*>(cnt_b + i0)[q];
+        a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+        b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { a[k] = i0 + k < n ? cnt_a[i0 + k] : 0u; b[k] = i0 + k < n ? cnt_b[i0 + k] : 0u; }
+    }
+    uint32_t sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t xa = a[k], xb = b[k]; a[k] = sa; b[k] = sb; sa += xa; sb += xb; }  // exclusive, in place
     const uint32_t ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
     if (lane == WAVE - 1) { s_w[0][wv] = ia; s_w[1][wv] = ib; }
     __syncthreads();
@@ -112,11 +125,16 @@ __global__ __launch_bounds__(1024) void k_scan2_u32(const uint32_t* __restrict__
       ta += xa; tb += xb;
     }
     __syncthreads();
-    uint32_t ea = carry_a + pa + ia - sa, eb = carry_b + pb + ib - sb;
+    const uint32_t ea = carry_a + pa + ia - sa, eb = carry_b + pb + ib - sb;
+    if (i0 + 16 <= n) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (i + k < n) { off_a[i + k] = ea; off_b[i + k] = eb; }
-      ea += a[k]; eb += b[k];
+      for (int q = 0; q < 4; ++q) {
+        reinterpret_cast<uint4*>(off_a + i0)[q] = make_uint4(ea + a[4 * q], ea + a[4 * q + 1], ea + a[4 * q + 2], ea + a[4 * q + 3]);
+        reinterpret_cast<uint4*>(off_b + i0)[q] = make_uint4(eb + b[4 * q], eb + b[4 * q + 1], eb + b[4 * q + 2], eb + b[4 * q + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) if (i0 + k < n) { off_a[i0 + k] = ea + a[k]; off_b[i0 + k] = eb + b[k]; }
     }
     carry_a += ta; carry_b += tb;
   }
